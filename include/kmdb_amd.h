@@ -1,0 +1,170 @@
+/*
+ * kmdb_amd.h — C ABI of the MI355X-native common-k-mer counting engine.
+ *
+ * Drop-in boundary for the hot path of refresh-bio/kmer-db v2.3.1.  The reference has no
+ * FFI layer; its operator interface for this path is the C++ class SimilarityCalculator
+ * (reference src/similarity_calculator.h:4-16) called from the mode consoles.  Each entry
+ * point below replaces exactly one of those call sites (plain pointers and sizes only;
+ * no torch / STL types cross this boundary).  INTEGRATION.md shows the binding a kmer-db
+ * maintainer would add inside the reference's consoles.
+ *
+ * All functions return 0 on success, non-zero on failure; kmdb_last_error() then returns
+ * the message (the front-end turns it into the reference's "ERROR: <msg>" / exit(-1),
+ * reference src/main.cpp:51-59).  The GPU entry points FAIL (they never fall back to a CPU
+ * path) when no gfx950 device / HIP runtime is usable.
+ */
+#ifndef KMDB_AMD_H
+#define KMDB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMDB_ABI_VERSION 1
+
+/* ---------------------------------------------------------------------------------------
+ * Host-side view of a loaded database = what the reference hands to SimilarityCalculator:
+ *   PrefixKmerDb::getPatterns()      (prefix_kmer_db.h:112)   -> SoA pattern headers + bits
+ *   PrefixKmerDb::getHashtables()    (prefix_kmer_db.h:108)   -> bucket table + slots
+ *   AbstractKmerDb::getSamplesCount()(kmer_db.h:67)
+ * Pattern fields mirror pattern_t (pattern.h:42-53) as stored on disk (pattern.cpp:15-46).
+ * The view is read-only: unlike the reference (similarity_calculator.cpp:64-72) the engine
+ * never mutates num_kmers.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kmdb_db_view {
+    uint32_t abi_version;          /* KMDB_ABI_VERSION */
+    uint32_t kmer_length;
+    uint64_t n_samples;
+    uint64_t n_patterns;
+    const int64_t*  num_kmers;     /* [P] on-disk values (not subtree sums) */
+    const int64_t*  parent_id;     /* [P] -1 for roots; parent_id[p] < p */
+    const uint32_t* num_samples;   /* [P] ids in node + ancestors */
+    const uint32_t* num_local;     /* [P] ids stored in the node */
+    const uint32_t* last_sample_id;/* [P] */
+    const uint32_t* num_bits;      /* [P] gamma bitstream length */
+    const uint64_t* data_offset;   /* [P] index (in uint64 words) of the node's stream in `data` */
+    const uint64_t* data;          /* all gamma streams, MSB-first in little-endian uint64 words */
+    uint64_t n_data_words;
+    /* hashtables: needed by new2all only (all2all loads with SkipHashtables,
+     * console_all2all.cpp:26); n_buckets may be 0. item = {u32 key; i32 val} packed in a
+     * uint64 (key low), val == INT32_MAX means empty (hashmap_lp.h:71-78). */
+    uint64_t n_buckets;
+    const uint64_t* bucket_offset; /* [n_buckets+1] first slot of every bucket in `slots` */
+    const uint64_t* slots;         /* capacity of bucket b = bucket_offset[b+1]-bucket_offset[b], a power of two */
+} kmdb_db_view;
+
+typedef struct kmdb_opts {
+    uint32_t abi_version;          /* KMDB_ABI_VERSION */
+    int32_t  device;               /* HIP device ordinal */
+    /* pattern-stream sharding for multi-GPU runs: this call processes shard `shard_index`
+     * of `shard_count` equal-cost slices of the pattern stream; partial matrices from all
+     * shards sum (uint32, wrap-around) to the full result.  {0,1} = everything. */
+    uint32_t shard_index;
+    uint32_t shard_count;
+    uint32_t bubble_size;          /* all2all-sp: -bubble-size (params.h:78), kept for CLI compat; 0 = default 8000 */
+    uint32_t flags;                /* KMDB_FLAG_* */
+    void*    stream;               /* hipStream_t to run on, NULL = the engine's own stream */
+} kmdb_opts;
+
+#define KMDB_FLAG_FORCE_GLOBAL_ATOMICS 1u   /* debugging: bypass the LDS tile path */
+
+typedef struct kmdb_db kmdb_db;    /* database resident in HBM */
+
+/* Result of the sparse calls: CSR, library-allocated, free with kmdb_sparse_free().
+ * Row i lists (col, val) with val > 0, ascending col — the content of
+ * SparseMatrix::data_compacted after compact2 with pass-all filters (array.h:391-446). */
+typedef struct kmdb_sparse_rows {
+    uint64_t  n_rows;
+    uint64_t  nnz;
+    uint64_t* row_ptr;             /* [n_rows+1] */
+    uint32_t* col;                 /* [nnz] 0-based */
+    uint32_t* val;                 /* [nnz] */
+} kmdb_sparse_rows;
+
+typedef struct kmdb_stats {        /* measurements of the LAST call on this db handle */
+    double   kernel_ms;            /* HIP-event time of the whole device pipeline of the call */
+    double   dominant_kernel_ms;   /* HIP-event time of the dominant kernel alone */
+    uint64_t algorithmic_bytes;    /* B_pat + 4*N(N-1)/2 (dense) */
+    uint64_t tree_updates;         /* cell updates performed (tree form) */
+    uint64_t sum_pairs;            /* sum_p w_p*C(n_p,2) = sum of the matrix = k-mer pair comparisons */
+    uint64_t device_bytes;         /* HBM footprint of the resident db */
+    uint64_t n_segments;
+    uint64_t tile_flushes;
+} kmdb_stats;
+
+const char* kmdb_last_error(void);
+int  kmdb_abi_version(void);
+/* number of usable gfx950 devices, 0 if none (never fails) */
+int  kmdb_device_count(void);
+
+/* Lay the database out in HBM (replaces PrefixKmerDb living in host RAM after
+ * deserialize, prefix_kmer_db.cpp:578-748).  with_hashtables != 0 also uploads the
+ * bucket tables (DeserializationMode::Everything vs SkipHashtables, kmer_db.h:55-60). */
+int  kmdb_db_upload(const kmdb_db_view* view, const kmdb_opts* opts, int with_hashtables, kmdb_db** out);
+void kmdb_db_free(kmdb_db* db);
+int  kmdb_db_stats(const kmdb_db* db, kmdb_stats* out);
+
+/* Replaces SimilarityCalculator::all2all(db, LowerTriangularMatrix&)
+ * (similarity_calculator.cpp:42-438; call site console_all2all.cpp:34).
+ * out_lower_tri: N(N-1)/2 uint32 in HOST memory, row i at i(i-1)/2 (array.h:136-140). */
+int  kmdb_all2all_dense(kmdb_db* db, uint32_t* out_lower_tri, const kmdb_opts* opts);
+/* Same, result left in DEVICE memory (caller-owned, N(N-1)/2 uint32, need not be zeroed)
+ * so that per-GPU partial matrices can be reduced with RCCL without a host round trip. */
+int  kmdb_all2all_dense_device(kmdb_db* db, void* out_lower_tri_dev, const kmdb_opts* opts);
+
+/* Replaces SimilarityCalculator::all2all_sp(db, SparseMatrix&, CBubbleHelper&) followed by
+ * SparseMatrix::compact2 with pass-all filters (similarity_calculator.cpp:442-657,
+ * array.h:391-446; call sites console_all2all_sparse.cpp:44,79). */
+int  kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmdb_opts* opts);
+void kmdb_sparse_free(kmdb_sparse_rows* rows);
+
+/* Replaces T concurrent calls of SimilarityCalculator::one2all<false>
+ * (similarity_calculator.cpp:809-925; call site console_new2all.cpp:82): nq queries, each a
+ * sorted, duplicate-free k-mer array (KmerHelper::unique, console_new2all.cpp:73).
+ * out_dense: nq x N uint32 in host memory, row q = similarities of query q. */
+int  kmdb_new2all_batch(kmdb_db* db, const uint64_t* const* kmers, const size_t* counts, size_t nq,
+                        uint32_t* out_dense, const kmdb_opts* opts);
+/* Replaces one2all_sp (similarity_calculator.cpp:929-1051; call site console_new2all.cpp:78):
+ * row q = ascending (sample_id, count) pairs with count > 0. */
+int  kmdb_new2all_batch_sparse(kmdb_db* db, const uint64_t* const* kmers, const size_t* counts, size_t nq,
+                               kmdb_sparse_rows* out, const kmdb_opts* opts);
+
+/* ---------------------------------------------------------------------------------------
+ * Host-side helpers of the front-end (no GPU needed).  They mirror the reference's loader
+ * and writer so that the CLI stays byte-compatible; exported so tests can drive them.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kmdbh_db kmdbh_db;  /* a .db file parsed into flat host arrays */
+
+/* PrefixKmerDb::deserialize (prefix_kmer_db.cpp:578-748). mode: 0 Everything, 2 SkipHashtables */
+int  kmdbh_db_load(const char* path, int mode, kmdbh_db** out);
+void kmdbh_db_free(kmdbh_db* db);
+const kmdb_db_view* kmdbh_db_view(const kmdbh_db* db);
+uint32_t    kmdbh_db_kmer_length(const kmdbh_db* db);
+double      kmdbh_db_fraction(const kmdbh_db* db);
+double      kmdbh_db_start_fraction(const kmdbh_db* db);
+int32_t     kmdbh_db_alphabet(const kmdbh_db* db);
+uint64_t    kmdbh_db_n_samples(const kmdbh_db* db);
+const char* kmdbh_db_sample_name(const kmdbh_db* db, uint64_t i);
+uint64_t    kmdbh_db_sample_kmers(const kmdbh_db* db, uint64_t i);
+uint64_t    kmdbh_db_pattern_section_bytes(const kmdbh_db* db);
+
+/* KmerHelper::extract + MinHashFilter (kmer_extract.h:13-97, filter.h:28-115), nt alphabets.
+ * Writes at most len k-mers to out; returns the count. */
+size_t kmdbh_extract_kmers(const char* seq, size_t len, uint32_t k, double fraction, double start_fraction,
+                           int preserve_strand, uint64_t* out);
+/* KmerHelper::unique (kmer_extract.h:112-118): sort + dedupe in place, returns new count */
+size_t kmdbh_sort_unique(uint64_t* kmers, size_t n);
+
+/* CSV text (console_all2all.cpp:40-78, console_new2all.cpp:99-160, conversion.h:246-298).
+ * Each returns bytes written to `out` (caller sizes it: 10000 + 100*N like the reference). */
+size_t kmdbh_format_header(const kmdbh_db* db, char* out, size_t cap);
+size_t kmdbh_format_dense_row(const char* name, uint64_t kmers, const uint32_t* row, size_t n, char* out);
+size_t kmdbh_format_sparse_row(const char* name, uint64_t kmers, const uint32_t* cols, const uint32_t* vals, size_t n, char* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMDB_AMD_H */

@@ -1,0 +1,348 @@
+"""ctypes declarations for include/kmdb_amd.h and thin numpy-facing wrappers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ABI_VERSION = 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class KmdbError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libkmdb_amd.so")
+
+
+class _View(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("kmer_length", C.c_uint32),
+        ("n_samples", C.c_uint64), ("n_patterns", C.c_uint64),
+        ("num_kmers", C.c_void_p), ("parent_id", C.c_void_p), ("num_samples", C.c_void_p),
+        ("num_local", C.c_void_p), ("last_sample_id", C.c_void_p), ("num_bits", C.c_void_p),
+        ("data_offset", C.c_void_p), ("data", C.c_void_p), ("n_data_words", C.c_uint64),
+        ("n_buckets", C.c_uint64), ("bucket_offset", C.c_void_p), ("slots", C.c_void_p),
+    ]
+
+
+class _Opts(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device", C.c_int32), ("shard_index", C.c_uint32),
+        ("shard_count", C.c_uint32), ("bubble_size", C.c_uint32), ("flags", C.c_uint32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class _Sparse(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("nnz", C.c_uint64), ("row_ptr", C.POINTER(C.c_uint64)),
+                ("col", C.POINTER(C.c_uint32)), ("val", C.POINTER(C.c_uint32))]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
+                ("algorithmic_bytes", C.c_uint64), ("tree_updates", C.c_uint64), ("sum_pairs", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("n_segments", C.c_uint64), ("tile_flushes", C.c_uint64)]
+
+
+FLAG_FORCE_GLOBAL_ATOMICS = 1
+
+# every symbol include/kmdb_amd.h declares
+EXPORTS = [
+    "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_free", "kmdb_db_stats",
+    "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_sparse_free",
+    "kmdb_new2all_batch", "kmdb_new2all_batch_sparse",
+    "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
+    "kmdbh_db_start_fraction", "kmdbh_db_alphabet", "kmdbh_db_n_samples", "kmdbh_db_sample_name",
+    "kmdbh_db_sample_kmers", "kmdbh_db_pattern_section_bytes", "kmdbh_extract_kmers", "kmdbh_sort_unique",
+    "kmdbh_format_header", "kmdbh_format_dense_row", "kmdbh_format_sparse_row",
+]
+
+
+def lib():
+    """Load libkmdb_amd.so; never falls back to anything else."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise KmdbError("libkmdb_amd.so is not built (run __graft_entry__.build() or `make -C kmer-db_amd`)")
+    L = C.CDLL(p)
+    L.kmdb_last_error.restype = C.c_char_p
+    L.kmdb_db_upload.argtypes = [C.POINTER(_View), C.POINTER(_Opts), C.c_int, C.POINTER(C.c_void_p)]
+    L.kmdb_db_free.argtypes = [C.c_void_p]
+    L.kmdb_db_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    L.kmdb_all2all_dense.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
+    L.kmdb_all2all_dense_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
+    L.kmdb_all2all_sparse.argtypes = [C.c_void_p, C.POINTER(_Sparse), C.POINTER(_Opts)]
+    L.kmdb_sparse_free.argtypes = [C.POINTER(_Sparse)]
+    L.kmdb_new2all_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_void_p, C.POINTER(_Opts)]
+    L.kmdb_new2all_batch_sparse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(_Sparse), C.POINTER(_Opts)]
+    L.kmdbh_db_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.kmdbh_db_free.argtypes = [C.c_void_p]
+    L.kmdbh_db_view.restype = C.POINTER(_View)
+    L.kmdbh_db_view.argtypes = [C.c_void_p]
+    L.kmdbh_db_kmer_length.restype = C.c_uint32
+    L.kmdbh_db_kmer_length.argtypes = [C.c_void_p]
+    L.kmdbh_db_fraction.restype = C.c_double
+    L.kmdbh_db_fraction.argtypes = [C.c_void_p]
+    L.kmdbh_db_start_fraction.restype = C.c_double
+    L.kmdbh_db_start_fraction.argtypes = [C.c_void_p]
+    L.kmdbh_db_alphabet.restype = C.c_int32
+    L.kmdbh_db_alphabet.argtypes = [C.c_void_p]
+    L.kmdbh_db_n_samples.restype = C.c_uint64
+    L.kmdbh_db_n_samples.argtypes = [C.c_void_p]
+    L.kmdbh_db_sample_name.restype = C.c_char_p
+    L.kmdbh_db_sample_name.argtypes = [C.c_void_p, C.c_uint64]
+    L.kmdbh_db_sample_kmers.restype = C.c_uint64
+    L.kmdbh_db_sample_kmers.argtypes = [C.c_void_p, C.c_uint64]
+    L.kmdbh_db_pattern_section_bytes.restype = C.c_uint64
+    L.kmdbh_db_pattern_section_bytes.argtypes = [C.c_void_p]
+    L.kmdbh_extract_kmers.restype = C.c_size_t
+    L.kmdbh_extract_kmers.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    L.kmdbh_sort_unique.restype = C.c_size_t
+    L.kmdbh_sort_unique.argtypes = [C.c_void_p, C.c_size_t]
+    L.kmdbh_format_header.restype = C.c_size_t
+    L.kmdbh_format_header.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.kmdbh_format_dense_row.restype = C.c_size_t
+    L.kmdbh_format_dense_row.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_char_p]
+    L.kmdbh_format_sparse_row.restype = C.c_size_t
+    L.kmdbh_format_sparse_row.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise KmdbError(lib().kmdb_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return int(lib().kmdb_device_count())
+
+
+def _opts(device=0, shard=(0, 1), flags=0, stream=None, bubble=0):
+    o = _Opts()
+    o.abi_version = ABI_VERSION
+    o.device = device
+    o.shard_index, o.shard_count = shard
+    o.bubble_size = bubble
+    o.flags = flags
+    o.stream = stream
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+class HostDB:
+    """A .db file parsed by the front-end's reader (kmdbh_db_load)."""
+
+    def __init__(self, path, skip_hashtables=False):
+        self._h = C.c_void_p()
+        _check(lib().kmdbh_db_load(os.fsencode(path), 2 if skip_hashtables else 0, C.byref(self._h)))
+        L = lib()
+        self.N = int(L.kmdbh_db_n_samples(self._h))
+        self.k = int(L.kmdbh_db_kmer_length(self._h))
+        self.fraction = float(L.kmdbh_db_fraction(self._h))
+        self.start_fraction = float(L.kmdbh_db_start_fraction(self._h))
+        self.alphabet = int(L.kmdbh_db_alphabet(self._h))
+        self.names = [L.kmdbh_db_sample_name(self._h, i).decode() for i in range(self.N)]
+        self.sample_kmers = np.array([L.kmdbh_db_sample_kmers(self._h, i) for i in range(self.N)], dtype=np.uint64)
+        self.pattern_section_bytes = int(L.kmdbh_db_pattern_section_bytes(self._h))
+
+    @property
+    def view(self):
+        return lib().kmdbh_db_view(self._h)
+
+    def view_arrays(self):
+        """numpy copies of the flat view (for tests of the reader)."""
+        v = self.view.contents
+        P = int(v.n_patterns)
+
+        def arr(ptr, n, dt):
+            if not ptr or n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+
+        out = {
+            "num_kmers": arr(v.num_kmers, P, np.int64), "parent_id": arr(v.parent_id, P, np.int64),
+            "num_samples": arr(v.num_samples, P, np.uint32), "num_local": arr(v.num_local, P, np.uint32),
+            "last_sample_id": arr(v.last_sample_id, P, np.uint32), "num_bits": arr(v.num_bits, P, np.uint32),
+            "data_offset": arr(v.data_offset, P, np.uint64), "data": arr(v.data, int(v.n_data_words), np.uint64),
+            "n_buckets": int(v.n_buckets),
+        }
+        if v.n_buckets:
+            out["bucket_offset"] = arr(v.bucket_offset, int(v.n_buckets) + 1, np.uint64)
+            out["slots"] = arr(v.slots, int(out["bucket_offset"][-1]), np.uint64)
+        return out
+
+    def header_bytes(self):
+        buf = C.create_string_buffer(20000 + 200 * self.N + sum(len(n) for n in self.names))
+        n = lib().kmdbh_format_header(self._h, buf, len(buf))
+        return buf.raw[:n]
+
+    def close(self):
+        if self._h:
+            lib().kmdbh_db_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_view(kmer_length, n_samples, num_kmers, parent_id, num_samples, num_local, last_sample_id, num_bits,
+              data_offset, data, bucket_offset=None, slots=None):
+    """Build a kmdb_db_view over caller-owned numpy arrays; returns (view, keepalive)."""
+    keep = [np.ascontiguousarray(num_kmers, np.int64), np.ascontiguousarray(parent_id, np.int64),
+            np.ascontiguousarray(num_samples, np.uint32), np.ascontiguousarray(num_local, np.uint32),
+            np.ascontiguousarray(last_sample_id, np.uint32), np.ascontiguousarray(num_bits, np.uint32),
+            np.ascontiguousarray(data_offset, np.uint64), np.ascontiguousarray(data, np.uint64)]
+    v = _View()
+    v.abi_version = ABI_VERSION
+    v.kmer_length = kmer_length
+    v.n_samples = n_samples
+    v.n_patterns = keep[0].size
+    (v.num_kmers, v.parent_id, v.num_samples, v.num_local, v.last_sample_id, v.num_bits, v.data_offset, v.data) = [
+        a.ctypes.data for a in keep]
+    v.n_data_words = keep[7].size
+    if bucket_offset is not None:
+        bo = np.ascontiguousarray(bucket_offset, np.uint64)
+        sl = np.ascontiguousarray(slots, np.uint64)
+        keep += [bo, sl]
+        v.n_buckets = bo.size - 1
+        v.bucket_offset = bo.ctypes.data
+        v.slots = sl.ctypes.data
+    return v, keep
+
+
+class SparseRows:
+    def __init__(self, raw):
+        n, nnz = int(raw.n_rows), int(raw.nnz)
+        self.row_ptr = np.ctypeslib.as_array(raw.row_ptr, shape=(n + 1,)).copy()
+        self.col = np.ctypeslib.as_array(raw.col, shape=(max(nnz, 1),))[:nnz].copy()
+        self.val = np.ctypeslib.as_array(raw.val, shape=(max(nnz, 1),))[:nnz].copy()
+        self.n_rows, self.nnz = n, nnz
+
+    def row(self, i):
+        a, b = int(self.row_ptr[i]), int(self.row_ptr[i + 1])
+        return self.col[a:b], self.val[a:b]
+
+
+class DeviceDB:
+    """A database resident in HBM (kmdb_db_upload)."""
+
+    def __init__(self, src, device=0, with_hashtables=False):
+        self._keep = None
+        if isinstance(src, HostDB):
+            view = src.view
+            self._keep = src
+        elif isinstance(src, tuple):
+            view, self._keep = C.pointer(src[0]), src
+        else:
+            raise TypeError("DeviceDB expects a HostDB or the (view, keepalive) pair from make_view()")
+        self.device = device
+        self._d = C.c_void_p()
+        o = _opts(device)
+        _check(lib().kmdb_db_upload(view, C.byref(o), int(with_hashtables), C.byref(self._d)))
+        self.N = int(view.contents.n_samples)
+        self.P = int(view.contents.n_patterns)
+
+    def tri_size(self):
+        return self.N * (self.N - 1) // 2 if self.N else 0
+
+    def all2all_dense(self, shard=(0, 1), flags=0):
+        out = np.zeros(max(1, self.tri_size()), dtype=np.uint32)
+        o = _opts(self.device, shard, flags)
+        _check(lib().kmdb_all2all_dense(self._d, out.ctypes.data, C.byref(o)))
+        return out[: self.tri_size()]
+
+    def all2all_dense_device(self, dev_ptr, stream=None, shard=(0, 1), flags=0):
+        """Result stays in device memory at dev_ptr (e.g. torch tensor .data_ptr())."""
+        o = _opts(self.device, shard, flags, stream)
+        _check(lib().kmdb_all2all_dense_device(self._d, C.c_void_p(dev_ptr), C.byref(o)))
+
+    def all2all_sparse(self, shard=(0, 1)):
+        raw = _Sparse()
+        o = _opts(self.device, shard)
+        _check(lib().kmdb_all2all_sparse(self._d, C.byref(raw), C.byref(o)))
+        try:
+            return SparseRows(raw)
+        finally:
+            lib().kmdb_sparse_free(C.byref(raw))
+
+    def new2all(self, queries):
+        qs = [np.ascontiguousarray(q, np.uint64) for q in queries]
+        nq = len(qs)
+        ptrs = (C.c_void_p * max(nq, 1))(*[q.ctypes.data for q in qs])
+        cnts = (C.c_size_t * max(nq, 1))(*[q.size for q in qs])
+        out = np.zeros((nq, self.N), dtype=np.uint32)
+        o = _opts(self.device)
+        _check(lib().kmdb_new2all_batch(self._d, ptrs, cnts, nq, out.ctypes.data if out.size else None, C.byref(o)))
+        return out
+
+    def new2all_sparse(self, queries):
+        qs = [np.ascontiguousarray(q, np.uint64) for q in queries]
+        nq = len(qs)
+        ptrs = (C.c_void_p * max(nq, 1))(*[q.ctypes.data for q in qs])
+        cnts = (C.c_size_t * max(nq, 1))(*[q.size for q in qs])
+        raw = _Sparse()
+        o = _opts(self.device)
+        _check(lib().kmdb_new2all_batch_sparse(self._d, ptrs, cnts, nq, C.byref(raw), C.byref(o)))
+        try:
+            return SparseRows(raw)
+        finally:
+            lib().kmdb_sparse_free(C.byref(raw))
+
+    def stats(self):
+        s = _Stats()
+        _check(lib().kmdb_db_stats(self._d, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in _Stats._fields_}
+
+    def close(self):
+        if self._d:
+            lib().kmdb_db_free(self._d)
+            self._d = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+def extract_kmers(seq, k, fraction=1.0, start_fraction=0.0, preserve_strand=False):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    out = np.zeros(max(1, len(seq)), dtype=np.uint64)
+    n = lib().kmdbh_extract_kmers(seq, len(seq), k, fraction, start_fraction, int(preserve_strand), out.ctypes.data)
+    return out[:n]
+
+
+def sort_unique(kmers):
+    a = np.ascontiguousarray(kmers, np.uint64).copy()
+    n = lib().kmdbh_sort_unique(a.ctypes.data, a.size)
+    return a[:n]
+
+
+def format_header(hostdb):
+    return hostdb.header_bytes()
+
+
+def format_dense_row(name, kmers, row):
+    r = np.ascontiguousarray(row, np.uint32)
+    buf = C.create_string_buffer(len(name) + 64 + 11 * r.size)
+    n = lib().kmdbh_format_dense_row(name.encode(), int(kmers), r.ctypes.data, r.size, buf)
+    return buf.raw[:n]
+
+
+def format_sparse_row(name, kmers, cols, vals):
+    c = np.ascontiguousarray(cols, np.uint32)
+    v = np.ascontiguousarray(vals, np.uint32)
+    buf = C.create_string_buffer(len(name) + 64 + 22 * c.size)
+    n = lib().kmdbh_format_sparse_row(name.encode(), int(kmers), c.ctypes.data, v.ctypes.data, c.size, buf)
+    return buf.raw[:n]

@@ -1,0 +1,858 @@
+// engine.hip — MI355X (gfx950) engine behind include/kmdb_amd.h.
+//
+// Replaces the reference's SimilarityCalculator::all2all / all2all_sp
+// (reference src/similarity_calculator.cpp:42-438, 442-657) with a design built for CDNA4:
+//
+//  * HBM layout (kmdb_db_upload).  The pattern tree is re-laid in DFS PRE-ORDER.  Then
+//      - subtree(p) is the contiguous index range [p, sub_end[p]), so the subtree weights the
+//        reference accumulates bottom-up (:64-72) are two reads of an exclusive prefix sum;
+//      - the full sample list of node p is "the list of the previous node, truncated to
+//        n_p - l_p entries, plus p's own l_p local ids": a wave that walks a contiguous DFS
+//        range keeps ONE stack of decoded ids and decodes every gamma stream exactly once
+//        (the reference re-decodes the whole parent chain per pattern, :126-152);
+//      - node headers are 16-byte records {n, l, last_id, nbits} read fully coalesced, and
+//        all gamma streams are bit-packed back to back (no 128-bit padding as on disk).
+//  * Kernel a2a_tile_kernel.  One wave = one equal-cost segment of the DFS stream.
+//      lanes decode 64 nodes' gamma streams in parallel (lane-per-node) into LDS, then the
+//      wave replays the nodes in order: truncate/extend the id stack, and for every local id
+//      (= matrix row) add the subtree weight to the cells of all earlier ids (= columns):
+//      the GPU form of row_add (reference src/simd/row_add_avx2.cpp:30-124).  Updates go to a
+//      wave-private lower-triangular TILE in LDS indexed by compact sample indices (the set
+//      of samples a DFS neighbourhood touches is small); the tile is written back to the
+//      N x N matrix in HBM with one global atomic per non-zero cell when the compact index
+//      space overflows or the segment ends.  Lists longer than the tile side go straight to
+//      HBM atomics.
+//  * Kernel a2a_global_kernel: same walk with the stack in global scratch and plain HBM
+//      atomics — any N, used for N > 4096 and as the debugging fallback.
+//  No MFMA: this is integer scatter/histogram work (BASELINE.json north_star).
+//  uint32 adds wrap and commute, so any schedule is bit-exact with the reference.
+#include "kmdb_amd.h"
+#include "kmdb_internal.h"
+#include "engine_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+int kmdb_set_error(const std::string& msg) { g_last_error = msg; return 1; }
+extern "C" const char* kmdb_last_error(void) { return g_last_error.c_str(); }
+extern "C" int kmdb_abi_version(void) { return KMDB_ABI_VERSION; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+extern "C" int kmdb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// resident database
+// ------------------------------------------------------------------------------------------
+struct Segment { uint32_t first, end; };
+
+struct kmdb_db {
+    int device = 0;
+    uint64_t N = 0, P = 0;
+    uint4* meta = nullptr;          // {n, l, last_id, nbits} per node, DFS order
+    uint64_t* bitpos = nullptr;     // absolute bit offset of the node's gamma stream
+    int32_t* parent = nullptr;      // DFS index of the parent, -1 for roots
+    uint32_t* w = nullptr;          // on-disk num_kmers truncated to u32, P+1 entries (last = 0)
+    uint32_t* sub_end = nullptr;    // DFS index one past the node's subtree
+    uint32_t* wprefix = nullptr;    // P+1, exclusive scan of w (recomputed by every call)
+    uint64_t* bits = nullptr;
+    uint64_t n_bit_words = 0;
+    Segment* segs = nullptr;
+    uint32_t n_segs = 0;
+    void* scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    uint32_t* stack_scratch = nullptr;  // global kernel: per-wave id stacks
+    size_t stack_scratch_words = 0;
+    unsigned long long* counters = nullptr;   // [0] tile flushes
+    // hashtables (new2all)
+    uint64_t n_buckets = 0;
+    uint64_t* bucket_offset = nullptr;
+    uint64_t* slots = nullptr;
+    uint32_t* pid2dfs = nullptr;    // original pattern id -> DFS index
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    kmdb_stats stats{};
+    uint32_t kmer_length = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int DEC_CAP = 1024;       // decoded local ids buffered per wave per batch
+
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// make this wave's earlier LDS / global writes visible to its other lanes (same CU: the
+// workgroup-scope fence is enough, no cache maintenance involved)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src_lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)v, d, WAVE);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// 64 bits of the stream starting at absolute bit `pos` (stream is MSB-first in LE uint64
+// words, reference src/elias_gamma.h:113-125); the bit array carries two padding words.
+__device__ __forceinline__ uint64_t bit_window(const uint64_t* __restrict__ bits, uint64_t pos) {
+    uint64_t wi = pos >> 6;
+    uint32_t s = (uint32_t)pos & 63u;
+    uint64_t w0 = bits[wi];
+    uint64_t w1 = bits[wi + 1];
+    return s ? ((w0 << s) | (w1 >> (64u - s))) : w0;
+}
+
+// one Elias-gamma value: (L-1) ones, a zero, (L-1) low bits (reference src/elias_gamma.h:104-128)
+__device__ __forceinline__ uint32_t gamma_next(const uint64_t* __restrict__ bits, uint64_t& pos) {
+    uint64_t win = bit_window(bits, pos);
+    uint32_t ones = (uint32_t)__clzll((long long)~win);
+    ones = ones > 31u ? 31u : ones;                 // a valid code has at most 31 leading ones
+    uint32_t low = (uint32_t)((win << ones) >> (63u - ones));
+    pos += 2u * ones + 1u;
+    return low | (1u << ones);
+}
+
+// Decode the l local ids of one node into out[0..l) (ascending).  pattern_t::decodeSamples
+// (reference src/pattern.cpp:99-109): l-1 gamma-coded deltas in append order, last id explicit.
+template <class T>
+__device__ __forceinline__ void decode_node(const uint64_t* __restrict__ bits, uint64_t pos, uint32_t l, uint32_t last, T* out) {
+    if (l == 0) return;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i + 1 < l; ++i) {
+        uint32_t d = gamma_next(bits, pos);
+        out[i] = (T)d;
+        sum += d;
+    }
+    uint32_t id = last - sum;
+    for (uint32_t i = 0; i + 1 < l; ++i) {
+        uint32_t d = (uint32_t)out[i];
+        out[i] = (T)id;
+        id += d;
+    }
+    out[l - 1] = (T)last;
+}
+
+__device__ __forceinline__ uint64_t tri64(uint64_t a) { return a * (a - 1) / 2; }
+
+struct A2AParams {
+    const uint4* meta;
+    const uint64_t* bitpos;
+    const int32_t* parent;
+    const uint32_t* sub_end;
+    const uint32_t* wprefix;
+    const uint64_t* bits;
+    const Segment* segs;
+    uint32_t seg_begin, seg_end;
+    uint32_t* M;                    // N(N-1)/2 lower-triangular matrix in HBM
+    uint32_t* stack_scratch;        // global kernel only
+    uint32_t stack_stride;          // words per wave
+    unsigned long long* counters;
+};
+
+// rebuild the id stack for the ancestors of `first` by walking parent links
+template <class T>
+__device__ __forceinline__ void init_stack(const A2AParams& p, uint32_t first, T* stack, uint32_t lane) {
+    int32_t cur = p.parent[first];
+    while (cur >= 0) {
+        uint4 m = p.meta[cur];
+        if (lane == 0) decode_node<T>(p.bits, p.bitpos[cur], m.y, m.z, stack + (m.x - m.y));
+        cur = p.parent[cur];
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------
+// generic kernel: stack in global scratch, HBM atomics
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_global_kernel(A2AParams p) {
+    __shared__ uint32_t dec_all[WAVES_PER_BLOCK][DEC_CAP];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t seg = p.seg_begin + blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (seg >= p.seg_end) return;
+    uint32_t* dec = dec_all[wave];
+    uint32_t* stack = p.stack_scratch + (size_t)(blockIdx.x * WAVES_PER_BLOCK + wave) * p.stack_stride;
+    const Segment sg = p.segs[seg];
+    const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
+    if (first >= end) return;
+    init_stack<uint32_t>(p, first, stack, lane);
+
+    for (uint32_t base = first; base < end;) {
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        uint4 m = valid ? p.meta[i] : make_uint4(0, 0, 0, 0);
+        const uint64_t bp = valid ? p.bitpos[i] : 0;
+        const uint32_t W = valid ? (p.wprefix[p.sub_end[i]] - p.wprefix[i]) : 0u;
+        const uint32_t l = m.y;
+        const uint32_t incl = wave_incl_scan(l, lane);
+        const unsigned long long fit = __ballot(valid && incl <= (uint32_t)DEC_CAP);
+        uint32_t cnt = fit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fit);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        const uint32_t off = incl - l;
+        if (cnt == 0) {
+            // a single node with more than DEC_CAP local ids: decode straight into the stack
+            const uint32_t n0 = bcast(m.x, 0), l0 = bcast(m.y, 0), last0 = bcast(m.z, 0), W0 = bcast(W, 0);
+            const uint64_t bp0 = ((uint64_t)bcast((uint32_t)(bp >> 32), 0) << 32) | bcast((uint32_t)bp, 0);
+            const uint32_t top = n0 - l0;
+            if (lane == 0) decode_node<uint32_t>(p.bits, bp0, l0, last0, stack + top);
+            wave_sync();
+            if (W0 != 0) {
+                for (uint32_t t = top; t < n0; ++t) {
+                    const uint64_t rb = tri64(stack[t]);
+                    for (uint32_t u = lane; u < t; u += WAVE) atomicAdd(&p.M[rb + stack[u]], W0);
+                }
+            }
+            wave_sync();
+            base += 1;
+            continue;
+        }
+        if (lane < cnt) decode_node<uint32_t>(p.bits, bp, l, m.z, dec + off);
+        wave_sync();
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t nj = bcast(m.x, j), lj = bcast(m.y, j), oj = bcast(off, j), Wj = bcast(W, j);
+            const uint32_t top = nj - lj;
+            for (uint32_t k = lane; k < lj; k += WAVE) stack[top + k] = dec[oj + k];
+            wave_sync();
+            if (Wj != 0) {
+                for (uint32_t t = top; t < nj; ++t) {
+                    const uint64_t rb = tri64(stack[t]);
+                    for (uint32_t u = lane; u < t; u += WAVE) atomicAdd(&p.M[rb + stack[u]], Wj);
+                }
+            }
+            wave_sync();
+        }
+        base += cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile kernel: everything wave-private in LDS
+// ------------------------------------------------------------------------------------------
+template <int S, int NCAP>
+struct WaveLds {
+    uint32_t tile[S * (S - 1) / 2];
+    uint32_t dec[DEC_CAP];
+    uint16_t rstack[NCAP];          // real sample ids, root -> current node
+    uint8_t cstack[NCAP];           // compact indices of the same entries (valid below `cvalid`)
+    uint8_t map[NCAP];              // sample id -> compact index, 0xFF = none
+    uint16_t rid[S];                // compact index -> sample id
+};
+
+template <int S, int NCAP>
+__device__ __forceinline__ void tile_flush(WaveLds<S, NCAP>& L, uint32_t& ns, uint32_t* __restrict__ M, uint32_t lane,
+                                           unsigned long long* counters) {
+    for (uint32_t i = 1; i < ns; ++i) {
+        const uint32_t x = L.rid[i];
+        const uint32_t rowoff = i * (i - 1) / 2;
+        for (uint32_t j = lane; j < i; j += WAVE) {
+            const uint32_t v = L.tile[rowoff + j];
+            if (v) {
+                const uint32_t y = L.rid[j];
+                const uint32_t hi = x > y ? x : y, lo = x > y ? y : x;
+                atomicAdd(&M[tri64(hi) + lo], v);
+                L.tile[rowoff + j] = 0;
+            }
+        }
+    }
+    for (uint32_t k = lane; k < ns; k += WAVE) L.map[L.rid[k]] = 0xFF;
+    if (lane == 0 && ns) atomicAdd(&counters[0], 1ull);
+    ns = 0;
+    wave_sync();
+}
+
+template <int S, int NCAP>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2AParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    using LDS = WaveLds<S, NCAP>;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t seg = p.seg_begin + blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (seg >= p.seg_end) return;
+    LDS& L = reinterpret_cast<LDS*>(lds_raw)[wave];
+    for (uint32_t k = lane; k < (uint32_t)(S * (S - 1) / 2); k += WAVE) L.tile[k] = 0;
+    for (uint32_t k = lane; k < (uint32_t)NCAP; k += WAVE) L.map[k] = 0xFF;
+    wave_sync();
+
+    const Segment sg = p.segs[seg];
+    const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
+    if (first >= end) return;
+    init_stack<uint16_t>(p, first, L.rstack, lane);
+    uint32_t ns = 0;        // compact indices in use
+    uint32_t cvalid = 0;    // cstack[0..cvalid) is valid for the current epoch
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (uint32_t base = first; base < end;) {
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        uint4 m = valid ? p.meta[i] : make_uint4(0, 0, 0, 0);
+        const uint64_t bp = valid ? p.bitpos[i] : 0;
+        const uint32_t W = valid ? (p.wprefix[p.sub_end[i]] - p.wprefix[i]) : 0u;
+        const uint32_t l = m.y;
+        const uint32_t incl = wave_incl_scan(l, lane);
+        const unsigned long long fit = __ballot(valid && incl <= (uint32_t)DEC_CAP);
+        uint32_t cnt = fit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fit);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        const uint32_t off = incl - l;
+        uint32_t nproc = cnt;
+        if (cnt == 0) {
+            // one node with > DEC_CAP local ids (possible only when N > DEC_CAP): decode into rstack
+            const uint32_t n0 = bcast(m.x, 0), l0 = bcast(m.y, 0), last0 = bcast(m.z, 0);
+            const uint64_t bp0 = ((uint64_t)bcast((uint32_t)(bp >> 32), 0) << 32) | bcast((uint32_t)bp, 0);
+            if (lane == 0) decode_node<uint16_t>(p.bits, bp0, l0, last0, L.rstack + (n0 - l0));
+            nproc = 1;
+        } else if (lane < cnt) {
+            decode_node<uint32_t>(p.bits, bp, l, m.z, L.dec + off);
+        }
+        wave_sync();
+        for (uint32_t j = 0; j < nproc; ++j) {
+            const uint32_t nj = bcast(m.x, j), lj = bcast(m.y, j), oj = bcast(off, j), Wj = bcast(W, j);
+            const uint32_t top = nj - lj;
+            if (cnt != 0)
+                for (uint32_t k = lane; k < lj; k += WAVE) L.rstack[top + k] = (uint16_t)L.dec[oj + k];
+            cvalid = cvalid < top ? cvalid : top;
+            wave_sync();
+            if (Wj == 0 || nj < 2) continue;
+            if (nj > (uint32_t)S) {
+                // list longer than the tile side: straight to HBM
+                for (uint32_t t = top; t < nj; ++t) {
+                    const uint64_t rb = tri64(L.rstack[t]);
+                    for (uint32_t u = lane; u < t; u += WAVE) atomicAdd(&p.M[rb + L.rstack[u]], Wj);
+                }
+                wave_sync();
+                continue;
+            }
+            // --- make sure stack entries [cvalid, nj) have compact indices ------------------
+            uint32_t need = 0;
+            for (uint32_t c0 = cvalid; c0 < nj; c0 += WAVE) {
+                const uint32_t pos = c0 + lane;
+                const bool isnew = pos < nj && L.map[L.rstack[pos]] == 0xFF;
+                need += (uint32_t)__popcll(__ballot(isnew));
+            }
+            if (ns + need > (uint32_t)S) {
+                tile_flush<S, NCAP>(L, ns, p.M, lane, p.counters);
+                cvalid = 0;
+            }
+            for (uint32_t c0 = cvalid; c0 < nj; c0 += WAVE) {
+                const uint32_t pos = c0 + lane;
+                const bool act = pos < nj;
+                const uint32_t id = act ? L.rstack[pos] : 0;
+                uint32_t ci = act ? L.map[id] : 0;
+                const bool isnew = act && ci == 0xFF;
+                const unsigned long long bal = __ballot(isnew);
+                if (isnew) {
+                    ci = ns + (uint32_t)__popcll(bal & lt_mask);
+                    L.map[id] = (uint8_t)ci;
+                    L.rid[ci] = (uint16_t)id;
+                }
+                if (act) L.cstack[pos] = (uint8_t)ci;
+                ns += (uint32_t)__popcll(bal);
+            }
+            cvalid = nj;
+            wave_sync();
+            // --- scatter-add: rows = local ids, columns = everything before them -------------
+            // nj <= S <= 128: the whole compact list lives in two registers per lane
+            const uint32_t c0v = lane < nj ? L.cstack[lane] : 0u;
+            const uint32_t c1v = (S > 64 && lane + 64 < nj) ? L.cstack[lane + 64] : 0u;
+            const uint32_t t0v = c0v * (c0v - 1) / 2;       // garbage for c=0 is never used as a base with c<r false... guarded below
+            const uint32_t t1v = c1v * (c1v - 1) / 2;
+            for (uint32_t t = top; t < nj; ++t) {
+                const uint32_t r = t < 64 ? bcast(c0v, t) : bcast(c1v, t - 64);
+                const uint32_t rr = r * (r - 1) / 2;
+                if (lane < t) {
+                    const uint32_t idx = c0v < r ? rr + c0v : t0v + r;
+                    atomicAdd(&L.tile[idx], Wj);
+                }
+                if (S > 64 && lane + 64 < t) {
+                    const uint32_t idx = c1v < r ? rr + c1v : t1v + r;
+                    atomicAdd(&L.tile[idx], Wj);
+                }
+            }
+            wave_sync();
+        }
+        wave_sync();
+        base += nproc;
+    }
+    tile_flush<S, NCAP>(L, ns, p.M, lane, p.counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// dense -> CSR compaction for the sparse entry point
+// ------------------------------------------------------------------------------------------
+__global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t N, unsigned long long* __restrict__ row_nnz) {
+    const uint64_t row = blockIdx.x;
+    const uint32_t* r = M + tri64(row);
+    uint32_t c = 0;
+    for (uint64_t j = threadIdx.x; j < row; j += blockDim.x) c += r[j] != 0;
+    __shared__ uint32_t red[256];
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_nnz[row] = red[0];
+}
+
+// one block per row, ordered compaction with a block-wide running offset
+__global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t N, const unsigned long long* __restrict__ row_ptr,
+                                   uint32_t* __restrict__ col, uint32_t* __restrict__ val) {
+    const uint64_t row = blockIdx.x;
+    const uint32_t* r = M + tri64(row);
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ unsigned long long running;
+    if (threadIdx.x == 0) running = row_ptr[row];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t j0 = 0; j0 < row; j0 += blockDim.x) {
+        const uint64_t j = j0 + threadIdx.x;
+        const uint32_t v = j < row ? r[j] : 0u;
+        const unsigned long long bal = __ballot(v != 0);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < wave; ++k) before += wave_cnt[k];
+        const unsigned long long base = running;
+        if (v) {
+            const unsigned long long o = base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            col[o] = (uint32_t)j;
+            val[o] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running = base + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// upload: pid order -> DFS pre-order layout
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct BitWriter {
+    std::vector<uint64_t>& words;
+    uint64_t pos = 0;
+    explicit BitWriter(std::vector<uint64_t>& w) : words(w) {}
+    // append the first `nbits` bits (MSB-first) of src
+    void append(const uint64_t* src, uint32_t nbits) {
+        uint64_t need = (pos + nbits + 63) / 64 + 1;
+        if (words.size() < need) words.resize(std::max<uint64_t>(need, words.size() * 2), 0);
+        uint32_t done = 0;
+        while (done < nbits) {
+            uint32_t take = std::min<uint32_t>(64, nbits - done);
+            uint64_t chunk = src[done >> 6];                     // done is always a multiple of 64 here
+            if (take < 64) chunk &= ~0ull << (64 - take);
+            uint32_t s = (uint32_t)(pos & 63);
+            words[pos >> 6] |= chunk >> s;
+            if (s && take > 64 - s) words[(pos >> 6) + 1] |= chunk << (64 - s);
+            pos += take;
+            done += take;
+        }
+    }
+};
+
+template <class T>
+int dev_upload(T** dst, const T* src, size_t n) {
+    size_t bytes = std::max<size_t>(1, n) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dst, bytes));
+    if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, kmdb_db** out) {
+    *out = nullptr;
+    if (!v || v->abi_version != KMDB_ABI_VERSION) return kmdb_set_error("kmdb_db_upload: bad view / ABI version");
+    const uint64_t P = v->n_patterns, N = v->n_samples;
+    if (P >= (1ull << 31)) return kmdb_set_error("kmdb_db_upload: more than 2^31 patterns");
+    if (N > 65535) return kmdb_set_error("kmdb_db_upload: more than 65535 samples is not supported yet");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return kmdb_set_error("kmdb_db_upload: no HIP device available (the engine has no CPU fallback)");
+    }
+    const int device = opts ? opts->device : 0;
+    HIP_TRY(hipSetDevice(device));
+
+    // ---- children lists (parent_id[p] < p, SURVEY §7 invariants) ------------------------------
+    std::vector<uint32_t> child_count(P + 1, 0), order(P), dfs_of(P);
+    std::vector<uint32_t> roots;
+    for (uint64_t p = 0; p < P; ++p) {
+        int64_t par = v->parent_id[p];
+        if (par >= (int64_t)p) return kmdb_set_error("kmdb_db_upload: parent_id >= pattern id");
+        if (par < 0) roots.push_back((uint32_t)p); else ++child_count[par];
+    }
+    std::vector<uint64_t> child_begin(P + 1, 0);
+    for (uint64_t p = 0; p < P; ++p) child_begin[p + 1] = child_begin[p] + child_count[p];
+    std::vector<uint32_t> children(child_begin[P]);
+    {
+        std::vector<uint64_t> fill(child_begin.begin(), child_begin.end() - 1);
+        for (uint64_t p = 0; p < P; ++p) {
+            int64_t par = v->parent_id[p];
+            if (par >= 0) children[fill[par]++] = (uint32_t)p;
+        }
+    }
+    std::vector<uint32_t> sub_end(P);
+    {
+        // iterative pre-order; children in increasing pattern id
+        std::vector<std::pair<uint32_t, uint64_t>> st;   // (pid, next child cursor)
+        uint32_t idx = 0;
+        for (uint32_t r : roots) {
+            st.emplace_back(r, child_begin[r]);
+            order[idx] = r; dfs_of[r] = idx++;
+            while (!st.empty()) {
+                auto& top = st.back();
+                if (top.second < child_begin[top.first + 1]) {
+                    uint32_t c = children[top.second++];
+                    order[idx] = c; dfs_of[c] = idx++;
+                    st.emplace_back(c, child_begin[c]);
+                } else {
+                    sub_end[dfs_of[top.first]] = idx;
+                    st.pop_back();
+                }
+            }
+        }
+        if (idx != P) return kmdb_set_error("kmdb_db_upload: pattern tree is not a forest");
+    }
+    std::vector<uint32_t>().swap(children);
+
+    // ---- DFS-ordered arrays, bit-packed streams, cost model ----------------------------------
+    std::vector<uint4> meta(P);
+    std::vector<uint64_t> bitpos(P);
+    std::vector<int32_t> parent(P);
+    std::vector<uint32_t> w(P + 1, 0);
+    std::vector<uint64_t> bits;
+    bits.reserve(v->n_data_words / 4 + 16);
+    BitWriter bw(bits);
+    std::vector<uint64_t> cost_prefix(P + 1, 0);
+    uint64_t alg_bytes = 0, tree_updates = 0, sum_pairs = 0;
+    for (uint64_t i = 0; i < P; ++i) {
+        const uint32_t pid = order[i];
+        const uint32_t n = v->num_samples[pid], l = v->num_local[pid], nb = v->num_bits[pid];
+        if (l > n || n > N) return kmdb_set_error("kmdb_db_upload: inconsistent pattern header");
+        meta[i] = make_uint4(n, l, v->last_sample_id[pid], nb);
+        bitpos[i] = bw.pos;
+        if (nb) bw.append(v->data + v->data_offset[pid], nb);
+        const int64_t par = v->parent_id[pid];
+        parent[i] = par < 0 ? -1 : (int32_t)dfs_of[par];
+        w[i] = (uint32_t)v->num_kmers[pid];
+        const uint64_t upd = (uint64_t)(n - l) * l + (uint64_t)l * (l ? l - 1 : 0) / 2;
+        tree_updates += upd;
+        sum_pairs += (uint64_t)v->num_kmers[pid] * ((uint64_t)n * (n ? n - 1 : 0) / 2);
+        alg_bytes += 40 + (uint64_t)((nb + 127) / 128) * 16;
+        // per-node cost in "wave instructions": decode share + one scatter instruction per 64 columns per row
+        uint64_t rows_cost = 0;
+        if (l) {
+            // sum over t in [n-l, n) of (t/64 + 1)
+            for (uint32_t blk = (n - l) / 64; blk <= (n - 1) / 64; ++blk) {
+                uint32_t lo = std::max<uint32_t>(n - l, blk * 64), hi = std::min<uint32_t>(n, blk * 64 + 64);
+                rows_cost += (uint64_t)(hi - lo) * (blk + 1);
+            }
+        }
+        cost_prefix[i + 1] = cost_prefix[i] + 4 + l / 2 + rows_cost * 2;
+    }
+    bits.resize((bw.pos + 63) / 64 + 2, 0);            // two zero padding words for bit_window()
+    alg_bytes += 4ull * (N ? N * (N - 1) / 2 : 0);
+
+    // ---- equal-cost segments -------------------------------------------------------------------
+    uint32_t want = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1, P / 48));
+    want = (want + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+    std::vector<Segment> segs;
+    {
+        const uint64_t total = cost_prefix[P];
+        uint64_t start = 0;
+        for (uint32_t s = 0; s < want && start < P; ++s) {
+            uint64_t target = total / want * (s + 1);
+            if (s + 1 == want) target = total;
+            uint64_t e = std::upper_bound(cost_prefix.begin() + start + 1, cost_prefix.end(), target) - cost_prefix.begin() - 1;
+            e = std::max<uint64_t>(e, start + 1);
+            e = std::min<uint64_t>(e, P);
+            if (s + 1 == want) e = P;
+            segs.push_back({(uint32_t)start, (uint32_t)e});
+            start = e;
+        }
+        if (segs.empty()) segs.push_back({0u, (uint32_t)P});
+        else segs.back().end = (uint32_t)P;
+    }
+
+    auto* db = new kmdb_db();
+    db->device = device; db->N = N; db->P = P; db->kmer_length = v->kmer_length;
+    db->n_bit_words = bits.size();
+    db->n_segs = (uint32_t)segs.size();
+    int rc = 0;
+    rc |= dev_upload(&db->meta, meta.data(), P);
+    rc |= dev_upload(&db->bitpos, bitpos.data(), P);
+    rc |= dev_upload(&db->parent, parent.data(), P);
+    rc |= dev_upload(&db->w, w.data(), P + 1);
+    rc |= dev_upload(&db->sub_end, sub_end.data(), P);
+    rc |= dev_upload(&db->bits, bits.data(), bits.size());
+    rc |= dev_upload(&db->segs, segs.data(), segs.size());
+    if (rc) { kmdb_db_free(db); return 1; }
+    if (hipMalloc((void**)&db->wprefix, (P + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&db->counters, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        kmdb_db_free(db);
+        return kmdb_set_error("kmdb_db_upload: out of device memory");
+    }
+    hipcub::DeviceScan::ExclusiveSum(nullptr, db->scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1));
+    if (hipMalloc(&db->scan_tmp, std::max<size_t>(db->scan_tmp_bytes, 16)) != hipSuccess) {
+        kmdb_db_free(db);
+        return kmdb_set_error("kmdb_db_upload: out of device memory");
+    }
+    uint64_t dev_bytes = P * (16 + 8 + 4 + 4 + 4 + 4) + bits.size() * 8 + segs.size() * 8;
+    if (with_hashtables && v->n_buckets) {
+        db->n_buckets = v->n_buckets;
+        rc |= dev_upload(&db->bucket_offset, v->bucket_offset, v->n_buckets + 1);
+        rc |= dev_upload(&db->slots, v->slots, v->bucket_offset[v->n_buckets]);
+        rc |= dev_upload(&db->pid2dfs, dfs_of.data(), P);
+        if (rc) { kmdb_db_free(db); return 1; }
+        dev_bytes += (v->n_buckets + 1) * 8 + v->bucket_offset[v->n_buckets] * 8 + P * 4;
+    }
+    if (hipStreamCreate(&db->stream) != hipSuccess) { kmdb_db_free(db); return kmdb_set_error("hipStreamCreate failed"); }
+    for (auto& e : db->ev)
+        if (hipEventCreate(&e) != hipSuccess) { kmdb_db_free(db); return kmdb_set_error("hipEventCreate failed"); }
+    db->stats.algorithmic_bytes = alg_bytes;
+    db->stats.tree_updates = tree_updates;
+    db->stats.sum_pairs = sum_pairs;
+    db->stats.device_bytes = dev_bytes;
+    db->stats.n_segments = segs.size();
+    *out = db;
+    return 0;
+}
+
+extern "C" void kmdb_db_free(kmdb_db* db) {
+    if (!db) return;
+    (void)hipSetDevice(db->device);
+    void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->scan_tmp,
+                    db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
+    if (db->stream) (void)hipStreamDestroy(db->stream);
+    delete db;
+}
+
+void kmdb_engine_get(kmdb_db* db, kmdb_engine_view* o) {
+    o->device = db->device; o->N = db->N; o->P = db->P;
+    o->meta = db->meta; o->bitpos = db->bitpos; o->parent = db->parent; o->w = db->w; o->sub_end = db->sub_end;
+    o->bits = db->bits; o->n_buckets = db->n_buckets; o->bucket_offset = db->bucket_offset; o->slots = db->slots;
+    o->pid2dfs = db->pid2dfs; o->stream = db->stream;
+    for (int i = 0; i < 4; ++i) o->ev[i] = db->ev[i];
+}
+
+void kmdb_engine_set_times(kmdb_db* db, double kernel_ms, double dominant_ms) {
+    db->stats.kernel_ms = kernel_ms;
+    db->stats.dominant_kernel_ms = dominant_ms;
+}
+
+extern "C" int kmdb_db_stats(const kmdb_db* db, kmdb_stats* out) {
+    if (!db || !out) return kmdb_set_error("kmdb_db_stats: null argument");
+    *out = db->stats;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense all2all
+// ------------------------------------------------------------------------------------------
+namespace {
+
+template <int S, int NCAP>
+int launch_tile(kmdb_db* db, const A2AParams& p, uint32_t blocks, hipStream_t st) {
+    const size_t lds = sizeof(WaveLds<S, NCAP>) * WAVES_PER_BLOCK;
+    HIP_TRY(hipFuncSetAttribute((const void*)a2a_tile_kernel<S, NCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((a2a_tile_kernel<S, NCAP>), dim3(blocks), dim3(WAVE * WAVES_PER_BLOCK), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// enqueue the whole dense pipeline on `st`; M is device memory of N(N-1)/2 uint32
+int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
+    const uint64_t N = db->N, P = db->P;
+    const uint64_t cells = N ? N * (N - 1) / 2 : 0;
+    uint32_t shard_index = opts ? opts->shard_index : 0, shard_count = opts && opts->shard_count ? opts->shard_count : 1;
+    if (shard_index >= shard_count) return kmdb_set_error("kmdb_all2all: shard_index >= shard_count");
+    const uint32_t seg_begin = (uint32_t)((uint64_t)db->n_segs * shard_index / shard_count);
+    const uint32_t seg_end = (uint32_t)((uint64_t)db->n_segs * (shard_index + 1) / shard_count);
+    const bool force_global = opts && (opts->flags & KMDB_FLAG_FORCE_GLOBAL_ATOMICS);
+
+    HIP_TRY(hipEventRecord(db->ev[0], st));
+    if (cells) HIP_TRY(hipMemsetAsync(M, 0, cells * 4, st));
+    HIP_TRY(hipMemsetAsync(db->counters, 0, 8 * sizeof(unsigned long long), st));
+    // subtree weights (reference similarity_calculator.cpp:64-72): exclusive scan of w in DFS order
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->scan_tmp, db->scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1), st));
+
+    A2AParams p{};
+    p.meta = db->meta; p.bitpos = db->bitpos; p.parent = db->parent; p.sub_end = db->sub_end;
+    p.wprefix = db->wprefix; p.bits = db->bits; p.segs = db->segs;
+    p.seg_begin = seg_begin; p.seg_end = seg_end; p.M = M; p.counters = db->counters;
+    const uint32_t nseg = seg_end - seg_begin;
+    const uint32_t blocks = (nseg + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    HIP_TRY(hipEventRecord(db->ev[1], st));
+    if (blocks && cells) {
+        if (!force_global && N <= 1024) {
+            if (launch_tile<120, 1024>(db, p, blocks, st)) return 1;
+        } else if (!force_global && N <= 4096) {
+            if (launch_tile<96, 4096>(db, p, blocks, st)) return 1;
+        } else {
+            const size_t stride = (N + 63) / 64 * 64;
+            const size_t words = (size_t)blocks * WAVES_PER_BLOCK * stride;
+            if (db->stack_scratch_words < words) {
+                if (db->stack_scratch) (void)hipFree(db->stack_scratch);
+                db->stack_scratch = nullptr; db->stack_scratch_words = 0;
+                HIP_TRY(hipMalloc((void**)&db->stack_scratch, words * 4));
+                db->stack_scratch_words = words;
+            }
+            p.stack_scratch = db->stack_scratch;
+            p.stack_stride = (uint32_t)stride;
+            hipLaunchKernelGGL(a2a_global_kernel, dim3(blocks), dim3(WAVE * WAVES_PER_BLOCK), 0, st, p);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(db->ev[2], st));
+    return 0;
+}
+
+int finish_stats(kmdb_db* db, hipStream_t st) {
+    HIP_TRY(hipEventRecord(db->ev[3], st));
+    HIP_TRY(hipEventSynchronize(db->ev[3]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, db->ev[0], db->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&b, db->ev[1], db->ev[2]));
+    db->stats.kernel_ms = a;
+    db->stats.dominant_kernel_ms = b;
+    unsigned long long c[8];
+    HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));
+    db->stats.tile_flushes = c[0];
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int kmdb_all2all_dense_device(kmdb_db* db, void* out_dev, const kmdb_opts* opts) {
+    if (!db || !out_dev) return kmdb_set_error("kmdb_all2all_dense_device: null argument");
+    HIP_TRY(hipSetDevice(db->device));
+    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : db->stream;
+    if (run_dense(db, (uint32_t*)out_dev, opts, st)) return 1;
+    return finish_stats(db, st);
+}
+
+extern "C" int kmdb_all2all_dense(kmdb_db* db, uint32_t* out, const kmdb_opts* opts) {
+    if (!db || (!out && db->N > 1)) return kmdb_set_error("kmdb_all2all_dense: null argument");
+    HIP_TRY(hipSetDevice(db->device));
+    const uint64_t cells = db->N ? db->N * (db->N - 1) / 2 : 0;
+    uint32_t* M = nullptr;
+    HIP_TRY(hipMalloc((void**)&M, std::max<uint64_t>(cells, 1) * 4));
+    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : db->stream;
+    int rc = run_dense(db, M, opts, st);
+    if (!rc) rc = finish_stats(db, st);
+    if (!rc && cells && hipMemcpy(out, M, cells * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = kmdb_set_error("kmdb_all2all_dense: copy back failed");
+    (void)hipFree(M);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse all2all: same accumulation in HBM (tree form and flat form give the same cells,
+// SURVEY §7), then on-device compaction of the non-zeros into CSR.  Bubbles
+// (reference src/bubble_helper.h) only exist to spare the CPU hash maps; their contributions are part
+// of the same sums, so bubble_size does not change the result.
+// ------------------------------------------------------------------------------------------
+extern "C" int kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmdb_opts* opts) {
+    if (!db || !out) return kmdb_set_error("kmdb_all2all_sparse: null argument");
+    std::memset(out, 0, sizeof *out);
+    HIP_TRY(hipSetDevice(db->device));
+    const uint64_t N = db->N;
+    const uint64_t cells = N ? N * (N - 1) / 2 : 0;
+    uint32_t* M = nullptr;
+    unsigned long long *row_nnz = nullptr, *row_ptr = nullptr;
+    uint32_t *col = nullptr, *val = nullptr;
+    void* tmp = nullptr;
+    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : db->stream;
+    int rc = 0;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)M, (void*)row_nnz, (void*)row_ptr, (void*)col, (void*)val, tmp}) if (p) (void)hipFree(p);
+    };
+#define SP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    SP_TRY(hipMalloc((void**)&M, std::max<uint64_t>(cells, 1) * 4));
+    SP_TRY(hipMalloc((void**)&row_nnz, (N + 1) * 8));
+    SP_TRY(hipMalloc((void**)&row_ptr, (N + 1) * 8));
+    rc = run_dense(db, M, opts, st);
+    if (rc) { cleanup(); return rc; }
+    SP_TRY(hipMemsetAsync(row_nnz, 0, (N + 1) * 8, st));
+    if (N) hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_nnz);
+    size_t tmp_bytes = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st);
+    SP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    SP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
+    std::vector<unsigned long long> h_ptr(N + 1, 0);
+    SP_TRY(hipMemcpyAsync(h_ptr.data(), row_ptr, (N + 1) * 8, hipMemcpyDeviceToHost, st));
+    SP_TRY(hipStreamSynchronize(st));
+    const uint64_t nnz = h_ptr[N];
+    SP_TRY(hipMalloc((void**)&col, std::max<uint64_t>(nnz, 1) * 4));
+    SP_TRY(hipMalloc((void**)&val, std::max<uint64_t>(nnz, 1) * 4));
+    if (N) hipLaunchKernelGGL(row_compact_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_ptr, col, val);
+    rc = finish_stats(db, st);
+    if (rc) { cleanup(); return rc; }
+    out->n_rows = N;
+    out->nnz = nnz;
+    out->row_ptr = (uint64_t*)std::malloc((N + 1) * 8);
+    out->col = (uint32_t*)std::malloc(std::max<uint64_t>(nnz, 1) * 4);
+    out->val = (uint32_t*)std::malloc(std::max<uint64_t>(nnz, 1) * 4);
+    for (uint64_t i = 0; i <= N; ++i) out->row_ptr[i] = h_ptr[i];
+    if (nnz) {
+        SP_TRY(hipMemcpy(out->col, col, nnz * 4, hipMemcpyDeviceToHost));
+        SP_TRY(hipMemcpy(out->val, val, nnz * 4, hipMemcpyDeviceToHost));
+    }
+#undef SP_TRY
+    cleanup();
+    return 0;
+}
+
+extern "C" void kmdb_sparse_free(kmdb_sparse_rows* rows) {
+    if (!rows) return;
+    std::free(rows->row_ptr); std::free(rows->col); std::free(rows->val);
+    std::memset(rows, 0, sizeof *rows);
+}

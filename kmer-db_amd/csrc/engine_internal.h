@@ -1,0 +1,27 @@
+// engine_internal.h — lets the other translation units of libkmdb_amd.so (new2all.hip) reach
+// the HBM-resident database that engine.hip owns.  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+struct kmdb_db;
+
+struct kmdb_engine_view {
+    int device;
+    uint64_t N, P;
+    const uint4* meta;
+    const uint64_t* bitpos;
+    const int32_t* parent;
+    const uint32_t* w;
+    const uint32_t* sub_end;
+    const uint64_t* bits;
+    uint64_t n_buckets;
+    const uint64_t* bucket_offset;
+    const uint64_t* slots;
+    const uint32_t* pid2dfs;
+    void* stream;
+    void* ev[4];
+};
+
+void kmdb_engine_get(kmdb_db* db, kmdb_engine_view* out);
+void kmdb_engine_set_times(kmdb_db* db, double kernel_ms, double dominant_ms);

@@ -1,0 +1,439 @@
+// kmer-db-amd — command line front-end for the MI355X engine.
+//
+// Drop-in for the three kmer-db modes on the hot path:
+//     kmer-db-amd all2all    [-sparse [-min [m:]v] [-max [m:]v]] <db> <out.csv>
+//     kmer-db-amd all2all-sp [-min [m:]v] [-max [m:]v]           <db> <out.csv>
+//     kmer-db-amd new2all    [-multisample-fasta] [-sparse ...]  <db> <sample-list> <out.csv>
+// mirroring the reference consoles (reference src/console_all2all.cpp, console_all2all_sparse.cpp,
+// console_new2all.cpp) around the calls that the C ABI replaces.  Options that only tune the
+// reference's CPU engine (-t, -rt, -buffer, -bubble-size) are accepted; -t also sizes the
+// query-parsing thread pool.  Output files are byte-identical to the reference's.
+// Everything below the three kmdb_* compute calls runs on the GPU; there is no CPU engine here.
+#include "kmdb_amd.h"
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <zlib.h>
+
+namespace {
+
+using clk = std::chrono::high_resolution_clock;
+double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+struct usage_error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ---- option helpers (same removal semantics as Params::findSwitch/findOption, params.h) -------
+bool take_switch(std::vector<std::string>& a, const std::string& name) {
+    for (size_t i = 0; i < a.size(); ++i)
+        if (a[i] == name) { a.erase(a.begin() + i); return true; }
+    return false;
+}
+bool take_option(std::vector<std::string>& a, const std::string& name, std::string& value) {
+    for (size_t i = 0; i + 1 < a.size(); ++i)
+        if (a[i] == name) { value = a[i + 1]; a.erase(a.begin() + i, a.begin() + i + 2); return true; }
+    return false;
+}
+
+// ---- -min / -max filters (params.cpp:14-42, 418-455; sparse_filters.h) ---------------------------
+using metric_fn = std::function<double(uint32_t, uint32_t, uint32_t, int)>;
+
+std::map<std::string, metric_fn> metrics() {
+    std::map<std::string, metric_fn> m;
+    auto mash_of = [](double j, int k) { return j == 0 ? 1.0 : (-1.0 / k) * std::log((2 * j) / (j + 1)); };
+    m["jaccard"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / (uint32_t)(a + b - c); };
+    m["min"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / std::min(a, b); };
+    m["max"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / std::max(a, b); };
+    m["cosine"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / std::sqrt((uint32_t)(a * b)); };
+    m["mash"] = [mash_of](uint32_t c, uint32_t q, uint32_t d, int k) { return mash_of((double)c / (uint32_t)(q + d - c), k); };
+    m["ani"] = [mash_of](uint32_t c, uint32_t q, uint32_t d, int k) { return 1.0 - mash_of((double)c / (uint32_t)(q + d - c), k); };
+    m["ani-shorter"] = [mash_of](uint32_t c, uint32_t q, uint32_t d, int k) { return 1.0 - mash_of((double)c / std::min(q, d), k); };
+    m["mash-query"] = [mash_of](uint32_t c, uint32_t q, uint32_t, int k) { return mash_of((double)c / q, k); };
+    m["num-kmers"] = [](uint32_t c, uint32_t, uint32_t, int) { return (double)c; };
+    return m;
+}
+
+struct Filters {
+    struct Bound { metric_fn fn; double lo = std::numeric_limits<double>::lowest(), hi = std::numeric_limits<double>::max(); };
+    std::map<std::string, Bound> metric;
+    uint32_t kmer_lo = 0, kmer_hi = std::numeric_limits<uint32_t>::max();
+
+    void parse(std::vector<std::string>& args) {
+        auto avail = metrics();
+        const char* names[2] = {"-min", "-max"};
+        for (int which = 0; which < 2; ++which) {
+            std::string v;
+            while (take_option(args, names[which], v)) {
+                std::string metric_name = "num-kmers", num = v;
+                auto sep = v.rfind(':');
+                if (sep != std::string::npos) { metric_name = v.substr(0, sep); num = v.substr(sep + 1); }
+                std::istringstream iss(num);
+                double value;
+                if (!(iss >> value)) throw std::runtime_error("Filtering error - unable to parse numerical value: " + v);
+                if (metric_name == "num-kmers") {
+                    (which == 0 ? kmer_lo : kmer_hi) = (uint32_t)std::lrint(value);
+                } else if (avail.count(metric_name)) {
+                    auto& b = metric[metric_name];
+                    b.fn = avail[metric_name];
+                    (which == 0 ? b.lo : b.hi) = value;
+                } else {
+                    throw std::runtime_error("Filtering error - unknown metric: " + metric_name);
+                }
+            }
+        }
+    }
+    bool pass(uint32_t common, uint32_t row_cnt, uint32_t col_cnt, int k) const {
+        for (auto& kv : metric) {
+            double x = kv.second.fn(common, row_cnt, col_cnt, k);
+            if (!(x >= kv.second.lo && x <= kv.second.hi)) return false;
+        }
+        return common >= kmer_lo && common <= kmer_hi;
+    }
+};
+
+void check(int rc) {
+    if (rc) throw std::runtime_error(kmdb_last_error());
+}
+
+struct Db {
+    kmdbh_db* h = nullptr;
+    kmdb_db* d = nullptr;
+    ~Db() { if (d) kmdb_db_free(d); if (h) kmdbh_db_free(h); }
+};
+
+struct Common {
+    int threads = 0;
+    int device = 0;
+    bool sparse = false;
+    Filters filters;
+};
+
+void write_header(const Db& db, std::ofstream& ofs) {
+    uint64_t n = kmdbh_db_n_samples(db.h);
+    std::vector<char> buf(10000 + n * 100);
+    for (uint64_t i = 0; i < n; ++i) buf.resize(buf.size() + std::strlen(kmdbh_db_sample_name(db.h, i)));
+    size_t len = kmdbh_format_header(db.h, buf.data(), buf.size());
+    ofs.write(buf.data(), (std::streamsize)len);
+}
+
+// ---- all2all (console_all2all.cpp:7-89) -----------------------------------------------------------
+int run_all2all(std::vector<std::string>& args, Common& c) {
+    std::string v;
+    take_option(args, "-buffer", v);
+    take_option(args, "-bubble-size", v);
+    c.sparse = take_switch(args, "-sparse");
+    if (c.sparse) c.filters.parse(args);
+    if (args.size() != 2) throw usage_error("all2all");
+    std::cerr << "All versus all comparison" << std::endl;
+    Db db;
+    std::cerr << "Loading k-mer database " << args[0] << "..." << std::endl;
+    std::ofstream ofs(args[1]);
+    check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
+    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1;
+    check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
+    const uint64_t n = kmdbh_db_n_samples(db.h);
+    const int k = (int)kmdbh_db_kmer_length(db.h);
+    std::cerr << "Calculating matrix of common k-mers..." << std::endl;
+    auto t0 = clk::now();
+    std::vector<uint32_t> m(n ? n * (n - 1) / 2 + 1 : 1);
+    check(kmdb_all2all_dense(db.d, m.data(), &o));
+    std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    std::cerr << "Storing matrix of common k-mers in " << args[1] << "...";
+    t0 = clk::now();
+    write_header(db, ofs);
+    std::vector<char> row(10000 + n * 100);
+    std::vector<uint32_t> cols, vals;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t* r = m.data() + i * (i - 1) / 2;
+        const char* name = kmdbh_db_sample_name(db.h, i);
+        if (row.size() < 10000 + n * 100 + std::strlen(name)) row.resize(10000 + n * 100 + std::strlen(name));
+        size_t len;
+        if (c.sparse) {
+            cols.clear(); vals.clear();
+            for (uint64_t j = 0; j < i; ++j)     // LowerTriangularMatrix::compact + saveRowSparse (array.h:169-181,259-262)
+                if (r[j] && c.filters.pass(r[j], (uint32_t)kmdbh_db_sample_kmers(db.h, i), (uint32_t)kmdbh_db_sample_kmers(db.h, j), k)) {
+                    cols.push_back((uint32_t)j); vals.push_back(r[j]);
+                }
+            len = kmdbh_format_sparse_row(name, kmdbh_db_sample_kmers(db.h, i), cols.data(), vals.data(), cols.size(), row.data());
+        } else {
+            len = kmdbh_format_dense_row(name, kmdbh_db_sample_kmers(db.h, i), r, i, row.data());
+        }
+        ofs.write(row.data(), (std::streamsize)len);
+    }
+    std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    return 0;
+}
+
+// ---- all2all-sp (console_all2all_sparse.cpp:13-111) -------------------------------------------------
+int run_all2all_sp(std::vector<std::string>& args, Common& c) {
+    std::string v;
+    take_option(args, "-buffer", v);
+    uint32_t bubble = 8000;
+    if (take_option(args, "-bubble-size", v)) bubble = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+    take_switch(args, "-sparse");
+    c.filters.parse(args);
+    if (take_option(args, "-sample-rows", v)) throw std::runtime_error("-sample-rows is not supported by the GPU front-end");
+    if (args.size() != 2) throw usage_error("all2all-sp");
+    std::cerr << "All versus all comparison (sparse computation)" << std::endl;
+    Db db;
+    std::cerr << "Loading k-mer database " << args[0] << "..." << std::endl;
+    std::ofstream ofs(args[1], std::ios::binary);
+    check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
+    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1; o.bubble_size = bubble;
+    check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
+    const uint64_t n = kmdbh_db_n_samples(db.h);
+    const int k = (int)kmdbh_db_kmer_length(db.h);
+    std::cerr << "Calculating matrix of common k-mers...";
+    auto t0 = clk::now();
+    kmdb_sparse_rows sp{};
+    check(kmdb_all2all_sparse(db.d, &sp, &o));
+    std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    std::cerr << "Storing matrix of common k-mers in " << args[1] << "...";
+    t0 = clk::now();
+    write_header(db, ofs);
+    std::vector<char> row(10000 + n * 100);
+    std::vector<uint32_t> cols, vals;
+    size_t saved = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        cols.clear(); vals.clear();
+        for (uint64_t e = sp.row_ptr[i]; e < sp.row_ptr[i + 1]; ++e)   // compact2's filter (array.h:424-427)
+            if (c.filters.pass(sp.val[e], (uint32_t)kmdbh_db_sample_kmers(db.h, i), (uint32_t)kmdbh_db_sample_kmers(db.h, sp.col[e]), k)) {
+                cols.push_back(sp.col[e]); vals.push_back(sp.val[e]);
+            }
+        const char* name = kmdbh_db_sample_name(db.h, i);
+        if (row.size() < 10000 + n * 100 + std::strlen(name)) row.resize(10000 + n * 100 + std::strlen(name));
+        size_t len = kmdbh_format_sparse_row(name, kmdbh_db_sample_kmers(db.h, i), cols.data(), vals.data(), cols.size(), row.data());
+        ofs.write(row.data(), (std::streamsize)len);
+        saved += cols.size();
+    }
+    kmdb_sparse_free(&sp);
+    std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    std::cerr << "No. saved pairs: " << saved << std::endl;
+    return 0;
+}
+
+// ---- query loading (genome_input_file.h:60-137, 287-337; loader_ex.cpp:22-124,168) ------------------
+bool slurp(const std::string& base, std::string& data) {
+    static const char* exts[] = {"", ".fa", ".fna", ".fasta", ".gz", ".fa.gz", ".fna.gz", ".fasta.gz"};
+    for (const char* e : exts) {
+        std::string p = base + e;
+        if (FILE* f = std::fopen(p.c_str(), "rb")) {
+            std::fclose(f);
+            gzFile g = gzopen(p.c_str(), "rb");          // transparent for plain text
+            if (!g) return false;
+            data.clear();
+            char buf[1 << 16];
+            int n;
+            while ((n = gzread(g, buf, sizeof buf)) > 0) data.append(buf, (size_t)n);
+            gzclose(g);
+            return true;
+        }
+    }
+    return false;
+}
+
+struct Record { std::string header, seq; };
+
+void split_fasta(const std::string& data, std::vector<Record>& recs) {
+    size_t pos = data.find('>');
+    while (pos != std::string::npos) {
+        size_t eol = data.find('\n', pos);
+        if (eol == std::string::npos) eol = data.size();
+        Record r;
+        r.header = data.substr(pos + 1, eol - pos - 1);
+        if (!r.header.empty() && r.header.back() == '\r') r.header.pop_back();
+        size_t sp = r.header.find(' ');
+        if (sp != std::string::npos) r.header.resize(sp);        // header up to the first space
+        size_t next = data.find('>', eol);
+        size_t end = next == std::string::npos ? data.size() : next;
+        r.seq.reserve(end > eol ? end - eol : 0);
+        for (size_t i = eol + 1; i < end; ++i) {
+            char ch = data[i];
+            if (ch != '\n' && ch != '\r') r.seq.push_back(ch);
+        }
+        recs.push_back(std::move(r));
+        pos = next;
+    }
+}
+
+struct Query { std::string name; std::vector<uint64_t> kmers; };
+
+std::string basename_of(const std::string& p) {
+    size_t s = p.find_last_of('/');
+    return s == std::string::npos ? p : p.substr(s + 1);
+}
+
+// ---- new2all (console_new2all.cpp:12-174) ---------------------------------------------------------
+int run_new2all(std::vector<std::string>& args, Common& c) {
+    if (take_switch(args, "-from-kmers") || take_switch(args, "-from-minhash"))
+        throw std::runtime_error("only genome (FASTA) query input is supported by the GPU front-end");
+    const bool multi = take_switch(args, "-multisample-fasta");
+    c.sparse = take_switch(args, "-sparse");
+    if (c.sparse) c.filters.parse(args);
+    if (args.size() != 3) throw usage_error("new2all");
+    std::cerr << "Set of new samples  (from genomes) versus entire database comparison" << std::endl;
+    Db db;
+    std::cerr << "Loading k-mer database " << args[0] << "..." << std::endl;
+    auto t0 = clk::now();
+    check(kmdbh_db_load(args[0].c_str(), 0, &db.h));
+    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1;
+    check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 1, &db.d));
+    std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    const uint64_t n = kmdbh_db_n_samples(db.h);
+    const uint32_t k = kmdbh_db_kmer_length(db.h);
+    const double fraction = kmdbh_db_fraction(db.h), fstart = kmdbh_db_start_fraction(db.h);
+    const int preserve = kmdbh_db_alphabet(db.h) == 1;             // AlphabetType::nt_preserve (alphabet.h:10-18)
+    if (kmdbh_db_alphabet(db.h) > 1) throw std::runtime_error("protein alphabets are not supported by the GPU front-end");
+
+    std::ifstream lst(args[1]);
+    if (!lst) throw std::runtime_error("Unable to open sample list " + args[1]);
+    std::vector<std::string> entries;
+    for (std::string ln; std::getline(lst, ln);) {
+        while (!ln.empty() && (ln.back() == '\r' || ln.back() == ' ')) ln.pop_back();
+        if (!ln.empty()) entries.push_back(ln);
+    }
+    std::cerr << "Processing queries..." << std::endl;
+    auto total0 = clk::now();
+    std::ofstream ofs(args[2]);
+    write_header(db, ofs);
+    std::vector<char> row(10000 + n * 100);
+    int nthreads = c.threads > 0 ? c.threads : (int)std::max(1u, std::thread::hardware_concurrency());
+
+    // queries are produced in input order; similarities are computed in batches on the GPU and rows
+    // written in the same order (the reference re-orders through a priority queue, :60,114-117)
+    std::vector<Query> batch;
+    auto flush = [&]() {
+        if (batch.empty()) return;
+        std::vector<const uint64_t*> ptrs(batch.size());
+        std::vector<size_t> cnts(batch.size());
+        for (size_t q = 0; q < batch.size(); ++q) { ptrs[q] = batch[q].kmers.data(); cnts[q] = batch[q].kmers.size(); }
+        std::vector<uint32_t> out(batch.size() * n + 1);
+        check(kmdb_new2all_batch(db.d, ptrs.data(), cnts.data(), batch.size(), out.data(), &o));
+        std::vector<uint32_t> cols, vals;
+        for (size_t q = 0; q < batch.size(); ++q) {
+            const uint32_t* r = out.data() + q * n;
+            if (row.size() < 10000 + n * 100 + batch[q].name.size()) row.resize(10000 + n * 100 + batch[q].name.size());
+            size_t len;
+            if (c.sparse) {
+                cols.clear(); vals.clear();
+                for (uint64_t j = 0; j < n; ++j)           // one2all_sp keeps count>0 (:1040-1047), then the filter (:131-148)
+                    if (r[j] && c.filters.pass(r[j], (uint32_t)cnts[q], (uint32_t)kmdbh_db_sample_kmers(db.h, j), (int)k)) {
+                        cols.push_back((uint32_t)j); vals.push_back(r[j]);
+                    }
+                len = kmdbh_format_sparse_row(batch[q].name.c_str(), cnts[q], cols.data(), vals.data(), cols.size(), row.data());
+            } else {
+                len = kmdbh_format_dense_row(batch[q].name.c_str(), cnts[q], r, n, row.data());
+            }
+            ofs.write(row.data(), (std::streamsize)len);
+        }
+        batch.clear();
+    };
+
+    auto make_query = [&](const std::string& name, const std::vector<const std::string*>& seqs) {
+        Query q;
+        q.name = name;
+        size_t total = 0;
+        for (auto* s : seqs) total += s->size();
+        q.kmers.resize(total + 1);
+        size_t cnt = 0;
+        for (auto* s : seqs) cnt += kmdbh_extract_kmers(s->data(), s->size(), k, fraction, fstart, preserve, q.kmers.data() + cnt);
+        cnt = kmdbh_sort_unique(q.kmers.data(), cnt);              // KmerHelper::unique (console_new2all.cpp:73)
+        q.kmers.resize(cnt);
+        return q;
+    };
+
+    const size_t BATCH = 64;
+    if (multi) {
+        for (auto& e : entries) {
+            std::string data;
+            if (!slurp(e, data)) { std::cerr << "failed:" << e << std::endl; continue; }
+            std::vector<Record> recs;
+            split_fasta(data, recs);
+            for (auto& r : recs) {
+                batch.push_back(make_query(r.header, {&r.seq}));
+                if (batch.size() == BATCH) flush();
+            }
+        }
+    } else {
+        for (size_t base = 0; base < entries.size(); base += BATCH) {
+            size_t cntq = std::min(BATCH, entries.size() - base);
+            std::vector<Query> qs(cntq);
+            std::vector<char> okv(cntq, 0);
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (size_t i; (i = next.fetch_add(1)) < cntq;) {
+                    std::string data;
+                    if (!slurp(entries[base + i], data)) continue;
+                    std::vector<Record> recs;
+                    split_fasta(data, recs);
+                    std::vector<const std::string*> seqs;
+                    for (auto& r : recs) seqs.push_back(&r.seq);
+                    qs[i] = make_query(basename_of(entries[base + i]), seqs);
+                    okv[i] = 1;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 0; t < std::min<int>(nthreads, (int)cntq); ++t) pool.emplace_back(worker);
+            for (auto& t : pool) t.join();
+            for (size_t i = 0; i < cntq; ++i) {
+                if (!okv[i]) { std::cerr << "failed:" << entries[base + i] << std::endl; continue; }
+                batch.push_back(std::move(qs[i]));
+            }
+            flush();
+        }
+    }
+    flush();
+    std::cerr << std::endl << std::endl << "EXECUTION TIMES" << std::endl << "Total: " << since(total0) << std::endl;
+    return 0;
+}
+
+void usage() {
+    std::cerr << "kmer-db-amd (MI355X engine for kmer-db's all2all / all2all-sp / new2all)\n"
+                 "USAGE\n"
+                 "    kmer-db-amd all2all [-sparse [-min [<criterion>:]<v>] [-max [<criterion>:]<v>]] <database> <common_table>\n"
+                 "    kmer-db-amd all2all-sp [-min ...] [-max ...] <database> <common_table>\n"
+                 "    kmer-db-amd new2all [-multisample-fasta] [-sparse [-min ...] [-max ...]] <database> <sample_list> <common_table>\n"
+                 "Common options: -t <threads>, -gpu <device>\n";
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::vector<std::string> args(argv + 1, argv + argc);
+    try {
+        if (args.empty()) { usage(); return 0; }
+        std::string mode = args[0];
+        args.erase(args.begin());
+        Common c;
+        std::string v;
+        if (take_option(args, "-t", v)) c.threads = std::atoi(v.c_str());
+        take_option(args, "-rt", v);
+        if (take_option(args, "-gpu", v)) c.device = std::atoi(v.c_str());
+        take_switch(args, "-v");
+        take_switch(args, "-vv");
+        if (mode == "all2all") return run_all2all(args, c);
+        if (mode == "all2all-sp") return run_all2all_sp(args, c);
+        if (mode == "new2all") return run_new2all(args, c);
+        usage();
+        return -1;
+    } catch (usage_error&) {
+        usage();
+        return -1;
+    } catch (std::exception& e) {
+        std::cerr << "ERROR: " << e.what() << std::endl;       // main.cpp:56-59
+        return -1;
+    }
+}

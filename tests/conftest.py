@@ -1,0 +1,50 @@
+import lzma
+import os
+import sys
+import tarfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def K():
+    from _kmerdb_loader import import_kmerdb_amd
+    return import_kmerdb_amd()
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def golden_dir(tmp_path_factory):
+    """tests/golden with the .db.xz fixtures and the virus FASTA tarball unpacked into a temp dir."""
+    d = tmp_path_factory.mktemp("golden")
+    for fn in os.listdir(GOLDEN):
+        src = os.path.join(GOLDEN, fn)
+        if fn.endswith(".db.xz"):
+            with lzma.open(src) as f, open(os.path.join(d, fn[:-3]), "wb") as o:
+                o.write(f.read())
+        elif fn == "virus_data.tar.xz":
+            os.makedirs(os.path.join(d, "test", "virus"), exist_ok=True)
+            with tarfile.open(src) as tf:
+                tf.extractall(os.path.join(d, "test", "virus"))
+        else:
+            os.symlink(src, os.path.join(d, fn))
+    return str(d)
+
+
+DBS = ["virus_k18", "virus_k18_part1", "virus_k18_parts", "virus_k24", "virus_k18_f01", "synth_k21", "clade64",
+       "clade64_k25_f01"]

@@ -1,0 +1,132 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and
+the committed outputs of the real reference, bit-exact (all arithmetic is uint32 / integer)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import DBS, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(K):
+    assert K.device_count() > 0, "the -m gpu tests need an MI355X; the engine has no CPU fallback"
+    return 0
+
+
+def _ref_dense(golden_dir, stem):
+    stem = "virus_k18" if stem == "virus_k18_parts" else stem
+    return np.fromfile(os.path.join(golden_dir, stem + ".a2a.ref.u32"), dtype=np.uint32)
+
+
+@pytest.mark.parametrize("stem", DBS)
+def test_all2all_dense_bit_exact(K, O, golden_dir, dev, stem):
+    path = os.path.join(golden_dir, stem + ".db")
+    h = K.HostDB(path, skip_hashtables=True)
+    d = K.DeviceDB(h, device=dev)
+    ref = _ref_dense(golden_dir, stem)
+    got = d.all2all_dense()
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got, O.OracleDB(path, skip_hashtables=True).all2all_dense())
+    st = d.stats()
+    assert st["sum_pairs"] == int(ref.astype(np.uint64).sum())
+    assert st["algorithmic_bytes"] == h.pattern_section_bytes + 4 * d.tri_size()
+    # idempotent: the resident db is not mutated (the reference accumulates num_kmers in place, :64-72)
+    assert np.array_equal(d.all2all_dense(), ref)
+    # generic kernel (global stack + HBM atomics)
+    assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_FORCE_GLOBAL_ATOMICS), ref)
+
+
+@pytest.mark.parametrize("stem", ["virus_k18", "clade64", "clade64_k25_f01"])
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_shards_sum_to_full_matrix(K, golden_dir, dev, stem, shards):
+    h = K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True)
+    d = K.DeviceDB(h, device=dev)
+    acc = np.zeros(d.tri_size(), dtype=np.uint32)
+    for s in range(shards):
+        acc += d.all2all_dense(shard=(s, shards))
+    assert np.array_equal(acc, _ref_dense(golden_dir, stem))
+
+
+@pytest.mark.parametrize("stem", ["virus_k18", "synth_k21", "clade64", "clade64_k25_f01"])
+def test_all2all_sparse_bit_exact(K, O, golden_dir, dev, stem):
+    path = os.path.join(golden_dir, stem + ".db")
+    d = K.DeviceDB(K.HostDB(path, skip_hashtables=True), device=dev)
+    sp = d.all2all_sparse()
+    flat = O.OracleDB(path, skip_hashtables=True).all2all_flat()
+    lines = open(os.path.join(golden_dir, stem + ".a2a_sp.ref.txt"), "rb").read().split(b"\n")
+    assert sp.n_rows == d.N
+    for i in range(d.N):
+        c, v = sp.row(i)
+        row = O.tri_row(flat, i)
+        nz = np.nonzero(row)[0]
+        assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
+        assert "".join("%d:%d," % (a + 1, b) for a, b in zip(c, v)).encode() == lines[i]
+
+
+def test_new2all_bit_exact(K, O, golden_dir, dev):
+    path = os.path.join(golden_dir, "clade64.db")
+    d = K.DeviceDB(K.HostDB(path), device=dev, with_hashtables=True)
+    q = np.load(os.path.join(golden_dir, "clade64.queries.npz"))
+    qs = [K.sort_unique(q[k]) for k in sorted(q.files, key=lambda s: int(s[1:]))]
+    # plus edge cases: an empty query, k-mers absent from the db, a single k-mer
+    qs += [np.zeros(0, np.uint64), np.array([1, 2, 3, (255 << 32) | 12345], np.uint64), qs[0][:1]]
+    got = d.new2all(qs)
+    o = O.OracleDB(path)
+    exp = np.stack([o.one2all(x) for x in qs])
+    assert np.array_equal(got, exp)
+    ref = np.fromfile(os.path.join(golden_dir, "clade64.n2a.ref.u32"), dtype=np.uint32).reshape(-1, d.N)
+    assert np.array_equal(got[: ref.shape[0]], ref)
+    sp = d.new2all_sparse(qs)
+    for i in range(len(qs)):
+        c, v = sp.row(i)
+        nz = np.nonzero(exp[i])[0]
+        assert np.array_equal(c, nz) and np.array_equal(v, exp[i][nz])
+    with pytest.raises(K.KmdbError, match="without hashtables"):
+        K.DeviceDB(K.HostDB(path, skip_hashtables=True), device=dev).new2all(qs[:1])
+
+
+def _cli(*args):
+    exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
+    r = subprocess.run([exe] + list(args), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+def _same(a, b):
+    assert open(a, "rb").read() == open(b, "rb").read(), (a, b)
+
+
+def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
+    g = lambda n: os.path.join(golden_dir, n)   # noqa: E731
+    t = lambda n: str(tmp_path / n)             # noqa: E731
+    # .github/workflows/main.yml:87-95 / 110-114 / 135-152
+    _cli("all2all", g("virus_k18_parts.db"), t("k18.csv")); _same(t("k18.csv"), g("virus.k18.csv"))
+    _cli("all2all", "-sparse", g("virus_k18_parts.db"), t("k18.sparse.csv")); _same(t("k18.sparse.csv"), g("virus.k18.sparse.csv"))
+    _cli("all2all-sp", g("virus_k18.db"), t("k18.sp.csv")); _same(t("k18.sp.csv"), g("virus.k18.sparse.csv"))
+    _cli("all2all", "-t", "2", g("virus_k18_f01.db"), t("frac.csv")); _same(t("frac.csv"), g("virus.k18.frac.csv"))
+    _cli("all2all", g("virus_k24.db"), t("k24.csv")); _same(t("k24.csv"), g("virus.k24.csv"))
+    # self-hosted.yml:110-146 (synth, with min/max filters)
+    _cli("all2all", g("synth_k21.db"), t("a2a")); _same(t("a2a"), g("synth.a2a"))
+    _cli("all2all", "-sparse", g("synth_k21.db"), t("a2a-sparse")); _same(t("a2a-sparse"), g("synth.a2a-sparse"))
+    _cli("all2all", "-sparse", "-max", "39", "-min", "num-kmers:31", g("synth_k21.db"), t("a2a-mm")); _same(t("a2a-mm"), g("synth.a2a.sparse.above-below"))
+    _cli("all2all-sp", g("synth_k21.db"), t("a2a-sp")); _same(t("a2a-sp"), g("synth.a2a-sparse"))
+    _cli("all2all-sp", "-max", "39", "-min", "num-kmers:31", g("synth_k21.db"), t("a2a-sp-mm")); _same(t("a2a-sp-mm"), g("synth.a2a.sparse.above-below"))
+    # new2all: main.yml:73-81, 160-163; self-hosted.yml:188-201
+    cwd = os.getcwd()
+    os.chdir(golden_dir)          # list entries are ./test/virus/data/<name>
+    try:
+        _cli("new2all", g("virus_k18_part1.db"), g("virus.seqs.part2.list"), t("n2a.csv")); _same(t("n2a.csv"), g("virus.k18.n2a.csv"))
+        _cli("new2all", "-sparse", g("virus_k18_part1.db"), g("virus.seqs.part2.list"), t("n2a.sp.csv")); _same(t("n2a.sp.csv"), g("virus.k18.n2a.sparse.csv"))
+        _cli("new2all", g("virus_k18.db"), g("virus.seqs.list"), t("n2a.it.csv")); _same(t("n2a.it.csv"), g("virus.k18.n2a.itself.csv"))
+        with open(t("synth.list"), "w") as f:
+            f.write(g("synth.synth") + "\n")
+        _cli("new2all", "-multisample-fasta", g("synth_k21.db"), t("synth.list"), t("n2a")); _same(t("n2a"), g("synth.n2a"))
+        _cli("new2all", "-multisample-fasta", "-sparse", g("synth_k21.db"), t("synth.list"), t("n2a-sp")); _same(t("n2a-sp"), g("synth.n2a-sparse"))
+        _cli("new2all", "-multisample-fasta", "-sparse", "-max", "69", "-min", "num-kmers:21", g("synth_k21.db"), t("synth.list"), t("n2a-mm"))
+        _same(t("n2a-mm"), g("synth.n2a.sparse.above-below"))
+    finally:
+        os.chdir(cwd)

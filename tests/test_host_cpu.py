@@ -1,0 +1,150 @@
+"""CPU-side tests of the product: the C-ABI library loads and exports what include/kmdb_amd.h
+declares, the front-end's .db reader / k-mer extractor / CSV writer agree with the oracle, and
+the GPU entry points fail loudly (no CPU fallback) when there is no device."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import DBS, ROOT
+
+
+def test_library_exports_every_declared_symbol(K):
+    hdr = open(os.path.join(ROOT, "include", "kmdb_amd.h")).read()
+    declared = set(re.findall(r"\b(kmdbh?_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(K.capi.EXPORTS)
+    L = ctypes.CDLL(K.lib_path())
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert K.lib().kmdb_abi_version() == K.ABI_VERSION
+
+
+def test_product_does_not_touch_the_oracle():
+    # the product path must never import / link / call anything under oracle/
+    for base, _, files in os.walk(os.path.join(ROOT, "kmer-db_amd")):
+        if os.path.basename(base) in ("build", "bin", "__pycache__"):
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(base, fn), errors="replace").read()
+                assert "kmdb_oracle" not in txt and "oracle." not in txt and "from oracle" not in txt, fn
+    out = subprocess.run(["ldd", os.path.join(ROOT, "kmer-db_amd", "libkmdb_amd.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+@pytest.mark.parametrize("stem", DBS)
+def test_db_reader_matches_oracle_reader(K, O, golden_dir, stem):
+    path = os.path.join(golden_dir, stem + ".db")
+    h = K.HostDB(path)
+    o = O.OracleDB(path)
+    assert (h.N, h.k, h.fraction, h.names) == (o.N, o.k, o.fraction, o.names)
+    assert np.array_equal(h.sample_kmers, o.sample_kmers)
+    assert h.pattern_section_bytes == o.pattern_section_bytes
+    v = h.view_arrays()
+    hd = o.pattern_headers()
+    assert np.array_equal(v["num_kmers"], hd[:, 0]) and np.array_equal(v["parent_id"], hd[:, 1])
+    assert np.array_equal(v["num_samples"], hd[:, 2]) and np.array_equal(v["num_local"], hd[:, 3])
+    assert np.array_equal(v["last_sample_id"], hd[:, 4]) and np.array_equal(v["num_bits"], hd[:, 5])
+    assert v["n_buckets"] == o.n_buckets
+    # gamma streams: decode every pattern's local ids from the product's flat view with the oracle decoder
+    for pid in range(0, o.P, max(1, o.P // 400)):
+        l, nb = int(hd[pid, 3]), int(hd[pid, 5])
+        if l > 1:
+            off = int(v["data_offset"][pid])
+            deltas = O.gamma_decode(v["data"][off: off + (nb + 127) // 128 * 2], nb, l)
+            chain = o.decode_chain(pid)
+            local = chain[len(chain) - l:]
+            assert np.array_equal(np.diff(local.astype(np.int64)), deltas.astype(np.int64))
+    # hashtables: every stored key is found by the oracle's find at the same pattern id
+    if stem in ("virus_k18_part1", "clade64"):
+        bo, sl = v["bucket_offset"], v["slots"]
+        tested = 0
+        for b in range(v["n_buckets"]):
+            seg = sl[int(bo[b]): int(bo[b + 1])]
+            vals = (seg >> np.uint64(32)).astype(np.int64)
+            for it in seg[vals != 0x7fffffff][:50]:
+                kmer = (np.uint64(b) << np.uint64(32)) | (it & np.uint64(0xffffffff))
+                pid = int(it >> np.uint64(32))
+                row = o.one2all(np.array([kmer], dtype=np.uint64))
+                exp = np.zeros(o.N, np.uint32)
+                if hd[pid, 0] != 0:
+                    exp[o.decode_chain(pid)] = 1
+                assert np.array_equal(row, exp)
+                tested += 1
+        assert tested > 100
+    h2 = K.HostDB(path, skip_hashtables=True)
+    assert h2.view_arrays()["n_buckets"] == 0
+    assert np.array_equal(h2.view_arrays()["data"], v["data"])
+
+
+def test_db_reader_errors(K, tmp_path):
+    with pytest.raises(K.KmdbError, match="Cannot open k-mer database"):
+        K.HostDB(str(tmp_path / "missing.db"))
+    p = tmp_path / "trunc.db"
+    p.write_bytes(b"\x01" + b"\x00" * 60)
+    with pytest.raises(K.KmdbError):
+        K.HostDB(str(p))
+
+
+def test_kmer_extraction_matches_oracle(K, O, golden_dir):
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"ACGTacgtNnUuRYX-", dtype=np.uint8)
+    for k, frac in [(18, 1.0), (18, 0.1), (21, 1.0), (24, 1.0), (25, 0.1), (16, 1.0), (12, 1.0), (31, 0.5)]:
+        for _ in range(6):
+            n = int(rng.integers(0, 3000))
+            p = np.array([10] * 8 + [1] * 8, dtype=float)
+            seq = bytes(alphabet[rng.choice(16, size=n, p=p / p.sum())])
+            for preserve in (False, True):
+                a = K.extract_kmers(seq, k, frac, 0.0, preserve)
+                b = O.extract_seq(seq, k, frac, 0.0, preserve)
+                assert np.array_equal(a, b)
+            assert np.array_equal(K.sort_unique(a), O.sort_unique(a))
+    # short and empty inputs
+    assert K.extract_kmers(b"ACGT", 18).size == 0 and K.extract_kmers(b"", 18).size == 0
+    # a real genome from the reference's fixtures
+    raw = open(os.path.join(golden_dir, "test", "virus", "data", "MN908947.fasta"), "rb").read()
+    seq = b"".join(raw.split(b"\n")[1:])
+    assert np.array_equal(K.extract_kmers(seq, 18), O.extract_seq(seq, 18))
+    # k=18 words are 40 bits wide: 256 prefix buckets (kmer_extract.h:37-45)
+    assert int(K.extract_kmers(seq, 18).max()) >> 32 < 256
+
+
+def test_csv_formatting_matches_oracle(K, O, golden_dir):
+    path = os.path.join(golden_dir, "virus_k18.db")
+    h = K.HostDB(path, skip_hashtables=True)
+    o = O.OracleDB(path, skip_hashtables=True)
+    m = o.all2all_dense()
+    txt = K.format_header(h)
+    for i in range(h.N):
+        txt += K.format_dense_row(h.names[i], h.sample_kmers[i], O.tri_row(m, i))
+    assert txt == open(os.path.join(golden_dir, "virus.k18.csv"), "rb").read()
+    txt = K.format_header(h)
+    for i in range(h.N):
+        row = O.tri_row(m, i)
+        nz = np.nonzero(row)[0]
+        txt += K.format_sparse_row(h.names[i], h.sample_kmers[i], nz, row[nz])
+    assert txt == open(os.path.join(golden_dir, "virus.k18.sparse.csv"), "rb").read()
+    assert K.format_dense_row("x", 4294967295, np.array([0, 4294967295, 10], np.uint32)) == b"x,4294967295,0,4294967295,10,\n"
+
+
+def test_gpu_entry_points_fail_loudly_without_a_device(K, golden_dir):
+    if K.device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = K.HostDB(os.path.join(golden_dir, "synth_k21.db"))
+    with pytest.raises(K.KmdbError, match="no HIP device|no CPU fallback"):
+        K.DeviceDB(h)
+    exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
+    r = subprocess.run([exe, "all2all", os.path.join(golden_dir, "synth_k21.db"), os.path.join(golden_dir, "o.csv")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR:" in r.stderr
+
+
+def test_cli_usage_and_open_errors(golden_dir):
+    exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
+    r = subprocess.run([exe, "all2all", "/nonexistent.db", os.path.join(golden_dir, "o2.csv")], capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR: Cannot open k-mer database /nonexistent.db" in r.stderr
+    r = subprocess.run([exe, "all2all", "onlyone"], capture_output=True, text=True)
+    assert r.returncode != 0 and "USAGE" in r.stderr

@@ -1,0 +1,114 @@
+"""Pins the CPU oracle (oracle/kmdb_oracle.c) against the reference: its own golden CSVs
+(test/virus, test/synth) and raw outputs of the real reference hot path (tests/golden/*.ref.*,
+produced by oracle/_ref/ref_driver in tests/golden/make_fixtures.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DBS
+
+
+def _read(golden_dir, name):
+    with open(os.path.join(golden_dir, name), "rb") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("stem", [d for d in DBS if d != "virus_k18_parts"])
+def test_dense_matches_reference_raw(O, golden_dir, stem):
+    db = O.OracleDB(os.path.join(golden_dir, stem + ".db"))
+    ref = np.fromfile(os.path.join(golden_dir, stem + ".a2a.ref.u32"), dtype=np.uint32)
+    m = db.all2all_dense()
+    assert np.array_equal(m, ref)
+    # flat form (all2all_sp semantics) gives the same cells, and the checksum identity holds
+    assert np.array_equal(db.all2all_flat(), ref)
+    assert int(m.astype(np.uint64).sum()) == db.update_counts()["sum_matrix"]
+
+
+@pytest.mark.parametrize("stem,golden,sparse", [
+    ("virus_k18", "virus.k18.csv", False), ("virus_k18_parts", "virus.k18.csv", False),
+    ("virus_k18", "virus.k18.sparse.csv", True), ("virus_k24", "virus.k24.csv", False),
+    ("virus_k18_f01", "virus.k18.frac.csv", False), ("synth_k21", "synth.a2a", False),
+    ("synth_k21", "synth.a2a-sparse", True)])
+def test_all2all_csv_matches_reference_golden(O, golden_dir, stem, golden, sparse):
+    db = O.OracleDB(os.path.join(golden_dir, stem + ".db"))
+    csv = O.format_all2all(db.k, db.fraction, db.names, db.sample_kmers, db.all2all_dense(), sparse=sparse)
+    assert csv == _read(golden_dir, golden)
+
+
+@pytest.mark.parametrize("stem", ["virus_k18", "clade64", "clade64_k25_f01", "synth_k21"])
+def test_sparse_rows_match_reference_all2all_sp(O, golden_dir, stem):
+    db = O.OracleDB(os.path.join(golden_dir, stem + ".db"))
+    m = db.all2all_flat()
+    lines = _read(golden_dir, stem + ".a2a_sp.ref.txt").split(b"\n")
+    for i in range(db.N):
+        row = O.tri_row(m, i)
+        mine = "".join("%d:%d," % (j + 1, row[j]) for j in np.nonzero(row)[0]).encode()
+        assert mine == lines[i]
+
+
+def _virus_queries(O, golden_dir, lst):
+    cwd = os.getcwd()
+    os.chdir(golden_dir)
+    try:
+        return O.load_samples(os.path.join(golden_dir, lst), 18, unique=False)
+    finally:
+        os.chdir(cwd)
+
+
+def test_new2all_matches_reference(O, golden_dir):
+    db = O.OracleDB(os.path.join(golden_dir, "virus_k18_part1.db"))
+    qs = _virus_queries(O, golden_dir, "virus.seqs.part2.list")
+    rows, meta = [], []
+    for name, km in qs:
+        u = O.sort_unique(km)
+        rows.append(db.one2all(u))
+        meta.append((name, len(u)))
+    ref = np.fromfile(os.path.join(golden_dir, "virus_k18_part1.n2a_part2.ref.u32"), dtype=np.uint32).reshape(len(qs), db.N)
+    assert np.array_equal(np.stack(rows), ref)
+    assert O.format_new2all(db.k, db.fraction, db.names, db.sample_kmers, meta, rows) == _read(golden_dir, "virus.k18.n2a.csv")
+    assert O.format_new2all(db.k, db.fraction, db.names, db.sample_kmers, meta, rows, sparse=True) == _read(golden_dir, "virus.k18.n2a.sparse.csv")
+    sp = _read(golden_dir, "virus_k18_part1.n2a_part2_sp.ref.txt").split(b"\n")
+    for r, line in zip(rows, sp):
+        assert "".join("%d:%d," % (j + 1, r[j]) for j in np.nonzero(r)[0]).encode() == line
+
+
+def test_new2all_itself_golden(O, golden_dir):
+    db = O.OracleDB(os.path.join(golden_dir, "virus_k18.db"))
+    qs = _virus_queries(O, golden_dir, "virus.seqs.list")
+    rows, meta = [], []
+    for name, km in qs:
+        u = O.sort_unique(km)
+        rows.append(db.one2all(u))
+        meta.append((name, len(u)))
+    assert O.format_new2all(db.k, db.fraction, db.names, db.sample_kmers, meta, rows) == _read(golden_dir, "virus.k18.n2a.itself.csv")
+
+
+def test_new2all_clade_queries(O, golden_dir):
+    db = O.OracleDB(os.path.join(golden_dir, "clade64.db"))
+    q = np.load(os.path.join(golden_dir, "clade64.queries.npz"))
+    rows = np.stack([db.one2all(O.sort_unique(q[k])) for k in sorted(q.files, key=lambda s: int(s[1:]))])
+    assert np.array_equal(rows, np.fromfile(os.path.join(golden_dir, "clade64.n2a.ref.u32"), dtype=np.uint32).reshape(-1, db.N))
+
+
+def test_gamma_roundtrip_and_known_answers(O):
+    # code shape (elias_gamma.h:104-128): 1 -> "0", 2 -> "100", 3 -> "101", 4 -> "11000", 5 -> "11001"
+    words, nbits = O.gamma_encode([1, 2, 3, 4, 5])
+    assert nbits == 1 + 3 + 3 + 5 + 5
+    assert int(words[0]) >> (64 - nbits) == int("0" "100" "101" "11000" "11001", 2)
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        vals = rng.integers(1, 2 ** rng.integers(1, 31), size=rng.integers(1, 200)).astype(np.uint32)
+        w, nb = O.gamma_encode(vals)
+        assert np.array_equal(O.gamma_decode(w, nb, vals.size + 1), vals)
+    # a value whose code straddles a 64-bit word boundary
+    vals = np.array([1] * 60 + [1000, 7, 1], dtype=np.uint32)
+    w, nb = O.gamma_encode(vals)
+    assert np.array_equal(O.gamma_decode(w, nb, vals.size), vals)
+
+
+def test_chain_lists_strictly_increasing(O, golden_dir):
+    db = O.OracleDB(os.path.join(golden_dir, "clade64.db"), skip_hashtables=True)
+    for pid in range(0, db.P, 97):
+        ids = db.decode_chain(pid).astype(np.int64)
+        assert np.all(np.diff(ids) > 0)
