@@ -188,6 +188,7 @@ struct A2AParams {
     uint32_t* stack_scratch;        // global kernel only
     uint32_t stack_stride;          // words per wave
     unsigned long long* counters;
+    uint32_t dbg;                   // timing experiments only: 2 = skip scatter, 4 = skip flush, 8 = skip mapping+scatter
 };
 
 // rebuild the id stack for the ancestors of `first` by walking parent links
@@ -264,6 +265,66 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_global_kernel(A2AP
             wave_sync();
         }
         base += cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// direct kernel: stack + decode buffer in LDS (small per-wave footprint -> high occupancy),
+// every update is an HBM/L2 atomic
+// ------------------------------------------------------------------------------------------
+constexpr int DIRECT_WAVES = 8;
+template <int NCAP>
+__global__ __launch_bounds__(WAVE * DIRECT_WAVES) void a2a_direct_kernel(A2AParams p) {
+    __shared__ uint16_t dec_all[DIRECT_WAVES][DEC_CAP];
+    __shared__ uint16_t stack_all[DIRECT_WAVES][NCAP];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t seg = p.seg_begin + blockIdx.x * DIRECT_WAVES + wave;
+    if (seg >= p.seg_end) return;
+    uint16_t* dec = dec_all[wave];
+    uint16_t* stack = stack_all[wave];
+    const Segment sg = p.segs[seg];
+    const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
+    if (first >= end) return;
+    init_stack<uint16_t>(p, first, stack, lane);
+    for (uint32_t base = first; base < end;) {
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        uint4 m = valid ? p.meta[i] : make_uint4(0, 0, 0, 0);
+        const uint64_t bp = valid ? p.bitpos[i] : 0;
+        const uint32_t W = valid ? (p.wprefix[p.sub_end[i]] - p.wprefix[i]) : 0u;
+        const uint32_t l = m.y;
+        const uint32_t incl = wave_incl_scan(l, lane);
+        const unsigned long long fit = __ballot(valid && incl <= (uint32_t)DEC_CAP);
+        uint32_t cnt = fit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fit);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        const uint32_t off = incl - l;
+        uint32_t nproc = cnt;
+        if (cnt == 0) {
+            const uint32_t n0 = bcast(m.x, 0), l0 = bcast(m.y, 0), last0 = bcast(m.z, 0);
+            const uint64_t bp0 = ((uint64_t)bcast((uint32_t)(bp >> 32), 0) << 32) | bcast((uint32_t)bp, 0);
+            if (lane == 0) decode_node<uint16_t>(p.bits, bp0, l0, last0, stack + (n0 - l0));
+            nproc = 1;
+        } else if (lane < cnt) {
+            decode_node<uint16_t>(p.bits, bp, l, m.z, dec + off);
+        }
+        wave_sync();
+        for (uint32_t j = 0; j < nproc; ++j) {
+            const uint32_t nj = bcast(m.x, j), lj = bcast(m.y, j), oj = bcast(off, j), Wj = bcast(W, j);
+            const uint32_t top = nj - lj;
+            if (cnt != 0)
+                for (uint32_t k = lane; k < lj; k += WAVE) stack[top + k] = dec[oj + k];
+            wave_sync();
+            if (Wj != 0 && nj > 1 && !(p.dbg & 2)) {
+                for (uint32_t t = top; t < nj; ++t) {
+                    const uint64_t rb = tri64(stack[t]);
+                    for (uint32_t u = lane; u < t; u += WAVE) atomicAdd(&p.M[rb + stack[u]], Wj);
+                }
+            }
+            wave_sync();
+        }
+        base += nproc;
     }
 }
 
@@ -355,7 +416,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
             cvalid = cvalid < top ? cvalid : top;
             wave_sync();
             if (Wj == 0 || nj < 2) continue;
+            if (p.dbg & 8) continue;
             if (nj > (uint32_t)S) {
+                if (p.dbg & 16) continue;
                 // list longer than the tile side: straight to HBM
                 for (uint32_t t = top; t < nj; ++t) {
                     const uint64_t rb = tri64(L.rstack[t]);
@@ -372,6 +435,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
                 need += (uint32_t)__popcll(__ballot(isnew));
             }
             if (ns + need > (uint32_t)S) {
+                if (p.dbg & 4) { for (uint32_t k = lane; k < ns; k += WAVE) L.map[L.rid[k]] = 0xFF; ns = 0; wave_sync(); } else
                 tile_flush<S, NCAP>(L, ns, p.M, lane, p.counters);
                 cvalid = 0;
             }
@@ -398,6 +462,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
             const uint32_t c1v = (S > 64 && lane + 64 < nj) ? L.cstack[lane + 64] : 0u;
             const uint32_t t0v = c0v * (c0v - 1) / 2;       // garbage for c=0 is never used as a base with c<r false... guarded below
             const uint32_t t1v = c1v * (c1v - 1) / 2;
+            if (!(p.dbg & 2))
             for (uint32_t t = top; t < nj; ++t) {
                 const uint32_t r = t < 64 ? bcast(c0v, t) : bcast(c1v, t - 64);
                 const uint32_t rr = r * (r - 1) / 2;
@@ -728,10 +793,17 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
     p.meta = db->meta; p.bitpos = db->bitpos; p.parent = db->parent; p.sub_end = db->sub_end;
     p.wprefix = db->wprefix; p.bits = db->bits; p.segs = db->segs;
     p.seg_begin = seg_begin; p.seg_end = seg_end; p.M = M; p.counters = db->counters;
+    p.dbg = opts ? (opts->flags >> 8) : 0;
     const uint32_t nseg = seg_end - seg_begin;
     const uint32_t blocks = (nseg + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     HIP_TRY(hipEventRecord(db->ev[1], st));
-    if (blocks && cells) {
+    const bool force_direct = opts && (opts->flags & 2u);
+    if (blocks && cells && force_direct && N <= 4096) {
+        const uint32_t dblocks = (nseg + DIRECT_WAVES - 1) / DIRECT_WAVES;
+        if (N <= 1024) hipLaunchKernelGGL((a2a_direct_kernel<1024>), dim3(dblocks), dim3(WAVE * DIRECT_WAVES), 0, st, p);
+        else hipLaunchKernelGGL((a2a_direct_kernel<4096>), dim3(dblocks), dim3(WAVE * DIRECT_WAVES), 0, st, p);
+        HIP_TRY(hipGetLastError());
+    } else if (blocks && cells) {
         if (!force_global && N <= 1024) {
             if (launch_tile<120, 1024>(db, p, blocks, st)) return 1;
         } else if (!force_global && N <= 4096) {
