@@ -11,7 +11,7 @@ print('P',n.size,'mean n',n.mean(),'mean l',l.mean(),'updates',upd.sum(), 'frac 
 print('hist n', np.percentile(n,[50,90,99,99.9,100]), 'l', np.percentile(l,[50,90,99,99.9,100]))
 d = bench.upload(K, arr, 1000, 18, 0)
 M = torch.zeros(d.tri_size(), dtype=torch.int32, device=dev)
-for name, fl in [('full',0),('skip scatter',2<<8),('skip flush',4<<8),('skip map+scatter',8<<8),('skip direct',16<<8),('global kernel',1),('direct lds-stack',2),('direct no scatter',2|(2<<8))]:
+for name, fl in [('full',0),('skip scatter',2<<8),('skip flush',4<<8),('skip map+scatter',8<<8),('skip direct',16<<8),('global kernel',1)]:
     for _ in range(2):
         d.all2all_dense_device(M.data_ptr(), flags=fl)
     print(name, d.stats()['dominant_kernel_ms'], 'flushes', d.stats()['tile_flushes'])
