@@ -69,7 +69,9 @@ typedef struct kmdb_opts {
     void*    stream;               /* hipStream_t to run on, NULL = the engine's own stream */
 } kmdb_opts;
 
-#define KMDB_FLAG_FORCE_GLOBAL_ATOMICS 1u   /* debugging: bypass the LDS tile path */
+#define KMDB_FLAG_FORCE_GLOBAL_ATOMICS 1u   /* debugging: generic kernel, stack in global scratch, HBM atomics */
+#define KMDB_FLAG_FORCE_DIRECT         2u   /* debugging: LDS stack, HBM atomics */
+#define KMDB_FLAG_FORCE_TILE           4u   /* v1 wave-private LDS tile kernel instead of the block-record pipeline */
 
 typedef struct kmdb_db kmdb_db;    /* database resident in HBM */
 
@@ -93,6 +95,9 @@ typedef struct kmdb_stats {        /* measurements of the LAST call on this db h
     uint64_t device_bytes;         /* HBM footprint of the resident db */
     uint64_t n_segments;
     uint64_t tile_flushes;
+    double   k1_ms;                /* block-record pipeline: emit kernel */
+    double   k2_ms;                /* block-record pipeline: apply kernel */
+    uint64_t n_records;            /* block records per pass (0 when the v1 kernels ran) */
 } kmdb_stats;
 
 const char* kmdb_last_error(void);

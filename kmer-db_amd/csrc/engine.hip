@@ -34,6 +34,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -97,6 +98,15 @@ struct kmdb_db {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     kmdb_stats stats{};
     uint32_t kmer_length = 0;
+    // v2 (block record) pipeline state, built at upload when the database qualifies
+    bool b2_ready = false;
+    uint32_t b2_maxn_pad = 0, b2_dec_cap = 0, b2_nctr = 0, b2_n_items = 0;
+    uint32_t* b2_table = nullptr;       // [n_segs][nctr] record bases
+    void* b2_rec = nullptr;             // B2Rec[total]
+    void* b2_items = nullptr;           // B2Item[n_items]
+    uint64_t b2_total = 0;
+    hipEvent_t ev_k2[2] = {nullptr, nullptr};
+    double k1_ms = 0, k2_ms = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -120,6 +130,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// ordering point for data that lives in LDS only: the LDS pipeline executes one wave's DS
+// instructions in order, so only the compiler has to be kept from moving accesses across it.
+// (wave_sync() also drains outstanding global stores, which costs microseconds per call.)
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src_lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
 }
@@ -133,44 +152,87 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-// 64 bits of the stream starting at absolute bit `pos` (stream is MSB-first in LE uint64
-// words, reference src/elias_gamma.h:113-125); the bit array carries two padding words.
-__device__ __forceinline__ uint64_t bit_window(const uint64_t* __restrict__ bits, uint64_t pos) {
-    uint64_t wi = pos >> 6;
-    uint32_t s = (uint32_t)pos & 63u;
-    uint64_t w0 = bits[wi];
-    uint64_t w1 = bits[wi + 1];
-    return s ? ((w0 << s) | (w1 >> (64u - s))) : w0;
-}
-
-// one Elias-gamma value: (L-1) ones, a zero, (L-1) low bits (reference src/elias_gamma.h:104-128)
-__device__ __forceinline__ uint32_t gamma_next(const uint64_t* __restrict__ bits, uint64_t& pos) {
-    uint64_t win = bit_window(bits, pos);
-    uint32_t ones = (uint32_t)__clzll((long long)~win);
-    ones = ones > 31u ? 31u : ones;                 // a valid code has at most 31 leading ones
-    uint32_t low = (uint32_t)((win << ones) >> (63u - ones));
-    pos += 2u * ones + 1u;
-    return low | (1u << ones);
-}
+// Gamma streams are MSB-first in little-endian uint64 words (reference src/elias_gamma.h:113-125).
+// BitCursor keeps three consecutive words in registers: a code (<= 63 bits) is extracted from
+// c0:c1 with shifts only, and the word two ahead is fetched when the cursor crosses a word
+// boundary, so the decode loop has no load on its dependency chain.  The bit array carries four
+// padding words.
+struct BitCursor {
+    const uint64_t* __restrict__ bits;
+    uint64_t wi;
+    uint64_t c0, c1, c2;
+    uint32_t s;                                    // bit offset inside c0
+    __device__ __forceinline__ BitCursor(const uint64_t* __restrict__ b, uint64_t pos) : bits(b) {
+        wi = pos >> 6;
+        s = (uint32_t)pos & 63u;
+        c0 = bits[wi]; c1 = bits[wi + 1]; c2 = bits[wi + 2];
+    }
+    // one Elias-gamma value: (L-1) ones, a zero, (L-1) low bits (reference src/elias_gamma.h:104-128)
+    __device__ __forceinline__ uint32_t next() {
+        const uint64_t win = s ? ((c0 << s) | (c1 >> (64u - s))) : c0;
+        uint32_t ones = (uint32_t)__clzll((long long)~win);
+        ones = ones > 31u ? 31u : ones;             // a valid code has at most 31 leading ones
+        const uint32_t low = (uint32_t)((win << ones) >> (63u - ones));
+        s += 2u * ones + 1u;
+        if (s >= 64u) {
+            s -= 64u;
+            ++wi;
+            c0 = c1; c1 = c2; c2 = bits[wi + 2];
+        }
+        return low | (1u << ones);
+    }
+};
 
 // Decode the l local ids of one node into out[0..l) (ascending).  pattern_t::decodeSamples
 // (reference src/pattern.cpp:99-109): l-1 gamma-coded deltas in append order, last id explicit.
 template <class T>
 __device__ __forceinline__ void decode_node(const uint64_t* __restrict__ bits, uint64_t pos, uint32_t l, uint32_t last, T* out) {
     if (l == 0) return;
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i + 1 < l; ++i) {
-        uint32_t d = gamma_next(bits, pos);
-        out[i] = (T)d;
-        sum += d;
-    }
-    uint32_t id = last - sum;
-    for (uint32_t i = 0; i + 1 < l; ++i) {
-        uint32_t d = (uint32_t)out[i];
-        out[i] = (T)id;
-        id += d;
+    if (l > 1) {
+        BitCursor cur(bits, pos);
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i + 1 < l; ++i) {
+            const uint32_t d = cur.next();
+            out[i] = (T)d;
+            sum += d;
+        }
+        uint32_t id = last - sum;
+        for (uint32_t i = 0; i + 1 < l; ++i) {
+            const uint32_t d = (uint32_t)out[i];
+            out[i] = (T)id;
+            id += d;
+        }
     }
     out[l - 1] = (T)last;
+}
+
+// decode_node plus, per id, the running bit mask of the ids of the same 64-id block seen so far
+// in this node ("cum"): the block-record kernel needs it per stack position.
+__device__ __forceinline__ void decode_node_cum(const uint64_t* __restrict__ bits, uint64_t pos, uint32_t l, uint32_t last,
+                                                uint16_t* out, unsigned long long* cum) {
+    if (l == 0) return;
+    uint32_t id = last;
+    if (l > 1) {
+        BitCursor cur(bits, pos);
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i + 1 < l; ++i) {
+            const uint32_t d = cur.next();
+            out[i] = (uint16_t)d;
+            sum += d;
+        }
+        id = last - sum;
+    }
+    uint32_t curblk = 0xFFFFFFFFu;
+    unsigned long long acc = 0;
+    for (uint32_t i = 0; i < l; ++i) {
+        const uint32_t d = (i + 1 < l) ? (uint32_t)out[i] : 0u;
+        const uint32_t blk = id >> 6;
+        if (blk != curblk) { curblk = blk; acc = 0; }
+        acc |= 1ull << (id & 63u);
+        out[i] = (uint16_t)id;
+        cum[i] = acc;
+        id += d;
+    }
 }
 
 __device__ __forceinline__ uint64_t tri64(uint64_t a) { return a * (a - 1) / 2; }
@@ -484,6 +546,323 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
 }
 
 // ------------------------------------------------------------------------------------------
+// v2 pipeline: block records + wavefront ballot / popcount accumulation
+//
+// The N x N matrix is cut into 64 x 64 blocks (X, Y), X >= Y, by sample-id range.  Because a
+// pattern's id list is ascending, the ids that fall into one block are a contiguous run of
+// stack positions, so the whole update of a node
+//        for every local id a (row), every earlier id b (column):  M[a][b] += W
+// factors into a few BLOCK RECORDS  (X, Y, rowmask, colmask, W):
+//        M[64X + r][64Y + c] += W   for r in rowmask, c in colmask (and c < r when X == Y).
+// K1 (b2_emit_kernel) walks the DFS stream exactly like the v1 kernels (lane-per-node gamma
+//   decode, one id stack per wave) but keeps, per stack position, the running bit mask of the
+//   ids of the same block ("cum"), and writes records instead of touching the matrix.
+//   Records go straight to their final, bucket-grouped position: the per-(segment, bucket)
+//   record counts are a pure function of the database and are tabulated once at upload
+//   (count mode of the same kernel), so no atomics and no sort are needed at run time.
+// K2 (b2_apply_kernel) gives one workgroup a chunk of one bucket and a 64 x 64 uint32
+//   accumulator in LDS.  Records with W == 1 and many rows (the bulk: unique k-mer patterns)
+//   are reduced 64 at a time with ballots: R_r = ballot(row r in record j), C^T by a 64 x 64
+//   bit transpose across lanes, cell(r, c) += popcount(R_r & C^T_c) — one LDS add per cell per
+//   64 records instead of one per record.  The other records are applied row by row with the
+//   column mask as the lane mask.  The accumulator is written back with one HBM atomic per
+//   non-zero cell.
+// ------------------------------------------------------------------------------------------
+struct B2Rec { unsigned long long rows, cols; uint32_t w, pad; };
+struct B2Item { uint32_t X, Y, cls, begin, end; };
+
+constexpr int B2_WAVES = 4;
+
+struct B2Params {
+    A2AParams a;
+    uint32_t maxn_pad;            // stack capacity (multiple of 64)
+    uint32_t dec_cap;             // decoded ids per batch (>= maxn_pad)
+    uint32_t nctr;                // 2 * number of buckets
+    uint32_t* table;              // [n_segs][nctr]: count mode writes counts, emit mode reads record bases
+    B2Rec* rec;
+    const uint32_t* w;            // on-disk weights, DFS order
+};
+
+__device__ __forceinline__ unsigned long long bcast64(unsigned long long v, uint32_t src) {
+    return ((unsigned long long)bcast((uint32_t)(v >> 32), src) << 32) | bcast((uint32_t)v, src);
+}
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int d) {
+    uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, WAVE);
+    uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, WAVE);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+struct B2Wave {
+    unsigned long long* cum;     // [maxn_pad] running mask of same-block ids at positions <= p
+    unsigned long long* dcum;    // [dec_cap]  per decoded id: running mask inside its own node
+    uint32_t* ctr;               // [nctr]
+    uint16_t* dec;               // [dec_cap]
+    uint16_t* ent_start;         // [64] first stack position of the k-th distinct block
+    uint8_t* ent_blk;            // [64]
+    uint8_t* pblk;               // [maxn_pad] block id of position p
+    uint32_t nb;                 // distinct blocks on the stack
+};
+
+__host__ __device__ inline size_t b2_wave_bytes(uint32_t maxn_pad, uint32_t dec_cap, uint32_t nctr) {
+    size_t per_wave = (size_t)maxn_pad * 8 + (size_t)dec_cap * 8 + (size_t)nctr * 4 + (size_t)dec_cap * 2 + 64 * 2 + 64 + maxn_pad;
+    return (per_wave + 15) & ~(size_t)15;
+}
+
+// extend the stack from `top` to `n` with the ids dec[off ..) / masks dcum[off ..); returns through refs
+// what record emission needs.  All arguments wave-uniform.
+__device__ __forceinline__ void b2_push(B2Wave& S, uint32_t top, uint32_t n, uint32_t off, uint32_t lane,
+                                        uint32_t& nbk, bool& first_is_head, unsigned long long& seed) {
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t prev_blk = 0xFFu;
+    seed = 0;
+    if (top > 0) { prev_blk = S.pblk[top - 1]; seed = S.cum[top - 1]; }
+    prev_blk = __builtin_amdgcn_readfirstlane(prev_blk);
+    const uint32_t my_start = lane < S.nb ? S.ent_start[lane] : 0xFFFFu;
+    nbk = (uint32_t)__popcll(__ballot(my_start < top));
+    if (n - top == 1) {
+        // the common case (every internal trie node): one new id
+        const uint32_t id = S.dec[off];
+        const uint32_t blk = __builtin_amdgcn_readfirstlane(id >> 6);
+        first_is_head = blk != prev_blk;
+        const unsigned long long v = (1ull << (id & 63u)) | (first_is_head ? 0ull : seed);
+        if (lane == 0) {
+            S.cum[top] = v;
+            S.pblk[top] = (uint8_t)blk;
+            if (first_is_head) { S.ent_start[nbk] = (uint16_t)top; S.ent_blk[nbk] = (uint8_t)blk; }
+        }
+        S.nb = nbk + (first_is_head ? 1u : 0u);
+        lds_sync();
+        return;
+    }
+    uint32_t carry_blk = prev_blk;
+    uint32_t newheads = 0;
+    first_is_head = true;
+    for (uint32_t p0 = top; p0 < n; p0 += WAVE) {
+        const uint32_t p = p0 + lane;
+        const bool act = p < n;
+        const uint32_t id = act ? S.dec[off + (p - top)] : 0u;
+        unsigned long long v = act ? S.dcum[off + (p - top)] : 0ull;
+        const uint32_t blk = id >> 6;
+        uint32_t pb = (uint32_t)__shfl_up((int)blk, 1, WAVE);
+        if (lane == 0) pb = carry_blk;
+        const bool head = act && (blk != pb);
+        if (blk == prev_blk) v |= seed;            // ids ascend: only the first run can continue the parent's last block
+        if (act) { S.cum[p] = v; S.pblk[p] = (uint8_t)blk; }
+        const unsigned long long hb = __ballot(head);
+        if (head) {
+            const uint32_t e = nbk + newheads + (uint32_t)__popcll(hb & lt_mask);
+            S.ent_start[e] = (uint16_t)p;
+            S.ent_blk[e] = (uint8_t)blk;
+        }
+        if (p0 == top) first_is_head = (hb & 1ull) != 0;
+        newheads += (uint32_t)__popcll(hb);
+        const uint32_t lastl = (n - 1 - p0) < 63u ? (n - 1 - p0) : 63u;
+        carry_blk = bcast(blk, lastl);
+    }
+    S.nb = nbk + newheads;
+    lds_sync();
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const A2AParams& p = q.a;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t seg = p.seg_begin + blockIdx.x * B2_WAVES + wave;
+    if (seg >= p.seg_end) return;
+    // carve this wave's LDS
+    unsigned char* base = lds_raw + b2_wave_bytes(q.maxn_pad, q.dec_cap, q.nctr) * wave;
+    B2Wave S;
+    S.cum = (unsigned long long*)base;
+    S.dcum = S.cum + q.maxn_pad;
+    S.ctr = (uint32_t*)(S.dcum + q.dec_cap);
+    S.dec = (uint16_t*)(S.ctr + q.nctr);
+    S.ent_start = S.dec + q.dec_cap;
+    S.ent_blk = (uint8_t*)(S.ent_start + 64);
+    S.pblk = S.ent_blk + 64;
+    S.nb = 0;
+    uint32_t* my_table = q.table + (size_t)seg * q.nctr;
+    for (uint32_t k = lane; k < q.nctr; k += WAVE) S.ctr[k] = EMIT ? my_table[k] : 0u;
+
+    const Segment sg = p.segs[seg];
+    const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
+    if (first >= end) return;
+    uint32_t nbk;
+    bool first_is_head;
+    unsigned long long seed;
+    {
+        // ancestors of the first node: decode into dec[] at their stack positions, then push them
+        int32_t cur = p.parent[first];
+        const uint32_t depth = cur >= 0 ? p.meta[cur].x : 0u;
+        while (cur >= 0) {
+            const uint4 m = p.meta[cur];
+            if (lane == 0) decode_node<uint16_t>(p.bits, p.bitpos[cur], m.y, m.z, S.dec + (m.x - m.y));
+            cur = p.parent[cur];
+        }
+        lds_sync();
+        if (lane == 0) {
+            uint32_t curblk = 0xFFFFFFFFu;
+            unsigned long long acc = 0;
+            for (uint32_t i = 0; i < depth; ++i) {
+                const uint32_t id = S.dec[i], blk = id >> 6;
+                if (blk != curblk) { curblk = blk; acc = 0; }
+                acc |= 1ull << (id & 63u);
+                S.dcum[i] = acc;
+            }
+        }
+        lds_sync();
+        if (depth) b2_push(S, 0, depth, 0, lane, nbk, first_is_head, seed);
+        lds_sync();
+    }
+
+    const bool prof = (p.dbg & 32u) != 0;
+    unsigned long long t_load = 0, t_dec = 0, t_push = 0, t_emit = 0, t0 = 0, t1 = 0;
+    for (uint32_t base_i = first; base_i < end;) {
+        if (prof) t0 = __builtin_amdgcn_s_memtime();
+        const uint32_t i = base_i + lane;
+        const bool valid = i < end;
+        const uint4 m = valid ? p.meta[i] : make_uint4(0, 0, 0, 0);
+        const uint64_t bp = valid ? p.bitpos[i] : 0;
+        const uint32_t W = valid ? q.w[i] : 0u;              // on-disk num_kmers (flat form: no subtree sums)
+        const uint32_t l = m.y;
+        const uint32_t incl = wave_incl_scan(l, lane);
+        const unsigned long long fit = __ballot(valid && incl <= q.dec_cap);
+        uint32_t cnt = fit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fit);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);      // >= 1: dec_cap >= the longest list
+        const uint32_t off = incl - l;
+        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_load += t1 - t0; t0 = t1; }
+        if (lane < cnt) decode_node_cum(p.bits, bp, l, m.z, S.dec + off, S.dcum + off);
+        lds_sync();
+        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_dec += t1 - t0; }
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t nj = bcast(m.x, j), lj = bcast(m.y, j), oj = bcast(off, j), Wj = bcast(W, j);
+            const uint32_t top = nj - lj;
+            if (lj == 0) continue;
+            if (prof) t0 = __builtin_amdgcn_s_memtime();
+            b2_push(S, top, nj, oj, lane, nbk, first_is_head, seed);
+            if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_push += t1 - t0; t0 = t1; }
+            if (Wj == 0 || nj < 2) continue;
+            // ---- FLAT form (all2all_sp semantics, reference similarity_calculator.cpp:596-638): a pattern with
+            // its own on-disk weight w adds w to every pair of its full list.  One record per pair of
+            // distinct blocks (kX >= kY) of the list; all pairs of a node go to distinct buckets, so a lane
+            // per pair needs no coordination.  Patterns with w == 0 (inner trie nodes) emit nothing.
+            const uint32_t nb = S.nb;
+            const uint32_t total = nb * (nb + 1) / 2;
+            const uint32_t cls = Wj == 1u ? 0u : 1u;
+            for (uint32_t t = lane; t < total; t += WAVE) {
+                uint32_t kX = (uint32_t)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (kX * (kX + 1) / 2 > t) --kX;
+                while ((kX + 1) * (kX + 2) / 2 <= t) ++kX;
+                const uint32_t kY = t - kX * (kX + 1) / 2;
+                const uint32_t endX = (kX + 1 < nb) ? S.ent_start[kX + 1] : nj;
+                const uint32_t endY = (kY + 1 < nb) ? S.ent_start[kY + 1] : nj;
+                const uint32_t bX = S.ent_blk[kX], bY = S.ent_blk[kY];
+                const unsigned long long rows = S.cum[endX - 1];
+                const unsigned long long cols = S.cum[endY - 1];
+                const uint32_t b = (bX * (bX + 1) / 2 + bY) * 2 + cls;
+                const uint32_t slot = atomicAdd(&S.ctr[b], 1u);
+                if (EMIT) {
+                    B2Rec r;
+                    r.rows = rows; r.cols = cols; r.w = Wj; r.pad = 0;
+                    q.rec[slot] = r;
+                }
+            }
+            lds_sync();
+            if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_emit += t1 - t0; }
+        }
+        lds_sync();
+        base_i += cnt;
+    }
+    if (prof && lane == 0) {
+        atomicAdd(&p.counters[1], t_load); atomicAdd(&p.counters[2], t_dec);
+        atomicAdd(&p.counters[3], t_push); atomicAdd(&p.counters[4], t_emit);
+    }
+    if (!EMIT) {
+        lds_sync();
+        for (uint32_t k = lane; k < q.nctr; k += WAVE) my_table[k] = S.ctr[k];
+    }
+}
+
+// 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit
+__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, uint32_t lane) {
+    const unsigned long long masks[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
+                                         0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
+    int s = 32;
+#pragma unroll
+    for (int k = 0; k < 6; ++k, s >>= 1) {
+        const unsigned long long m = masks[k];
+        const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)x, s, WAVE);
+        const uint32_t phi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), s, WAVE);
+        const unsigned long long pv = ((unsigned long long)phi << 32) | plo;
+        x = (lane & (uint32_t)s) ? ((x & ~m) | ((pv >> s) & m)) : ((x & m) | ((pv & m) << s));
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void b2_apply_kernel(const B2Rec* __restrict__ rec, const B2Item* __restrict__ items,
+                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t dbg) {
+    __shared__ uint32_t acc[64 * 64];
+    const B2Item it = items[blockIdx.x];
+    if ((dbg & 64u) && it.cls == 0) return;
+    if ((dbg & 128u) && it.cls == 1) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
+    __syncthreads();
+    const bool diag = it.X == it.Y;
+    for (uint32_t g0 = it.begin + wave * 64; g0 < it.end; g0 += 256) {
+        const uint32_t j = g0 + lane;
+        unsigned long long R = 0, C = 0;
+        uint32_t W = 0;
+        if (j < it.end) { const B2Rec r = rec[j]; R = r.rows; C = r.cols; W = r.w; }
+        // lane c: bit j of Ct = record j contains column c
+        const unsigned long long Ct = transpose64(C, lane);
+        if (!__ballot(R != 0)) continue;
+        if (it.cls == 0) {
+            // every record has weight 1: cell(r, c) += number of records that contain row r and column c
+            for (uint32_t r = 0; r < 64; ++r) {
+                const unsigned long long Rr = __ballot(((R >> r) & 1ull) != 0);
+                if (!Rr) continue;
+                uint32_t c = (uint32_t)__popcll(Ct & Rr);
+                if (diag && lane >= r) c = 0;
+                if (c) atomicAdd(&acc[r * 64 + lane], c);
+            }
+        } else {
+            // general weights: the same count per bit plane of w, scaled by 2^plane.  Planes 0..3 are
+            // kept in scalar registers (weights are usually small); higher planes are rare.
+            uint32_t wor = W;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) wor |= (uint32_t)__shfl_xor((int)wor, d, WAVE);
+            wor = __builtin_amdgcn_readfirstlane(wor);
+            const unsigned long long W0 = __ballot((W & 1u) != 0), W1 = __ballot((W & 2u) != 0);
+            const unsigned long long W2 = __ballot((W & 4u) != 0), W3 = __ballot((W & 8u) != 0);
+            const uint32_t whigh = wor >> 4;
+            for (uint32_t r = 0; r < 64; ++r) {
+                const unsigned long long Rr = __ballot(((R >> r) & 1ull) != 0);
+                if (!Rr) continue;
+                const unsigned long long base = Ct & Rr;
+                uint32_t c = (uint32_t)__popcll(base & W0) + ((uint32_t)__popcll(base & W1) << 1) +
+                             ((uint32_t)__popcll(base & W2) << 2) + ((uint32_t)__popcll(base & W3) << 3);
+                for (uint32_t wb = whigh; wb; wb &= wb - 1) {
+                    const uint32_t b = 4u + (uint32_t)__builtin_ctz(wb);
+                    c += (uint32_t)__popcll(base & __ballot(((W >> b) & 1u) != 0)) << b;
+                }
+                if (diag && lane >= r) c = 0;
+                if (c) atomicAdd(&acc[r * 64 + lane], c);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
+        const uint32_t v = acc[k];
+        if (!v) continue;
+        const uint64_t row = (uint64_t)it.X * 64 + (k >> 6), col = (uint64_t)it.Y * 64 + (k & 63u);
+        atomicAdd(&M[tri64(row) + col], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // dense -> CSR compaction for the sparse entry point
 // ------------------------------------------------------------------------------------------
 __global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t N, unsigned long long* __restrict__ row_nnz) {
@@ -570,6 +949,83 @@ int dev_upload(T** dst, const T* src, size_t n) {
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------
+// v2 pipeline: host side
+// ------------------------------------------------------------------------------------------
+namespace {
+
+size_t b2_lds_per_wave(uint32_t maxn_pad, uint32_t dec_cap, uint32_t nctr) { return b2_wave_bytes(maxn_pad, dec_cap, nctr); }
+
+template <bool EMIT>
+int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t dbg, hipStream_t st) {
+    B2Params q{};
+    q.a.meta = db->meta; q.a.bitpos = db->bitpos; q.a.parent = db->parent; q.a.sub_end = db->sub_end;
+    q.a.wprefix = db->wprefix; q.a.bits = db->bits; q.a.segs = db->segs;
+    q.a.seg_begin = seg_begin; q.a.seg_end = seg_end; q.a.dbg = dbg; q.a.counters = db->counters;
+    q.maxn_pad = db->b2_maxn_pad; q.dec_cap = db->b2_dec_cap; q.nctr = db->b2_nctr;
+    q.table = db->b2_table; q.rec = (B2Rec*)db->b2_rec; q.w = db->w;
+    const size_t lds = b2_lds_per_wave(q.maxn_pad, q.dec_cap, q.nctr) * B2_WAVES;
+    HIP_TRY(hipFuncSetAttribute((const void*)b2_emit_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t nseg = seg_end - seg_begin;
+    const uint32_t blocks = (nseg + B2_WAVES - 1) / B2_WAVES;
+    if (blocks) hipLaunchKernelGGL((b2_emit_kernel<EMIT>), dim3(blocks), dim3(WAVE * B2_WAVES), lds, st, q);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Decide whether the database qualifies for the block-record pipeline and, if so, tabulate the
+// per-(segment, bucket) record counts with the count mode of the emit kernel (layout metadata:
+// a pure function of the database, like CSR row pointers), turn them into record bases and cut
+// the buckets into work items for the apply kernel.
+int b2_prepare(kmdb_db* db, uint32_t max_n) {
+    const uint64_t N = db->N, P = db->P;
+    if (N < 2 || P == 0 || N > 2048 || max_n > 1024) return 0;
+    const uint32_t NB = (uint32_t)((N + 63) / 64);
+    db->b2_maxn_pad = std::max<uint32_t>(64, (max_n + 63) / 64 * 64);
+    db->b2_dec_cap = std::max<uint32_t>(512, db->b2_maxn_pad);
+    db->b2_nctr = NB * (NB + 1) / 2 * 2;
+    if (b2_lds_per_wave(db->b2_maxn_pad, db->b2_dec_cap, db->b2_nctr) * B2_WAVES > 160 * 1024) return 0;
+    const size_t tbl = (size_t)db->n_segs * db->b2_nctr;
+    HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
+    HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->scan_tmp, db->scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1), db->stream));
+    if (b2_launch_emit<false>(db, 0, db->n_segs, 0, db->stream)) return 1;
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    std::vector<uint32_t> counts(tbl);
+    HIP_TRY(hipMemcpy(counts.data(), db->b2_table, tbl * 4, hipMemcpyDeviceToHost));
+    // bucket-major record order: all records of (bucket, class) c are contiguous, segment by segment
+    std::vector<uint32_t> bases(tbl);
+    std::vector<uint64_t> cstart(db->b2_nctr + 1, 0);
+    uint64_t run = 0;
+    for (uint32_t c = 0; c < db->b2_nctr; ++c) {
+        cstart[c] = run;
+        for (uint32_t sgi = 0; sgi < db->n_segs; ++sgi) {
+            bases[(size_t)sgi * db->b2_nctr + c] = (uint32_t)run;
+            run += counts[(size_t)sgi * db->b2_nctr + c];
+        }
+    }
+    cstart[db->b2_nctr] = run;
+    if (run >= (1ull << 32)) return 0;                    // record index must fit 32 bits; fall back to v1
+    db->b2_total = run;
+    std::vector<B2Item> items;
+    const uint32_t CH = 8192;
+    for (uint32_t X = 0, c = 0; X < NB; ++X)
+        for (uint32_t Y = 0; Y <= X; ++Y)
+            for (uint32_t cls = 0; cls < 2; ++cls, ++c)
+                for (uint64_t b = cstart[c]; b < cstart[c + 1]; b += CH)
+                    items.push_back({X, Y, cls, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + CH, cstart[c + 1])});
+    HIP_TRY(hipMemcpy(db->b2_table, bases.data(), tbl * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&db->b2_rec, std::max<uint64_t>(run, 1) * sizeof(B2Rec)));
+    HIP_TRY(hipMalloc(&db->b2_items, std::max<size_t>(items.size(), 1) * sizeof(B2Item)));
+    if (!items.empty()) HIP_TRY(hipMemcpy(db->b2_items, items.data(), items.size() * sizeof(B2Item), hipMemcpyHostToDevice));
+    db->b2_n_items = (uint32_t)items.size();
+    db->b2_ready = true;
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, kmdb_db** out) {
     *out = nullptr;
     if (!v || v->abi_version != KMDB_ABI_VERSION) return kmdb_set_error("kmdb_db_upload: bad view / ABI version");
@@ -636,11 +1092,13 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
     BitWriter bw(bits);
     std::vector<uint64_t> cost_prefix(P + 1, 0);
     uint64_t alg_bytes = 0, tree_updates = 0, sum_pairs = 0;
+    uint32_t max_n = 0;
     for (uint64_t i = 0; i < P; ++i) {
         const uint32_t pid = order[i];
         const uint32_t n = v->num_samples[pid], l = v->num_local[pid], nb = v->num_bits[pid];
         if (l > n || n > N) return kmdb_set_error("kmdb_db_upload: inconsistent pattern header");
         meta[i] = make_uint4(n, l, v->last_sample_id[pid], nb);
+        max_n = std::max(max_n, n);
         bitpos[i] = bw.pos;
         if (nb) bw.append(v->data + v->data_offset[pid], nb);
         const int64_t par = v->parent_id[pid];
@@ -661,7 +1119,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
         }
         cost_prefix[i + 1] = cost_prefix[i] + 4 + l / 2 + rows_cost * 2;
     }
-    bits.resize((bw.pos + 63) / 64 + 2, 0);            // two zero padding words for bit_window()
+    bits.resize((bw.pos + 63) / 64 + 4, 0);            // zero padding words for BitCursor's look-ahead
     alg_bytes += 4ull * (N ? N * (N - 1) / 2 : 0);
 
     // ---- equal-cost segments -------------------------------------------------------------------
@@ -725,6 +1183,10 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
     db->stats.sum_pairs = sum_pairs;
     db->stats.device_bytes = dev_bytes;
     db->stats.n_segments = segs.size();
+    for (auto& e : db->ev_k2)
+        if (hipEventCreate(&e) != hipSuccess) { kmdb_db_free(db); return kmdb_set_error("hipEventCreate failed"); }
+    if (b2_prepare(db, max_n)) { kmdb_db_free(db); return 1; }
+    db->stats.device_bytes += db->b2_total * sizeof(B2Rec) + (uint64_t)db->n_segs * db->b2_nctr * 4;
     *out = db;
     return 0;
 }
@@ -733,9 +1195,11 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
     void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->scan_tmp,
-                    db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs};
+                    db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec,
+                    db->b2_items};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : db->ev_k2) if (e) (void)hipEventDestroy(e);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;
 }
@@ -798,6 +1262,21 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
     const uint32_t blocks = (nseg + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     HIP_TRY(hipEventRecord(db->ev[1], st));
     const bool force_direct = opts && (opts->flags & 2u);
+    const bool force_v1 = opts && (opts->flags & 4u);
+    db->k1_ms = db->k2_ms = -1;
+    if (db->b2_ready && shard_count == 1 && !force_global && !force_direct && !force_v1 && cells) {
+        // v2: emit block records (K1), then ballot/popcount accumulate per 64 x 64 block (K2)
+        if (b2_launch_emit<true>(db, 0, db->n_segs, p.dbg, st)) return 1;
+        HIP_TRY(hipEventRecord(db->ev_k2[0], st));
+        if (db->b2_n_items && !(p.dbg & 2))
+            hipLaunchKernelGGL(b2_apply_kernel, dim3(db->b2_n_items), dim3(256), 0, st, (const B2Rec*)db->b2_rec,
+                               (const B2Item*)db->b2_items, M, (uint32_t)N, p.dbg);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(db->ev_k2[1], st));
+        HIP_TRY(hipEventRecord(db->ev[2], st));
+        db->k1_ms = 0;
+        return 0;
+    }
     if (blocks && cells && force_direct && N <= 4096) {
         const uint32_t dblocks = (nseg + DIRECT_WAVES - 1) / DIRECT_WAVES;
         if (N <= 1024) hipLaunchKernelGGL((a2a_direct_kernel<1024>), dim3(dblocks), dim3(WAVE * DIRECT_WAVES), 0, st, p);
@@ -835,9 +1314,21 @@ int finish_stats(kmdb_db* db, hipStream_t st) {
     HIP_TRY(hipEventElapsedTime(&b, db->ev[1], db->ev[2]));
     db->stats.kernel_ms = a;
     db->stats.dominant_kernel_ms = b;
+    if (db->k1_ms >= 0) {
+        float k1 = 0, k2 = 0;
+        HIP_TRY(hipEventElapsedTime(&k1, db->ev[1], db->ev_k2[0]));
+        HIP_TRY(hipEventElapsedTime(&k2, db->ev_k2[0], db->ev_k2[1]));
+        db->k1_ms = k1; db->k2_ms = k2;
+        db->stats.dominant_kernel_ms = std::max(k1, k2);
+        db->stats.k1_ms = k1; db->stats.k2_ms = k2; db->stats.n_records = db->b2_total;
+    } else {
+        db->stats.k1_ms = db->stats.k2_ms = 0; db->stats.n_records = 0;
+    }
     unsigned long long c[8];
     HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));
     db->stats.tile_flushes = c[0];
+    if (c[1] | c[2] | c[3] | c[4])
+        fprintf(stderr, "[kmdb prof] K1 wave-cycles (memtime ticks): load %llu decode %llu push %llu emit %llu\n", c[1], c[2], c[3], c[4]);
     return 0;
 }
 
