@@ -180,6 +180,12 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         kern_ms = float(np.mean(dom_ms))
+        stl = db.stats()
+        if stl["n_records"]:
+            dom_name = max(((stl["k0_ms"], "b3_decode_kernel"), (stl["k1_ms"], "b3_emit_kernel" if stl["k0_ms"] > 0 else "b2_emit_kernel"),
+                            (stl["k2_ms"], "b2_apply_kernel")))[1]
+        else:
+            dom_name = "a2a_tile_kernel"
         alg = st0["algorithmic_bytes"]
         achieved = alg / (kern_ms * 1e-3) / 1e9
         out = {
@@ -205,7 +211,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "a2a_tile_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
+                "traffic": None, "kernel": dom_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
+                "pipeline_ms": {k: stl[k] for k in ("kernel_ms", "k0_ms", "k1_ms", "k2_ms")},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,7 @@ typedef struct kmdb_opts {
 #define KMDB_FLAG_FORCE_GLOBAL_ATOMICS 1u   /* debugging: generic kernel, stack in global scratch, HBM atomics */
 #define KMDB_FLAG_FORCE_DIRECT         2u   /* debugging: LDS stack, HBM atomics */
 #define KMDB_FLAG_FORCE_TILE           4u   /* v1 wave-private LDS tile kernel instead of the block-record pipeline */
+#define KMDB_FLAG_FORCE_SEQ_EMIT       8u   /* block-record pipeline with the sequential (stack-replay) emit kernel */
 
 typedef struct kmdb_db kmdb_db;    /* database resident in HBM */
 
@@ -98,6 +99,7 @@ typedef struct kmdb_stats {        /* measurements of the LAST call on this db h
     double   k1_ms;                /* block-record pipeline: emit kernel */
     double   k2_ms;                /* block-record pipeline: apply kernel */
     uint64_t n_records;            /* block records per pass (0 when the v1 kernels ran) */
+    double   k0_ms;                /* block-record pipeline: gamma decode kernel (0 when the sequential emit ran) */
 } kmdb_stats;
 
 const char* kmdb_last_error(void);

@@ -45,12 +45,13 @@ class _Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
                 ("algorithmic_bytes", C.c_uint64), ("tree_updates", C.c_uint64), ("sum_pairs", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("n_segments", C.c_uint64), ("tile_flushes", C.c_uint64),
-                ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64)]
+                ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64), ("k0_ms", C.c_double)]
 
 
 FLAG_FORCE_GLOBAL_ATOMICS = 1
 FLAG_FORCE_DIRECT = 2
 FLAG_FORCE_TILE = 4
+FLAG_FORCE_SEQ_EMIT = 8
 
 # every symbol include/kmdb_amd.h declares
 EXPORTS = [

@@ -107,6 +107,18 @@ struct kmdb_db {
     uint64_t b2_total = 0;
     hipEvent_t ev_k2[2] = {nullptr, nullptr};
     double k1_ms = 0, k2_ms = 0;
+    // v3 front half (K0 decode + batch-parallel K1)
+    bool b3_ready = false;
+    uint32_t b3_nbw = 0;
+    uint32_t* b3_perm = nullptr;        // nodes by decreasing local-list length
+    uint32_t* b3_pair_ofs = nullptr;    // [P+1]
+    uint8_t* b3_pair_blk = nullptr;
+    unsigned long long* b3_pair_mask = nullptr;
+    uint32_t* b3_seg_anc = nullptr;     // [n_segs][B3_CHAIN]
+    uint32_t* b3_seg_anc_n = nullptr;
+    uint64_t b3_total_pairs = 0;
+    hipEvent_t ev_k0 = nullptr;
+    double k0_ms = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -785,6 +797,248 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// v3 front half of the block-record pipeline: no per-node sequential work.
+//   K0 b3_decode_kernel  — one THREAD per node, nodes visited in order of decreasing local-list
+//        length so that the lanes of a wave decode streams of similar length.  The gamma stream is
+//        turned into the node's LOCAL block masks: pairs (block, 64-bit mask), ids ascending so the
+//        pairs come out in block order.  This is the only place gamma codes are read.
+//   K1 b3_emit_kernel — one WAVE per DFS segment, 64 consecutive nodes per step, one lane each.
+//        A node's full list is F_j = F_parent(j) | L_j over NBW 64-bit words held in registers.
+//        Parents inside the batch are resolved with pointer doubling across lanes (log2 rounds of
+//        cross-lane reads); parents before the batch come from the "chain table" in LDS: the full
+//        masks of every node on the root path of the last node of the previous batch (DFS order
+//        guarantees every earlier parent is on that path).  Records (flat form, one per pair of
+//        non-empty words X >= Y) are written with ballot-ranked, coalesced stores.
+// ------------------------------------------------------------------------------------------
+constexpr int B3_WAVES = 4;
+constexpr int B3_CHAIN = 64;       // max root-path length (in nodes) the chain table holds
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
+                                                        const uint64_t* __restrict__ bits, const uint32_t* __restrict__ perm,
+                                                        uint32_t P, uint32_t* __restrict__ pair_ofs, uint8_t* __restrict__ pair_blk,
+                                                        unsigned long long* __restrict__ pair_mask) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P) return;
+    const uint32_t i = perm[t];
+    const uint4 m = meta[i];
+    const uint32_t l = m.y;
+    uint32_t out = COUNT ? 0u : pair_ofs[i];
+    uint32_t npairs = 0;
+    if (l) {
+        uint32_t id = m.z;
+        if (l > 1) {
+            BitCursor c1(bits, bitpos[i]);
+            uint32_t sum = 0;
+            for (uint32_t k = 0; k + 1 < l; ++k) sum += c1.next();
+            id = m.z - sum;
+        }
+        BitCursor c2(bits, bitpos[i]);
+        uint32_t curblk = id >> 6;
+        unsigned long long acc = 0;
+        for (uint32_t k = 0; k < l; ++k) {
+            const uint32_t blk = id >> 6;
+            if (blk != curblk) {
+                if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; }
+                ++out; ++npairs;
+                curblk = blk; acc = 0;
+            }
+            acc |= 1ull << (id & 63u);
+            if (k + 1 < l) id += c2.next();
+        }
+        if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; }
+        ++npairs;
+    }
+    if (COUNT) pair_ofs[i] = npairs;
+}
+
+struct B3Params {
+    const uint4* meta;
+    const int32_t* parent;
+    const uint32_t* w;
+    const Segment* segs;
+    const uint32_t* seg_anc;       // [n_segs][B3_CHAIN] root-first ancestors of the segment's first node
+    const uint32_t* seg_anc_n;     // [n_segs]
+    const uint32_t* pair_ofs;
+    const uint8_t* pair_blk;
+    const unsigned long long* pair_mask;
+    uint32_t n_segs;
+    uint32_t maxn_pad;
+    uint32_t nctr;
+    uint32_t* table;
+    B2Rec* rec;
+};
+
+__host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr) {
+    size_t b = (size_t)B3_CHAIN * nbw * 8 + (size_t)nctr * 4 + B3_CHAIN * 4 + (maxn_pad + 64);
+    return (b + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int NBW, bool EMIT>
+__global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t seg = blockIdx.x * B3_WAVES + wave;
+    if (seg >= q.n_segs) return;
+    unsigned char* basep = lds_raw + b3_wave_bytes(NBW, q.maxn_pad, q.nctr) * wave;
+    unsigned long long* chain = (unsigned long long*)basep;            // [B3_CHAIN][NBW]
+    uint32_t* ctr = (uint32_t*)(chain + (size_t)B3_CHAIN * NBW);       // [nctr]
+    uint32_t* chain_n = ctr + q.nctr;                                  // [B3_CHAIN] list length of the node in the slot
+    uint8_t* slot_of_n = (uint8_t*)(chain_n + B3_CHAIN);               // [maxn_pad + 64]
+    uint32_t* my_table = q.table + (size_t)seg * q.nctr;
+    for (uint32_t k = lane; k < q.nctr; k += WAVE) ctr[k] = EMIT ? my_table[k] : 0u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    const Segment sg = q.segs[seg];
+    const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
+    if (first >= end) return;
+
+    auto load_local = [&](uint32_t node, bool on, unsigned long long (&F)[NBW]) {
+#pragma unroll
+        for (int w = 0; w < NBW; ++w) F[w] = 0;
+        const uint32_t po = on ? q.pair_ofs[node] : 0u, pe = on ? q.pair_ofs[node + 1] : 0u;
+        uint32_t np = pe - po, mx = np;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
+        mx = __builtin_amdgcn_readfirstlane(mx);
+        for (uint32_t t = 0; t < mx; ++t) {
+            if (t < np) {
+                const uint32_t b = q.pair_blk[po + t];
+                const unsigned long long mk = q.pair_mask[po + t];
+#pragma unroll
+                for (int w = 0; w < NBW; ++w) F[w] |= (b == (uint32_t)w) ? mk : 0ull;
+            }
+        }
+    };
+
+    // ---- chain table for the first node: the ancestors' full masks = inclusive OR-scan along the root path
+    uint32_t nchain = 0;
+    {
+        const uint32_t d = q.seg_anc_n[seg];
+        unsigned long long F[NBW];
+        const bool on = lane < d;
+        const uint32_t node = on ? q.seg_anc[(size_t)seg * B3_CHAIN + lane] : 0u;
+        load_local(node, on, F);
+#pragma unroll
+        for (int s = 1; s < WAVE; s <<= 1) {
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) {
+                const unsigned long long o = shfl_up64(F[w], s);
+                if (lane >= (uint32_t)s) F[w] |= o;
+            }
+        }
+        if (on) {
+            const uint32_t nn = q.meta[node].x;
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) chain[(size_t)lane * NBW + w] = F[w];
+            chain_n[lane] = nn;
+            slot_of_n[nn] = (uint8_t)lane;
+        }
+        nchain = d;
+        lds_sync();
+    }
+
+    for (uint32_t base = first; base < end; base += WAVE) {
+        const uint32_t idx = base + lane;
+        const bool valid = idx < end;
+        const uint4 m = valid ? q.meta[idx] : make_uint4(0, 0, 0, 0);
+        const uint32_t wj = valid ? q.w[idx] : 0u;
+        const int32_t par = valid ? q.parent[idx] : -1;
+        unsigned long long F[NBW];
+        load_local(idx, valid, F);
+        const bool inb = valid && par >= (int32_t)base;
+        int pl = inb ? (int)(par - (int32_t)base) : -1;
+        const int plo = pl;
+        if (valid && !inb && par >= 0) {
+            // parent precedes the batch: it is on the chain of the previous batch's last node
+            const uint32_t slot = slot_of_n[m.x - m.y];
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) F[w] |= chain[(size_t)slot * NBW + w];
+        }
+        // ---- pointer doubling over in-batch parents
+        while (__ballot(pl >= 0)) {
+            const int src = pl >= 0 ? pl : (int)lane;
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) {
+                const unsigned long long o = shfl64(F[w], src);
+                if (pl >= 0) F[w] |= o;
+            }
+            const int npl = __shfl(pl, src, WAVE);
+            pl = pl >= 0 ? npl : -1;
+        }
+        // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
+        const bool act = valid && wj != 0 && m.x >= 2;
+        uint32_t nzm = 0;
+#pragma unroll
+        for (int w = 0; w < NBW; ++w) nzm |= (F[w] != 0 ? 1u : 0u) << w;
+        uint32_t U = act ? nzm : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) U |= (uint32_t)__shfl_xor((int)U, d, WAVE);
+        U = __builtin_amdgcn_readfirstlane(U);
+        const bool heavy = wj != 1u;
+#pragma unroll
+        for (int X = 0; X < NBW; ++X) {
+            if (!((U >> X) & 1u)) continue;
+#pragma unroll
+            for (int Y = 0; Y <= X; ++Y) {
+                if (!((U >> Y) & 1u)) continue;
+                const bool a = act && F[X] != 0 && F[Y] != 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bool mine = a && (heavy == (c == 1));
+                    const unsigned long long bal = __ballot(mine);
+                    if (!bal) continue;
+                    const uint32_t b = (uint32_t)((X * (X + 1) / 2 + Y) * 2 + c);
+                    const uint32_t cbase = ctr[b];
+                    if (EMIT && mine) {
+                        B2Rec r;
+                        r.rows = F[X]; r.cols = F[Y]; r.w = wj; r.pad = 0;
+                        q.rec[cbase + (uint32_t)__popcll(bal & lt_mask)] = r;
+                    }
+                    lds_sync();
+                    if (lane == 0) ctr[b] = cbase + (uint32_t)__popcll(bal);
+                    lds_sync();
+                }
+            }
+        }
+        // ---- chain table for the next batch: root path of this batch's last node
+        const uint32_t nvalid = (end - base) < (uint32_t)WAVE ? (end - base) : (uint32_t)WAVE;
+        if (base + WAVE < end) {
+            unsigned long long anc = 0;
+            int cur = (int)nvalid - 1;
+            while (cur >= 0) { anc |= 1ull << cur; cur = __builtin_amdgcn_readlane(plo, cur); }
+            const uint32_t r = (uint32_t)__builtin_ctzll(anc);                 // in-batch root of that path
+            const int32_t rpar = __builtin_amdgcn_readlane(par, (int)r);
+            const uint32_t rtop = bcast(m.x - m.y, r);
+            const uint32_t kept = rpar >= 0 ? (uint32_t)slot_of_n[rtop] + 1u : 0u;
+            lds_sync();
+            if ((anc >> lane) & 1ull) {
+                const uint32_t slot = kept + (uint32_t)__popcll(anc & lt_mask);
+#pragma unroll
+                for (int w = 0; w < NBW; ++w) chain[(size_t)slot * NBW + w] = F[w];
+                chain_n[slot] = m.x;
+                slot_of_n[m.x] = (uint8_t)slot;
+            }
+            nchain = kept + (uint32_t)__popcll(anc);
+            lds_sync();
+        }
+    }
+    (void)nchain;
+    if (!EMIT) {
+        lds_sync();
+        for (uint32_t k = lane; k < q.nctr; k += WAVE) my_table[k] = ctr[k];
+    }
+}
+
 // 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit
 __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, uint32_t lane) {
     const unsigned long long masks[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
@@ -978,7 +1232,43 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
 // per-(segment, bucket) record counts with the count mode of the emit kernel (layout metadata:
 // a pure function of the database, like CSR row pointers), turn them into record bases and cut
 // the buckets into work items for the apply kernel.
-int b2_prepare(kmdb_db* db, uint32_t max_n) {
+template <int NBW, bool EMIT>
+int b3_launch_emit_t(kmdb_db* db, hipStream_t st) {
+    B3Params q{};
+    q.meta = db->meta; q.parent = db->parent; q.w = db->w; q.segs = db->segs;
+    q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
+    q.pair_ofs = db->b3_pair_ofs; q.pair_blk = db->b3_pair_blk; q.pair_mask = db->b3_pair_mask;
+    q.n_segs = db->n_segs; q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr;
+    q.table = db->b2_table; q.rec = (B2Rec*)db->b2_rec;
+    const size_t lds = b3_wave_bytes(NBW, q.maxn_pad, q.nctr) * B3_WAVES;
+    HIP_TRY(hipFuncSetAttribute((const void*)b3_emit_kernel<NBW, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t blocks = (db->n_segs + B3_WAVES - 1) / B3_WAVES;
+    if (blocks) hipLaunchKernelGGL((b3_emit_kernel<NBW, EMIT>), dim3(blocks), dim3(WAVE * B3_WAVES), lds, st, q);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <bool EMIT>
+int b3_launch_emit(kmdb_db* db, hipStream_t st) {
+    return db->b3_nbw <= 16 ? b3_launch_emit_t<16, EMIT>(db, st) : b3_launch_emit_t<32, EMIT>(db, st);
+}
+
+template <bool COUNT>
+int b3_launch_decode(kmdb_db* db, hipStream_t st) {
+    const uint32_t P = (uint32_t)db->P;
+    if (P)
+        hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
+                           db->b3_perm, P, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Decide whether the database qualifies for the block-record pipeline and, if so, tabulate the
+// per-(segment, bucket) record counts with the count mode of the emit kernel (layout metadata:
+// a pure function of the database, like CSR row pointers), turn them into record bases and cut
+// the buckets into work items for the apply kernel.
+int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uint32_t>& perm,
+               const std::vector<uint32_t>& seg_anc, const std::vector<uint32_t>& seg_anc_n) {
     const uint64_t N = db->N, P = db->P;
     if (N < 2 || P == 0 || N > 2048 || max_n > 1024) return 0;
     const uint32_t NB = (uint32_t)((N + 63) / 64);
@@ -989,8 +1279,39 @@ int b2_prepare(kmdb_db* db, uint32_t max_n) {
     const size_t tbl = (size_t)db->n_segs * db->b2_nctr;
     HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
     HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->scan_tmp, db->scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1), db->stream));
-    if (b2_launch_emit<false>(db, 0, db->n_segs, 0, db->stream)) return 1;
+    bool use_b3 = chain_ok && b3_wave_bytes(NB <= 16 ? 16 : 32, db->b2_maxn_pad, db->b2_nctr) * B3_WAVES <= 160 * 1024;
+    if (use_b3) {
+        // K0 count pass -> pair offsets -> K0 emit (the pairs are needed by the record count pass below)
+        db->b3_nbw = NB <= 16 ? 16 : 32;
+        HIP_TRY(hipMalloc((void**)&db->b3_perm, P * 4));
+        HIP_TRY(hipMemcpy(db->b3_perm, perm.data(), P * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&db->b3_pair_ofs, (P + 1) * 4));
+        HIP_TRY(hipMemset(db->b3_pair_ofs, 0, (P + 1) * 4));
+        HIP_TRY(hipMalloc((void**)&db->b3_seg_anc, std::max<size_t>(seg_anc.size(), 1) * 4));
+        HIP_TRY(hipMalloc((void**)&db->b3_seg_anc_n, std::max<size_t>(seg_anc_n.size(), 1) * 4));
+        if (!seg_anc.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc, seg_anc.data(), seg_anc.size() * 4, hipMemcpyHostToDevice));
+        if (!seg_anc_n.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc_n, seg_anc_n.data(), seg_anc_n.size() * 4, hipMemcpyHostToDevice));
+        if (b3_launch_decode<true>(db, db->stream)) return 1;
+        uint32_t* tmp_counts = nullptr;
+        HIP_TRY(hipMalloc((void**)&tmp_counts, (P + 1) * 4));
+        HIP_TRY(hipMemcpyAsync(tmp_counts, db->b3_pair_ofs, (P + 1) * 4, hipMemcpyDeviceToDevice, db->stream));
+        size_t tb = 0;
+        void* tmp = nullptr;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, tmp_counts, db->b3_pair_ofs, (int)(P + 1), db->stream));
+        HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, tmp_counts, db->b3_pair_ofs, (int)(P + 1), db->stream));
+        uint32_t total_pairs = 0;
+        HIP_TRY(hipMemcpyAsync(&total_pairs, db->b3_pair_ofs + P, 4, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        (void)hipFree(tmp); (void)hipFree(tmp_counts);
+        db->b3_total_pairs = total_pairs;
+        HIP_TRY(hipMalloc((void**)&db->b3_pair_blk, std::max<uint32_t>(total_pairs, 1)));
+        HIP_TRY(hipMalloc((void**)&db->b3_pair_mask, (size_t)std::max<uint32_t>(total_pairs, 1) * 8));
+        if (b3_launch_decode<false>(db, db->stream)) return 1;
+        if (b3_launch_emit<false>(db, db->stream)) return 1;
+    } else {
+        if (b2_launch_emit<false>(db, 0, db->n_segs, 0, db->stream)) return 1;
+    }
     HIP_TRY(hipStreamSynchronize(db->stream));
     std::vector<uint32_t> counts(tbl);
     HIP_TRY(hipMemcpy(counts.data(), db->b2_table, tbl * 4, hipMemcpyDeviceToHost));
@@ -1021,6 +1342,7 @@ int b2_prepare(kmdb_db* db, uint32_t max_n) {
     if (!items.empty()) HIP_TRY(hipMemcpy(db->b2_items, items.data(), items.size() * sizeof(B2Item), hipMemcpyHostToDevice));
     db->b2_n_items = (uint32_t)items.size();
     db->b2_ready = true;
+    db->b3_ready = use_b3;
     return 0;
 }
 
@@ -1185,7 +1507,38 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
     db->stats.n_segments = segs.size();
     for (auto& e : db->ev_k2)
         if (hipEventCreate(&e) != hipSuccess) { kmdb_db_free(db); return kmdb_set_error("hipEventCreate failed"); }
-    if (b2_prepare(db, max_n)) { kmdb_db_free(db); return 1; }
+    if (hipEventCreate(&db->ev_k0) != hipSuccess) { kmdb_db_free(db); return kmdb_set_error("hipEventCreate failed"); }
+    {
+        // layout metadata for the batch-parallel front half: root-path length of every node, the nodes in
+        // order of decreasing local-list length, and the root path of every segment's first node
+        std::vector<uint16_t> depth(P, 0);
+        uint32_t max_depth = 0;
+        for (uint64_t i = 0; i < P; ++i) {
+            const uint32_t d = parent[i] < 0 ? 1u : (uint32_t)std::min<uint32_t>(65535u, depth[parent[i]] + 1u);
+            depth[i] = (uint16_t)d;
+            max_depth = std::max(max_depth, d);
+        }
+        std::vector<uint32_t> perm(P);
+        {
+            std::vector<uint32_t> bucket_cnt(max_n + 2, 0);
+            for (uint64_t i = 0; i < P; ++i) ++bucket_cnt[max_n - meta[i].y + 1];     // descending l
+            for (uint32_t b = 1; b < bucket_cnt.size(); ++b) bucket_cnt[b] += bucket_cnt[b - 1];
+            for (uint64_t i = 0; i < P; ++i) perm[bucket_cnt[max_n - meta[i].y]++] = (uint32_t)i;
+        }
+        std::vector<uint32_t> seg_anc, seg_anc_n(segs.size(), 0);
+        const bool chain_ok = max_depth <= (uint32_t)B3_CHAIN;
+        if (chain_ok) {
+            seg_anc.assign(segs.size() * (size_t)B3_CHAIN, 0);
+            for (size_t sidx = 0; sidx < segs.size(); ++sidx) {
+                if (segs[sidx].first >= segs[sidx].end) continue;
+                int32_t cur = parent[segs[sidx].first];
+                uint32_t d = cur < 0 ? 0u : depth[cur];
+                seg_anc_n[sidx] = d;
+                while (cur >= 0) { seg_anc[sidx * B3_CHAIN + (--d)] = (uint32_t)cur; cur = parent[cur]; }
+            }
+        }
+        if (b2_prepare(db, max_n, chain_ok, perm, seg_anc, seg_anc_n)) { kmdb_db_free(db); return 1; }
+    }
     db->stats.device_bytes += db->b2_total * sizeof(B2Rec) + (uint64_t)db->n_segs * db->b2_nctr * 4;
     *out = db;
     return 0;
@@ -1196,10 +1549,12 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     (void)hipSetDevice(db->device);
     void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->scan_tmp,
                     db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec,
-                    db->b2_items};
+                    db->b2_items, db->b3_perm, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask, db->b3_seg_anc,
+                    db->b3_seg_anc_n};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_k2) if (e) (void)hipEventDestroy(e);
+    if (db->ev_k0) (void)hipEventDestroy(db->ev_k0);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;
 }
@@ -1266,7 +1621,17 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
     db->k1_ms = db->k2_ms = -1;
     if (db->b2_ready && shard_count == 1 && !force_global && !force_direct && !force_v1 && cells) {
         // v2: emit block records (K1), then ballot/popcount accumulate per 64 x 64 block (K2)
-        if (b2_launch_emit<true>(db, 0, db->n_segs, p.dbg, st)) return 1;
+        const bool seq_emit = !db->b3_ready || (opts && (opts->flags & 8u));
+        if (seq_emit) {
+            if (b2_launch_emit<true>(db, 0, db->n_segs, p.dbg, st)) return 1;
+            HIP_TRY(hipEventRecord(db->ev_k0, st));
+            db->k0_ms = -1;
+        } else {
+            if (b3_launch_decode<false>(db, st)) return 1;
+            HIP_TRY(hipEventRecord(db->ev_k0, st));
+            if (b3_launch_emit<true>(db, st)) return 1;
+            db->k0_ms = 0;
+        }
         HIP_TRY(hipEventRecord(db->ev_k2[0], st));
         if (db->b2_n_items && !(p.dbg & 2))
             hipLaunchKernelGGL(b2_apply_kernel, dim3(db->b2_n_items), dim3(256), 0, st, (const B2Rec*)db->b2_rec,
@@ -1315,14 +1680,18 @@ int finish_stats(kmdb_db* db, hipStream_t st) {
     db->stats.kernel_ms = a;
     db->stats.dominant_kernel_ms = b;
     if (db->k1_ms >= 0) {
-        float k1 = 0, k2 = 0;
+        float k0 = 0, k1 = 0, k2 = 0;
+        if (db->k0_ms >= 0) {
+            HIP_TRY(hipEventElapsedTime(&k0, db->ev[1], db->ev_k0));
+            HIP_TRY(hipEventElapsedTime(&k1, db->ev_k0, db->ev_k2[0]));
+        } else
         HIP_TRY(hipEventElapsedTime(&k1, db->ev[1], db->ev_k2[0]));
         HIP_TRY(hipEventElapsedTime(&k2, db->ev_k2[0], db->ev_k2[1]));
         db->k1_ms = k1; db->k2_ms = k2;
-        db->stats.dominant_kernel_ms = std::max(k1, k2);
-        db->stats.k1_ms = k1; db->stats.k2_ms = k2; db->stats.n_records = db->b2_total;
+        db->stats.dominant_kernel_ms = std::max(k0, std::max(k1, k2));
+        db->stats.k0_ms = k0; db->stats.k1_ms = k1; db->stats.k2_ms = k2; db->stats.n_records = db->b2_total;
     } else {
-        db->stats.k1_ms = db->stats.k2_ms = 0; db->stats.n_records = 0;
+        db->stats.k0_ms = db->stats.k1_ms = db->stats.k2_ms = 0; db->stats.n_records = 0;
     }
     unsigned long long c[8];
     HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));

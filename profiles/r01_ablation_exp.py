@@ -22,10 +22,10 @@ print('P', n.size, 'mean n', n.mean(), 'mean l', l.mean(), 'updates', upd.sum(),
       'n>120', upd[n > 120].sum() / upd.sum(), 'n>256', upd[n > 256].sum() / upd.sum(), 'max n', n.max())
 d = bench.upload(K, arr, 1000, 18, 0)
 M = torch.zeros(d.tri_size(), dtype=torch.int32, device=dev)
-for name, fl in [('v2 block records', 0), ('v2 profiled', 32 << 8), ('v2 K2 without popcount items', 64 << 8), ('v2 K2 without scatter items', 128 << 8), ('v2 K1 only (no apply)', 2 << 8), ('v1 tile', 4), ('v1 tile, no scatter', 4 | (2 << 8)),
+for name, fl in [('v3 K0+K1par+K2', 0), ('v2 seq emit', 8), ('v2 profiled', 8 | (32 << 8)), ('v2 K2 without popcount items', 64 << 8), ('v2 K2 without scatter items', 128 << 8), ('v2 K1 only (no apply)', 2 << 8), ('v1 tile', 4), ('v1 tile, no scatter', 4 | (2 << 8)),
                  ('v1 tile, decode+stack only', 4 | (8 << 8)), ('generic HBM atomics', 1), ('LDS stack + HBM atomics', 2)]:
     for _ in range(2):
         d.all2all_dense_device(M.data_ptr(), flags=fl)
     st = d.stats()
-    print('%-28s total %.3f ms  dominant %.3f  k1 %.3f k2 %.3f  records %d flushes %d' % (
-        name, st['kernel_ms'], st['dominant_kernel_ms'], st['k1_ms'], st['k2_ms'], st['n_records'], st['tile_flushes']))
+    print('%-28s total %.3f ms  dominant %.3f  k0 %.3f k1 %.3f k2 %.3f  records %d flushes %d' % (
+        name, st['kernel_ms'], st['dominant_kernel_ms'], st['k0_ms'], st['k1_ms'], st['k2_ms'], st['n_records'], st['tile_flushes']))
