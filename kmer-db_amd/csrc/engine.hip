@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -111,7 +112,9 @@ struct kmdb_db {
     bool b3_ready = false;
     uint32_t b3_nbw = 0;
     uint32_t* b3_perm = nullptr;        // nodes by decreasing local-list length
-    uint32_t* b3_pair_ofs = nullptr;    // [P+1]
+    uint32_t* b3_pair_ofs = nullptr;    // [P+1] CSR of the pairs beyond a node's first
+    unsigned long long* b3_p0_mask = nullptr;   // [P] first pair, inline
+    uint16_t* b3_p0_info = nullptr;     // [P] block | npairs << 8
     uint8_t* b3_pair_blk = nullptr;
     unsigned long long* b3_pair_mask = nullptr;
     uint32_t* b3_seg_anc = nullptr;     // [n_segs][B3_CHAIN]
@@ -817,15 +820,19 @@ constexpr int B3_CHAIN = 64;       // max root-path length (in nodes) the chain 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
                                                         const uint64_t* __restrict__ bits, const uint32_t* __restrict__ perm,
-                                                        uint32_t P, uint32_t* __restrict__ pair_ofs, uint8_t* __restrict__ pair_blk,
+                                                        uint32_t P, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
+                                                        uint32_t* __restrict__ pair_ofs, uint8_t* __restrict__ pair_blk,
                                                         unsigned long long* __restrict__ pair_mask) {
+    // output per node: the first (block, mask) pair inline — p0_info = block | npairs << 8 — and any
+    // further pairs in a CSR side array (pair_ofs counts only the extra pairs)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P) return;
     const uint32_t i = perm[t];
     const uint4 m = meta[i];
     const uint32_t l = m.y;
     uint32_t out = COUNT ? 0u : pair_ofs[i];
-    uint32_t npairs = 0;
+    uint32_t npairs = 0, blk0 = 0;
+    unsigned long long mask0 = 0;
     if (l) {
         uint32_t id = m.z;
         if (l > 1) {
@@ -840,17 +847,20 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
         for (uint32_t k = 0; k < l; ++k) {
             const uint32_t blk = id >> 6;
             if (blk != curblk) {
-                if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; }
-                ++out; ++npairs;
+                if (npairs == 0) { blk0 = curblk; mask0 = acc; }
+                else { if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; } ++out; }
+                ++npairs;
                 curblk = blk; acc = 0;
             }
             acc |= 1ull << (id & 63u);
             if (k + 1 < l) id += c2.next();
         }
-        if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; }
+        if (npairs == 0) { blk0 = curblk; mask0 = acc; }
+        else if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; }
         ++npairs;
     }
-    if (COUNT) pair_ofs[i] = npairs;
+    if (COUNT) pair_ofs[i] = npairs ? npairs - 1 : 0;
+    else { p0_mask[i] = mask0; p0_info[i] = (uint16_t)(blk0 | (npairs << 8)); }
 }
 
 struct B3Params {
@@ -860,6 +870,8 @@ struct B3Params {
     const Segment* segs;
     const uint32_t* seg_anc;       // [n_segs][B3_CHAIN] root-first ancestors of the segment's first node
     const uint32_t* seg_anc_n;     // [n_segs]
+    const unsigned long long* p0_mask;
+    const uint16_t* p0_info;
     const uint32_t* pair_ofs;
     const uint8_t* pair_blk;
     const unsigned long long* pair_mask;
@@ -868,6 +880,8 @@ struct B3Params {
     uint32_t nctr;
     uint32_t* table;
     B2Rec* rec;
+    uint32_t dbg;
+    unsigned long long* counters;
 };
 
 __host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr) {
@@ -902,22 +916,29 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
     if (first >= end) return;
 
-    auto load_local = [&](uint32_t node, bool on, unsigned long long (&F)[NBW]) {
-#pragma unroll
-        for (int w = 0; w < NBW; ++w) F[w] = 0;
-        const uint32_t po = on ? q.pair_ofs[node] : 0u, pe = on ? q.pair_ofs[node + 1] : 0u;
-        uint32_t np = pe - po, mx = np;
+    // pairs beyond a node's first one (nodes whose local ids span several 64-id blocks)
+    auto load_extra = [&](uint32_t node, uint32_t np, unsigned long long (&F)[NBW]) {
+        const uint32_t po = np > 1 ? q.pair_ofs[node] : 0u;
+        uint32_t mx = np > 1 ? np - 1 : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
         mx = __builtin_amdgcn_readfirstlane(mx);
         for (uint32_t t = 0; t < mx; ++t) {
-            if (t < np) {
+            if (t + 1 < np) {
                 const uint32_t b = q.pair_blk[po + t];
                 const unsigned long long mk = q.pair_mask[po + t];
 #pragma unroll
                 for (int w = 0; w < NBW; ++w) F[w] |= (b == (uint32_t)w) ? mk : 0ull;
             }
         }
+    };
+    auto load_local = [&](uint32_t node, bool on, unsigned long long (&F)[NBW]) {
+        const uint32_t info = on ? q.p0_info[node] : 0u;
+        const unsigned long long m0 = on ? q.p0_mask[node] : 0ull;
+        const uint32_t b0 = info & 0xFFu, np = info >> 8;
+#pragma unroll
+        for (int w = 0; w < NBW; ++w) F[w] = (np != 0 && b0 == (uint32_t)w) ? m0 : 0ull;
+        if (__ballot(np > 1)) load_extra(node, np, F);
     };
 
     // ---- chain table for the first node: the ancestors' full masks = inclusive OR-scan along the root path
@@ -947,14 +968,40 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         lds_sync();
     }
 
+    const bool prof = (q.dbg & 32u) != 0;
+    unsigned long long t_load = 0, t_dbl = 0, t_emit = 0, t_chain = 0, t0 = 0, t1 = 0;
+    // node records of the NEXT batch are fetched while the current one is processed
+    uint4 nx_m = make_uint4(0, 0, 0, 0);
+    uint32_t nx_w = 0, nx_info = 0;
+    int32_t nx_par = -1;
+    unsigned long long nx_m0 = 0;
+    auto fetch = [&](uint32_t b0) {
+        const uint32_t ii = b0 + lane;
+        const bool v = ii < end;
+        nx_m = v ? q.meta[ii] : make_uint4(0, 0, 0, 0);
+        nx_w = v ? q.w[ii] : 0u;
+        nx_par = v ? q.parent[ii] : -1;
+        nx_info = v ? q.p0_info[ii] : 0u;
+        nx_m0 = v ? q.p0_mask[ii] : 0ull;
+    };
+    fetch(first);
     for (uint32_t base = first; base < end; base += WAVE) {
+        if (prof) t0 = __builtin_amdgcn_s_memtime();
         const uint32_t idx = base + lane;
         const bool valid = idx < end;
-        const uint4 m = valid ? q.meta[idx] : make_uint4(0, 0, 0, 0);
-        const uint32_t wj = valid ? q.w[idx] : 0u;
-        const int32_t par = valid ? q.parent[idx] : -1;
+        const uint4 m = nx_m;
+        const uint32_t wj = nx_w;
+        const int32_t par = nx_par;
+        const uint32_t info = nx_info;
+        const unsigned long long m0 = nx_m0;
+        if (base + WAVE < end) fetch(base + WAVE);
         unsigned long long F[NBW];
-        load_local(idx, valid, F);
+        {
+            const uint32_t b0 = info & 0xFFu, np = info >> 8;
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) F[w] = (np != 0 && b0 == (uint32_t)w) ? m0 : 0ull;
+            if (__ballot(np > 1)) load_extra(idx, np, F);
+        }
         const bool inb = valid && par >= (int32_t)base;
         int pl = inb ? (int)(par - (int32_t)base) : -1;
         const int plo = pl;
@@ -964,6 +1011,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
 #pragma unroll
             for (int w = 0; w < NBW; ++w) F[w] |= chain[(size_t)slot * NBW + w];
         }
+        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_load += t1 - t0; t0 = t1; }
         // ---- pointer doubling over in-batch parents
         while (__ballot(pl >= 0)) {
             const int src = pl >= 0 ? pl : (int)lane;
@@ -975,6 +1023,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
             const int npl = __shfl(pl, src, WAVE);
             pl = pl >= 0 ? npl : -1;
         }
+        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_dbl += t1 - t0; t0 = t1; }
         // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
         const bool act = valid && wj != 0 && m.x >= 2;
         uint32_t nzm = 0;
@@ -984,32 +1033,43 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) U |= (uint32_t)__shfl_xor((int)U, d, WAVE);
         U = __builtin_amdgcn_readfirstlane(U);
+        if (q.dbg & 512u) U = 0;
         const bool heavy = wj != 1u;
 #pragma unroll
         for (int X = 0; X < NBW; ++X) {
             if (!((U >> X) & 1u)) continue;
+            // all (Y, class) counters of row block X are bumped by ONE LDS atomic: lane 2Y + c owns combo (X, Y, c)
+            const bool ax = act && F[X] != 0;
+            uint32_t mycnt = 0;
 #pragma unroll
             for (int Y = 0; Y <= X; ++Y) {
                 if (!((U >> Y) & 1u)) continue;
-                const bool a = act && F[X] != 0 && F[Y] != 0;
+                const bool a = ax && F[Y] != 0;
+                const uint32_t c0 = (uint32_t)__popcll(__ballot(a && !heavy));
+                const uint32_t c1 = (uint32_t)__popcll(__ballot(a && heavy));
+                if (lane == (uint32_t)(2 * Y)) mycnt = c0;
+                if (lane == (uint32_t)(2 * Y + 1)) mycnt = c1;
+            }
+            uint32_t mybase = 0;
+            if (mycnt) mybase = atomicAdd(&ctr[(uint32_t)(X * (X + 1)) + lane], mycnt);   // (X(X+1)/2 + Y)*2 + c, lane = 2Y + c
+            if (EMIT && !(q.dbg & 256u)) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const bool mine = a && (heavy == (c == 1));
-                    const unsigned long long bal = __ballot(mine);
-                    if (!bal) continue;
-                    const uint32_t b = (uint32_t)((X * (X + 1) / 2 + Y) * 2 + c);
-                    const uint32_t cbase = ctr[b];
-                    if (EMIT && mine) {
+                for (int Y = 0; Y <= X; ++Y) {
+                    if (!((U >> Y) & 1u)) continue;
+                    const bool a = ax && F[Y] != 0;
+                    const unsigned long long bal = __ballot(a && !heavy), bah = __ballot(a && heavy);
+                    if (!(bal | bah)) continue;
+                    const uint32_t base0 = bcast(mybase, 2 * Y), base1 = bcast(mybase, 2 * Y + 1);
+                    if (a) {
                         B2Rec r;
                         r.rows = F[X]; r.cols = F[Y]; r.w = wj; r.pad = 0;
-                        q.rec[cbase + (uint32_t)__popcll(bal & lt_mask)] = r;
+                        const uint32_t slot = heavy ? base1 + (uint32_t)__popcll(bah & lt_mask) : base0 + (uint32_t)__popcll(bal & lt_mask);
+                        q.rec[slot] = r;
                     }
-                    lds_sync();
-                    if (lane == 0) ctr[b] = cbase + (uint32_t)__popcll(bal);
-                    lds_sync();
                 }
             }
         }
+        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_emit += t1 - t0; t0 = t1; }
         // ---- chain table for the next batch: root path of this batch's last node
         const uint32_t nvalid = (end - base) < (uint32_t)WAVE ? (end - base) : (uint32_t)WAVE;
         if (base + WAVE < end) {
@@ -1031,8 +1091,13 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
             nchain = kept + (uint32_t)__popcll(anc);
             lds_sync();
         }
+        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_chain += t1 - t0; }
     }
     (void)nchain;
+    if (prof && lane == 0) {
+        atomicAdd(&q.counters[1], t_load); atomicAdd(&q.counters[2], t_dbl);
+        atomicAdd(&q.counters[3], t_emit); atomicAdd(&q.counters[4], t_chain);
+    }
     if (!EMIT) {
         lds_sync();
         for (uint32_t k = lane; k < q.nctr; k += WAVE) my_table[k] = ctr[k];
@@ -1233,13 +1298,14 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
 // a pure function of the database, like CSR row pointers), turn them into record bases and cut
 // the buckets into work items for the apply kernel.
 template <int NBW, bool EMIT>
-int b3_launch_emit_t(kmdb_db* db, hipStream_t st) {
+int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg) {
     B3Params q{};
     q.meta = db->meta; q.parent = db->parent; q.w = db->w; q.segs = db->segs;
     q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
+    q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
     q.pair_ofs = db->b3_pair_ofs; q.pair_blk = db->b3_pair_blk; q.pair_mask = db->b3_pair_mask;
     q.n_segs = db->n_segs; q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr;
-    q.table = db->b2_table; q.rec = (B2Rec*)db->b2_rec;
+    q.table = db->b2_table; q.rec = (B2Rec*)db->b2_rec; q.dbg = dbg; q.counters = db->counters;
     const size_t lds = b3_wave_bytes(NBW, q.maxn_pad, q.nctr) * B3_WAVES;
     HIP_TRY(hipFuncSetAttribute((const void*)b3_emit_kernel<NBW, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t blocks = (db->n_segs + B3_WAVES - 1) / B3_WAVES;
@@ -1249,8 +1315,8 @@ int b3_launch_emit_t(kmdb_db* db, hipStream_t st) {
 }
 
 template <bool EMIT>
-int b3_launch_emit(kmdb_db* db, hipStream_t st) {
-    return db->b3_nbw <= 16 ? b3_launch_emit_t<16, EMIT>(db, st) : b3_launch_emit_t<32, EMIT>(db, st);
+int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0) {
+    return db->b3_nbw <= 16 ? b3_launch_emit_t<16, EMIT>(db, st, dbg) : b3_launch_emit_t<32, EMIT>(db, st, dbg);
 }
 
 template <bool COUNT>
@@ -1258,7 +1324,7 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
     const uint32_t P = (uint32_t)db->P;
     if (P)
         hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
-                           db->b3_perm, P, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
+                           db->b3_perm, P, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1286,6 +1352,8 @@ int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uin
         HIP_TRY(hipMalloc((void**)&db->b3_perm, P * 4));
         HIP_TRY(hipMemcpy(db->b3_perm, perm.data(), P * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&db->b3_pair_ofs, (P + 1) * 4));
+        HIP_TRY(hipMalloc((void**)&db->b3_p0_mask, P * 8));
+        HIP_TRY(hipMalloc((void**)&db->b3_p0_info, P * 2));
         HIP_TRY(hipMemset(db->b3_pair_ofs, 0, (P + 1) * 4));
         HIP_TRY(hipMalloc((void**)&db->b3_seg_anc, std::max<size_t>(seg_anc.size(), 1) * 4));
         HIP_TRY(hipMalloc((void**)&db->b3_seg_anc_n, std::max<size_t>(seg_anc_n.size(), 1) * 4));
@@ -1518,12 +1586,22 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
             depth[i] = (uint16_t)d;
             max_depth = std::max(max_depth, d);
         }
+        // K0 visits nodes in order of decreasing local-list length INSIDE windows of consecutive DFS nodes:
+        // lanes of a wave decode streams of similar length, and all accesses stay in a small address window
         std::vector<uint32_t> perm(P);
         {
-            std::vector<uint32_t> bucket_cnt(max_n + 2, 0);
-            for (uint64_t i = 0; i < P; ++i) ++bucket_cnt[max_n - meta[i].y + 1];     // descending l
-            for (uint32_t b = 1; b < bucket_cnt.size(); ++b) bucket_cnt[b] += bucket_cnt[b - 1];
-            for (uint64_t i = 0; i < P; ++i) perm[bucket_cnt[max_n - meta[i].y]++] = (uint32_t)i;
+            uint64_t WIN = 262144;
+            if (const char* e = getenv("KMDB_K0_WINDOW")) { WIN = strtoull(e, nullptr, 10); if (!WIN) WIN = P ? P : 1; }
+            std::vector<uint32_t> cntl;
+            for (uint64_t w0 = 0; w0 < P; w0 += WIN) {
+                const uint64_t w1 = std::min<uint64_t>(P, w0 + WIN);
+                uint32_t ml = 0;
+                for (uint64_t i = w0; i < w1; ++i) ml = std::max(ml, meta[i].y);
+                cntl.assign((size_t)ml + 2, 0);
+                for (uint64_t i = w0; i < w1; ++i) ++cntl[ml - meta[i].y + 1];
+                for (uint32_t b = 1; b < cntl.size(); ++b) cntl[b] += cntl[b - 1];
+                for (uint64_t i = w0; i < w1; ++i) perm[w0 + cntl[ml - meta[i].y]++] = (uint32_t)i;
+            }
         }
         std::vector<uint32_t> seg_anc, seg_anc_n(segs.size(), 0);
         const bool chain_ok = max_depth <= (uint32_t)B3_CHAIN;
@@ -1550,7 +1628,7 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->scan_tmp,
                     db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec,
                     db->b2_items, db->b3_perm, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask, db->b3_seg_anc,
-                    db->b3_seg_anc_n};
+                    db->b3_seg_anc_n, db->b3_p0_mask, db->b3_p0_info};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_k2) if (e) (void)hipEventDestroy(e);
@@ -1629,7 +1707,7 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
         } else {
             if (b3_launch_decode<false>(db, st)) return 1;
             HIP_TRY(hipEventRecord(db->ev_k0, st));
-            if (b3_launch_emit<true>(db, st)) return 1;
+            if (b3_launch_emit<true>(db, st, p.dbg)) return 1;
             db->k0_ms = 0;
         }
         HIP_TRY(hipEventRecord(db->ev_k2[0], st));
@@ -1697,7 +1775,7 @@ int finish_stats(kmdb_db* db, hipStream_t st) {
     HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));
     db->stats.tile_flushes = c[0];
     if (c[1] | c[2] | c[3] | c[4])
-        fprintf(stderr, "[kmdb prof] K1 wave-cycles (memtime ticks): load %llu decode %llu push %llu emit %llu\n", c[1], c[2], c[3], c[4]);
+        fprintf(stderr, "[kmdb prof] K1 wave-cycles (memtime ticks), phases 1..4: %llu %llu %llu %llu\n", c[1], c[2], c[3], c[4]);
     return 0;
 }
 

@@ -137,3 +137,59 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
         _same(t("n2a-mm"), g("synth.n2a.sparse.above-below"))
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.parametrize("N,cs,L,k", [(1000, 50, 30000, 18), (1500, 30, 6000, 18), (300, 300, 20000, 18), (2048, 64, 3000, 18)])
+def test_synthetic_databases_bit_exact(K, O, dev, tmp_path, N, cs, L, k):
+    """Bench-shaped inputs (BASELINE.json configs[1] at reduced genome length), generated on the GPU,
+    run through every all2all kernel and compared with the oracle (and the real reference when
+    oracle/_ref travelled with the snapshot)."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    g, pat = S.synth_database(N, cs, L, k=k, seed=3, device=torch.device("cuda", dev))
+    arr = S.to_view_arrays(pat)
+    path = str(tmp_path / "s.db")
+    S.write_db(path, k, 1.0, [g.name(i) for i in range(N)], pat["sample_counts"], arr)
+    exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+    if O.have_ref():
+        mr, _ = O.ref_all2all(path, str(tmp_path / "m.u32"), threads=8)
+        assert np.array_equal(mr, exp)
+    view = K.make_view(k, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    got = d.all2all_dense()
+    assert np.array_equal(got, exp)
+    st = d.stats()
+    assert st["n_records"] > 0 and st["sum_pairs"] == int(exp.astype(np.uint64).sum())
+    for fl in (K.capi.FLAG_FORCE_SEQ_EMIT, K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS):
+        assert np.array_equal(d.all2all_dense(flags=fl), exp), fl
+    # the same database read back through the front-end's .db reader
+    d2 = K.DeviceDB(K.HostDB(path, skip_hashtables=True), device=dev)
+    assert np.array_equal(d2.all2all_dense(), exp)
+
+
+def test_prefix_sharded_ranks_on_one_gpu(K, O, dev, tmp_path):
+    """bench.py's multi-GPU scheme with the ranks run one after another on a single GPU:
+    the partial matrices of the prefix-bucket shards add up to the unsharded matrix."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    N, cs, L, k = 200, 20, 20000, 18
+    device = torch.device("cuda", dev)
+    g = S.CladeGenomes(N, cs, L, seed=5, device=device)
+
+    def run(rank, world):
+        def km(i):
+            x = S.kmers_of(g.sample(i), k)
+            return x if world == 1 else x[((x >> 32) % world) == rank]
+        arr = S.to_view_arrays(S.build_patterns(km, N, device))
+        view = K.make_view(k, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                           arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+        return K.DeviceDB(view, device=dev).all2all_dense()
+    full = run(0, 1)
+    for world in (2, 8):
+        acc = np.zeros_like(full)
+        for r in range(world):
+            acc += run(r, world)
+        assert np.array_equal(acc, full)
