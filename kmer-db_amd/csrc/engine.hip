@@ -103,7 +103,9 @@ struct kmdb_db {
     bool b2_ready = false;
     uint32_t b2_maxn_pad = 0, b2_dec_cap = 0, b2_nctr = 0, b2_n_items = 0;
     uint32_t* b2_table = nullptr;       // [n_segs][nctr] record bases
-    void* b2_rec = nullptr;             // B2Rec[total]
+    unsigned long long* b2_rec_rows = nullptr;   // [total]
+    unsigned long long* b2_rec_cols = nullptr;   // [total]
+    uint32_t* b2_rec_w = nullptr;       // [total]
     void* b2_items = nullptr;           // B2Item[n_items]
     uint64_t b2_total = 0;
     hipEvent_t ev_k2[2] = {nullptr, nullptr};
@@ -111,7 +113,9 @@ struct kmdb_db {
     // v3 front half (K0 decode + batch-parallel K1)
     bool b3_ready = false;
     uint32_t b3_nbw = 0;
-    uint32_t* b3_perm = nullptr;        // nodes by decreasing local-list length
+    uint32_t* b3_perm = nullptr;        // the nodes with long local lists, longest first
+    uint32_t b3_n_long = 0, b3_short_max = 32;
+    uint32_t* b3_nl = nullptr;          // n | l << 16 per node
     uint32_t* b3_pair_ofs = nullptr;    // [P+1] CSR of the pairs beyond a node's first
     unsigned long long* b3_p0_mask = nullptr;   // [P] first pair, inline
     uint16_t* b3_p0_info = nullptr;     // [P] block | npairs << 8
@@ -583,7 +587,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
 //   column mask as the lane mask.  The accumulator is written back with one HBM atomic per
 //   non-zero cell.
 // ------------------------------------------------------------------------------------------
-struct B2Rec { unsigned long long rows, cols; uint32_t w, pad; };
+// block records, struct-of-arrays, one slot per record: rows always; cols only for off-diagonal
+// buckets (on the diagonal cols == rows); w only for the heavy class (class 0 records have w == 1)
+struct B2Recs { unsigned long long* rows; unsigned long long* cols; uint32_t* w; };
 struct B2Item { uint32_t X, Y, cls, begin, end; };
 
 constexpr int B2_WAVES = 4;
@@ -594,7 +600,7 @@ struct B2Params {
     uint32_t dec_cap;             // decoded ids per batch (>= maxn_pad)
     uint32_t nctr;                // 2 * number of buckets
     uint32_t* table;              // [n_segs][nctr]: count mode writes counts, emit mode reads record bases
-    B2Rec* rec;
+    B2Recs rec;
     const uint32_t* w;            // on-disk weights, DFS order
 };
 
@@ -779,9 +785,9 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
                 const uint32_t b = (bX * (bX + 1) / 2 + bY) * 2 + cls;
                 const uint32_t slot = atomicAdd(&S.ctr[b], 1u);
                 if (EMIT) {
-                    B2Rec r;
-                    r.rows = rows; r.cols = cols; r.w = Wj; r.pad = 0;
-                    q.rec[slot] = r;
+                    q.rec.rows[slot] = rows;
+                    if (bX != bY) q.rec.cols[slot] = cols;
+                    if (cls) q.rec.w[slot] = Wj;
                 }
             }
             lds_sync();
@@ -820,17 +826,21 @@ constexpr int B3_CHAIN = 64;       // max root-path length (in nodes) the chain 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
                                                         const uint64_t* __restrict__ bits, const uint32_t* __restrict__ perm,
-                                                        uint32_t P, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
+                                                        uint32_t P, uint32_t short_max, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
                                                         uint32_t* __restrict__ pair_ofs, uint8_t* __restrict__ pair_blk,
                                                         unsigned long long* __restrict__ pair_mask) {
     // output per node: the first (block, mask) pair inline — p0_info = block | npairs << 8 — and any
     // further pairs in a CSR side array (pair_ofs counts only the extra pairs)
+    // two launches cover the nodes: perm == nullptr walks ALL nodes in DFS order (coalesced) and skips the
+    // ones with more than short_max local ids; those few are listed in perm, longest first, and decoded
+    // by the second launch so that no wave waits on one long stream
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P) return;
-    const uint32_t i = perm[t];
+    const uint32_t i = perm ? perm[t] : t;
     const uint4 m = meta[i];
     const uint32_t l = m.y;
-    uint32_t out = COUNT ? 0u : pair_ofs[i];
+    if (!perm && l > short_max) return;
+    uint32_t out = 0;
     uint32_t npairs = 0, blk0 = 0;
     unsigned long long mask0 = 0;
     if (l) {
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
         for (uint32_t k = 0; k < l; ++k) {
             const uint32_t blk = id >> 6;
             if (blk != curblk) {
-                if (npairs == 0) { blk0 = curblk; mask0 = acc; }
+                if (npairs == 0) { blk0 = curblk; mask0 = acc; if (!COUNT) out = pair_ofs[i]; }
                 else { if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; } ++out; }
                 ++npairs;
                 curblk = blk; acc = 0;
@@ -864,7 +874,7 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
 }
 
 struct B3Params {
-    const uint4* meta;
+    const uint32_t* nl;            // n | l << 16 per node
     const int32_t* parent;
     const uint32_t* w;
     const Segment* segs;
@@ -879,7 +889,7 @@ struct B3Params {
     uint32_t maxn_pad;
     uint32_t nctr;
     uint32_t* table;
-    B2Rec* rec;
+    B2Recs rec;
     uint32_t dbg;
     unsigned long long* counters;
 };
@@ -958,7 +968,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
             }
         }
         if (on) {
-            const uint32_t nn = q.meta[node].x;
+            const uint32_t nn = q.nl[node] & 0xFFFFu;
 #pragma unroll
             for (int w = 0; w < NBW; ++w) chain[(size_t)lane * NBW + w] = F[w];
             chain_n[lane] = nn;
@@ -971,14 +981,14 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     const bool prof = (q.dbg & 32u) != 0;
     unsigned long long t_load = 0, t_dbl = 0, t_emit = 0, t_chain = 0, t0 = 0, t1 = 0;
     // node records of the NEXT batch are fetched while the current one is processed
-    uint4 nx_m = make_uint4(0, 0, 0, 0);
+    uint32_t nx_nl = 0;
     uint32_t nx_w = 0, nx_info = 0;
     int32_t nx_par = -1;
     unsigned long long nx_m0 = 0;
     auto fetch = [&](uint32_t b0) {
         const uint32_t ii = b0 + lane;
         const bool v = ii < end;
-        nx_m = v ? q.meta[ii] : make_uint4(0, 0, 0, 0);
+        nx_nl = v ? q.nl[ii] : 0u;
         nx_w = v ? q.w[ii] : 0u;
         nx_par = v ? q.parent[ii] : -1;
         nx_info = v ? q.p0_info[ii] : 0u;
@@ -989,7 +999,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         if (prof) t0 = __builtin_amdgcn_s_memtime();
         const uint32_t idx = base + lane;
         const bool valid = idx < end;
-        const uint4 m = nx_m;
+        const uint2 m = make_uint2(nx_nl & 0xFFFFu, nx_nl >> 16);     // x = n, y = l
         const uint32_t wj = nx_w;
         const int32_t par = nx_par;
         const uint32_t info = nx_info;
@@ -1061,10 +1071,10 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
                     if (!(bal | bah)) continue;
                     const uint32_t base0 = bcast(mybase, 2 * Y), base1 = bcast(mybase, 2 * Y + 1);
                     if (a) {
-                        B2Rec r;
-                        r.rows = F[X]; r.cols = F[Y]; r.w = wj; r.pad = 0;
                         const uint32_t slot = heavy ? base1 + (uint32_t)__popcll(bah & lt_mask) : base0 + (uint32_t)__popcll(bal & lt_mask);
-                        q.rec[slot] = r;
+                        q.rec.rows[slot] = F[X];
+                        if (X != Y) q.rec.cols[slot] = F[Y];
+                        if (heavy) q.rec.w[slot] = wj;
                     }
                 }
             }
@@ -1120,7 +1130,7 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
-__global__ __launch_bounds__(256) void b2_apply_kernel(const B2Rec* __restrict__ rec, const B2Item* __restrict__ items,
+__global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B2Item* __restrict__ items,
                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t dbg) {
     __shared__ uint32_t acc[64 * 64];
     const B2Item it = items[blockIdx.x];
@@ -1134,7 +1144,11 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Rec* __restrict__
         const uint32_t j = g0 + lane;
         unsigned long long R = 0, C = 0;
         uint32_t W = 0;
-        if (j < it.end) { const B2Rec r = rec[j]; R = r.rows; C = r.cols; W = r.w; }
+        if (j < it.end) {
+            R = rec.rows[j];
+            C = diag ? R : rec.cols[j];
+            W = it.cls ? rec.w[j] : 1u;
+        }
         // lane c: bit j of Ct = record j contains column c
         const unsigned long long Ct = transpose64(C, lane);
         if (!__ballot(R != 0)) continue;
@@ -1283,7 +1297,7 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
     q.a.wprefix = db->wprefix; q.a.bits = db->bits; q.a.segs = db->segs;
     q.a.seg_begin = seg_begin; q.a.seg_end = seg_end; q.a.dbg = dbg; q.a.counters = db->counters;
     q.maxn_pad = db->b2_maxn_pad; q.dec_cap = db->b2_dec_cap; q.nctr = db->b2_nctr;
-    q.table = db->b2_table; q.rec = (B2Rec*)db->b2_rec; q.w = db->w;
+    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}; q.w = db->w;
     const size_t lds = b2_lds_per_wave(q.maxn_pad, q.dec_cap, q.nctr) * B2_WAVES;
     HIP_TRY(hipFuncSetAttribute((const void*)b2_emit_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t nseg = seg_end - seg_begin;
@@ -1293,19 +1307,15 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
     return 0;
 }
 
-// Decide whether the database qualifies for the block-record pipeline and, if so, tabulate the
-// per-(segment, bucket) record counts with the count mode of the emit kernel (layout metadata:
-// a pure function of the database, like CSR row pointers), turn them into record bases and cut
-// the buckets into work items for the apply kernel.
 template <int NBW, bool EMIT>
 int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg) {
     B3Params q{};
-    q.meta = db->meta; q.parent = db->parent; q.w = db->w; q.segs = db->segs;
+    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.segs = db->segs;
     q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
     q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
     q.pair_ofs = db->b3_pair_ofs; q.pair_blk = db->b3_pair_blk; q.pair_mask = db->b3_pair_mask;
     q.n_segs = db->n_segs; q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr;
-    q.table = db->b2_table; q.rec = (B2Rec*)db->b2_rec; q.dbg = dbg; q.counters = db->counters;
+    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}; q.dbg = dbg; q.counters = db->counters;
     const size_t lds = b3_wave_bytes(NBW, q.maxn_pad, q.nctr) * B3_WAVES;
     HIP_TRY(hipFuncSetAttribute((const void*)b3_emit_kernel<NBW, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t blocks = (db->n_segs + B3_WAVES - 1) / B3_WAVES;
@@ -1324,7 +1334,12 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
     const uint32_t P = (uint32_t)db->P;
     if (P)
         hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
-                           db->b3_perm, P, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
+                           (const uint32_t*)nullptr, P, db->b3_short_max, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs,
+                           db->b3_pair_blk, db->b3_pair_mask);
+    if (db->b3_n_long)
+        hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((db->b3_n_long + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos,
+                           db->bits, (const uint32_t*)db->b3_perm, db->b3_n_long, db->b3_short_max, db->b3_p0_mask, db->b3_p0_info,
+                           db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1333,7 +1348,7 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
 // per-(segment, bucket) record counts with the count mode of the emit kernel (layout metadata:
 // a pure function of the database, like CSR row pointers), turn them into record bases and cut
 // the buckets into work items for the apply kernel.
-int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uint32_t>& perm,
+int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uint32_t>& perm, const std::vector<uint32_t>& nl,
                const std::vector<uint32_t>& seg_anc, const std::vector<uint32_t>& seg_anc_n) {
     const uint64_t N = db->N, P = db->P;
     if (N < 2 || P == 0 || N > 2048 || max_n > 1024) return 0;
@@ -1349,8 +1364,11 @@ int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uin
     if (use_b3) {
         // K0 count pass -> pair offsets -> K0 emit (the pairs are needed by the record count pass below)
         db->b3_nbw = NB <= 16 ? 16 : 32;
-        HIP_TRY(hipMalloc((void**)&db->b3_perm, P * 4));
-        HIP_TRY(hipMemcpy(db->b3_perm, perm.data(), P * 4, hipMemcpyHostToDevice));
+        db->b3_n_long = (uint32_t)perm.size();
+        HIP_TRY(hipMalloc((void**)&db->b3_perm, std::max<size_t>(perm.size(), 1) * 4));
+        if (!perm.empty()) HIP_TRY(hipMemcpy(db->b3_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&db->b3_nl, P * 4));
+        HIP_TRY(hipMemcpy(db->b3_nl, nl.data(), P * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&db->b3_pair_ofs, (P + 1) * 4));
         HIP_TRY(hipMalloc((void**)&db->b3_p0_mask, P * 8));
         HIP_TRY(hipMalloc((void**)&db->b3_p0_info, P * 2));
@@ -1405,7 +1423,9 @@ int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uin
                 for (uint64_t b = cstart[c]; b < cstart[c + 1]; b += CH)
                     items.push_back({X, Y, cls, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + CH, cstart[c + 1])});
     HIP_TRY(hipMemcpy(db->b2_table, bases.data(), tbl * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&db->b2_rec, std::max<uint64_t>(run, 1) * sizeof(B2Rec)));
+    HIP_TRY(hipMalloc((void**)&db->b2_rec_rows, std::max<uint64_t>(run, 1) * 8));
+    HIP_TRY(hipMalloc((void**)&db->b2_rec_cols, std::max<uint64_t>(run, 1) * 8));
+    HIP_TRY(hipMalloc((void**)&db->b2_rec_w, std::max<uint64_t>(run, 1) * 4));
     HIP_TRY(hipMalloc(&db->b2_items, std::max<size_t>(items.size(), 1) * sizeof(B2Item)));
     if (!items.empty()) HIP_TRY(hipMemcpy(db->b2_items, items.data(), items.size() * sizeof(B2Item), hipMemcpyHostToDevice));
     db->b2_n_items = (uint32_t)items.size();
@@ -1586,22 +1606,20 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
             depth[i] = (uint16_t)d;
             max_depth = std::max(max_depth, d);
         }
-        // K0 visits nodes in order of decreasing local-list length INSIDE windows of consecutive DFS nodes:
-        // lanes of a wave decode streams of similar length, and all accesses stay in a small address window
-        std::vector<uint32_t> perm(P);
+        // K0: nodes with more than 32 local ids (a few percent) are decoded by a second launch, longest first
+        const uint32_t SHORT_MAX = 32;
+        std::vector<uint32_t> perm, nl(P);
         {
-            uint64_t WIN = 262144;
-            if (const char* e = getenv("KMDB_K0_WINDOW")) { WIN = strtoull(e, nullptr, 10); if (!WIN) WIN = P ? P : 1; }
-            std::vector<uint32_t> cntl;
-            for (uint64_t w0 = 0; w0 < P; w0 += WIN) {
-                const uint64_t w1 = std::min<uint64_t>(P, w0 + WIN);
-                uint32_t ml = 0;
-                for (uint64_t i = w0; i < w1; ++i) ml = std::max(ml, meta[i].y);
-                cntl.assign((size_t)ml + 2, 0);
-                for (uint64_t i = w0; i < w1; ++i) ++cntl[ml - meta[i].y + 1];
-                for (uint32_t b = 1; b < cntl.size(); ++b) cntl[b] += cntl[b - 1];
-                for (uint64_t i = w0; i < w1; ++i) perm[w0 + cntl[ml - meta[i].y]++] = (uint32_t)i;
+            std::vector<uint32_t> cntl(max_n + 2, 0);
+            uint64_t nlong = 0;
+            for (uint64_t i = 0; i < P; ++i) {
+                nl[i] = meta[i].x | (meta[i].y << 16);
+                if (meta[i].y > SHORT_MAX) { ++cntl[max_n - meta[i].y + 1]; ++nlong; }
             }
+            for (uint32_t b = 1; b < cntl.size(); ++b) cntl[b] += cntl[b - 1];
+            perm.resize(nlong);
+            for (uint64_t i = 0; i < P; ++i)
+                if (meta[i].y > SHORT_MAX) perm[cntl[max_n - meta[i].y]++] = (uint32_t)i;
         }
         std::vector<uint32_t> seg_anc, seg_anc_n(segs.size(), 0);
         const bool chain_ok = max_depth <= (uint32_t)B3_CHAIN;
@@ -1615,9 +1633,9 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
                 while (cur >= 0) { seg_anc[sidx * B3_CHAIN + (--d)] = (uint32_t)cur; cur = parent[cur]; }
             }
         }
-        if (b2_prepare(db, max_n, chain_ok, perm, seg_anc, seg_anc_n)) { kmdb_db_free(db); return 1; }
+        if (b2_prepare(db, max_n, chain_ok, perm, nl, seg_anc, seg_anc_n)) { kmdb_db_free(db); return 1; }
     }
-    db->stats.device_bytes += db->b2_total * sizeof(B2Rec) + (uint64_t)db->n_segs * db->b2_nctr * 4;
+    db->stats.device_bytes += db->b2_total * 20 + (uint64_t)db->n_segs * db->b2_nctr * 4;
     *out = db;
     return 0;
 }
@@ -1626,9 +1644,9 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
     void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->scan_tmp,
-                    db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec,
+                    db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w,
                     db->b2_items, db->b3_perm, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask, db->b3_seg_anc,
-                    db->b3_seg_anc_n, db->b3_p0_mask, db->b3_p0_info};
+                    db->b3_seg_anc_n, db->b3_p0_mask, db->b3_p0_info, db->b3_nl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_k2) if (e) (void)hipEventDestroy(e);
@@ -1712,8 +1730,8 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
         }
         HIP_TRY(hipEventRecord(db->ev_k2[0], st));
         if (db->b2_n_items && !(p.dbg & 2))
-            hipLaunchKernelGGL(b2_apply_kernel, dim3(db->b2_n_items), dim3(256), 0, st, (const B2Rec*)db->b2_rec,
-                               (const B2Item*)db->b2_items, M, (uint32_t)N, p.dbg);
+            hipLaunchKernelGGL(b2_apply_kernel, dim3(db->b2_n_items), dim3(256), 0, st,
+                               B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}, (const B2Item*)db->b2_items, M, (uint32_t)N, p.dbg);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(db->ev_k2[1], st));
         HIP_TRY(hipEventRecord(db->ev[2], st));
