@@ -22,6 +22,7 @@ engine itself only ever sees the resulting kmdb_db_view.
 """
 import math
 import struct
+import sys
 
 import numpy as np
 import torch
@@ -228,7 +229,7 @@ def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progre
             target[new] = ids
             cur[slot[perm]] = torch.repeat_interleave(target, cnt).to(torch.int32)
         if progress and (s + 1) % progress == 0:
-            print("  synth build: %d/%d samples, %d patterns" % (s + 1, n_samples, here.n), flush=True)
+            print("  synth build: %d/%d samples, %d patterns" % (s + 1, n_samples, here.n), file=sys.stderr, flush=True)
 
     P = here.n
     ev_pid = torch.cat(ev_pid) if ev_pid else torch.zeros(0, dtype=torch.int32, device=dev)
