@@ -102,6 +102,7 @@ struct kmdb_db {
     // v2 (block record) pipeline state, built at upload when the database qualifies
     bool b2_ready = false;
     uint32_t b2_maxn_pad = 0, b2_dec_cap = 0, b2_nctr = 0, b2_n_items = 0;
+    uint32_t b2_width = 64;             // sample ids per block (<= 64), chosen at upload
     uint32_t* b2_table = nullptr;       // [n_segs][nctr] record bases
     unsigned long long* b2_rec_rows = nullptr;   // [total]
     unsigned long long* b2_rec_cols = nullptr;   // [total]
@@ -225,10 +226,24 @@ __device__ __forceinline__ void decode_node(const uint64_t* __restrict__ bits, u
     out[l - 1] = (T)last;
 }
 
-// decode_node plus, per id, the running bit mask of the ids of the same 64-id block seen so far
+// Sample ids are grouped into blocks of `width` (<= 64) consecutive ids; the width is chosen per database
+// at upload (a narrower block that matches the cluster structure of the samples means fewer block records).
+struct BlockMap {
+    uint32_t width, magic;                          // magic = floor(2^32 / width) + 1: exact division for ids < 2^16
+    __host__ __device__ __forceinline__ uint32_t blk(uint32_t id) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __umulhi(id, magic);
+#else
+        return id / width;
+#endif
+    }
+    __host__ __device__ __forceinline__ uint32_t bit(uint32_t id, uint32_t b) const { return id - b * width; }
+};
+
+// decode_node plus, per id, the running bit mask of the ids of the same block seen so far
 // in this node ("cum"): the block-record kernel needs it per stack position.
 __device__ __forceinline__ void decode_node_cum(const uint64_t* __restrict__ bits, uint64_t pos, uint32_t l, uint32_t last,
-                                                uint16_t* out, unsigned long long* cum) {
+                                                uint16_t* out, unsigned long long* cum, const BlockMap bm) {
     if (l == 0) return;
     uint32_t id = last;
     if (l > 1) {
@@ -245,9 +260,9 @@ __device__ __forceinline__ void decode_node_cum(const uint64_t* __restrict__ bit
     unsigned long long acc = 0;
     for (uint32_t i = 0; i < l; ++i) {
         const uint32_t d = (i + 1 < l) ? (uint32_t)out[i] : 0u;
-        const uint32_t blk = id >> 6;
+        const uint32_t blk = bm.blk(id);
         if (blk != curblk) { curblk = blk; acc = 0; }
-        acc |= 1ull << (id & 63u);
+        acc |= 1ull << bm.bit(id, blk);
         out[i] = (uint16_t)id;
         cum[i] = acc;
         id += d;
@@ -599,6 +614,7 @@ struct B2Params {
     uint32_t maxn_pad;            // stack capacity (multiple of 64)
     uint32_t dec_cap;             // decoded ids per batch (>= maxn_pad)
     uint32_t nctr;                // 2 * number of buckets
+    BlockMap bm;
     uint32_t* table;              // [n_segs][nctr]: count mode writes counts, emit mode reads record bases
     B2Recs rec;
     const uint32_t* w;            // on-disk weights, DFS order
@@ -631,7 +647,7 @@ __host__ __device__ inline size_t b2_wave_bytes(uint32_t maxn_pad, uint32_t dec_
 
 // extend the stack from `top` to `n` with the ids dec[off ..) / masks dcum[off ..); returns through refs
 // what record emission needs.  All arguments wave-uniform.
-__device__ __forceinline__ void b2_push(B2Wave& S, uint32_t top, uint32_t n, uint32_t off, uint32_t lane,
+__device__ __forceinline__ void b2_push(B2Wave& S, const BlockMap bm, uint32_t top, uint32_t n, uint32_t off, uint32_t lane,
                                         uint32_t& nbk, bool& first_is_head, unsigned long long& seed) {
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t prev_blk = 0xFFu;
@@ -643,9 +659,9 @@ __device__ __forceinline__ void b2_push(B2Wave& S, uint32_t top, uint32_t n, uin
     if (n - top == 1) {
         // the common case (every internal trie node): one new id
         const uint32_t id = S.dec[off];
-        const uint32_t blk = __builtin_amdgcn_readfirstlane(id >> 6);
+        const uint32_t blk = __builtin_amdgcn_readfirstlane(bm.blk(id));
         first_is_head = blk != prev_blk;
-        const unsigned long long v = (1ull << (id & 63u)) | (first_is_head ? 0ull : seed);
+        const unsigned long long v = (1ull << bm.bit(id, blk)) | (first_is_head ? 0ull : seed);
         if (lane == 0) {
             S.cum[top] = v;
             S.pblk[top] = (uint8_t)blk;
@@ -663,7 +679,7 @@ __device__ __forceinline__ void b2_push(B2Wave& S, uint32_t top, uint32_t n, uin
         const bool act = p < n;
         const uint32_t id = act ? S.dec[off + (p - top)] : 0u;
         unsigned long long v = act ? S.dcum[off + (p - top)] : 0ull;
-        const uint32_t blk = id >> 6;
+        const uint32_t blk = bm.blk(id);
         uint32_t pb = (uint32_t)__shfl_up((int)blk, 1, WAVE);
         if (lane == 0) pb = carry_blk;
         const bool head = act && (blk != pb);
@@ -727,14 +743,14 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
             uint32_t curblk = 0xFFFFFFFFu;
             unsigned long long acc = 0;
             for (uint32_t i = 0; i < depth; ++i) {
-                const uint32_t id = S.dec[i], blk = id >> 6;
+                const uint32_t id = S.dec[i], blk = q.bm.blk(id);
                 if (blk != curblk) { curblk = blk; acc = 0; }
-                acc |= 1ull << (id & 63u);
+                acc |= 1ull << q.bm.bit(id, blk);
                 S.dcum[i] = acc;
             }
         }
         lds_sync();
-        if (depth) b2_push(S, 0, depth, 0, lane, nbk, first_is_head, seed);
+        if (depth) b2_push(S, q.bm, 0, depth, 0, lane, nbk, first_is_head, seed);
         lds_sync();
     }
 
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
         cnt = __builtin_amdgcn_readfirstlane(cnt);      // >= 1: dec_cap >= the longest list
         const uint32_t off = incl - l;
         if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_load += t1 - t0; t0 = t1; }
-        if (lane < cnt) decode_node_cum(p.bits, bp, l, m.z, S.dec + off, S.dcum + off);
+        if (lane < cnt) decode_node_cum(p.bits, bp, l, m.z, S.dec + off, S.dcum + off, q.bm);
         lds_sync();
         if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_dec += t1 - t0; }
         for (uint32_t j = 0; j < cnt; ++j) {
@@ -762,7 +778,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
             const uint32_t top = nj - lj;
             if (lj == 0) continue;
             if (prof) t0 = __builtin_amdgcn_s_memtime();
-            b2_push(S, top, nj, oj, lane, nbk, first_is_head, seed);
+            b2_push(S, q.bm, top, nj, oj, lane, nbk, first_is_head, seed);
             if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_push += t1 - t0; t0 = t1; }
             if (Wj == 0 || nj < 2) continue;
             // ---- FLAT form (all2all_sp semantics, reference similarity_calculator.cpp:596-638): a pattern with
@@ -826,7 +842,7 @@ constexpr int B3_CHAIN = 64;       // max root-path length (in nodes) the chain 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
                                                         const uint64_t* __restrict__ bits, const uint32_t* __restrict__ perm,
-                                                        uint32_t P, uint32_t short_max, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
+                                                        uint32_t P, uint32_t short_max, BlockMap bm, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
                                                         uint32_t* __restrict__ pair_ofs, uint8_t* __restrict__ pair_blk,
                                                         unsigned long long* __restrict__ pair_mask) {
     // output per node: the first (block, mask) pair inline — p0_info = block | npairs << 8 — and any
@@ -852,17 +868,17 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
             id = m.z - sum;
         }
         BitCursor c2(bits, bitpos[i]);
-        uint32_t curblk = id >> 6;
+        uint32_t curblk = bm.blk(id);
         unsigned long long acc = 0;
         for (uint32_t k = 0; k < l; ++k) {
-            const uint32_t blk = id >> 6;
+            const uint32_t blk = bm.blk(id);
             if (blk != curblk) {
                 if (npairs == 0) { blk0 = curblk; mask0 = acc; if (!COUNT) out = pair_ofs[i]; }
                 else { if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; } ++out; }
                 ++npairs;
                 curblk = blk; acc = 0;
             }
-            acc |= 1ull << (id & 63u);
+            acc |= 1ull << bm.bit(id, blk);
             if (k + 1 < l) id += c2.next();
         }
         if (npairs == 0) { blk0 = curblk; mask0 = acc; }
@@ -895,7 +911,7 @@ struct B3Params {
 };
 
 __host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr) {
-    size_t b = (size_t)B3_CHAIN * nbw * 8 + (size_t)nctr * 4 + B3_CHAIN * 4 + (maxn_pad + 64);
+    size_t b = (size_t)B3_CHAIN * nbw * 8 + (size_t)nctr * 4 + B3_CHAIN * 4 * 2 + (maxn_pad + 64);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -905,6 +921,154 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int s
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// per-wave context of the emit kernel (LDS pointers + lane constants)
+struct B3Ctx {
+    unsigned long long* chain;     // [B3_CHAIN][NBW] full masks of the nodes on the current root path
+    uint32_t* chain_nz;            // [B3_CHAIN] which words of the slot are meaningful (others may be stale)
+    uint32_t* chain_n;             // [B3_CHAIN] list length of the node in the slot
+    uint8_t* slot_of_n;            // list length -> slot
+    uint32_t* ctr;                 // record cursors per (bucket, class)
+    uint32_t lane;
+    unsigned long long lt_mask;
+};
+
+struct B3Lane {                    // one node per lane
+    bool valid;
+    uint32_t n, l, w, info, idx;
+    int32_t par;
+    unsigned long long m0;
+};
+
+// One batch of 64 consecutive DFS nodes.  Every lane keeps the full-list masks of its node in W 64-bit
+// registers.  W == NBW with IDENT: register s is word s.  Otherwise the batch only touches ku <= W distinct
+// words (the usual case: one or two clades) and register s holds word wl[s] — the work then does not grow
+// with the number of blocks of the matrix.
+template <int W, bool IDENT, int NBW, bool EMIT>
+__device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, const B3Lane& L, uint32_t base, uint32_t end,
+                                         uint32_t U, const uint32_t (&wl)[W], uint32_t ku, uint32_t rootslot, uint32_t inh) {
+    const uint32_t lane = C.lane;
+    auto slot_of_word = [&](uint32_t wd) -> uint32_t { return IDENT ? wd : (uint32_t)__popc(U & ((1u << wd) - 1u)); };
+    unsigned long long F[W];
+    const uint32_t b0 = L.info & 0xFFu, np = L.info >> 8;
+    {
+        const uint32_t s0 = slot_of_word(b0);
+#pragma unroll
+        for (int s = 0; s < W; ++s) F[s] = (np != 0 && s0 == (uint32_t)s) ? L.m0 : 0ull;
+        if (__ballot(np > 1)) {
+            const uint32_t po = np > 1 ? q.pair_ofs[L.idx] : 0u;
+            uint32_t mx = np > 1 ? np - 1 : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
+            mx = __builtin_amdgcn_readfirstlane(mx);
+            for (uint32_t t = 0; t < mx; ++t) {
+                if (t + 1 < np) {
+                    const uint32_t sb = slot_of_word(q.pair_blk[po + t]);
+                    const unsigned long long mk = q.pair_mask[po + t];
+#pragma unroll
+                    for (int s = 0; s < W; ++s) F[s] |= (sb == (uint32_t)s) ? mk : 0ull;
+                }
+            }
+        }
+    }
+    const bool inb = L.valid && L.par >= (int32_t)base;
+    int pl = inb ? (int)(L.par - (int32_t)base) : -1;
+    const int plo = pl;
+    if (rootslot != 0xFFFFFFFFu) {
+        // parent precedes the batch: it is on the root path of the previous batch's last node
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            if (!IDENT && (uint32_t)s >= ku) break;
+            const uint32_t wd = IDENT ? (uint32_t)s : wl[s];
+            if ((inh >> wd) & 1u) F[s] |= C.chain[(size_t)rootslot * NBW + wd];
+        }
+    }
+    // ---- pointer doubling over in-batch parents
+    while (__ballot(pl >= 0)) {
+        const int src = pl >= 0 ? pl : (int)lane;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            if (!IDENT && (uint32_t)s >= ku) break;
+            const unsigned long long o = shfl64(F[s], src);
+            if (pl >= 0) F[s] |= o;
+        }
+        const int npl = __shfl(pl, src, WAVE);
+        pl = pl >= 0 ? npl : -1;
+    }
+    // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
+    const bool act = L.valid && L.w != 0 && L.n >= 2 && !(q.dbg & 512u);
+    const bool heavy = L.w != 1u;
+    uint32_t mywl = 0;               // word of register (lane >> 1): lane 2*sY + c owns the counter of combo (X, Y, c)
+    if (IDENT) mywl = lane >> 1;
+    else {
+#pragma unroll
+        for (int s = 0; s < W; ++s) if ((lane >> 1) == (uint32_t)s) mywl = wl[s];
+    }
+    uint32_t Ua = act ? 1u : 0u;     // does any lane emit at all
+    if (!__ballot(Ua != 0)) goto chain_update;
+#pragma unroll
+    for (int sX = 0; sX < W; ++sX) {
+        if (!IDENT && (uint32_t)sX >= ku) break;
+        const uint32_t X = IDENT ? (uint32_t)sX : wl[sX];
+        const bool ax = act && F[sX] != 0;
+        if (!__ballot(ax)) continue;
+        uint32_t mycnt = 0;
+#pragma unroll
+        for (int sY = 0; sY <= sX; ++sY) {
+            const bool a = ax && F[sY] != 0;
+            const uint32_t c0 = (uint32_t)__popcll(__ballot(a && !heavy));
+            const uint32_t c1 = (uint32_t)__popcll(__ballot(a && heavy));
+            if (lane == (uint32_t)(2 * sY)) mycnt = c0;
+            if (lane == (uint32_t)(2 * sY + 1)) mycnt = c1;
+        }
+        uint32_t mybase = 0;
+        if (mycnt) mybase = atomicAdd(&C.ctr[(X * (X + 1) / 2 + mywl) * 2 + (lane & 1u)], mycnt);
+        if (EMIT && !(q.dbg & 256u)) {
+#pragma unroll
+            for (int sY = 0; sY <= sX; ++sY) {
+                const bool a = ax && F[sY] != 0;
+                const unsigned long long bal = __ballot(a && !heavy), bah = __ballot(a && heavy);
+                if (!(bal | bah)) continue;
+                const uint32_t base0 = bcast(mybase, 2 * sY), base1 = bcast(mybase, 2 * sY + 1);
+                if (a) {
+                    const uint32_t slot = heavy ? base1 + (uint32_t)__popcll(bah & C.lt_mask) : base0 + (uint32_t)__popcll(bal & C.lt_mask);
+                    q.rec.rows[slot] = F[sX];
+                    if (sX != sY) q.rec.cols[slot] = F[sY];
+                    if (heavy) q.rec.w[slot] = L.w;
+                }
+            }
+        }
+    }
+chain_update:
+    // ---- chain table for the next batch: root path of this batch's last node
+    if (base + WAVE < end) {
+        const uint32_t nvalid = (end - base) < (uint32_t)WAVE ? (end - base) : (uint32_t)WAVE;
+        unsigned long long anc = 0;
+        int cur = (int)nvalid - 1;
+        while (cur >= 0) { anc |= 1ull << cur; cur = __builtin_amdgcn_readlane(plo, cur); }
+        const uint32_t r = (uint32_t)__builtin_ctzll(anc);                 // in-batch root of that path
+        const int32_t rpar = __builtin_amdgcn_readlane(L.par, (int)r);
+        const uint32_t rtop = bcast(L.n - L.l, r);
+        const uint32_t kept = rpar >= 0 ? (uint32_t)C.slot_of_n[rtop] + 1u : 0u;
+        lds_sync();
+        if ((anc >> lane) & 1ull) {
+            const uint32_t slot = kept + (uint32_t)__popcll(anc & C.lt_mask);
+            uint32_t nzw = 0;
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                if (!IDENT && (uint32_t)s >= ku) break;
+                const uint32_t wd = IDENT ? (uint32_t)s : wl[s];
+                if (F[s] != 0) { C.chain[(size_t)slot * NBW + wd] = F[s]; nzw |= 1u << wd; }
+            }
+            C.chain_nz[slot] = nzw;
+            C.chain_n[slot] = L.n;
+            C.slot_of_n[L.n] = (uint8_t)slot;
+        }
+        lds_sync();
+    }
+}
+
+constexpr int B3_K = 8;            // word registers of the compact path
+
 template <int NBW, bool EMIT>
 __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -913,52 +1077,48 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     const uint32_t seg = blockIdx.x * B3_WAVES + wave;
     if (seg >= q.n_segs) return;
     unsigned char* basep = lds_raw + b3_wave_bytes(NBW, q.maxn_pad, q.nctr) * wave;
-    unsigned long long* chain = (unsigned long long*)basep;            // [B3_CHAIN][NBW]
-    uint32_t* ctr = (uint32_t*)(chain + (size_t)B3_CHAIN * NBW);       // [nctr]
-    uint32_t* chain_n = ctr + q.nctr;                                  // [B3_CHAIN] list length of the node in the slot
-    uint8_t* slot_of_n = (uint8_t*)(chain_n + B3_CHAIN);               // [maxn_pad + 64]
+    B3Ctx C;
+    C.chain = (unsigned long long*)basep;                                  // [B3_CHAIN][NBW]
+    C.ctr = (uint32_t*)(C.chain + (size_t)B3_CHAIN * NBW);                 // [nctr]
+    C.chain_n = C.ctr + q.nctr;                                            // [B3_CHAIN]
+    C.chain_nz = C.chain_n + B3_CHAIN;                                     // [B3_CHAIN]
+    C.slot_of_n = (uint8_t*)(C.chain_nz + B3_CHAIN);                       // [maxn_pad + 64]
+    C.lane = lane;
+    C.lt_mask = (1ull << lane) - 1ull;
     uint32_t* my_table = q.table + (size_t)seg * q.nctr;
-    for (uint32_t k = lane; k < q.nctr; k += WAVE) ctr[k] = EMIT ? my_table[k] : 0u;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t k = lane; k < q.nctr; k += WAVE) C.ctr[k] = EMIT ? my_table[k] : 0u;
 
     const Segment sg = q.segs[seg];
     const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
     const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
     if (first >= end) return;
 
-    // pairs beyond a node's first one (nodes whose local ids span several 64-id blocks)
-    auto load_extra = [&](uint32_t node, uint32_t np, unsigned long long (&F)[NBW]) {
-        const uint32_t po = np > 1 ? q.pair_ofs[node] : 0u;
-        uint32_t mx = np > 1 ? np - 1 : 0u;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
-        mx = __builtin_amdgcn_readfirstlane(mx);
-        for (uint32_t t = 0; t < mx; ++t) {
-            if (t + 1 < np) {
-                const uint32_t b = q.pair_blk[po + t];
-                const unsigned long long mk = q.pair_mask[po + t];
-#pragma unroll
-                for (int w = 0; w < NBW; ++w) F[w] |= (b == (uint32_t)w) ? mk : 0ull;
-            }
-        }
-    };
-    auto load_local = [&](uint32_t node, bool on, unsigned long long (&F)[NBW]) {
-        const uint32_t info = on ? q.p0_info[node] : 0u;
-        const unsigned long long m0 = on ? q.p0_mask[node] : 0ull;
-        const uint32_t b0 = info & 0xFFu, np = info >> 8;
-#pragma unroll
-        for (int w = 0; w < NBW; ++w) F[w] = (np != 0 && b0 == (uint32_t)w) ? m0 : 0ull;
-        if (__ballot(np > 1)) load_extra(node, np, F);
-    };
-
     // ---- chain table for the first node: the ancestors' full masks = inclusive OR-scan along the root path
-    uint32_t nchain = 0;
     {
         const uint32_t d = q.seg_anc_n[seg];
         unsigned long long F[NBW];
         const bool on = lane < d;
         const uint32_t node = on ? q.seg_anc[(size_t)seg * B3_CHAIN + lane] : 0u;
-        load_local(node, on, F);
+        const uint32_t info = on ? q.p0_info[node] : 0u;
+        const unsigned long long m0 = on ? q.p0_mask[node] : 0ull;
+        const uint32_t b0 = info & 0xFFu, np = info >> 8;
+#pragma unroll
+        for (int w = 0; w < NBW; ++w) F[w] = (np != 0 && b0 == (uint32_t)w) ? m0 : 0ull;
+        if (__ballot(np > 1)) {
+            const uint32_t po = np > 1 ? q.pair_ofs[node] : 0u;
+            uint32_t mx = np > 1 ? np - 1 : 0u;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, dd, WAVE); mx = o > mx ? o : mx; }
+            mx = __builtin_amdgcn_readfirstlane(mx);
+            for (uint32_t t = 0; t < mx; ++t) {
+                if (t + 1 < np) {
+                    const uint32_t b = q.pair_blk[po + t];
+                    const unsigned long long mk = q.pair_mask[po + t];
+#pragma unroll
+                    for (int w = 0; w < NBW; ++w) F[w] |= (b == (uint32_t)w) ? mk : 0ull;
+                }
+            }
+        }
 #pragma unroll
         for (int s = 1; s < WAVE; s <<= 1) {
 #pragma unroll
@@ -969,20 +1129,18 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         }
         if (on) {
             const uint32_t nn = q.nl[node] & 0xFFFFu;
+            uint32_t nzw = 0;
 #pragma unroll
-            for (int w = 0; w < NBW; ++w) chain[(size_t)lane * NBW + w] = F[w];
-            chain_n[lane] = nn;
-            slot_of_n[nn] = (uint8_t)lane;
+            for (int w = 0; w < NBW; ++w) { C.chain[(size_t)lane * NBW + w] = F[w]; nzw |= (F[w] != 0 ? 1u : 0u) << w; }
+            C.chain_nz[lane] = nzw;
+            C.chain_n[lane] = nn;
+            C.slot_of_n[nn] = (uint8_t)lane;
         }
-        nchain = d;
         lds_sync();
     }
 
-    const bool prof = (q.dbg & 32u) != 0;
-    unsigned long long t_load = 0, t_dbl = 0, t_emit = 0, t_chain = 0, t0 = 0, t1 = 0;
     // node records of the NEXT batch are fetched while the current one is processed
-    uint32_t nx_nl = 0;
-    uint32_t nx_w = 0, nx_info = 0;
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0;
     int32_t nx_par = -1;
     unsigned long long nx_m0 = 0;
     auto fetch = [&](uint32_t b0) {
@@ -995,122 +1153,58 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         nx_m0 = v ? q.p0_mask[ii] : 0ull;
     };
     fetch(first);
+    const bool prof = (q.dbg & 32u) != 0;
+    unsigned long long t_all = 0, t0 = 0;
+    unsigned long long n_compact = 0, n_mid = 0, n_full = 0;
     for (uint32_t base = first; base < end; base += WAVE) {
         if (prof) t0 = __builtin_amdgcn_s_memtime();
-        const uint32_t idx = base + lane;
-        const bool valid = idx < end;
-        const uint2 m = make_uint2(nx_nl & 0xFFFFu, nx_nl >> 16);     // x = n, y = l
-        const uint32_t wj = nx_w;
-        const int32_t par = nx_par;
-        const uint32_t info = nx_info;
-        const unsigned long long m0 = nx_m0;
+        B3Lane L;
+        L.idx = base + lane;
+        L.valid = L.idx < end;
+        L.n = nx_nl & 0xFFFFu; L.l = nx_nl >> 16;
+        L.w = nx_w; L.par = nx_par; L.info = nx_info; L.m0 = nx_m0;
         if (base + WAVE < end) fetch(base + WAVE);
-        unsigned long long F[NBW];
-        {
-            const uint32_t b0 = info & 0xFFu, np = info >> 8;
-#pragma unroll
-            for (int w = 0; w < NBW; ++w) F[w] = (np != 0 && b0 == (uint32_t)w) ? m0 : 0ull;
-            if (__ballot(np > 1)) load_extra(idx, np, F);
+        // words this batch touches: own local words + the words inherited from a parent before the batch
+        const uint32_t np = L.info >> 8;
+        uint32_t lw = np ? (1u << (L.info & 0xFFu)) : 0u;
+        if (__ballot(np > 1)) {
+            const uint32_t po = np > 1 ? q.pair_ofs[L.idx] : 0u;
+            for (uint32_t t = 0; t + 1 < np; ++t) lw |= 1u << q.pair_blk[po + t];
         }
-        const bool inb = valid && par >= (int32_t)base;
-        int pl = inb ? (int)(par - (int32_t)base) : -1;
-        const int plo = pl;
-        if (valid && !inb && par >= 0) {
-            // parent precedes the batch: it is on the chain of the previous batch's last node
-            const uint32_t slot = slot_of_n[m.x - m.y];
-#pragma unroll
-            for (int w = 0; w < NBW; ++w) F[w] |= chain[(size_t)slot * NBW + w];
+        uint32_t rootslot = 0xFFFFFFFFu, inh = 0;
+        if (L.valid && L.par >= 0 && L.par < (int32_t)base) {
+            rootslot = C.slot_of_n[L.n - L.l];
+            inh = C.chain_nz[rootslot];
         }
-        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_load += t1 - t0; t0 = t1; }
-        // ---- pointer doubling over in-batch parents
-        while (__ballot(pl >= 0)) {
-            const int src = pl >= 0 ? pl : (int)lane;
-#pragma unroll
-            for (int w = 0; w < NBW; ++w) {
-                const unsigned long long o = shfl64(F[w], src);
-                if (pl >= 0) F[w] |= o;
-            }
-            const int npl = __shfl(pl, src, WAVE);
-            pl = pl >= 0 ? npl : -1;
-        }
-        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_dbl += t1 - t0; t0 = t1; }
-        // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
-        const bool act = valid && wj != 0 && m.x >= 2;
-        uint32_t nzm = 0;
-#pragma unroll
-        for (int w = 0; w < NBW; ++w) nzm |= (F[w] != 0 ? 1u : 0u) << w;
-        uint32_t U = act ? nzm : 0u;
+        uint32_t U = L.valid ? (lw | inh) : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) U |= (uint32_t)__shfl_xor((int)U, d, WAVE);
         U = __builtin_amdgcn_readfirstlane(U);
-        if (q.dbg & 512u) U = 0;
-        const bool heavy = wj != 1u;
+        const uint32_t ku = (uint32_t)__popc(U);
+        if (false) {
+        } else if (ku <= (uint32_t)B3_K) {
+            uint32_t wl[B3_K];
+            uint32_t rest = U;
 #pragma unroll
-        for (int X = 0; X < NBW; ++X) {
-            if (!((U >> X) & 1u)) continue;
-            // all (Y, class) counters of row block X are bumped by ONE LDS atomic: lane 2Y + c owns combo (X, Y, c)
-            const bool ax = act && F[X] != 0;
-            uint32_t mycnt = 0;
+            for (int s = 0; s < B3_K; ++s) { wl[s] = rest ? (uint32_t)__builtin_ctz(rest) : 0u; rest &= rest - 1; }
+            b3_batch<B3_K, false, NBW, EMIT>(q, C, L, base, end, U, wl, ku, rootslot, inh);
+            ++n_mid;
+        } else {
+            uint32_t wl[NBW];
 #pragma unroll
-            for (int Y = 0; Y <= X; ++Y) {
-                if (!((U >> Y) & 1u)) continue;
-                const bool a = ax && F[Y] != 0;
-                const uint32_t c0 = (uint32_t)__popcll(__ballot(a && !heavy));
-                const uint32_t c1 = (uint32_t)__popcll(__ballot(a && heavy));
-                if (lane == (uint32_t)(2 * Y)) mycnt = c0;
-                if (lane == (uint32_t)(2 * Y + 1)) mycnt = c1;
-            }
-            uint32_t mybase = 0;
-            if (mycnt) mybase = atomicAdd(&ctr[(uint32_t)(X * (X + 1)) + lane], mycnt);   // (X(X+1)/2 + Y)*2 + c, lane = 2Y + c
-            if (EMIT && !(q.dbg & 256u)) {
-#pragma unroll
-                for (int Y = 0; Y <= X; ++Y) {
-                    if (!((U >> Y) & 1u)) continue;
-                    const bool a = ax && F[Y] != 0;
-                    const unsigned long long bal = __ballot(a && !heavy), bah = __ballot(a && heavy);
-                    if (!(bal | bah)) continue;
-                    const uint32_t base0 = bcast(mybase, 2 * Y), base1 = bcast(mybase, 2 * Y + 1);
-                    if (a) {
-                        const uint32_t slot = heavy ? base1 + (uint32_t)__popcll(bah & lt_mask) : base0 + (uint32_t)__popcll(bal & lt_mask);
-                        q.rec.rows[slot] = F[X];
-                        if (X != Y) q.rec.cols[slot] = F[Y];
-                        if (heavy) q.rec.w[slot] = wj;
-                    }
-                }
-            }
+            for (int s = 0; s < NBW; ++s) wl[s] = (uint32_t)s;
+            b3_batch<NBW, true, NBW, EMIT>(q, C, L, base, end, U, wl, (uint32_t)NBW, rootslot, inh);
+            ++n_full;
         }
-        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_emit += t1 - t0; t0 = t1; }
-        // ---- chain table for the next batch: root path of this batch's last node
-        const uint32_t nvalid = (end - base) < (uint32_t)WAVE ? (end - base) : (uint32_t)WAVE;
-        if (base + WAVE < end) {
-            unsigned long long anc = 0;
-            int cur = (int)nvalid - 1;
-            while (cur >= 0) { anc |= 1ull << cur; cur = __builtin_amdgcn_readlane(plo, cur); }
-            const uint32_t r = (uint32_t)__builtin_ctzll(anc);                 // in-batch root of that path
-            const int32_t rpar = __builtin_amdgcn_readlane(par, (int)r);
-            const uint32_t rtop = bcast(m.x - m.y, r);
-            const uint32_t kept = rpar >= 0 ? (uint32_t)slot_of_n[rtop] + 1u : 0u;
-            lds_sync();
-            if ((anc >> lane) & 1ull) {
-                const uint32_t slot = kept + (uint32_t)__popcll(anc & lt_mask);
-#pragma unroll
-                for (int w = 0; w < NBW; ++w) chain[(size_t)slot * NBW + w] = F[w];
-                chain_n[slot] = m.x;
-                slot_of_n[m.x] = (uint8_t)slot;
-            }
-            nchain = kept + (uint32_t)__popcll(anc);
-            lds_sync();
-        }
-        if (prof) { t1 = __builtin_amdgcn_s_memtime(); t_chain += t1 - t0; }
+        if (prof) t_all += __builtin_amdgcn_s_memtime() - t0;
     }
-    (void)nchain;
     if (prof && lane == 0) {
-        atomicAdd(&q.counters[1], t_load); atomicAdd(&q.counters[2], t_dbl);
-        atomicAdd(&q.counters[3], t_emit); atomicAdd(&q.counters[4], t_chain);
+        atomicAdd(&q.counters[1], t_all); atomicAdd(&q.counters[2], n_compact);
+        atomicAdd(&q.counters[3], n_mid); atomicAdd(&q.counters[4], n_full);
     }
     if (!EMIT) {
         lds_sync();
-        for (uint32_t k = lane; k < q.nctr; k += WAVE) my_table[k] = ctr[k];
+        for (uint32_t k = lane; k < q.nctr; k += WAVE) my_table[k] = C.ctr[k];
     }
 }
 
@@ -1131,8 +1225,9 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
 }
 
 __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B2Item* __restrict__ items,
-                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t dbg) {
+                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t dbg, uint32_t bwidth) {
     __shared__ uint32_t acc[64 * 64];
+    __shared__ unsigned long long rtbuf[4][64];
     const B2Item it = items[blockIdx.x];
     if ((dbg & 64u) && it.cls == 0) return;
     if ((dbg & 128u) && it.cls == 1) return;
@@ -1140,27 +1235,39 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     __syncthreads();
     const bool diag = it.X == it.Y;
-    for (uint32_t g0 = it.begin + wave * 64; g0 < it.end; g0 += 256) {
-        const uint32_t j = g0 + lane;
-        unsigned long long R = 0, C = 0;
-        uint32_t W = 0;
+    // per-wave accumulators in registers: lane c keeps the counts of column c for all 64 rows
+    uint32_t racc[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) racc[r] = 0;
+    // the next group's records are fetched while the current group is reduced
+    unsigned long long nR = 0, nC = 0;
+    uint32_t nW = 0;
+    auto fetch = [&](uint32_t g) {
+        const uint32_t j = g + lane;
+        nR = 0; nC = 0; nW = 0;
         if (j < it.end) {
-            R = rec.rows[j];
-            C = diag ? R : rec.cols[j];
-            W = it.cls ? rec.w[j] : 1u;
+            nR = rec.rows[j];
+            nC = diag ? nR : rec.cols[j];
+            nW = it.cls ? rec.w[j] : 1u;
         }
+    };
+    fetch(it.begin + wave * 64);
+    for (uint32_t g0 = it.begin + wave * 64; g0 < it.end; g0 += 256) {
+        const unsigned long long R = nR, C = nC;
+        const uint32_t W = nW;
+        if (g0 + 256 < it.end) fetch(g0 + 256);
         // lane c: bit j of Ct = record j contains column c
         const unsigned long long Ct = transpose64(C, lane);
-        if (!__ballot(R != 0)) continue;
+        if (dbg & 2048u) { racc[0] += (uint32_t)Ct + (uint32_t)R + W; continue; }
         if (it.cls == 0) {
             // every record has weight 1: cell(r, c) += number of records that contain row r and column c
-            for (uint32_t r = 0; r < 64; ++r) {
-                const unsigned long long Rr = __ballot(((R >> r) & 1ull) != 0);
-                if (!Rr) continue;
-                uint32_t c = (uint32_t)__popcll(Ct & Rr);
-                if (diag && lane >= r) c = 0;
-                if (c) atomicAdd(&acc[r * 64 + lane], c);
-            }
+            // R^T goes through LDS: row r's record mask is then a broadcast read instead of a ballot
+            // (a ballot writes an SGPR pair that the next VALU must wait for; 64 of them serialise the loop)
+            rtbuf[wave][lane] = transpose64(R, lane);
+            lds_sync();
+#pragma unroll
+            for (int r = 0; r < 64; ++r) racc[r] += (uint32_t)__popcll(Ct & rtbuf[wave][r]);
+            lds_sync();
         } else {
             // general weights: the same count per bit plane of w, scaled by 2^plane.  Planes 0..3 are
             // kept in scalar registers (weights are usually small); higher planes are rare.
@@ -1171,7 +1278,8 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
             const unsigned long long W0 = __ballot((W & 1u) != 0), W1 = __ballot((W & 2u) != 0);
             const unsigned long long W2 = __ballot((W & 4u) != 0), W3 = __ballot((W & 8u) != 0);
             const uint32_t whigh = wor >> 4;
-            for (uint32_t r = 0; r < 64; ++r) {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
                 const unsigned long long Rr = __ballot(((R >> r) & 1ull) != 0);
                 if (!Rr) continue;
                 const unsigned long long base = Ct & Rr;
@@ -1181,17 +1289,22 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
                     const uint32_t b = 4u + (uint32_t)__builtin_ctz(wb);
                     c += (uint32_t)__popcll(base & __ballot(((W >> b) & 1u) != 0)) << b;
                 }
-                if (diag && lane >= r) c = 0;
-                if (c) atomicAdd(&acc[r * 64 + lane], c);
+                racc[r] += c;
             }
         }
+    }
+    // merge the four waves (on the diagonal only the cells below it count: column id < row id)
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        const uint32_t v = (diag && lane >= (uint32_t)r) ? 0u : racc[r];
+        if (v) atomicAdd(&acc[r * 64 + lane], v);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
         const uint32_t v = acc[k];
         if (!v) continue;
-        const uint64_t row = (uint64_t)it.X * 64 + (k >> 6), col = (uint64_t)it.Y * 64 + (k & 63u);
-        atomicAdd(&M[tri64(row) + col], v);
+        const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
+        if (!(dbg & 1024u)) atomicAdd(&M[tri64(row) + col], v);
     }
 }
 
@@ -1297,6 +1410,7 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
     q.a.wprefix = db->wprefix; q.a.bits = db->bits; q.a.segs = db->segs;
     q.a.seg_begin = seg_begin; q.a.seg_end = seg_end; q.a.dbg = dbg; q.a.counters = db->counters;
     q.maxn_pad = db->b2_maxn_pad; q.dec_cap = db->b2_dec_cap; q.nctr = db->b2_nctr;
+    q.bm = BlockMap{db->b2_width, (uint32_t)((1ull << 32) / db->b2_width) + 1u};
     q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}; q.w = db->w;
     const size_t lds = b2_lds_per_wave(q.maxn_pad, q.dec_cap, q.nctr) * B2_WAVES;
     HIP_TRY(hipFuncSetAttribute((const void*)b2_emit_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1326,19 +1440,23 @@ int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg) {
 
 template <bool EMIT>
 int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0) {
-    return db->b3_nbw <= 16 ? b3_launch_emit_t<16, EMIT>(db, st, dbg) : b3_launch_emit_t<32, EMIT>(db, st, dbg);
+    if (db->b3_nbw <= 16) return b3_launch_emit_t<16, EMIT>(db, st, dbg);
+    if (db->b3_nbw <= 20) return b3_launch_emit_t<20, EMIT>(db, st, dbg);
+    if (db->b3_nbw <= 24) return b3_launch_emit_t<24, EMIT>(db, st, dbg);
+    return b3_launch_emit_t<32, EMIT>(db, st, dbg);
 }
 
 template <bool COUNT>
 int b3_launch_decode(kmdb_db* db, hipStream_t st) {
     const uint32_t P = (uint32_t)db->P;
+    const BlockMap bm{db->b2_width, (uint32_t)((1ull << 32) / db->b2_width) + 1u};
     if (P)
         hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
-                           (const uint32_t*)nullptr, P, db->b3_short_max, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs,
+                           (const uint32_t*)nullptr, P, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs,
                            db->b3_pair_blk, db->b3_pair_mask);
     if (db->b3_n_long)
         hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((db->b3_n_long + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos,
-                           db->bits, (const uint32_t*)db->b3_perm, db->b3_n_long, db->b3_short_max, db->b3_p0_mask, db->b3_p0_info,
+                           db->bits, (const uint32_t*)db->b3_perm, db->b3_n_long, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info,
                            db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1348,11 +1466,26 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
 // per-(segment, bucket) record counts with the count mode of the emit kernel (layout metadata:
 // a pure function of the database, like CSR row pointers), turn them into record bases and cut
 // the buckets into work items for the apply kernel.
-int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uint32_t>& perm, const std::vector<uint32_t>& nl,
-               const std::vector<uint32_t>& seg_anc, const std::vector<uint32_t>& seg_anc_n) {
+void b2_release_width(kmdb_db* db) {
+    void* ptrs[] = {db->b2_table, db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w, db->b2_items, db->b3_pair_ofs,
+                    db->b3_pair_blk, db->b3_pair_mask, db->b3_p0_mask, db->b3_p0_info};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    db->b2_table = nullptr; db->b2_rec_rows = db->b2_rec_cols = nullptr; db->b2_rec_w = nullptr; db->b2_items = nullptr;
+    db->b3_pair_ofs = nullptr; db->b3_pair_blk = nullptr; db->b3_pair_mask = nullptr; db->b3_p0_mask = nullptr;
+    db->b3_p0_info = nullptr;
+    db->b2_ready = db->b3_ready = false;
+}
+
+// Everything of the block-record pipeline that depends on the block width: run the count modes of the
+// kernels (layout metadata: a pure function of the database, like CSR row pointers), turn the
+// per-(segment, bucket) record counts into record bases and cut the buckets into work items for the
+// apply kernel.  *fits is false when the width cannot be used.
+int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok, bool* fits) {
+    *fits = false;
     const uint64_t N = db->N, P = db->P;
-    if (N < 2 || P == 0 || N > 2048 || max_n > 1024) return 0;
-    const uint32_t NB = (uint32_t)((N + 63) / 64);
+    const uint32_t NB = (uint32_t)((N + width - 1) / width);
+    if (NB > 32) return 0;
+    db->b2_width = width;
     db->b2_maxn_pad = std::max<uint32_t>(64, (max_n + 63) / 64 * 64);
     db->b2_dec_cap = std::max<uint32_t>(512, db->b2_maxn_pad);
     db->b2_nctr = NB * (NB + 1) / 2 * 2;
@@ -1360,23 +1493,15 @@ int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uin
     const size_t tbl = (size_t)db->n_segs * db->b2_nctr;
     HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
     HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
-    bool use_b3 = chain_ok && b3_wave_bytes(NB <= 16 ? 16 : 32, db->b2_maxn_pad, db->b2_nctr) * B3_WAVES <= 160 * 1024;
+    const uint32_t nbw = NB <= 16 ? 16 : NB <= 20 ? 20 : NB <= 24 ? 24 : 32;
+    const bool use_b3 = chain_ok && b3_wave_bytes(nbw, db->b2_maxn_pad, db->b2_nctr) * B3_WAVES <= 160 * 1024;
     if (use_b3) {
         // K0 count pass -> pair offsets -> K0 emit (the pairs are needed by the record count pass below)
-        db->b3_nbw = NB <= 16 ? 16 : 32;
-        db->b3_n_long = (uint32_t)perm.size();
-        HIP_TRY(hipMalloc((void**)&db->b3_perm, std::max<size_t>(perm.size(), 1) * 4));
-        if (!perm.empty()) HIP_TRY(hipMemcpy(db->b3_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&db->b3_nl, P * 4));
-        HIP_TRY(hipMemcpy(db->b3_nl, nl.data(), P * 4, hipMemcpyHostToDevice));
+        db->b3_nbw = nbw;
         HIP_TRY(hipMalloc((void**)&db->b3_pair_ofs, (P + 1) * 4));
+        HIP_TRY(hipMemset(db->b3_pair_ofs, 0, (P + 1) * 4));
         HIP_TRY(hipMalloc((void**)&db->b3_p0_mask, P * 8));
         HIP_TRY(hipMalloc((void**)&db->b3_p0_info, P * 2));
-        HIP_TRY(hipMemset(db->b3_pair_ofs, 0, (P + 1) * 4));
-        HIP_TRY(hipMalloc((void**)&db->b3_seg_anc, std::max<size_t>(seg_anc.size(), 1) * 4));
-        HIP_TRY(hipMalloc((void**)&db->b3_seg_anc_n, std::max<size_t>(seg_anc_n.size(), 1) * 4));
-        if (!seg_anc.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc, seg_anc.data(), seg_anc.size() * 4, hipMemcpyHostToDevice));
-        if (!seg_anc_n.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc_n, seg_anc_n.data(), seg_anc_n.size() * 4, hipMemcpyHostToDevice));
         if (b3_launch_decode<true>(db, db->stream)) return 1;
         uint32_t* tmp_counts = nullptr;
         HIP_TRY(hipMalloc((void**)&tmp_counts, (P + 1) * 4));
@@ -1413,10 +1538,11 @@ int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uin
         }
     }
     cstart[db->b2_nctr] = run;
-    if (run >= (1ull << 32)) return 0;                    // record index must fit 32 bits; fall back to v1
+    if (run >= (1ull << 32)) return 0;                    // record index must fit 32 bits
     db->b2_total = run;
     std::vector<B2Item> items;
-    const uint32_t CH = 8192;
+    uint32_t CH = 8192;
+    if (const char* e = getenv("KMDB_K2_CHUNK")) CH = std::max<uint32_t>(256, (uint32_t)strtoul(e, nullptr, 10));
     for (uint32_t X = 0, c = 0; X < NB; ++X)
         for (uint32_t Y = 0; Y <= X; ++Y)
             for (uint32_t cls = 0; cls < 2; ++cls, ++c)
@@ -1431,6 +1557,48 @@ int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uin
     db->b2_n_items = (uint32_t)items.size();
     db->b2_ready = true;
     db->b3_ready = use_b3;
+    *fits = true;
+    return 0;
+}
+
+// Decide whether the database qualifies for the block-record pipeline and pick the block width:
+// fewer sample ids per block than 64 pay off when the samples cluster (clades, species) in id ranges
+// that a 64-id grid would cut in two.  The candidate with the fewest block records wins.
+int b2_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uint32_t>& perm, const std::vector<uint32_t>& nl,
+               const std::vector<uint32_t>& seg_anc, const std::vector<uint32_t>& seg_anc_n) {
+    const uint64_t N = db->N, P = db->P;
+    if (N < 2 || P == 0 || N > 2048 || max_n > 1024) return 0;
+    if (chain_ok) {
+        db->b3_n_long = (uint32_t)perm.size();
+        HIP_TRY(hipMalloc((void**)&db->b3_perm, std::max<size_t>(perm.size(), 1) * 4));
+        if (!perm.empty()) HIP_TRY(hipMemcpy(db->b3_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&db->b3_nl, P * 4));
+        HIP_TRY(hipMemcpy(db->b3_nl, nl.data(), P * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&db->b3_seg_anc, std::max<size_t>(seg_anc.size(), 1) * 4));
+        HIP_TRY(hipMalloc((void**)&db->b3_seg_anc_n, std::max<size_t>(seg_anc_n.size(), 1) * 4));
+        if (!seg_anc.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc, seg_anc.data(), seg_anc.size() * 4, hipMemcpyHostToDevice));
+        if (!seg_anc_n.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc_n, seg_anc_n.data(), seg_anc_n.size() * 4, hipMemcpyHostToDevice));
+    }
+    uint32_t forced = 0;
+    if (const char* e = getenv("KMDB_BLOCK_WIDTH")) forced = (uint32_t)strtoul(e, nullptr, 10);
+    std::vector<uint32_t> cands = {64, 60, 56, 52, 50, 48, 44, 40, 36, 32};
+    if (forced >= 8 && forced <= 64) cands = {forced};
+    uint32_t best_w = 0;
+    uint64_t best_cost = ~0ull;
+    for (uint32_t wd : cands) {
+        bool fits = false;
+        if (b2_prepare_width(db, wd, max_n, chain_ok, &fits)) { b2_release_width(db); return 1; }
+        if (fits) {
+            // records dominate K1/K2; wider per-lane register sets (more blocks) make K1 a little dearer
+            const uint64_t cost = db->b2_total + P * (db->b3_nbw > 16 ? (db->b3_nbw - 16) : 0) / 64;
+            if (cost < best_cost) { best_cost = cost; best_w = wd; }
+        }
+        b2_release_width(db);
+    }
+    if (!best_w) return 0;
+    bool fits = false;
+    if (b2_prepare_width(db, best_w, max_n, chain_ok, &fits)) { b2_release_width(db); return 1; }
+    if (!fits) b2_release_width(db);
     return 0;
 }
 
@@ -1731,7 +1899,7 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
         HIP_TRY(hipEventRecord(db->ev_k2[0], st));
         if (db->b2_n_items && !(p.dbg & 2))
             hipLaunchKernelGGL(b2_apply_kernel, dim3(db->b2_n_items), dim3(256), 0, st,
-                               B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}, (const B2Item*)db->b2_items, M, (uint32_t)N, p.dbg);
+                               B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}, (const B2Item*)db->b2_items, M, (uint32_t)N, p.dbg, db->b2_width);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(db->ev_k2[1], st));
         HIP_TRY(hipEventRecord(db->ev[2], st));
