@@ -39,6 +39,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------
@@ -83,8 +84,10 @@ struct kmdb_db {
     uint32_t* wprefix = nullptr;    // P+1, exclusive scan of w (recomputed by every call)
     uint64_t* bits = nullptr;
     uint64_t n_bit_words = 0;
-    Segment* segs = nullptr;
+    Segment* segs = nullptr;            // equal-COST slices (tree-form updates) for the v1 scatter kernels
     uint32_t n_segs = 0;
+    Segment* rsegs = nullptr;           // equal-NODE-COUNT slices for the block-record emit kernels
+    uint32_t n_rsegs = 0;
     void* scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     uint32_t* stack_scratch = nullptr;  // global kernel: per-wave id stacks
@@ -115,7 +118,7 @@ struct kmdb_db {
     bool b3_ready = false;
     uint32_t b3_nbw = 0;
     uint32_t* b3_perm = nullptr;        // the nodes with long local lists, longest first
-    uint32_t b3_n_long = 0, b3_short_max = 32;
+    uint32_t b3_n_long = 0, b3_short_max = 32, b3_chain_cap = 64;
     uint32_t* b3_nl = nullptr;          // n | l << 16 per node
     uint32_t* b3_pair_ofs = nullptr;    // [P+1] CSR of the pairs beyond a node's first
     unsigned long long* b3_p0_mask = nullptr;   // [P] first pair, inline
@@ -198,6 +201,37 @@ struct BitCursor {
             s -= 64u;
             ++wi;
             c0 = c1; c1 = c2; c2 = bits[wi + 2];
+        }
+        return low | (1u << ones);
+    }
+};
+
+// Same decoder with a deeper look-ahead (PF words in flight): for the threads that walk long streams
+// alone, where the single look-ahead word of BitCursor leaves a full memory latency per 64 bits.
+template <int PF>
+struct BitCursorDeep {
+    const uint64_t* __restrict__ bits;
+    uint64_t wi;
+    uint64_t c[PF + 2];
+    uint32_t s;
+    __device__ __forceinline__ BitCursorDeep(const uint64_t* __restrict__ b, uint64_t pos) : bits(b) {
+        wi = pos >> 6;
+        s = (uint32_t)pos & 63u;
+#pragma unroll
+        for (int k = 0; k < PF + 2; ++k) c[k] = bits[wi + k];
+    }
+    __device__ __forceinline__ uint32_t next() {
+        const uint64_t win = s ? ((c[0] << s) | (c[1] >> (64u - s))) : c[0];
+        uint32_t ones = (uint32_t)__clzll((long long)~win);
+        ones = ones > 31u ? 31u : ones;
+        const uint32_t low = (uint32_t)((win << ones) >> (63u - ones));
+        s += 2u * ones + 1u;
+        if (s >= 64u) {
+            s -= 64u;
+            ++wi;
+#pragma unroll
+            for (int k = 0; k < PF + 1; ++k) c[k] = c[k + 1];
+            c[PF + 1] = bits[wi + PF + 1];
         }
         return low | (1u << ones);
     }
@@ -836,10 +870,11 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
 //        guarantees every earlier parent is on that path).  Records (flat form, one per pair of
 //        non-empty words X >= Y) are written with ballot-ranked, coalesced stores.
 // ------------------------------------------------------------------------------------------
-constexpr int B3_WAVES = 4;
+constexpr int B3_WAVES = 1;
 constexpr int B3_CHAIN = 64;       // max root-path length (in nodes) the chain table holds
+constexpr bool B3_WIDE_SPLIT = false;   // experiment: wide leaves handled after the batch (measured slower, kept for A/B)
 
-template <bool COUNT>
+template <bool COUNT, bool LONG>
 __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
                                                         const uint64_t* __restrict__ bits, const uint32_t* __restrict__ perm,
                                                         uint32_t P, uint32_t short_max, BlockMap bm, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
@@ -851,8 +886,32 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
     // ones with more than short_max local ids; those few are listed in perm, longest first, and decoded
     // by the second launch so that no wave waits on one long stream
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P) return;
-    const uint32_t i = perm ? perm[t] : t;
+    uint32_t i;
+    if (perm) {
+        if (t >= P) return;
+        i = perm[t];
+    } else {
+        // DFS-order launch: the 256 nodes of the block are re-dealt to its threads by decreasing list length
+        // (counting sort in LDS), so every wave decodes streams of similar length while all global accesses
+        // of the block stay inside its own 256-node window
+        __shared__ uint32_t bins[64];
+        __shared__ uint16_t order[256];
+        if (threadIdx.x < 64) bins[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t lt = t < P ? meta[t].y : 0u;
+        const uint32_t key = (t < P && lt <= short_max) ? lt : 0u;      // 0: nothing to decode here
+        atomicAdd(&bins[short_max - key], 1u);                           // bin 0 = longest
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t b = 0; b <= short_max; ++b) { const uint32_t c = bins[b]; bins[b] = run; run += c; }
+        }
+        __syncthreads();
+        order[atomicAdd(&bins[short_max - key], 1u)] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        i = blockIdx.x * blockDim.x + order[threadIdx.x];
+        if (i >= P) return;
+    }
     const uint4 m = meta[i];
     const uint32_t l = m.y;
     if (!perm && l > short_max) return;
@@ -861,13 +920,14 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
     unsigned long long mask0 = 0;
     if (l) {
         uint32_t id = m.z;
+        using Cursor = typename std::conditional<LONG, BitCursorDeep<6>, BitCursor>::type;
         if (l > 1) {
-            BitCursor c1(bits, bitpos[i]);
+            Cursor c1(bits, bitpos[i]);
             uint32_t sum = 0;
             for (uint32_t k = 0; k + 1 < l; ++k) sum += c1.next();
             id = m.z - sum;
         }
-        BitCursor c2(bits, bitpos[i]);
+        Cursor c2(bits, bitpos[i]);
         uint32_t curblk = bm.blk(id);
         unsigned long long acc = 0;
         for (uint32_t k = 0; k < l; ++k) {
@@ -904,14 +964,15 @@ struct B3Params {
     uint32_t n_segs;
     uint32_t maxn_pad;
     uint32_t nctr;
+    uint32_t chain_cap;            // slots of the chain table (longest root path of the database, rounded up)
     uint32_t* table;
     B2Recs rec;
     uint32_t dbg;
     unsigned long long* counters;
 };
 
-__host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr) {
-    size_t b = (size_t)B3_CHAIN * nbw * 8 + (size_t)nctr * 4 + B3_CHAIN * 4 * 2 + (maxn_pad + 64);
+__host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr, uint32_t chain_cap) {
+    size_t b = (size_t)chain_cap * nbw * 8 + (size_t)nctr * 4 + (size_t)chain_cap * 4 * 2 + 32 * 12 + (maxn_pad + 64);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -928,12 +989,15 @@ struct B3Ctx {
     uint32_t* chain_n;             // [B3_CHAIN] list length of the node in the slot
     uint8_t* slot_of_n;            // list length -> slot
     uint32_t* ctr;                 // record cursors per (bucket, class)
+    unsigned long long* zmask;     // [32] scratch: word list of one wide leaf
+    uint32_t* zblk;                // [32]
     uint32_t lane;
     unsigned long long lt_mask;
 };
 
 struct B3Lane {                    // one node per lane
     bool valid;
+    bool wide;                     // leaf whose local ids span >= 3 blocks: only its first block is kept in registers
     uint32_t n, l, w, info, idx;
     int32_t par;
     unsigned long long m0;
@@ -949,7 +1013,8 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
     const uint32_t lane = C.lane;
     auto slot_of_word = [&](uint32_t wd) -> uint32_t { return IDENT ? wd : (uint32_t)__popc(U & ((1u << wd) - 1u)); };
     unsigned long long F[W];
-    const uint32_t b0 = L.info & 0xFFu, np = L.info >> 8;
+    const uint32_t b0 = L.info & 0xFFu, np_all = L.info >> 8;
+    const uint32_t np = L.wide ? 1u : np_all;          // a wide leaf's further blocks are handled after the batch
     {
         const uint32_t s0 = slot_of_word(b0);
 #pragma unroll
@@ -1039,6 +1104,49 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         }
     }
 chain_update:
+    // ---- wide leaves: records of the pairs that involve one of their further blocks.  Nobody inherits from
+    // a leaf, so those blocks never had to enter the registers of the batch.
+    {
+        unsigned long long wm = B3_WIDE_SPLIT ? __ballot(L.wide && act) : 0ull;
+        while (B3_WIDE_SPLIT && wm) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(wm);
+            wm &= wm - 1;
+            // word list Z of node j: its non-empty register words, then its further (block, mask) pairs
+            uint32_t na = 0;
+            if (lane == j) {
+#pragma unroll
+                for (int s2 = 0; s2 < W; ++s2) {
+                    if (!IDENT && (uint32_t)s2 >= ku) break;
+                    if (F[s2] != 0) { C.zblk[na] = IDENT ? (uint32_t)s2 : wl[s2]; C.zmask[na] = F[s2]; ++na; }
+                }
+            }
+            na = bcast(na, j);
+            const uint32_t ne = bcast(np_all, j) - 1u;
+            const uint32_t poj = bcast(np_all > 1 ? q.pair_ofs[L.idx] : 0u, j);
+            if (lane < ne) { C.zblk[na + lane] = q.pair_blk[poj + lane]; C.zmask[na + lane] = q.pair_mask[poj + lane]; }
+            lds_sync();
+            const uint32_t wjj = bcast(L.w, j);
+            const uint32_t cls = wjj != 1u ? 1u : 0u;
+            // pairs (x, y), x an extra entry (na <= x < na + ne), y <= x, enumerated flat: one lane per pair
+            const uint32_t g0 = na * (na + 1) / 2;
+            const uint32_t total = (na + ne) * (na + ne + 1) / 2 - g0;
+            for (uint32_t t = lane; t < total; t += WAVE) {
+                const uint32_t g = g0 + t;
+                uint32_t x = (uint32_t)((__fsqrt_rn(8.0f * (float)g + 1.0f) - 1.0f) * 0.5f);
+                while (x * (x + 1) / 2 > g) --x;
+                while ((x + 1) * (x + 2) / 2 <= g) ++x;
+                const uint32_t y = g - x * (x + 1) / 2;
+                const uint32_t X = C.zblk[x], Y = C.zblk[y];
+                const uint32_t slot = atomicAdd(&C.ctr[(X * (X + 1) / 2 + Y) * 2 + cls], 1u);
+                if (EMIT && !(q.dbg & 256u)) {
+                    q.rec.rows[slot] = C.zmask[x];
+                    if (X != Y) q.rec.cols[slot] = C.zmask[y];
+                    if (cls) q.rec.w[slot] = wjj;
+                }
+            }
+            lds_sync();
+        }
+    }
     // ---- chain table for the next batch: root path of this batch's last node
     if (base + WAVE < end) {
         const uint32_t nvalid = (end - base) < (uint32_t)WAVE ? (end - base) : (uint32_t)WAVE;
@@ -1076,13 +1184,15 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg = blockIdx.x * B3_WAVES + wave;
     if (seg >= q.n_segs) return;
-    unsigned char* basep = lds_raw + b3_wave_bytes(NBW, q.maxn_pad, q.nctr) * wave;
+    unsigned char* basep = lds_raw + b3_wave_bytes(NBW, q.maxn_pad, q.nctr, q.chain_cap) * wave;
     B3Ctx C;
     C.chain = (unsigned long long*)basep;                                  // [B3_CHAIN][NBW]
-    C.ctr = (uint32_t*)(C.chain + (size_t)B3_CHAIN * NBW);                 // [nctr]
-    C.chain_n = C.ctr + q.nctr;                                            // [B3_CHAIN]
-    C.chain_nz = C.chain_n + B3_CHAIN;                                     // [B3_CHAIN]
-    C.slot_of_n = (uint8_t*)(C.chain_nz + B3_CHAIN);                       // [maxn_pad + 64]
+    C.ctr = (uint32_t*)(C.chain + (size_t)q.chain_cap * NBW);              // [nctr]
+    C.chain_n = C.ctr + q.nctr;                                            // [chain_cap]
+    C.chain_nz = C.chain_n + q.chain_cap;                                  // [chain_cap]
+    C.zmask = (unsigned long long*)(C.chain_nz + q.chain_cap);             // [32]
+    C.zblk = (uint32_t*)(C.zmask + 32);                                    // [32]
+    C.slot_of_n = (uint8_t*)(C.zblk + 32);                                 // [maxn_pad + 64]
     C.lane = lane;
     C.lt_mask = (1ull << lane) - 1ull;
     uint32_t* my_table = q.table + (size_t)seg * q.nctr;
@@ -1166,10 +1276,13 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         if (base + WAVE < end) fetch(base + WAVE);
         // words this batch touches: own local words + the words inherited from a parent before the batch
         const uint32_t np = L.info >> 8;
+        // a leaf (the next node in DFS order is not its child) passes its masks to nobody
+        const int nextpar = __shfl_down(L.par, 1, WAVE);
+        L.wide = B3_WIDE_SPLIT && L.valid && lane < 63u && nextpar != (int)L.idx && np >= 3u && !(q.dbg & 4096u);
         uint32_t lw = np ? (1u << (L.info & 0xFFu)) : 0u;
-        if (__ballot(np > 1)) {
-            const uint32_t po = np > 1 ? q.pair_ofs[L.idx] : 0u;
-            for (uint32_t t = 0; t + 1 < np; ++t) lw |= 1u << q.pair_blk[po + t];
+        if (__ballot(np > 1 && !L.wide)) {
+            const uint32_t po = (np > 1 && !L.wide) ? q.pair_ofs[L.idx] : 0u;
+            if (!L.wide) for (uint32_t t = 0; t + 1 < np; ++t) lw |= 1u << q.pair_blk[po + t];
         }
         uint32_t rootslot = 0xFFFFFFFFu, inh = 0;
         if (L.valid && L.par >= 0 && L.par < (int32_t)base) {
@@ -1407,7 +1520,7 @@ template <bool EMIT>
 int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t dbg, hipStream_t st) {
     B2Params q{};
     q.a.meta = db->meta; q.a.bitpos = db->bitpos; q.a.parent = db->parent; q.a.sub_end = db->sub_end;
-    q.a.wprefix = db->wprefix; q.a.bits = db->bits; q.a.segs = db->segs;
+    q.a.wprefix = db->wprefix; q.a.bits = db->bits; q.a.segs = db->rsegs;
     q.a.seg_begin = seg_begin; q.a.seg_end = seg_end; q.a.dbg = dbg; q.a.counters = db->counters;
     q.maxn_pad = db->b2_maxn_pad; q.dec_cap = db->b2_dec_cap; q.nctr = db->b2_nctr;
     q.bm = BlockMap{db->b2_width, (uint32_t)((1ull << 32) / db->b2_width) + 1u};
@@ -1424,15 +1537,25 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
 template <int NBW, bool EMIT>
 int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg) {
     B3Params q{};
-    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.segs = db->segs;
+    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.segs = db->rsegs;
     q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
     q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
     q.pair_ofs = db->b3_pair_ofs; q.pair_blk = db->b3_pair_blk; q.pair_mask = db->b3_pair_mask;
-    q.n_segs = db->n_segs; q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr;
+    q.n_segs = db->n_rsegs; q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr; q.chain_cap = db->b3_chain_cap;
     q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}; q.dbg = dbg; q.counters = db->counters;
-    const size_t lds = b3_wave_bytes(NBW, q.maxn_pad, q.nctr) * B3_WAVES;
+    const size_t lds = b3_wave_bytes(NBW, q.maxn_pad, q.nctr, q.chain_cap) * B3_WAVES;
     HIP_TRY(hipFuncSetAttribute((const void*)b3_emit_kernel<NBW, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint32_t blocks = (db->n_segs + B3_WAVES - 1) / B3_WAVES;
+    if (EMIT && getenv("KMDB_VERBOSE")) {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)b3_emit_kernel<NBW, EMIT>, WAVE * B3_WAVES, lds);
+            fprintf(stderr, "[kmdb] emit kernel: NBW %d, width %u, chain_cap %u, LDS/block %zu B, resident blocks/CU %d, segments %u\n",
+                    NBW, db->b2_width, q.chain_cap, lds, nb, db->n_rsegs);
+        }
+    }
+    const uint32_t blocks = (db->n_rsegs + B3_WAVES - 1) / B3_WAVES;
     if (blocks) hipLaunchKernelGGL((b3_emit_kernel<NBW, EMIT>), dim3(blocks), dim3(WAVE * B3_WAVES), lds, st, q);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1450,12 +1573,12 @@ template <bool COUNT>
 int b3_launch_decode(kmdb_db* db, hipStream_t st) {
     const uint32_t P = (uint32_t)db->P;
     const BlockMap bm{db->b2_width, (uint32_t)((1ull << 32) / db->b2_width) + 1u};
-    if (P)
-        hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
+    if (P && !getenv("KMDB_SKIP_K0A"))
+        hipLaunchKernelGGL((b3_decode_kernel<COUNT, false>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
                            (const uint32_t*)nullptr, P, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs,
                            db->b3_pair_blk, db->b3_pair_mask);
-    if (db->b3_n_long)
-        hipLaunchKernelGGL((b3_decode_kernel<COUNT>), dim3((db->b3_n_long + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos,
+    if (db->b3_n_long && !getenv("KMDB_SKIP_K0B"))
+        hipLaunchKernelGGL((b3_decode_kernel<COUNT, true>), dim3((db->b3_n_long + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos,
                            db->bits, (const uint32_t*)db->b3_perm, db->b3_n_long, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info,
                            db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
     HIP_TRY(hipGetLastError());
@@ -1490,11 +1613,11 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
     db->b2_dec_cap = std::max<uint32_t>(512, db->b2_maxn_pad);
     db->b2_nctr = NB * (NB + 1) / 2 * 2;
     if (b2_lds_per_wave(db->b2_maxn_pad, db->b2_dec_cap, db->b2_nctr) * B2_WAVES > 160 * 1024) return 0;
-    const size_t tbl = (size_t)db->n_segs * db->b2_nctr;
+    const size_t tbl = (size_t)db->n_rsegs * db->b2_nctr;
     HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
     HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
     const uint32_t nbw = NB <= 16 ? 16 : NB <= 20 ? 20 : NB <= 24 ? 24 : 32;
-    const bool use_b3 = chain_ok && b3_wave_bytes(nbw, db->b2_maxn_pad, db->b2_nctr) * B3_WAVES <= 160 * 1024;
+    const bool use_b3 = chain_ok && b3_wave_bytes(nbw, db->b2_maxn_pad, db->b2_nctr, db->b3_chain_cap) * B3_WAVES <= 160 * 1024;
     if (use_b3) {
         // K0 count pass -> pair offsets -> K0 emit (the pairs are needed by the record count pass below)
         db->b3_nbw = nbw;
@@ -1521,7 +1644,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
         if (b3_launch_decode<false>(db, db->stream)) return 1;
         if (b3_launch_emit<false>(db, db->stream)) return 1;
     } else {
-        if (b2_launch_emit<false>(db, 0, db->n_segs, 0, db->stream)) return 1;
+        if (b2_launch_emit<false>(db, 0, db->n_rsegs, 0, db->stream)) return 1;
     }
     HIP_TRY(hipStreamSynchronize(db->stream));
     std::vector<uint32_t> counts(tbl);
@@ -1532,7 +1655,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
     uint64_t run = 0;
     for (uint32_t c = 0; c < db->b2_nctr; ++c) {
         cstart[c] = run;
-        for (uint32_t sgi = 0; sgi < db->n_segs; ++sgi) {
+        for (uint32_t sgi = 0; sgi < db->n_rsegs; ++sgi) {
             bases[(size_t)sgi * db->b2_nctr + c] = (uint32_t)run;
             run += counts[(size_t)sgi * db->b2_nctr + c];
         }
@@ -1697,7 +1820,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
         }
         cost_prefix[i + 1] = cost_prefix[i] + 4 + l / 2 + rows_cost * 2;
     }
-    bits.resize((bw.pos + 63) / 64 + 4, 0);            // zero padding words for BitCursor's look-ahead
+    bits.resize((bw.pos + 63) / 64 + 16, 0);           // zero padding words for the cursors' look-ahead
     alg_bytes += 4ull * (N ? N * (N - 1) / 2 : 0);
 
     // ---- equal-cost segments -------------------------------------------------------------------
@@ -1789,13 +1912,19 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
             for (uint64_t i = 0; i < P; ++i)
                 if (meta[i].y > SHORT_MAX) perm[cntl[max_n - meta[i].y]++] = (uint32_t)i;
         }
-        std::vector<uint32_t> seg_anc, seg_anc_n(segs.size(), 0);
+        // segments of the emit kernels.  Measured: the equal-cost slices of the scatter model (long multi-clade
+        // lists weigh more) also balance the emit kernel better than equal node counts do, so they are reused.
+        std::vector<Segment> rsegs(segs.begin(), segs.end());
+        if (dev_upload(&db->rsegs, rsegs.data(), rsegs.size())) { kmdb_db_free(db); return 1; }
+        db->n_rsegs = (uint32_t)rsegs.size();
+        std::vector<uint32_t> seg_anc, seg_anc_n(rsegs.size(), 0);
         const bool chain_ok = max_depth <= (uint32_t)B3_CHAIN;
+        db->b3_chain_cap = std::min<uint32_t>(B3_CHAIN, std::max<uint32_t>(8, (max_depth + 7) / 8 * 8));
         if (chain_ok) {
-            seg_anc.assign(segs.size() * (size_t)B3_CHAIN, 0);
-            for (size_t sidx = 0; sidx < segs.size(); ++sidx) {
-                if (segs[sidx].first >= segs[sidx].end) continue;
-                int32_t cur = parent[segs[sidx].first];
+            seg_anc.assign(rsegs.size() * (size_t)B3_CHAIN, 0);
+            for (size_t sidx = 0; sidx < rsegs.size(); ++sidx) {
+                if (rsegs[sidx].first >= rsegs[sidx].end) continue;
+                int32_t cur = parent[rsegs[sidx].first];
                 uint32_t d = cur < 0 ? 0u : depth[cur];
                 seg_anc_n[sidx] = d;
                 while (cur >= 0) { seg_anc[sidx * B3_CHAIN + (--d)] = (uint32_t)cur; cur = parent[cur]; }
@@ -1803,7 +1932,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
         }
         if (b2_prepare(db, max_n, chain_ok, perm, nl, seg_anc, seg_anc_n)) { kmdb_db_free(db); return 1; }
     }
-    db->stats.device_bytes += db->b2_total * 20 + (uint64_t)db->n_segs * db->b2_nctr * 4;
+    db->stats.device_bytes += db->b2_total * 20 + (uint64_t)db->n_rsegs * db->b2_nctr * 4;
     *out = db;
     return 0;
 }
@@ -1811,7 +1940,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
 extern "C" void kmdb_db_free(kmdb_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
-    void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->scan_tmp,
+    void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->rsegs, db->scan_tmp,
                     db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w,
                     db->b2_items, db->b3_perm, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask, db->b3_seg_anc,
                     db->b3_seg_anc_n, db->b3_p0_mask, db->b3_p0_info, db->b3_nl};
@@ -1887,7 +2016,7 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
         // v2: emit block records (K1), then ballot/popcount accumulate per 64 x 64 block (K2)
         const bool seq_emit = !db->b3_ready || (opts && (opts->flags & 8u));
         if (seq_emit) {
-            if (b2_launch_emit<true>(db, 0, db->n_segs, p.dbg, st)) return 1;
+            if (b2_launch_emit<true>(db, 0, db->n_rsegs, p.dbg, st)) return 1;
             HIP_TRY(hipEventRecord(db->ev_k0, st));
             db->k0_ms = -1;
         } else {

@@ -169,6 +169,32 @@ def test_synthetic_databases_bit_exact(K, O, dev, tmp_path, N, cs, L, k):
     assert np.array_equal(d2.all2all_dense(), exp)
 
 
+@pytest.mark.parametrize("N,cs,L", [(3000, 100, 1500), (5000, 50, 600)])
+def test_many_samples_fall_back_to_v1_kernels(K, O, dev, tmp_path, N, cs, L):
+    """N > 2048 is outside the block-record pipeline: the LDS-tile kernel (N <= 4096) and the generic
+    HBM-atomics kernel (any N <= 65535) take over, same bit-exact result."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    g, pat = S.synth_database(N, cs, L, k=18, seed=9, device=torch.device("cuda", dev))
+    arr = S.to_view_arrays(pat)
+    path = str(tmp_path / "s.db")
+    S.write_db(path, 18, 1.0, [g.name(i) for i in range(N)], pat["sample_counts"], arr)
+    exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+    view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    assert np.array_equal(d.all2all_dense(), exp)
+    assert d.stats()["n_records"] == 0
+    assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_FORCE_GLOBAL_ATOMICS), exp)
+    sp = d.all2all_sparse()
+    for i in (1, N // 2, N - 1):
+        c, v = sp.row(i)
+        row = O.tri_row(exp, i)
+        nz = np.nonzero(row)[0]
+        assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
+
+
 def test_prefix_sharded_ranks_on_one_gpu(K, O, dev, tmp_path):
     """bench.py's multi-GPU scheme with the ranks run one after another on a single GPU:
     the partial matrices of the prefix-bucket shards add up to the unsharded matrix."""
