@@ -195,6 +195,14 @@ def main():
             dom_name = "a2a_tile_kernel"
         alg = st0["algorithmic_bytes"]
         achieved = alg / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per pass come from separate rocprofv3 --pmc runs of this same command (profiles/): they
+        # cannot be collected from inside the timed process; quoted only for the default workload
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath) and world == 1 and args.length == 5_000_000 and args.samples == 1000:
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj["traffic_bytes_per_pass"], "profiles/latest_traffic.json: " + tj["source"]
         out = {
             "metric": "all2all k-mer pair-comparisons/sec",
             "value": sum_pairs / (elapsed / args.steps),
@@ -218,7 +226,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": dom_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
                 "per_kernel_ms": {"decode": stl["k0_ms"], "emit": stl["k1_ms"], "apply": stl["k2_ms"], "whole_call": stl["kernel_ms"]},
                 "block_records_per_launch": stl["n_records"],
             },

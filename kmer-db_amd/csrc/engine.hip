@@ -108,7 +108,7 @@ struct kmdb_db {
     uint32_t b2_width = 64;             // sample ids per block (<= 64), chosen at upload
     uint32_t* b2_table = nullptr;       // [n_segs][nctr] record bases
     unsigned long long* b2_rec_rows = nullptr;   // [total]
-    unsigned long long* b2_rec_cols = nullptr;   // [total]
+    ulonglong2* b2_rec_rc = nullptr;    // [total]
     uint32_t* b2_rec_w = nullptr;       // [total]
     void* b2_items = nullptr;           // B2Item[n_items]
     uint64_t b2_total = 0;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
 // ------------------------------------------------------------------------------------------
 // block records, struct-of-arrays, one slot per record: rows always; cols only for off-diagonal
 // buckets (on the diagonal cols == rows); w only for the heavy class (class 0 records have w == 1)
-struct B2Recs { unsigned long long* rows; unsigned long long* cols; uint32_t* w; };
+struct B2Recs { unsigned long long* rows; ulonglong2* rc; uint32_t* w; };   // rows: diagonal buckets; rc = {rows, cols}: others
 struct B2Item { uint32_t X, Y, cls, begin, end; };
 
 constexpr int B2_WAVES = 4;
@@ -835,8 +835,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
                 const uint32_t b = (bX * (bX + 1) / 2 + bY) * 2 + cls;
                 const uint32_t slot = atomicAdd(&S.ctr[b], 1u);
                 if (EMIT) {
-                    q.rec.rows[slot] = rows;
-                    if (bX != bY) q.rec.cols[slot] = cols;
+                    if (bX != bY) q.rec.rc[slot] = make_ulonglong2(rows, cols); else q.rec.rows[slot] = rows;
                     if (cls) q.rec.w[slot] = Wj;
                 }
             }
@@ -1096,8 +1095,7 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
                 const uint32_t base0 = bcast(mybase, 2 * sY), base1 = bcast(mybase, 2 * sY + 1);
                 if (a) {
                     const uint32_t slot = heavy ? base1 + (uint32_t)__popcll(bah & C.lt_mask) : base0 + (uint32_t)__popcll(bal & C.lt_mask);
-                    q.rec.rows[slot] = F[sX];
-                    if (sX != sY) q.rec.cols[slot] = F[sY];
+                    if (sX != sY) q.rec.rc[slot] = make_ulonglong2(F[sX], F[sY]); else q.rec.rows[slot] = F[sX];
                     if (heavy) q.rec.w[slot] = L.w;
                 }
             }
@@ -1139,8 +1137,7 @@ chain_update:
                 const uint32_t X = C.zblk[x], Y = C.zblk[y];
                 const uint32_t slot = atomicAdd(&C.ctr[(X * (X + 1) / 2 + Y) * 2 + cls], 1u);
                 if (EMIT && !(q.dbg & 256u)) {
-                    q.rec.rows[slot] = C.zmask[x];
-                    if (X != Y) q.rec.cols[slot] = C.zmask[y];
+                    if (X != Y) q.rec.rc[slot] = make_ulonglong2(C.zmask[x], C.zmask[y]); else q.rec.rows[slot] = C.zmask[x];
                     if (cls) q.rec.w[slot] = wjj;
                 }
             }
@@ -1359,8 +1356,8 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
         const uint32_t j = g + lane;
         nR = 0; nC = 0; nW = 0;
         if (j < it.end) {
-            nR = rec.rows[j];
-            nC = diag ? nR : rec.cols[j];
+            if (diag) { nR = rec.rows[j]; nC = nR; }
+            else { const ulonglong2 rc = rec.rc[j]; nR = rc.x; nC = rc.y; }
             nW = it.cls ? rec.w[j] : 1u;
         }
     };
@@ -1524,7 +1521,7 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
     q.a.seg_begin = seg_begin; q.a.seg_end = seg_end; q.a.dbg = dbg; q.a.counters = db->counters;
     q.maxn_pad = db->b2_maxn_pad; q.dec_cap = db->b2_dec_cap; q.nctr = db->b2_nctr;
     q.bm = BlockMap{db->b2_width, (uint32_t)((1ull << 32) / db->b2_width) + 1u};
-    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}; q.w = db->w;
+    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.w = db->w;
     const size_t lds = b2_lds_per_wave(q.maxn_pad, q.dec_cap, q.nctr) * B2_WAVES;
     HIP_TRY(hipFuncSetAttribute((const void*)b2_emit_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t nseg = seg_end - seg_begin;
@@ -1542,7 +1539,7 @@ int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg) {
     q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
     q.pair_ofs = db->b3_pair_ofs; q.pair_blk = db->b3_pair_blk; q.pair_mask = db->b3_pair_mask;
     q.n_segs = db->n_rsegs; q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr; q.chain_cap = db->b3_chain_cap;
-    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}; q.dbg = dbg; q.counters = db->counters;
+    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.dbg = dbg; q.counters = db->counters;
     const size_t lds = b3_wave_bytes(NBW, q.maxn_pad, q.nctr, q.chain_cap) * B3_WAVES;
     HIP_TRY(hipFuncSetAttribute((const void*)b3_emit_kernel<NBW, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (EMIT && getenv("KMDB_VERBOSE")) {
@@ -1590,10 +1587,10 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
 // a pure function of the database, like CSR row pointers), turn them into record bases and cut
 // the buckets into work items for the apply kernel.
 void b2_release_width(kmdb_db* db) {
-    void* ptrs[] = {db->b2_table, db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w, db->b2_items, db->b3_pair_ofs,
+    void* ptrs[] = {db->b2_table, db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w, db->b2_items, db->b3_pair_ofs,
                     db->b3_pair_blk, db->b3_pair_mask, db->b3_p0_mask, db->b3_p0_info};
     for (void* q : ptrs) if (q) (void)hipFree(q);
-    db->b2_table = nullptr; db->b2_rec_rows = db->b2_rec_cols = nullptr; db->b2_rec_w = nullptr; db->b2_items = nullptr;
+    db->b2_table = nullptr; db->b2_rec_rows = nullptr; db->b2_rec_rc = nullptr; db->b2_rec_w = nullptr; db->b2_items = nullptr;
     db->b3_pair_ofs = nullptr; db->b3_pair_blk = nullptr; db->b3_pair_mask = nullptr; db->b3_p0_mask = nullptr;
     db->b3_p0_info = nullptr;
     db->b2_ready = db->b3_ready = false;
@@ -1673,7 +1670,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
                     items.push_back({X, Y, cls, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + CH, cstart[c + 1])});
     HIP_TRY(hipMemcpy(db->b2_table, bases.data(), tbl * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&db->b2_rec_rows, std::max<uint64_t>(run, 1) * 8));
-    HIP_TRY(hipMalloc((void**)&db->b2_rec_cols, std::max<uint64_t>(run, 1) * 8));
+    HIP_TRY(hipMalloc((void**)&db->b2_rec_rc, std::max<uint64_t>(run, 1) * 16));
     HIP_TRY(hipMalloc((void**)&db->b2_rec_w, std::max<uint64_t>(run, 1) * 4));
     HIP_TRY(hipMalloc(&db->b2_items, std::max<size_t>(items.size(), 1) * sizeof(B2Item)));
     if (!items.empty()) HIP_TRY(hipMemcpy(db->b2_items, items.data(), items.size() * sizeof(B2Item), hipMemcpyHostToDevice));
@@ -1941,7 +1938,7 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
     void* ptrs[] = {db->meta, db->bitpos, db->parent, db->w, db->sub_end, db->wprefix, db->bits, db->segs, db->rsegs, db->scan_tmp,
-                    db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w,
+                    db->stack_scratch, db->counters, db->bucket_offset, db->slots, db->pid2dfs, db->b2_table, db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w,
                     db->b2_items, db->b3_perm, db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask, db->b3_seg_anc,
                     db->b3_seg_anc_n, db->b3_p0_mask, db->b3_p0_info, db->b3_nl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2028,7 +2025,7 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
         HIP_TRY(hipEventRecord(db->ev_k2[0], st));
         if (db->b2_n_items && !(p.dbg & 2))
             hipLaunchKernelGGL(b2_apply_kernel, dim3(db->b2_n_items), dim3(256), 0, st,
-                               B2Recs{db->b2_rec_rows, db->b2_rec_cols, db->b2_rec_w}, (const B2Item*)db->b2_items, M, (uint32_t)N, p.dbg, db->b2_width);
+                               B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}, (const B2Item*)db->b2_items, M, (uint32_t)N, p.dbg, db->b2_width);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(db->ev_k2[1], st));
         HIP_TRY(hipEventRecord(db->ev[2], st));
