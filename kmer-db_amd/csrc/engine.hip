@@ -37,7 +37,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -871,7 +870,6 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
 // ------------------------------------------------------------------------------------------
 constexpr int B3_WAVES = 1;
 constexpr int B3_CHAIN = 64;       // max root-path length (in nodes) the chain table holds
-constexpr bool B3_WIDE_SPLIT = false;   // experiment: wide leaves handled after the batch (measured slower, kept for A/B)
 
 template <bool COUNT, bool LONG>
 __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
@@ -971,7 +969,7 @@ struct B3Params {
 };
 
 __host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr, uint32_t chain_cap) {
-    size_t b = (size_t)chain_cap * nbw * 8 + (size_t)nctr * 4 + (size_t)chain_cap * 4 * 2 + 32 * 12 + (maxn_pad + 64);
+    size_t b = (size_t)chain_cap * nbw * 8 + (size_t)nctr * 4 + (size_t)chain_cap * 4 * 2 + (maxn_pad + 64);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -988,15 +986,12 @@ struct B3Ctx {
     uint32_t* chain_n;             // [B3_CHAIN] list length of the node in the slot
     uint8_t* slot_of_n;            // list length -> slot
     uint32_t* ctr;                 // record cursors per (bucket, class)
-    unsigned long long* zmask;     // [32] scratch: word list of one wide leaf
-    uint32_t* zblk;                // [32]
     uint32_t lane;
     unsigned long long lt_mask;
 };
 
 struct B3Lane {                    // one node per lane
     bool valid;
-    bool wide;                     // leaf whose local ids span >= 3 blocks: only its first block is kept in registers
     uint32_t n, l, w, info, idx;
     int32_t par;
     unsigned long long m0;
@@ -1012,8 +1007,7 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
     const uint32_t lane = C.lane;
     auto slot_of_word = [&](uint32_t wd) -> uint32_t { return IDENT ? wd : (uint32_t)__popc(U & ((1u << wd) - 1u)); };
     unsigned long long F[W];
-    const uint32_t b0 = L.info & 0xFFu, np_all = L.info >> 8;
-    const uint32_t np = L.wide ? 1u : np_all;          // a wide leaf's further blocks are handled after the batch
+    const uint32_t b0 = L.info & 0xFFu, np = L.info >> 8;
     {
         const uint32_t s0 = slot_of_word(b0);
 #pragma unroll
@@ -1102,48 +1096,6 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         }
     }
 chain_update:
-    // ---- wide leaves: records of the pairs that involve one of their further blocks.  Nobody inherits from
-    // a leaf, so those blocks never had to enter the registers of the batch.
-    {
-        unsigned long long wm = B3_WIDE_SPLIT ? __ballot(L.wide && act) : 0ull;
-        while (B3_WIDE_SPLIT && wm) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(wm);
-            wm &= wm - 1;
-            // word list Z of node j: its non-empty register words, then its further (block, mask) pairs
-            uint32_t na = 0;
-            if (lane == j) {
-#pragma unroll
-                for (int s2 = 0; s2 < W; ++s2) {
-                    if (!IDENT && (uint32_t)s2 >= ku) break;
-                    if (F[s2] != 0) { C.zblk[na] = IDENT ? (uint32_t)s2 : wl[s2]; C.zmask[na] = F[s2]; ++na; }
-                }
-            }
-            na = bcast(na, j);
-            const uint32_t ne = bcast(np_all, j) - 1u;
-            const uint32_t poj = bcast(np_all > 1 ? q.pair_ofs[L.idx] : 0u, j);
-            if (lane < ne) { C.zblk[na + lane] = q.pair_blk[poj + lane]; C.zmask[na + lane] = q.pair_mask[poj + lane]; }
-            lds_sync();
-            const uint32_t wjj = bcast(L.w, j);
-            const uint32_t cls = wjj != 1u ? 1u : 0u;
-            // pairs (x, y), x an extra entry (na <= x < na + ne), y <= x, enumerated flat: one lane per pair
-            const uint32_t g0 = na * (na + 1) / 2;
-            const uint32_t total = (na + ne) * (na + ne + 1) / 2 - g0;
-            for (uint32_t t = lane; t < total; t += WAVE) {
-                const uint32_t g = g0 + t;
-                uint32_t x = (uint32_t)((__fsqrt_rn(8.0f * (float)g + 1.0f) - 1.0f) * 0.5f);
-                while (x * (x + 1) / 2 > g) --x;
-                while ((x + 1) * (x + 2) / 2 <= g) ++x;
-                const uint32_t y = g - x * (x + 1) / 2;
-                const uint32_t X = C.zblk[x], Y = C.zblk[y];
-                const uint32_t slot = atomicAdd(&C.ctr[(X * (X + 1) / 2 + Y) * 2 + cls], 1u);
-                if (EMIT && !(q.dbg & 256u)) {
-                    if (X != Y) q.rec.rc[slot] = make_ulonglong2(C.zmask[x], C.zmask[y]); else q.rec.rows[slot] = C.zmask[x];
-                    if (cls) q.rec.w[slot] = wjj;
-                }
-            }
-            lds_sync();
-        }
-    }
     // ---- chain table for the next batch: root path of this batch's last node
     if (base + WAVE < end) {
         const uint32_t nvalid = (end - base) < (uint32_t)WAVE ? (end - base) : (uint32_t)WAVE;
@@ -1187,9 +1139,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     C.ctr = (uint32_t*)(C.chain + (size_t)q.chain_cap * NBW);              // [nctr]
     C.chain_n = C.ctr + q.nctr;                                            // [chain_cap]
     C.chain_nz = C.chain_n + q.chain_cap;                                  // [chain_cap]
-    C.zmask = (unsigned long long*)(C.chain_nz + q.chain_cap);             // [32]
-    C.zblk = (uint32_t*)(C.zmask + 32);                                    // [32]
-    C.slot_of_n = (uint8_t*)(C.zblk + 32);                                 // [maxn_pad + 64]
+    C.slot_of_n = (uint8_t*)(C.chain_nz + q.chain_cap);                    // [maxn_pad + 64]
     C.lane = lane;
     C.lt_mask = (1ull << lane) - 1ull;
     uint32_t* my_table = q.table + (size_t)seg * q.nctr;
@@ -1273,13 +1223,10 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         if (base + WAVE < end) fetch(base + WAVE);
         // words this batch touches: own local words + the words inherited from a parent before the batch
         const uint32_t np = L.info >> 8;
-        // a leaf (the next node in DFS order is not its child) passes its masks to nobody
-        const int nextpar = __shfl_down(L.par, 1, WAVE);
-        L.wide = B3_WIDE_SPLIT && L.valid && lane < 63u && nextpar != (int)L.idx && np >= 3u && !(q.dbg & 4096u);
         uint32_t lw = np ? (1u << (L.info & 0xFFu)) : 0u;
-        if (__ballot(np > 1 && !L.wide)) {
-            const uint32_t po = (np > 1 && !L.wide) ? q.pair_ofs[L.idx] : 0u;
-            if (!L.wide) for (uint32_t t = 0; t + 1 < np; ++t) lw |= 1u << q.pair_blk[po + t];
+        if (__ballot(np > 1)) {
+            const uint32_t po = np > 1 ? q.pair_ofs[L.idx] : 0u;
+            for (uint32_t t = 0; t + 1 < np; ++t) lw |= 1u << q.pair_blk[po + t];
         }
         uint32_t rootslot = 0xFFFFFFFFu, inh = 0;
         if (L.valid && L.par >= 0 && L.par < (int32_t)base) {

@@ -219,3 +219,104 @@ def test_prefix_sharded_ranks_on_one_gpu(K, O, dev, tmp_path):
         for r in range(world):
             acc += run(r, world)
         assert np.array_equal(acc, full)
+
+
+def _random_forest(rng, N, P, max_local, heavy_frac=0.2, zero_frac=0.2):
+    """A random but valid pattern forest (not derived from genomes): pattern 0 is empty; every other
+    pattern hangs under a random earlier pattern (or is a root) and owns 1..max_local ids larger than
+    everything above it.  Returns pattern dict in the format of synth.build_patterns."""
+    import torch
+    parent = np.full(P, -1, dtype=np.int64)
+    nsam = np.zeros(P, dtype=np.int64)
+    last = np.full(P, -1, dtype=np.int64)
+    locs = [np.zeros(0, dtype=np.int64)]
+    w = np.zeros(P, dtype=np.int64)
+    for p in range(1, P):
+        for _ in range(20):
+            par = int(rng.integers(0, p)) if rng.random() < 0.85 else 0
+            lo = last[par] + 1 if par else 0
+            if lo < N:
+                break
+        else:
+            par, lo = 0, 0
+        room = N - lo
+        l = int(min(room, rng.integers(1, max_local + 1)))
+        ids = np.sort(rng.choice(room, size=l, replace=False)) + lo
+        parent[p] = par if par else -1
+        nsam[p] = (nsam[par] if par else 0) + l
+        last[p] = ids[-1]
+        locs.append(ids.astype(np.int64))
+        r = rng.random()
+        w[p] = 0 if r < zero_frac else (int(rng.integers(2, 1 << 20)) if r < zero_frac + heavy_frac else int(rng.integers(1, 4)))
+    num_local = np.array([len(x) for x in locs], dtype=np.int64)
+    lp = np.zeros(P + 1, dtype=np.int64)
+    lp[1:] = np.cumsum(num_local)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
+    return {"num_kmers": t(w), "parent": t(parent), "num_samples": t(nsam), "num_local": t(num_local),
+            "local_ptr": t(lp), "local_ids": t(np.concatenate(locs))}
+
+
+@pytest.mark.parametrize("seed,N,P,max_local", [(1, 2, 5, 1), (2, 64, 300, 5), (3, 65, 2000, 3), (4, 700, 6000, 40),
+                                                (5, 1024, 3000, 300), (6, 2048, 4000, 64), (7, 130, 20000, 2),
+                                                (8, 1500, 500, 1200)])
+def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local):
+    """Fuzz: arbitrary valid pattern forests (deep chains, long local lists, zero and huge weights, lists
+    longer than 1024 ids -> v1 fallback) through every all2all path, against the oracle's tree form AND
+    flat form."""
+    import importlib
+    S = importlib.import_module("kmerdb_amd.synth")
+    rng = np.random.default_rng(seed)
+    pat = _random_forest(rng, N, P, max_local)
+    arr = S.to_view_arrays(pat)
+    path = str(tmp_path / "f.db")
+    S.write_db(path, 18, 1.0, ["s%d" % i for i in range(N)], [1] * N, arr)
+    odb = O.OracleDB(path, skip_hashtables=True)
+    exp = odb.all2all_dense()
+    assert np.array_equal(odb.all2all_flat(), exp)
+    view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    assert np.array_equal(d.all2all_dense(), exp)
+    for fl in (K.capi.FLAG_FORCE_SEQ_EMIT, K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT):
+        assert np.array_equal(d.all2all_dense(flags=fl), exp), fl
+    acc = np.zeros_like(exp)
+    for sh in range(3):
+        acc += d.all2all_dense(shard=(sh, 3))
+    assert np.array_equal(acc, exp)
+    sp = d.all2all_sparse()
+    for i in range(0, N, max(1, N // 7)):
+        c, v = sp.row(i)
+        row = O.tri_row(exp, i)
+        nz = np.nonzero(row)[0]
+        assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
+
+
+def test_degenerate_databases(K, O, dev, tmp_path):
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    z = lambda n: torch.zeros(n, dtype=torch.int64)     # noqa: E731
+    # only the empty pattern, one sample
+    pat = {"num_kmers": z(1), "parent": torch.tensor([-1]), "num_samples": z(1), "num_local": z(1),
+           "local_ptr": z(2), "local_ids": z(0)}
+    arr = S.to_view_arrays(pat)
+    view = K.make_view(18, 1, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    assert d.all2all_dense().size == 0 and d.all2all_sparse().nnz == 0
+    # three samples, singleton patterns only: no pair is shared
+    pat = {"num_kmers": torch.tensor([0, 5, 7, 9]), "parent": torch.tensor([-1, -1, -1, -1]),
+           "num_samples": torch.tensor([0, 1, 1, 1]), "num_local": torch.tensor([0, 1, 1, 1]),
+           "local_ptr": torch.tensor([0, 0, 1, 2, 3]), "local_ids": torch.tensor([0, 1, 2])}
+    arr = S.to_view_arrays(pat)
+    view = K.make_view(18, 3, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    assert np.array_equal(d.all2all_dense(), np.zeros(3, np.uint32))
+    # a bad view is refused, not crashed on
+    bad = arr["parent_id"].copy()
+    bad[1] = 3
+    view = K.make_view(18, 3, arr["num_kmers"], bad, arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    with pytest.raises(K.KmdbError, match="parent_id"):
+        K.DeviceDB(view, device=dev)
