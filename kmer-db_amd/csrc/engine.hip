@@ -1292,10 +1292,6 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     __syncthreads();
     const bool diag = it.X == it.Y;
-    // per-wave accumulators in registers: lane c keeps the counts of column c for all 64 rows
-    uint32_t racc[64];
-#pragma unroll
-    for (int r = 0; r < 64; ++r) racc[r] = 0;
     // the next group's records are fetched while the current group is reduced
     unsigned long long nR = 0, nC = 0;
     uint32_t nW = 0;
@@ -1315,15 +1311,26 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
         if (g0 + 256 < it.end) fetch(g0 + 256);
         // lane c: bit j of Ct = record j contains column c
         const unsigned long long Ct = transpose64(C, lane);
-        if (dbg & 2048u) { racc[0] += (uint32_t)Ct + (uint32_t)R + W; continue; }
+        if (dbg & 2048u) { if ((uint32_t)Ct + (uint32_t)R + W == 0x12345u) acc[lane] = 1; continue; }
         if (it.cls == 0) {
             // every record has weight 1: cell(r, c) += number of records that contain row r and column c
             // R^T goes through LDS: row r's record mask is then a broadcast read instead of a ballot
             // (a ballot writes an SGPR pair that the next VALU must wait for; 64 of them serialise the loop)
             rtbuf[wave][lane] = transpose64(R, lane);
             lds_sync();
-#pragma unroll
-            for (int r = 0; r < 64; ++r) racc[r] += (uint32_t)__popcll(Ct & rtbuf[wave][r]);
+            if (!diag) {
+#pragma unroll 8
+                for (uint32_t r = 0; r < bwidth; ++r) {             // rows >= the block width never occur
+                    const uint32_t c = (uint32_t)__popcll(Ct & rtbuf[wave][r]);
+                    if (c) atomicAdd(&acc[r * 64 + lane], c);
+                }
+            } else {
+#pragma unroll 8
+                for (uint32_t r = 0; r < bwidth; ++r) {
+                    const uint32_t c = lane < r ? (uint32_t)__popcll(Ct & rtbuf[wave][r]) : 0u;
+                    if (c) atomicAdd(&acc[r * 64 + lane], c);
+                }
+            }
             lds_sync();
         } else {
             // general weights: the same count per bit plane of w, scaled by 2^plane.  Planes 0..3 are
@@ -1346,15 +1353,9 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
                     const uint32_t b = 4u + (uint32_t)__builtin_ctz(wb);
                     c += (uint32_t)__popcll(base & __ballot(((W >> b) & 1u) != 0)) << b;
                 }
-                racc[r] += c;
+                if (c && !(diag && lane >= (uint32_t)r)) atomicAdd(&acc[r * 64 + lane], c);
             }
         }
-    }
-    // merge the four waves (on the diagonal only the cells below it count: column id < row id)
-#pragma unroll
-    for (int r = 0; r < 64; ++r) {
-        const uint32_t v = (diag && lane >= (uint32_t)r) ? 0u : racc[r];
-        if (v) atomicAdd(&acc[r * 64 + lane], v);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
