@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20260928 + 1)
     ap.add_argument("--cpu-sample-length", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
+                         "(ranks share devices, the matrix reduce goes through host memory); never used for reported numbers")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,11 +125,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU path to time")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
     K = import_kmerdb_amd()
     import importlib
     S = importlib.import_module("kmerdb_amd.synth")
@@ -135,7 +142,7 @@ def main():
     arr, names, counts, nk = build_shard_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device,
                                             rank, world, progress=100 if rank == 0 else None)
     torch.cuda.empty_cache()
-    db = upload(K, arr, args.samples, args.k, local_rank)
+    db = upload(K, arr, args.samples, args.k, dev_index)
     del arr
     st0 = db.stats()
     cells = db.tri_size()
@@ -145,7 +152,14 @@ def main():
     def step():
         db.all2all_dense_device(M.data_ptr(), stream=stream)
         if world > 1:
-            dist.reduce(M, dst=0, op=dist.ReduceOp.SUM)      # uint32 wrap-around sum == int32 sum bitwise
+            if args.backend == "nccl":
+                dist.reduce(M, dst=0, op=dist.ReduceOp.SUM)      # uint32 wrap-around sum == int32 sum bitwise
+            else:
+                torch.cuda.synchronize()
+                h = M.cpu()
+                dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    M.copy_(h)
 
     def fence():
         if world > 1:
@@ -165,10 +179,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        cdev = device if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([st0["sum_pairs"], st0["tree_updates"], st0["algorithmic_bytes"]], dtype=torch.float64, device=device)
+        tot = torch.tensor([st0["sum_pairs"], st0["tree_updates"], st0["algorithmic_bytes"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         sum_pairs, tree_updates = float(tot[0]), float(tot[1])
     else:

@@ -320,3 +320,34 @@ def test_degenerate_databases(K, O, dev, tmp_path):
                        arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
     with pytest.raises(K.KmdbError, match="parent_id"):
         K.DeviceDB(view, device=dev)
+
+
+def test_bench_contract_single_and_two_ranks(dev, tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys; the multi-rank path (prefix-bucket shards +
+    matrix reduce) runs end to end with two ranks sharing this GPU over gloo and reproduces the
+    single-rank checksum structure (the bench asserts sum(M) == sum_p w_p C(n_p,2) over all ranks)."""
+    import json
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--length", "60000", "--cpu-sample-length", "20000",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "u32" and "workload" in d["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                         "--length", "30000", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    lines = [ln for ln in r2.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["genome_length_bp"] == 60000
+    # both runs cover a 60 kbp genome set of the same model: two prefix shards do the same total work
+    assert abs(d2["value"] * d2["ms_per_step"] - d["value"] * d["ms_per_step"]) / (d["value"] * d["ms_per_step"]) < 1e-9
