@@ -869,7 +869,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
 //        non-empty words X >= Y) are written with ballot-ranked, coalesced stores.
 // ------------------------------------------------------------------------------------------
 constexpr int B3_WAVES = 1;
-constexpr int B3_CHAIN = 64;       // max root-path length (in nodes) the chain table holds
+constexpr int B3_CHAIN = 192;      // max root-path length (in nodes) the chain table can hold (slot ids are bytes)
 
 template <bool COUNT, bool LONG>
 __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
@@ -1150,48 +1150,59 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
     if (first >= end) return;
 
-    // ---- chain table for the first node: the ancestors' full masks = inclusive OR-scan along the root path
+    // ---- chain table for the first node: the ancestors' full masks = inclusive OR-scan along the root path,
+    // 64 ancestors per round with the last lane's masks carried into the next round
     {
         const uint32_t d = q.seg_anc_n[seg];
-        unsigned long long F[NBW];
-        const bool on = lane < d;
-        const uint32_t node = on ? q.seg_anc[(size_t)seg * B3_CHAIN + lane] : 0u;
-        const uint32_t info = on ? q.p0_info[node] : 0u;
-        const unsigned long long m0 = on ? q.p0_mask[node] : 0ull;
-        const uint32_t b0 = info & 0xFFu, np = info >> 8;
+        unsigned long long carry[NBW];
 #pragma unroll
-        for (int w = 0; w < NBW; ++w) F[w] = (np != 0 && b0 == (uint32_t)w) ? m0 : 0ull;
-        if (__ballot(np > 1)) {
-            const uint32_t po = np > 1 ? q.pair_ofs[node] : 0u;
-            uint32_t mx = np > 1 ? np - 1 : 0u;
+        for (int w = 0; w < NBW; ++w) carry[w] = 0;
+        for (uint32_t c0 = 0; c0 < d; c0 += WAVE) {
+            unsigned long long F[NBW];
+            const uint32_t k = c0 + lane;
+            const bool on = k < d;
+            const uint32_t node = on ? q.seg_anc[(size_t)seg * q.chain_cap + k] : 0u;
+            const uint32_t info = on ? q.p0_info[node] : 0u;
+            const unsigned long long m0 = on ? q.p0_mask[node] : 0ull;
+            const uint32_t b0 = info & 0xFFu, np = info >> 8;
 #pragma unroll
-            for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, dd, WAVE); mx = o > mx ? o : mx; }
-            mx = __builtin_amdgcn_readfirstlane(mx);
-            for (uint32_t t = 0; t < mx; ++t) {
-                if (t + 1 < np) {
-                    const uint32_t b = q.pair_blk[po + t];
-                    const unsigned long long mk = q.pair_mask[po + t];
+            for (int w = 0; w < NBW; ++w) F[w] = (np != 0 && b0 == (uint32_t)w) ? m0 : 0ull;
+            if (__ballot(np > 1)) {
+                const uint32_t po = np > 1 ? q.pair_ofs[node] : 0u;
+                uint32_t mx = np > 1 ? np - 1 : 0u;
 #pragma unroll
-                    for (int w = 0; w < NBW; ++w) F[w] |= (b == (uint32_t)w) ? mk : 0ull;
+                for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, dd, WAVE); mx = o > mx ? o : mx; }
+                mx = __builtin_amdgcn_readfirstlane(mx);
+                for (uint32_t t = 0; t < mx; ++t) {
+                    if (t + 1 < np) {
+                        const uint32_t b = q.pair_blk[po + t];
+                        const unsigned long long mk = q.pair_mask[po + t];
+#pragma unroll
+                        for (int w = 0; w < NBW; ++w) F[w] |= (b == (uint32_t)w) ? mk : 0ull;
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int s = 1; s < WAVE; s <<= 1) {
+            for (int w = 0; w < NBW; ++w) if (lane == 0) F[w] |= carry[w];
 #pragma unroll
-            for (int w = 0; w < NBW; ++w) {
-                const unsigned long long o = shfl_up64(F[w], s);
-                if (lane >= (uint32_t)s) F[w] |= o;
+            for (int s = 1; s < WAVE; s <<= 1) {
+#pragma unroll
+                for (int w = 0; w < NBW; ++w) {
+                    const unsigned long long o = shfl_up64(F[w], s);
+                    if (lane >= (uint32_t)s) F[w] |= o;
+                }
             }
-        }
-        if (on) {
-            const uint32_t nn = q.nl[node] & 0xFFFFu;
-            uint32_t nzw = 0;
+            if (on) {
+                const uint32_t nn = q.nl[node] & 0xFFFFu;
+                uint32_t nzw = 0;
 #pragma unroll
-            for (int w = 0; w < NBW; ++w) { C.chain[(size_t)lane * NBW + w] = F[w]; nzw |= (F[w] != 0 ? 1u : 0u) << w; }
-            C.chain_nz[lane] = nzw;
-            C.chain_n[lane] = nn;
-            C.slot_of_n[nn] = (uint8_t)lane;
+                for (int w = 0; w < NBW; ++w) { C.chain[(size_t)k * NBW + w] = F[w]; nzw |= (F[w] != 0 ? 1u : 0u) << w; }
+                C.chain_nz[k] = nzw;
+                C.chain_n[k] = nn;
+                C.slot_of_n[nn] = (uint8_t)k;
+            }
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) carry[w] = shfl64(F[w], WAVE - 1);
         }
         lds_sync();
     }
@@ -1508,6 +1519,7 @@ int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg) {
 
 template <bool EMIT>
 int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0) {
+    if (db->b3_nbw <= 8) return b3_launch_emit_t<8, EMIT>(db, st, dbg);
     if (db->b3_nbw <= 16) return b3_launch_emit_t<16, EMIT>(db, st, dbg);
     if (db->b3_nbw <= 20) return b3_launch_emit_t<20, EMIT>(db, st, dbg);
     if (db->b3_nbw <= 24) return b3_launch_emit_t<24, EMIT>(db, st, dbg);
@@ -1561,7 +1573,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
     const size_t tbl = (size_t)db->n_rsegs * db->b2_nctr;
     HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
     HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
-    const uint32_t nbw = NB <= 16 ? 16 : NB <= 20 ? 20 : NB <= 24 ? 24 : 32;
+    const uint32_t nbw = NB <= 8 ? 8 : NB <= 16 ? 16 : NB <= 20 ? 20 : NB <= 24 ? 24 : 32;
     const bool use_b3 = chain_ok && b3_wave_bytes(nbw, db->b2_maxn_pad, db->b2_nctr, db->b3_chain_cap) * B3_WAVES <= 160 * 1024;
     if (use_b3) {
         // K0 count pass -> pair offsets -> K0 emit (the pairs are needed by the record count pass below)
@@ -1865,14 +1877,15 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
         std::vector<uint32_t> seg_anc, seg_anc_n(rsegs.size(), 0);
         const bool chain_ok = max_depth <= (uint32_t)B3_CHAIN;
         db->b3_chain_cap = std::min<uint32_t>(B3_CHAIN, std::max<uint32_t>(8, (max_depth + 7) / 8 * 8));
+        const size_t anc_stride = db->b3_chain_cap;
         if (chain_ok) {
-            seg_anc.assign(rsegs.size() * (size_t)B3_CHAIN, 0);
+            seg_anc.assign(rsegs.size() * anc_stride, 0);
             for (size_t sidx = 0; sidx < rsegs.size(); ++sidx) {
                 if (rsegs[sidx].first >= rsegs[sidx].end) continue;
                 int32_t cur = parent[rsegs[sidx].first];
                 uint32_t d = cur < 0 ? 0u : depth[cur];
                 seg_anc_n[sidx] = d;
-                while (cur >= 0) { seg_anc[sidx * B3_CHAIN + (--d)] = (uint32_t)cur; cur = parent[cur]; }
+                while (cur >= 0) { seg_anc[sidx * anc_stride + (--d)] = (uint32_t)cur; cur = parent[cur]; }
             }
         }
         if (b2_prepare(db, max_n, chain_ok, perm, nl, seg_anc, seg_anc_n)) { kmdb_db_free(db); return 1; }

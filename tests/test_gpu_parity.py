@@ -39,8 +39,8 @@ def test_all2all_dense_bit_exact(K, O, golden_dir, dev, stem):
     # the default path for these sizes is the block-record pipeline
     assert d.stats()["n_records"] > 0 or d.P <= 1
     # the other kernels: generic (global stack + HBM atomics), LDS stack + HBM atomics, wave-private LDS tile
-    if stem.startswith("clade64"):
-        assert d.stats()["k0_ms"] > 0                    # shallow trie: the batch-parallel front half ran
+    if stem != "synth_k21":
+        assert d.stats()["k0_ms"] > 0                    # root paths <= 192 nodes: the batch-parallel front half ran
     assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_FORCE_SEQ_EMIT), ref)
     for fl in (K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT, K.capi.FLAG_FORCE_TILE):
         assert np.array_equal(d.all2all_dense(flags=fl), ref), fl
