@@ -308,9 +308,55 @@ def to_view_arrays(pat):
     }
 
 
-def write_db(path, k, fraction, names, sample_counts, arrays, n_buckets=None, kmers_count=0):
-    """Serialise in the reference's .db format (prefix_kmer_db.cpp:438-574) with EMPTY raw hashtables —
-    enough for all2all / all2all-sp, which skip them (console_all2all.cpp:26)."""
+def build_hashtables(dictionary, kmer_pid, k):
+    """Prefix-bucketed linear-probing tables in the reference's layout (src/hashmap_lp.h): bucket =
+    kmer >> 32, key = low 32 bits, home slot = murmur3 fmix32(key) & (capacity - 1), capacity a power of two
+    with fill <= 0.8 (:150,427-437), empty slots = {0, INT32_MAX}.  Slot positions differ from a table the
+    reference grew incrementally (insertion order), but `find` (:308-333) only needs a valid probe sequence.
+    Returns (bucket_offset uint64[nb+1], slots uint64[total]) with item = key | val << 32."""
+    kmers = dictionary.cpu().numpy().view(np.uint64)
+    pids = kmer_pid.cpu().numpy().astype(np.int64)
+    nb = 1 << max(8, 2 * k - 32)
+    bucket = (kmers >> np.uint64(32)).astype(np.int64)
+    counts = np.bincount(bucket, minlength=nb)
+    caps = np.maximum(16, 1 << np.ceil(np.log2(np.maximum(counts, 1) / 0.8)).astype(np.int64))
+    caps = np.where(counts > caps * 0.8, caps * 2, caps)
+    boff = np.zeros(nb + 1, dtype=np.uint64)
+    boff[1:] = np.cumsum(caps).astype(np.uint64)
+    slots = np.full(int(boff[-1]), np.uint64(0x7fffffff) << np.uint64(32), dtype=np.uint64)
+    key = (kmers & np.uint64(0xffffffff)).astype(np.uint64)
+    h = key.astype(np.uint32)
+    h ^= h >> np.uint32(16); h *= np.uint32(0x85ebca6b); h ^= h >> np.uint32(13); h *= np.uint32(0xc2b2ae35); h ^= h >> np.uint32(16)
+    order = np.argsort(bucket, kind="stable")
+    start = 0
+    for b in range(nb):
+        n = int(counts[b])
+        if not n:
+            continue
+        idx = order[start: start + n]
+        start += n
+        cap = int(caps[b])
+        home = (h[idx].astype(np.int64)) & (cap - 1)
+        o2 = np.argsort(home, kind="stable")
+        hs = home[o2]
+        # sorted homes: position = max(home, previous + 1) = i + running max of (home - i)
+        pos = np.arange(n) + np.maximum.accumulate(hs - np.arange(n))
+        items = key[idx][o2] | (pids[idx][o2].astype(np.uint64) << np.uint64(32))
+        base = int(boff[b])
+        fit = pos < cap
+        slots[base + pos[fit]] = items[fit]
+        for it, hm in zip(items[~fit], hs[~fit]):              # the few that wrap past the end of the table
+            p_ = int(hm)
+            while (slots[base + p_] >> np.uint64(32)) != np.uint64(0x7fffffff):
+                p_ = (p_ + 1) & (cap - 1)
+            slots[base + p_] = it
+    return boff, slots
+
+
+def write_db(path, k, fraction, names, sample_counts, arrays, n_buckets=None, kmers_count=0, tables=None):
+    """Serialise in the reference's .db format (prefix_kmer_db.cpp:438-574).  Without `tables` the raw
+    hashtables are EMPTY — enough for all2all / all2all-sp, which skip them (console_all2all.cpp:26); with
+    tables = build_hashtables(...) the file also serves new2all."""
     if n_buckets is None:
         n_buckets = 1 << max(8, 2 * k - 32)
     with open(path, "wb") as f:
@@ -321,8 +367,21 @@ def write_db(path, k, fraction, names, sample_counts, arrays, n_buckets=None, km
             f.write(struct.pack("<QQ", int(c), len(b)))
             f.write(b)
         f.write(struct.pack("<Q", n_buckets))
-        empty = struct.pack("<dQQQQQQQ", 0.8, 0, 16, 12, 15, 128, 0, 0) + struct.pack("<Q", 0)   # header + 1 bit-vector word
-        f.write(empty * n_buckets)
+        if tables is None:
+            empty = struct.pack("<dQQQQQQQ", 0.8, 0, 16, 12, 15, 128, 0, 0) + struct.pack("<Q", 0)   # header + 1 bit-vector word
+            f.write(empty * n_buckets)
+        else:
+            boff, slots = tables                                   # hashmap_lp.h:481-528
+            for b in range(n_buckets):
+                seg = slots[int(boff[b]): int(boff[b + 1])]
+                cap = seg.size
+                used = (seg >> np.uint64(32)) != np.uint64(0x7fffffff)
+                filled = int(used.sum())
+                f.write(struct.pack("<dQQQQQQQ", 0.8, filled, cap, int(cap * 0.8), cap - 1, cap * 8, 0, 0))
+                bv = np.zeros((cap + 63) // 64 * 64, dtype=np.uint8)
+                bv[:cap] = used
+                f.write(np.packbits(bv, bitorder="little").tobytes())      # bit i of word i/64 = slot i filled
+                f.write(seg[used].tobytes())
         P = arrays["num_kmers"].size
         f.write(struct.pack("<Q", P))
         nb = arrays["num_bits"].astype(np.int64)

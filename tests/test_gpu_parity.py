@@ -351,3 +351,42 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
     assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["genome_length_bp"] == 60000
     # both runs cover a 60 kbp genome set of the same model: two prefix shards do the same total work
     assert abs(d2["value"] * d2["ms_per_step"] - d["value"] * d["ms_per_step"]) / (d["value"] * d["ms_per_step"]) < 1e-9
+
+
+def test_new2all_synthetic_scale(K, O, dev, tmp_path):
+    """new2all on a bench-shaped database (1000 samples) with synthetic hashtables: members, fresh strains of
+    known clades, an unrelated genome and an empty query, dense and sparse, against the oracle and the
+    real reference."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    N, cs, L, k = 1000, 50, 12000, 18
+    device = torch.device("cuda", dev)
+    g, pat = S.synth_database(N, cs, L, k=k, seed=31, device=device)
+    arr = S.to_view_arrays(pat)
+    tables = S.build_hashtables(pat["dictionary"], pat["kmer_pid"], k)
+    path = str(tmp_path / "s.db")
+    S.write_db(path, k, 1.0, [g.name(i) for i in range(N)], pat["sample_counts"], arr,
+               kmers_count=int(pat["dictionary"].numel()), tables=tables)
+    g_more = S.CladeGenomes(N + 100, cs, L, seed=31, device=device)          # strains 1000.. are new members of clades 20, 21
+    other = S.CladeGenomes(10, 5, L, seed=77, device=device)
+    qs = [S.kmers_of(g.sample(i), k).cpu().numpy().view(np.uint64) for i in (0, 499, 999)]
+    qs += [S.kmers_of(g_more.sample(i), k).cpu().numpy().view(np.uint64) for i in (1000, 1049)]
+    qs += [S.kmers_of(other.sample(2), k).cpu().numpy().view(np.uint64), np.zeros(0, np.uint64)]
+    o = O.OracleDB(path)
+    exp = np.stack([o.one2all(q) for q in qs])
+    d = K.DeviceDB(K.HostDB(path), device=dev, with_hashtables=True)
+    got = d.new2all(qs)
+    assert np.array_equal(got, exp)
+    assert got[0, 0] == qs[0].size and got[2, 999] == qs[2].size
+    sp = d.new2all_sparse(qs)
+    for i in range(len(qs)):
+        c, v = sp.row(i)
+        nz = np.nonzero(exp[i])[0]
+        assert np.array_equal(c, nz) and np.array_equal(v, exp[i][nz])
+    if O.have_ref():
+        O.write_kmers_bin(str(tmp_path / "q.bin"), k, 1.0, [("q%d" % i, q) for i, q in enumerate(qs)])
+        rows, _ = O.ref_one2all(path, str(tmp_path / "q.bin"), str(tmp_path / "o.u32"), 4)
+        assert np.array_equal(rows.reshape(len(qs), N), exp)
+    # all2all of the same upload still works (hashtables do not disturb it)
+    assert np.array_equal(d.all2all_dense(), o.all2all_dense())

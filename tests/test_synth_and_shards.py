@@ -147,3 +147,37 @@ def test_gamma_encoder_of_generator_matches_oracle(S, O):
             assert np.array_equal(d.astype(np.int64), np.diff(ids[p]))
         else:
             assert int(nbits[p]) == 0
+
+
+def test_synthetic_hashtables_serve_new2all(S, O, K):
+    """build_hashtables + write_db(tables=...) give a .db the oracle, the front-end reader and (when present)
+    the real reference answer new2all queries from; a query equal to database sample i must see row i of the
+    all2all matrix and its own k-mer count on the diagonal."""
+    N, cs, L, k = 40, 10, 9000, 18
+    g, pat = S.synth_database(N, cs, L, k=k, seed=21)
+    arr = S.to_view_arrays(pat)
+    tables = S.build_hashtables(pat["dictionary"], pat["kmer_pid"], k)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "s.db")
+        S.write_db(path, k, 1.0, [g.name(i) for i in range(N)], pat["sample_counts"], arr,
+                   kmers_count=int(pat["dictionary"].numel()), tables=tables)
+        o = O.OracleDB(path)
+        m = o.all2all_dense()
+        fresh = S.CladeGenomes(N, cs, L, seed=22)
+        qs = [S.kmers_of(g.sample(i), k).numpy().view(np.uint64) for i in (0, 17, N - 1)]
+        qs.append(S.kmers_of(fresh.sample(3), k).numpy().view(np.uint64))
+        for qi, q in zip((0, 17, N - 1), qs):
+            row = o.one2all(q)
+            for j in range(N):
+                if j == qi:
+                    assert row[j] == q.size
+                else:
+                    a, b = max(qi, j), min(qi, j)
+                    assert row[j] == m[a * (a - 1) // 2 + b]
+        h = K.HostDB(path)
+        v = h.view_arrays()
+        assert np.array_equal(v["slots"], tables[1]) and np.array_equal(v["bucket_offset"], tables[0])
+        if O.have_ref():
+            O.write_kmers_bin(os.path.join(td, "q.bin"), k, 1.0, [("q%d" % i, q) for i, q in enumerate(qs)])
+            rows, _ = O.ref_one2all(path, os.path.join(td, "q.bin"), os.path.join(td, "o.u32"), 2)
+            assert np.array_equal(rows.reshape(len(qs), N), np.stack([o.one2all(q) for q in qs]))
