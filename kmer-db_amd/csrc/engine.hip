@@ -915,9 +915,36 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
     uint32_t out = 0;
     uint32_t npairs = 0, blk0 = 0;
     unsigned long long mask0 = 0;
-    if (l) {
+    if (l && !LONG) {
+        // short lists: ONE decode pass.  The deltas are parked in LDS ([k][thread], conflict-free) and the ids
+        // are rebuilt from the explicit last id downwards (pattern_t::decodeSamples does the same subtraction,
+        // reference src/pattern.cpp:104-107); blocks therefore come out in DESCENDING order: the lowest block is the
+        // node's inline first pair, the others fill its CSR range from the top.
+        __shared__ uint16_t dl[32 * 256];
+        if (l > 1) {
+            BitCursor c1(bits, bitpos[i]);
+            for (uint32_t k = 0; k + 1 < l; ++k) dl[k * 256 + threadIdx.x] = (uint16_t)c1.next();
+        }
         uint32_t id = m.z;
-        using Cursor = typename std::conditional<LONG, BitCursorDeep<6>, BitCursor>::type;
+        uint32_t curblk = bm.blk(id);
+        unsigned long long acc = 0;
+        uint32_t top = 0;
+        if (!COUNT) top = pair_ofs[i + 1];                 // one past this node's extra pairs
+        for (uint32_t k = l; k-- > 0;) {
+            const uint32_t blk = bm.blk(id);
+            if (blk != curblk) {
+                if (!COUNT) { --top; pair_blk[top] = (uint8_t)curblk; pair_mask[top] = acc; }
+                ++npairs;
+                curblk = blk; acc = 0;
+            }
+            acc |= 1ull << bm.bit(id, blk);
+            if (k) id -= dl[(k - 1) * 256 + threadIdx.x];
+        }
+        blk0 = curblk; mask0 = acc;
+        ++npairs;
+    } else if (l) {
+        uint32_t id = m.z;
+        using Cursor = BitCursorDeep<6>;
         if (l > 1) {
             Cursor c1(bits, bitpos[i]);
             uint32_t sum = 0;
