@@ -1,0 +1,208 @@
+// device_common.h — device-side helpers shared by the kernels of libkmdb_amd.so: wave-level primitives,
+// the Elias-gamma stream reader, node decoding, block mapping.  Everything is internal to each
+// translation unit (anonymous namespace).
+#pragma once
+#include "engine_state.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int DEC_CAP = 1024;       // decoded local ids buffered per wave per batch
+
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// make this wave's earlier LDS / global writes visible to its other lanes (same CU: the
+// workgroup-scope fence is enough, no cache maintenance involved)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ordering point for data that lives in LDS only: the LDS pipeline executes one wave's DS
+// instructions in order, so only the compiler has to be kept from moving accesses across it.
+// (wave_sync() also drains outstanding global stores, which costs microseconds per call.)
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src_lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)v, d, WAVE);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// Gamma streams are MSB-first in little-endian uint64 words (reference src/elias_gamma.h:113-125).
+// BitCursor keeps three consecutive words in registers: a code (<= 63 bits) is extracted from
+// c0:c1 with shifts only, and the word two ahead is fetched when the cursor crosses a word
+// boundary, so the decode loop has no load on its dependency chain.  The bit array carries four
+// padding words.
+struct BitCursor {
+    const uint64_t* __restrict__ bits;
+    uint64_t wi;
+    uint64_t c0, c1, c2;
+    uint32_t s;                                    // bit offset inside c0
+    __device__ __forceinline__ BitCursor(const uint64_t* __restrict__ b, uint64_t pos) : bits(b) {
+        wi = pos >> 6;
+        s = (uint32_t)pos & 63u;
+        c0 = bits[wi]; c1 = bits[wi + 1]; c2 = bits[wi + 2];
+    }
+    // one Elias-gamma value: (L-1) ones, a zero, (L-1) low bits (reference src/elias_gamma.h:104-128)
+    __device__ __forceinline__ uint32_t next() {
+        const uint64_t win = s ? ((c0 << s) | (c1 >> (64u - s))) : c0;
+        uint32_t ones = (uint32_t)__clzll((long long)~win);
+        ones = ones > 31u ? 31u : ones;             // a valid code has at most 31 leading ones
+        const uint32_t low = (uint32_t)((win << ones) >> (63u - ones));
+        s += 2u * ones + 1u;
+        if (s >= 64u) {
+            s -= 64u;
+            ++wi;
+            c0 = c1; c1 = c2; c2 = bits[wi + 2];
+        }
+        return low | (1u << ones);
+    }
+};
+
+// Same decoder with a deeper look-ahead (PF words in flight): for the threads that walk long streams
+// alone, where the single look-ahead word of BitCursor leaves a full memory latency per 64 bits.
+template <int PF>
+struct BitCursorDeep {
+    const uint64_t* __restrict__ bits;
+    uint64_t wi;
+    uint64_t c[PF + 2];
+    uint32_t s;
+    __device__ __forceinline__ BitCursorDeep(const uint64_t* __restrict__ b, uint64_t pos) : bits(b) {
+        wi = pos >> 6;
+        s = (uint32_t)pos & 63u;
+#pragma unroll
+        for (int k = 0; k < PF + 2; ++k) c[k] = bits[wi + k];
+    }
+    __device__ __forceinline__ uint32_t next() {
+        const uint64_t win = s ? ((c[0] << s) | (c[1] >> (64u - s))) : c[0];
+        uint32_t ones = (uint32_t)__clzll((long long)~win);
+        ones = ones > 31u ? 31u : ones;
+        const uint32_t low = (uint32_t)((win << ones) >> (63u - ones));
+        s += 2u * ones + 1u;
+        if (s >= 64u) {
+            s -= 64u;
+            ++wi;
+#pragma unroll
+            for (int k = 0; k < PF + 1; ++k) c[k] = c[k + 1];
+            c[PF + 1] = bits[wi + PF + 1];
+        }
+        return low | (1u << ones);
+    }
+};
+
+// Decode the l local ids of one node into out[0..l) (ascending).  pattern_t::decodeSamples
+// (reference src/pattern.cpp:99-109): l-1 gamma-coded deltas in append order, last id explicit.
+template <class T>
+__device__ __forceinline__ void decode_node(const uint64_t* __restrict__ bits, uint64_t pos, uint32_t l, uint32_t last, T* out) {
+    if (l == 0) return;
+    if (l > 1) {
+        BitCursor cur(bits, pos);
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i + 1 < l; ++i) {
+            const uint32_t d = cur.next();
+            out[i] = (T)d;
+            sum += d;
+        }
+        uint32_t id = last - sum;
+        for (uint32_t i = 0; i + 1 < l; ++i) {
+            const uint32_t d = (uint32_t)out[i];
+            out[i] = (T)id;
+            id += d;
+        }
+    }
+    out[l - 1] = (T)last;
+}
+
+// Sample ids are grouped into blocks of `width` (<= 64) consecutive ids; the width is chosen per database
+// at upload (a narrower block that matches the cluster structure of the samples means fewer block records).
+struct BlockMap {
+    uint32_t width, magic;                          // magic = floor(2^32 / width) + 1: exact division for ids < 2^16
+    __host__ __device__ __forceinline__ uint32_t blk(uint32_t id) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __umulhi(id, magic);
+#else
+        return id / width;
+#endif
+    }
+    __host__ __device__ __forceinline__ uint32_t bit(uint32_t id, uint32_t b) const { return id - b * width; }
+};
+
+// decode_node plus, per id, the running bit mask of the ids of the same block seen so far
+// in this node ("cum"): the block-record kernel needs it per stack position.
+__device__ __forceinline__ void decode_node_cum(const uint64_t* __restrict__ bits, uint64_t pos, uint32_t l, uint32_t last,
+                                                uint16_t* out, unsigned long long* cum, const BlockMap bm) {
+    if (l == 0) return;
+    uint32_t id = last;
+    if (l > 1) {
+        BitCursor cur(bits, pos);
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i + 1 < l; ++i) {
+            const uint32_t d = cur.next();
+            out[i] = (uint16_t)d;
+            sum += d;
+        }
+        id = last - sum;
+    }
+    uint32_t curblk = 0xFFFFFFFFu;
+    unsigned long long acc = 0;
+    for (uint32_t i = 0; i < l; ++i) {
+        const uint32_t d = (i + 1 < l) ? (uint32_t)out[i] : 0u;
+        const uint32_t blk = bm.blk(id);
+        if (blk != curblk) { curblk = blk; acc = 0; }
+        acc |= 1ull << bm.bit(id, blk);
+        out[i] = (uint16_t)id;
+        cum[i] = acc;
+        id += d;
+    }
+}
+
+__device__ __forceinline__ uint64_t tri64(uint64_t a) { return a * (a - 1) / 2; }
+
+struct A2AParams {
+    const uint4* meta;
+    const uint64_t* bitpos;
+    const int32_t* parent;
+    const uint32_t* sub_end;
+    const uint32_t* wprefix;
+    const uint64_t* bits;
+    const Segment* segs;
+    uint32_t seg_begin, seg_end;
+    uint32_t* M;                    // N(N-1)/2 lower-triangular matrix in HBM
+    uint32_t* stack_scratch;        // global kernel only
+    uint32_t stack_stride;          // words per wave
+    unsigned long long* counters;
+    uint32_t dbg;                   // timing experiments only: 2 = skip scatter, 4 = skip flush, 8 = skip mapping+scatter
+};
+
+// rebuild the id stack for the ancestors of `first` by walking parent links
+template <class T>
+__device__ __forceinline__ void init_stack(const A2AParams& p, uint32_t first, T* stack, uint32_t lane) {
+    int32_t cur = p.parent[first];
+    while (cur >= 0) {
+        uint4 m = p.meta[cur];
+        if (lane == 0) decode_node<T>(p.bits, p.bitpos[cur], m.y, m.z, stack + (m.x - m.y));
+        cur = p.parent[cur];
+    }
+    wave_sync();
+}
+
+
+}  // namespace
