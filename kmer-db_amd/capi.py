@@ -1,6 +1,7 @@
 """ctypes declarations for include/kmdb_amd.h and thin numpy-facing wrappers."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -73,6 +74,13 @@ def lib():
     p = lib_path()
     if not os.path.exists(p):
         raise KmdbError("libkmdb_amd.so is not built (run __graft_entry__.build() or `make -C kmer-db_amd`)")
+    # torch ships its own copy of the HIP runtime; if the process is going to use torch as well (device
+    # buffers for the RCCL reduce), it has to be the first one loaded or torch finds no device afterwards
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(p)
     L.kmdb_last_error.restype = C.c_char_p
     L.kmdb_db_upload.argtypes = [C.POINTER(_View), C.POINTER(_Opts), C.c_int, C.POINTER(C.c_void_p)]

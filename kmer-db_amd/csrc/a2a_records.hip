@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
                                                         const uint64_t* __restrict__ bits, const uint32_t* __restrict__ perm,
                                                         uint32_t P, uint32_t short_max, BlockMap bm, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
                                                         uint32_t* __restrict__ pair_ofs, uint8_t* __restrict__ pair_blk,
-                                                        unsigned long long* __restrict__ pair_mask) {
+                                                        unsigned long long* __restrict__ pair_mask, uint32_t kdbg) {
     // output per node: the first (block, mask) pair inline — p0_info = block | npairs << 8 — and any
     // further pairs in a CSR side array (pair_ofs counts only the extra pairs)
     // two launches cover the nodes: perm == nullptr walks ALL nodes in DFS order (coalesced) and skips the
@@ -284,89 +284,115 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
         if (t >= P) return;
         i = perm[t];
     } else {
-        // DFS-order launch: the 256 nodes of the block are re-dealt to its threads by decreasing list length
-        // (counting sort in LDS), so every wave decodes streams of similar length while all global accesses
+        // DFS-order launch: the 256 nodes of the block are re-dealt to its threads by decreasing amount of work
+        // (counting sort in LDS), so every wave runs decode loops of similar length while all global accesses
         // of the block stay inside its own 256-node window
         __shared__ uint32_t bins[64];
         __shared__ uint16_t order[256];
         if (threadIdx.x < 64) bins[threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t lt = t < P ? meta[t].y : 0u;
-        const uint32_t key = (t < P && lt <= short_max) ? lt : 0u;      // 0: nothing to decode here
-        atomicAdd(&bins[short_max - key], 1u);                           // bin 0 = longest
+        const uint2 lt2 = t < P ? make_uint2(meta[t].y, meta[t].w) : make_uint2(0u, 0u);
+        // work of a node ~ number of codes that are not "0" ~ stream bits beyond one per delta
+        uint32_t key = 0;                                                // 0: nothing to decode here
+        if (t < P && lt2.x > 1 && !kmdb_long_node(lt2.x, lt2.y)) {
+            key = (kdbg & 8u) ? 1u + (lt2.y - (lt2.x - 1u)) / 2u : 1u + (lt2.y - (lt2.x - 1u));
+            key = key > 63u ? 63u : key;
+        }
+        atomicAdd(&bins[63u - key], 1u);                                 // bin 0 = most work
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (uint32_t b = 0; b <= short_max; ++b) { const uint32_t c = bins[b]; bins[b] = run; run += c; }
+        if (threadIdx.x < 64) {
+            const uint32_t c = bins[threadIdx.x];
+            bins[threadIdx.x] = wave_incl_scan(c, threadIdx.x) - c;
         }
         __syncthreads();
-        order[atomicAdd(&bins[short_max - key], 1u)] = (uint16_t)threadIdx.x;
+        order[atomicAdd(&bins[63u - key], 1u)] = (uint16_t)threadIdx.x;
         __syncthreads();
-        i = blockIdx.x * blockDim.x + order[threadIdx.x];
+        i = blockIdx.x * blockDim.x + ((kdbg & 1u) ? threadIdx.x : order[threadIdx.x]);
         if (i >= P) return;
     }
     const uint4 m = meta[i];
     const uint32_t l = m.y;
-    if (!perm && l > short_max) return;
-    uint32_t out = 0;
+    if (!perm && kmdb_long_node(l, m.w)) return;
     uint32_t npairs = 0, blk0 = 0;
     unsigned long long mask0 = 0;
-    if (l && !LONG) {
-        // short lists: ONE decode pass.  The deltas are parked in LDS ([k][thread], conflict-free) and the ids
-        // are rebuilt from the explicit last id downwards (pattern_t::decodeSamples does the same subtraction,
-        // reference src/pattern.cpp:104-107); blocks therefore come out in DESCENDING order: the lowest block is the
-        // node's inline first pair, the others fill its CSR range from the top.
-        __shared__ uint16_t dl[32 * 256];
-        if (l > 1) {
-            BitCursor c1(bits, bitpos[i]);
-            for (uint32_t k = 0; k + 1 < l; ++k) dl[k * 256 + threadIdx.x] = (uint16_t)c1.next();
-        }
-        uint32_t id = m.z;
-        uint32_t curblk = bm.blk(id);
-        unsigned long long acc = 0;
-        uint32_t top = 0;
-        if (!COUNT) top = pair_ofs[i + 1];                 // one past this node's extra pairs
-        for (uint32_t k = l; k-- > 0;) {
-            const uint32_t blk = bm.blk(id);
-            if (blk != curblk) {
-                if (!COUNT) { --top; pair_blk[top] = (uint8_t)curblk; pair_mask[top] = acc; }
-                ++npairs;
-                curblk = blk; acc = 0;
-            }
-            acc |= 1ull << bm.bit(id, blk);
-            if (k) id -= dl[(k - 1) * 256 + threadIdx.x];
-        }
-        blk0 = curblk; mask0 = acc;
-        ++npairs;
+    if (l == 1 || (kdbg & 4u)) {
+        blk0 = bm.blk(m.z); mask0 = 1ull << bm.bit(m.z, blk0); npairs = 1;
     } else if (l) {
-        uint32_t id = m.z;
-        using Cursor = BitCursorDeep<6>;
-        if (l > 1) {
-            Cursor c1(bits, bitpos[i]);
-            uint32_t sum = 0;
-            for (uint32_t k = 0; k + 1 < l; ++k) sum += c1.next();
-            id = m.z - sum;
+        // Pass 1 walks the stream run by run and builds the list RELATIVE to its (still unknown) first id:
+        // bit k of R <=> id_0 + k is in the list.  pattern_t::decodeSamples (reference src/pattern.cpp:99-109)
+        // gets id_0 the same way: last id minus the sum of the deltas.
+        using Cursor = RunCursor<LONG ? 8 : 3, LONG>;
+        const uint64_t pos = bitpos[i];
+        unsigned long long R = 1ull;
+        uint32_t span = 0;
+        {
+            Cursor c(bits, pos);
+            uint32_t rem = l - 1;
+            while (rem) {
+                const uint32_t z = c.zeros(rem);
+                if (z) {
+                    if (span + z < 64u) R |= ((2ull << (z - 1)) - 1ull) << (span + 1);
+                    span += z; rem -= z;
+                } else {
+                    span += c.big(); --rem;
+                    if (span < 64u) R |= 1ull << span;
+                }
+            }
         }
-        Cursor c2(bits, bitpos[i]);
-        uint32_t curblk = bm.blk(id);
-        unsigned long long acc = 0;
-        for (uint32_t k = 0; k < l; ++k) {
-            const uint32_t blk = bm.blk(id);
-            if (blk != curblk) {
-                if (npairs == 0) { blk0 = curblk; mask0 = acc; if (!COUNT) out = pair_ofs[i]; }
+        const uint32_t id0 = m.z - span;
+        blk0 = bm.blk(id0);
+        const uint32_t bit0 = bm.bit(id0, blk0);
+        const unsigned long long wm = bm.width == 64 ? ~0ull : (1ull << bm.width) - 1ull;
+        if (span < 64u || (kdbg & 16u)) {
+            // the whole list fits the relative mask: cut it at the block boundaries (at most 3 blocks: width >= 32)
+            const unsigned long long lo = R << bit0, hi = bit0 ? R >> (64u - bit0) : 0ull;
+            auto ext = [&](uint32_t sh) -> unsigned long long {
+                return sh == 0 ? lo : sh < 64u ? ((lo >> sh) | (hi << (64u - sh))) : sh == 64u ? hi : sh < 128u ? (hi >> (sh - 64u)) : 0ull;
+            };
+            mask0 = lo & wm;
+            const unsigned long long m1 = ext(bm.width) & wm, m2 = ext(2 * bm.width) & wm;
+            npairs = 1u + (m1 != 0) + (m2 != 0);
+            if (!COUNT && npairs > 1) {
+                uint32_t out = pair_ofs[i];
+                if (m1) { pair_blk[out] = (uint8_t)(blk0 + 1); pair_mask[out] = m1; ++out; }
+                if (m2) { pair_blk[out] = (uint8_t)(blk0 + 2); pair_mask[out] = m2; }
+            }
+        } else {
+            // wide list: second pass with absolute ids, blocks come out in ascending order
+            Cursor c(bits, pos);
+            uint32_t out = 0;
+            if (!COUNT) out = pair_ofs[i];
+            uint32_t curblk = blk0, bit = bit0, rem = l - 1;
+            unsigned long long acc = 1ull << bit0;
+            auto flush = [&]() {
+                if (npairs == 0) mask0 = acc;
                 else { if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; } ++out; }
                 ++npairs;
-                curblk = blk; acc = 0;
+            };
+            while (rem) {
+                uint32_t z = c.zeros(rem);
+                if (z) {
+                    rem -= z;
+                    while (z) {
+                        const uint32_t room = bm.width - 1u - bit;
+                        const uint32_t t = z < room ? z : room;
+                        if (t) { acc |= ((2ull << (t - 1)) - 1ull) << (bit + 1); bit += t; z -= t; }
+                        if (z) { flush(); ++curblk; acc = 1ull; bit = 0; --z; }
+                    }
+                } else {
+                    const uint32_t id = curblk * bm.width + bit + c.big();
+                    --rem;
+                    const uint32_t blk = bm.blk(id);
+                    if (blk != curblk) { flush(); curblk = blk; acc = 0; }
+                    bit = bm.bit(id, blk);
+                    acc |= 1ull << bit;
+                }
             }
-            acc |= 1ull << bm.bit(id, blk);
-            if (k + 1 < l) id += c2.next();
+            flush();
         }
-        if (npairs == 0) { blk0 = curblk; mask0 = acc; }
-        else if (!COUNT) { pair_blk[out] = (uint8_t)curblk; pair_mask[out] = acc; }
-        ++npairs;
     }
     if (COUNT) pair_ofs[i] = npairs ? npairs - 1 : 0;
-    else { p0_mask[i] = mask0; p0_info[i] = (uint16_t)(blk0 | (npairs << 8)); }
+    else if (!(kdbg & 2u) || mask0 == 0x123456789ull) { p0_mask[i] = mask0; p0_info[i] = (uint16_t)(blk0 | (npairs << 8)); }
 }
 
 struct B3Params {
@@ -865,14 +891,15 @@ template <bool COUNT>
 int b3_launch_decode(kmdb_db* db, hipStream_t st) {
     const uint32_t P = (uint32_t)db->P;
     const BlockMap bm{db->b2_width, (uint32_t)((1ull << 32) / db->b2_width) + 1u};
+    const uint32_t kdbg = getenv("KMDB_K0_DBG") ? (uint32_t)atoi(getenv("KMDB_K0_DBG")) : 0u;
     if (P && !getenv("KMDB_SKIP_K0A"))
         hipLaunchKernelGGL((b3_decode_kernel<COUNT, false>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
                            (const uint32_t*)nullptr, P, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs,
-                           db->b3_pair_blk, db->b3_pair_mask);
+                           db->b3_pair_blk, db->b3_pair_mask, kdbg);
     if (db->b3_n_long && !getenv("KMDB_SKIP_K0B"))
         hipLaunchKernelGGL((b3_decode_kernel<COUNT, true>), dim3((db->b3_n_long + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos,
                            db->bits, (const uint32_t*)db->b3_perm, db->b3_n_long, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info,
-                           db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask);
+                           db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask, kdbg);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -108,6 +108,63 @@ struct BitCursorDeep {
     }
 };
 
+// Run-aware reader of the same streams.  Most deltas of a local list are 1 (code "0": the samples of a
+// cluster are consecutive ids), so the decoder consumes a whole run of "0" codes with one count-leading-zeros
+// and only walks code by code through the larger deltas.  NW stream words live in registers and are all fetched
+// together: a load inside the decode loop would put a full memory latency on every word the cursor crosses
+// (the loop is divergent, so some lane crosses a word in nearly every iteration).  RELOAD = false: the stream
+// is known to end inside the first NW words.  RELOAD = true: when only one word is left, the next NW - 1 are
+// fetched in one go.
+template <int NW, bool RELOAD>
+struct RunCursor {
+    const uint64_t* __restrict__ bits;
+    uint64_t wi;
+    uint64_t c[NW];
+    uint32_t s;                                    // bit offset inside c[0]
+    uint32_t valid;                                // words of c[] that hold stream data
+    __device__ __forceinline__ RunCursor(const uint64_t* __restrict__ b, uint64_t pos) : bits(b) {
+        wi = pos >> 6;
+        s = (uint32_t)pos & 63u;
+        valid = NW;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) c[k] = bits[wi + k];
+    }
+    __device__ __forceinline__ void advance(uint32_t nbits) {          // nbits <= 64
+        s += nbits;
+        if (s >= 64u) {
+            s -= 64u;
+            ++wi;
+#pragma unroll
+            for (int k = 0; k + 1 < NW; ++k) c[k] = c[k + 1];
+            if (RELOAD) {
+                if (--valid == 1u) {
+#pragma unroll
+                    for (int k = 1; k < NW; ++k) c[k] = bits[wi + k];
+                    valid = NW;
+                }
+            } else c[NW - 1] = 0;
+        }
+    }
+    __device__ __forceinline__ uint64_t window() const { return s ? ((c[0] << s) | (c[1] >> (64u - s))) : c[0]; }
+    // number of consecutive "0" codes (deltas of 1) at the cursor, at most `limit`; consumes them
+    __device__ __forceinline__ uint32_t zeros(uint32_t limit) {
+        const uint64_t win = window();
+        uint32_t z = win ? (uint32_t)__clzll((long long)win) : 64u;
+        z = z < limit ? z : limit;
+        if (z) advance(z);
+        return z;
+    }
+    // one code that is known to start with a 1 bit (value >= 2)
+    __device__ __forceinline__ uint32_t big() {
+        const uint64_t win = window();
+        uint32_t ones = (uint32_t)__clzll((long long)~win);
+        ones = ones > 31u ? 31u : ones;
+        const uint32_t low = (uint32_t)((win << ones) >> (63u - ones));
+        advance(2u * ones + 1u);
+        return low | (1u << ones);
+    }
+};
+
 // Decode the l local ids of one node into out[0..l) (ascending).  pattern_t::decodeSamples
 // (reference src/pattern.cpp:99-109): l-1 gamma-coded deltas in append order, last id explicit.
 template <class T>

@@ -314,20 +314,19 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
             depth[i] = (uint16_t)d;
             max_depth = std::max(max_depth, d);
         }
-        // K0: nodes with more than 32 local ids (a few percent) are decoded by a second launch, longest first
-        const uint32_t SHORT_MAX = 32;
+        // K0: nodes with long lists or streams (a few percent) are decoded by a second launch, longest list first
         std::vector<uint32_t> perm, nl(P);
         {
             std::vector<uint32_t> cntl(max_n + 2, 0);
             uint64_t nlong = 0;
             for (uint64_t i = 0; i < P; ++i) {
                 nl[i] = meta[i].x | (meta[i].y << 16);
-                if (meta[i].y > SHORT_MAX) { ++cntl[max_n - meta[i].y + 1]; ++nlong; }
+                if (kmdb_long_node(meta[i].y, meta[i].w)) { ++cntl[max_n - meta[i].y + 1]; ++nlong; }
             }
             for (uint32_t b = 1; b < cntl.size(); ++b) cntl[b] += cntl[b - 1];
             perm.resize(nlong);
             for (uint64_t i = 0; i < P; ++i)
-                if (meta[i].y > SHORT_MAX) perm[cntl[max_n - meta[i].y]++] = (uint32_t)i;
+                if (kmdb_long_node(meta[i].y, meta[i].w)) perm[cntl[max_n - meta[i].y]++] = (uint32_t)i;
         }
         // segments of the emit kernels.  Measured: the equal-cost slices of the scatter model (long multi-clade
         // lists weigh more) also balance the emit kernel better than equal node counts do, so they are reused.

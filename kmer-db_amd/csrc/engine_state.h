@@ -79,6 +79,10 @@ struct kmdb_db {
 };
 
 
+// K0 decodes a node in the coalesced DFS-order launch when its stream is short enough to sit in three
+// registers; the others (a few percent) go to a second launch, longest list first.
+constexpr uint32_t KMDB_SHORT_MAX_IDS = 32, KMDB_SHORT_MAX_BITS = 128;
+__host__ __device__ inline bool kmdb_long_node(uint32_t l, uint32_t num_bits) { return l > KMDB_SHORT_MAX_IDS || num_bits > KMDB_SHORT_MAX_BITS; }
 constexpr int KMDB_CHAIN_MAX = 192;   // longest root path (in nodes) the batch-parallel emit kernel can hold (slot ids are bytes)
 
 // ---- a2a_v1.hip: tree-form scatter kernels (LDS tile / HBM atomics); M is zeroed, wprefix is scanned
