@@ -72,7 +72,8 @@ typedef struct kmdb_opts {
 #define KMDB_FLAG_FORCE_GLOBAL_ATOMICS 1u   /* debugging: generic kernel, stack in global scratch, HBM atomics */
 #define KMDB_FLAG_FORCE_DIRECT         2u   /* debugging: LDS stack, HBM atomics */
 #define KMDB_FLAG_FORCE_TILE           4u   /* v1 wave-private LDS tile kernel instead of the block-record pipeline */
-#define KMDB_FLAG_FORCE_SEQ_EMIT       8u   /* block-record pipeline with the sequential (stack-replay) emit kernel */
+#define KMDB_FLAG_FORCE_SEQ_EMIT       8u   /* kmdb_db_upload only: lay the block-record pipeline out for the sequential (stack-replay)
+                                              emit kernel, the one used when root paths exceed 192 nodes */
 
 typedef struct kmdb_db kmdb_db;    /* database resident in HBM */
 

@@ -247,7 +247,7 @@ class SparseRows:
 class DeviceDB:
     """A database resident in HBM (kmdb_db_upload)."""
 
-    def __init__(self, src, device=0, with_hashtables=False):
+    def __init__(self, src, device=0, with_hashtables=False, flags=0):
         self._keep = None
         if isinstance(src, HostDB):
             view = src.view
@@ -258,7 +258,7 @@ class DeviceDB:
             raise TypeError("DeviceDB expects a HostDB or the (view, keepalive) pair from make_view()")
         self.device = device
         self._d = C.c_void_p()
-        o = _opts(device)
+        o = _opts(device, (0, 1), flags)
         _check(lib().kmdb_db_upload(view, C.byref(o), int(with_hashtables), C.byref(self._d)))
         self.N = int(view.contents.n_samples)
         self.P = int(view.contents.n_patterns)

@@ -32,9 +32,13 @@ namespace {
 //   non-zero cell.
 // ------------------------------------------------------------------------------------------
 // block records, struct-of-arrays, one slot per record: rows always; cols only for off-diagonal
-// buckets (on the diagonal cols == rows); w only for the heavy class (class 0 records have w == 1)
+// buckets (on the diagonal cols == rows); w only for the classes with w > 1
 struct B2Recs { unsigned long long* rows; ulonglong2* rc; uint32_t* w; };   // rows: diagonal buckets; rc = {rows, cols}: others
 struct B2Item { uint32_t X, Y, cls, begin, end; };
+// Records are grouped by weight class so that the apply kernel runs a fixed number of bit planes per group:
+// class 0: w == 1 (no weight stored), class 1: w in {2, 3} (two planes), class 2: w >= 4 (all planes).
+constexpr uint32_t B2_NCLS = 3;
+__host__ __device__ __forceinline__ uint32_t b2_weight_class(uint32_t w) { return w == 1u ? 0u : w < 4u ? 1u : 2u; }
 
 constexpr int B2_WAVES = 4;
 
@@ -42,7 +46,7 @@ struct B2Params {
     A2AParams a;
     uint32_t maxn_pad;            // stack capacity (multiple of 64)
     uint32_t dec_cap;             // decoded ids per batch (>= maxn_pad)
-    uint32_t nctr;                // 2 * number of buckets
+    uint32_t nctr;                // B2_NCLS * number of buckets
     BlockMap bm;
     uint32_t* table;              // [n_segs][nctr]: count mode writes counts, emit mode reads record bases
     B2Recs rec;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
             // per pair needs no coordination.  Patterns with w == 0 (inner trie nodes) emit nothing.
             const uint32_t nb = S.nb;
             const uint32_t total = nb * (nb + 1) / 2;
-            const uint32_t cls = Wj == 1u ? 0u : 1u;
+            const uint32_t cls = b2_weight_class(Wj);
             for (uint32_t t = lane; t < total; t += WAVE) {
                 uint32_t kX = (uint32_t)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
                 while (kX * (kX + 1) / 2 > t) --kX;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
                 const uint32_t bX = S.ent_blk[kX], bY = S.ent_blk[kY];
                 const unsigned long long rows = S.cum[endX - 1];
                 const unsigned long long cols = S.cum[endY - 1];
-                const uint32_t b = (bX * (bX + 1) / 2 + bY) * 2 + cls;
+                const uint32_t b = (bX * (bX + 1) / 2 + bY) * B2_NCLS + cls;
                 const uint32_t slot = atomicAdd(&S.ctr[b], 1u);
                 if (EMIT) {
                     if (bX != bY) q.rec.rc[slot] = make_ulonglong2(rows, cols); else q.rec.rows[slot] = rows;
@@ -415,6 +419,13 @@ struct B3Params {
     B2Recs rec;
     uint32_t dbg;
     unsigned long long* counters;
+    // wide-list launch (INDIRECT): lane k of a batch handles node widx[base + k]; parents are positions in the list
+    const uint32_t* widx;
+    const int32_t* wparent;
+    const unsigned long long* fnarrow;
+    const int32_t* seg_np;
+    uint32_t seg_row0;             // first row of this launch in the count / base table
+    uint8_t* nwords;               // count mode of the all-nodes launch: non-empty words of every node's full list
 };
 
 __host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr, uint32_t chain_cap) {
@@ -444,6 +455,8 @@ struct B3Lane {                    // one node per lane
     uint32_t n, l, w, info, idx;
     int32_t par;
     unsigned long long m0;
+    uint32_t npw;                  // wide-list launch: word and full mask of a narrow parent (npm == 0: none)
+    unsigned long long npm;
 };
 
 // One batch of 64 consecutive DFS nodes.  Every lane keeps the full-list masks of its node in W 64-bit
@@ -477,6 +490,11 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
             }
         }
     }
+    if (__ballot(L.npm != 0)) {
+        const uint32_t sp = slot_of_word(L.npw);
+#pragma unroll
+        for (int s = 0; s < W; ++s) F[s] |= (L.npm != 0 && sp == (uint32_t)s) ? L.npm : 0ull;
+    }
     const bool inb = L.valid && L.par >= (int32_t)base;
     int pl = inb ? (int)(L.par - (int32_t)base) : -1;
     const int plo = pl;
@@ -501,45 +519,53 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         const int npl = __shfl(pl, src, WAVE);
         pl = pl >= 0 ? npl : -1;
     }
+    if (!EMIT && q.nwords != nullptr && L.valid) {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int s = 0; s < W; ++s) nz += F[s] != 0 ? 1u : 0u;
+        q.nwords[L.idx] = (uint8_t)nz;
+    }
     // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
     const bool act = L.valid && L.w != 0 && L.n >= 2 && !(q.dbg & 512u);
-    const bool heavy = L.w != 1u;
-    uint32_t mywl = 0;               // word of register (lane >> 1): lane 2*sY + c owns the counter of combo (X, Y, c)
-    if (IDENT) mywl = lane >> 1;
-    else {
-#pragma unroll
-        for (int s = 0; s < W; ++s) if ((lane >> 1) == (uint32_t)s) mywl = wl[s];
-    }
-    uint32_t Ua = act ? 1u : 0u;     // does any lane emit at all
-    if (!__ballot(Ua != 0)) goto chain_update;
+    const uint32_t cls = b2_weight_class(L.w);
+    const uint32_t l3 = lane / 3u, lc = lane - 3u * l3;      // lane 3 * (sY - y0) + c owns the counter of combo (X, Y, c)
+    if (!__ballot(act)) goto chain_update;
 #pragma unroll
     for (int sX = 0; sX < W; ++sX) {
         if (!IDENT && (uint32_t)sX >= ku) break;
         const uint32_t X = IDENT ? (uint32_t)sX : wl[sX];
         const bool ax = act && F[sX] != 0;
         if (!__ballot(ax)) continue;
-        uint32_t mycnt = 0;
+        // 21 column words (63 counters) per round: one LDS atomic per lane reserves the slots of its combo
 #pragma unroll
-        for (int sY = 0; sY <= sX; ++sY) {
-            const bool a = ax && F[sY] != 0;
-            const uint32_t c0 = (uint32_t)__popcll(__ballot(a && !heavy));
-            const uint32_t c1 = (uint32_t)__popcll(__ballot(a && heavy));
-            if (lane == (uint32_t)(2 * sY)) mycnt = c0;
-            if (lane == (uint32_t)(2 * sY + 1)) mycnt = c1;
-        }
-        uint32_t mybase = 0;
-        if (mycnt) mybase = atomicAdd(&C.ctr[(X * (X + 1) / 2 + mywl) * 2 + (lane & 1u)], mycnt);
-        if (EMIT && !(q.dbg & 256u)) {
+        for (int y0 = 0; y0 <= sX; y0 += 21) {
+            const int y1 = sX < y0 + 20 ? sX : y0 + 20;
+            uint32_t mycnt = 0, mywl = 0;
 #pragma unroll
-            for (int sY = 0; sY <= sX; ++sY) {
+            for (int sY = y0; sY <= y1; ++sY) {
                 const bool a = ax && F[sY] != 0;
-                const unsigned long long bal = __ballot(a && !heavy), bah = __ballot(a && heavy);
-                if (!(bal | bah)) continue;
-                const uint32_t base0 = bcast(mybase, 2 * sY), base1 = bcast(mybase, 2 * sY + 1);
-                if (a) {
-                    const uint32_t slot = heavy ? base1 + (uint32_t)__popcll(bah & C.lt_mask) : base0 + (uint32_t)__popcll(bal & C.lt_mask);
-                    if (sX != sY) q.rec.rc[slot] = make_ulonglong2(F[sX], F[sY]); else q.rec.rows[slot] = F[sX];
-                    if (heavy) q.rec.w[slot] = L.w;
+                const uint32_t c0 = (uint32_t)__popcll(__ballot(a && cls == 0u));
+                const uint32_t c1 = (uint32_t)__popcll(__ballot(a && cls == 1u));
+                const uint32_t c2 = (uint32_t)__popcll(__ballot(a && cls == 2u));
+                if (l3 == (uint32_t)(sY - y0)) { mycnt = lc == 0u ? c0 : lc == 1u ? c1 : c2; mywl = IDENT ? (uint32_t)sY : wl[sY]; }
+            }
+            uint32_t mybase = 0;
+            if (mycnt) mybase = atomicAdd(&C.ctr[(X * (X + 1) / 2 + mywl) * B2_NCLS + lc], mycnt);
+            if (EMIT && !(q.dbg & 256u)) {
+#pragma unroll
+                for (int sY = y0; sY <= y1; ++sY) {
+                    const bool a = ax && F[sY] != 0;
+                    const unsigned long long ba = __ballot(a);
+                    if (!ba) continue;
+                    const unsigned long long b0 = __ballot(a && cls == 0u), b1 = __ballot(a && cls == 1u);
+                    const uint32_t base0 = bcast(mybase, 3 * (sY - y0)), base1 = bcast(mybase, 3 * (sY - y0) + 1),
+                                   base2 = bcast(mybase, 3 * (sY - y0) + 2);
+                    if (a) {
+                        const unsigned long long mine = cls == 0u ? b0 : cls == 1u ? b1 : (ba & ~b0 & ~b1);
+                        const uint32_t slot = (cls == 0u ? base0 : cls == 1u ? base1 : base2) + (uint32_t)__popcll(mine & C.lt_mask);
+                        if (sX != sY) q.rec.rc[slot] = make_ulonglong2(F[sX], F[sY]); else q.rec.rows[slot] = F[sX];
+                        if (cls) q.rec.w[slot] = L.w;
+                    }
                 }
             }
         }
@@ -575,7 +601,7 @@ chain_update:
 
 constexpr int B3_K = 8;            // word registers of the compact path
 
-template <int NBW, bool EMIT>
+template <int NBW, bool EMIT, bool INDIRECT>
 __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
@@ -591,7 +617,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     C.slot_of_n = (uint8_t*)(C.chain_nz + q.chain_cap);                    // [maxn_pad + 64]
     C.lane = lane;
     C.lt_mask = (1ull << lane) - 1ull;
-    uint32_t* my_table = q.table + (size_t)seg * q.nctr;
+    uint32_t* my_table = q.table + (size_t)(q.seg_row0 + seg) * q.nctr;
     for (uint32_t k = lane; k < q.nctr; k += WAVE) C.ctr[k] = EMIT ? my_table[k] : 0u;
 
     const Segment sg = q.segs[seg];
@@ -631,6 +657,15 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
                     }
                 }
             }
+            if (INDIRECT && c0 == 0 && lane == 0) {
+                const int32_t np0 = q.seg_np[seg];
+                if (np0 >= 0) {
+                    const uint32_t wd = q.p0_info[np0] & 0xFFu;
+                    const unsigned long long mk = q.fnarrow[np0];
+#pragma unroll
+                    for (int w = 0; w < NBW; ++w) F[w] |= (wd == (uint32_t)w) ? mk : 0ull;
+                }
+            }
 #pragma unroll
             for (int w = 0; w < NBW; ++w) if (lane == 0) F[w] |= carry[w];
 #pragma unroll
@@ -657,17 +692,25 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     }
 
     // node records of the NEXT batch are fetched while the current one is processed
-    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0;
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_idx = 0, nx_npw = 0;
     int32_t nx_par = -1;
-    unsigned long long nx_m0 = 0;
+    unsigned long long nx_m0 = 0, nx_npm = 0;
     auto fetch = [&](uint32_t b0) {
-        const uint32_t ii = b0 + lane;
-        const bool v = ii < end;
+        const uint32_t k = b0 + lane;
+        const bool v = k < end;
+        const uint32_t ii = INDIRECT ? (v ? q.widx[k] : 0u) : k;
+        nx_idx = ii;
         nx_nl = v ? q.nl[ii] : 0u;
         nx_w = v ? q.w[ii] : 0u;
-        nx_par = v ? q.parent[ii] : -1;
+        nx_par = v ? (INDIRECT ? q.wparent[k] : q.parent[ii]) : -1;
         nx_info = v ? q.p0_info[ii] : 0u;
         nx_m0 = v ? q.p0_mask[ii] : 0ull;
+        nx_npw = 0; nx_npm = 0;
+        if (INDIRECT && nx_par <= -2) {
+            const uint32_t np = (uint32_t)(-(nx_par + 2));
+            nx_npw = q.p0_info[np] & 0xFFu;
+            nx_npm = q.fnarrow[np];
+        }
     };
     fetch(first);
     const bool prof = (q.dbg & 32u) != 0;
@@ -676,10 +719,11 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     for (uint32_t base = first; base < end; base += WAVE) {
         if (prof) t0 = __builtin_amdgcn_s_memtime();
         B3Lane L;
-        L.idx = base + lane;
-        L.valid = L.idx < end;
-        L.n = nx_nl & 0xFFFFu; L.l = nx_nl >> 16;
-        L.w = nx_w; L.par = nx_par; L.info = nx_info; L.m0 = nx_m0;
+        L.idx = nx_idx;
+        L.valid = base + lane < end;
+        L.n = nx_nl & 0xFFFFu; L.l = (nx_nl >> 16) & 0x3FFFu;
+        L.w = nx_w; L.par = nx_par; L.info = nx_info; L.m0 = nx_m0; L.npw = nx_npw; L.npm = nx_npm;
+        if ((q.dbg & 8192u) && (L.info >> 8) > 1u) L.info = (L.info & 0xFFu) | 0x100u;   // timing experiment: ignore extra pairs
         if (base + WAVE < end) fetch(base + WAVE);
         // words this batch touches: own local words + the words inherited from a parent before the batch
         const uint32_t np = L.info >> 8;
@@ -693,7 +737,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
             rootslot = C.slot_of_n[L.n - L.l];
             inh = C.chain_nz[rootslot];
         }
-        uint32_t U = L.valid ? (lw | inh) : 0u;
+        uint32_t U = L.valid ? (lw | inh | (L.npm != 0 ? 1u << L.npw : 0u)) : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) U |= (uint32_t)__shfl_xor((int)U, d, WAVE);
         U = __builtin_amdgcn_readfirstlane(U);
@@ -725,6 +769,158 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K1 for NARROW nodes: full list inside one block (about 4 nodes in 5).  Their ancestors are narrow too, so
+// a full list is ONE 64-bit mask and a record is (X, X, F, F, w).  The kernel walks the whole DFS stream,
+// 64 nodes per step, one per lane (lanes of wide nodes idle):
+//   F = local mask | F(parent): parents inside the batch by pointer doubling over one register, parents
+//   before the batch from chain[depth - 2] in LDS (one 64-bit slot per depth: the latest node of every depth
+//   on the current root path); records go straight to the diagonal bucket of their block.
+// Narrow nodes that have a wide child also leave their mask in HBM (fnarrow) for the wide-list launch.
+// ------------------------------------------------------------------------------------------
+struct B3NParams {
+    const uint32_t* nl;            // n | l << 16 | has-wide-child << 30 | wide << 31
+    const int32_t* parent;
+    const uint32_t* w;
+    const uint8_t* depth;
+    const Segment* segs;
+    const uint32_t* seg_anc;       // [n_segs][chain_cap] root-first ancestors of the segment's first node
+    const uint32_t* seg_anc_n;
+    const unsigned long long* p0_mask;
+    const uint16_t* p0_info;
+    unsigned long long* fnarrow;
+    uint32_t n_segs, chain_cap, nctr, nb;
+    uint32_t* table;
+    B2Recs rec;
+    uint32_t dbg;
+};
+constexpr int B3N_WAVES = 4;
+
+__host__ __device__ inline size_t b3n_wave_bytes(uint32_t chain_cap, uint32_t nb) {
+    return ((size_t)chain_cap * 8 + (size_t)nb * B2_NCLS * 4 + 15) & ~(size_t)15;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(WAVE * B3N_WAVES) void b3_narrow_kernel(B3NParams q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t seg = blockIdx.x * B3N_WAVES + wave;
+    if (seg >= q.n_segs) return;
+    unsigned long long* chain = (unsigned long long*)(lds_raw + b3n_wave_bytes(q.chain_cap, q.nb) * wave);   // [chain_cap]
+    uint32_t* ctr = (uint32_t*)(chain + q.chain_cap);                                                        // [nb][B2_NCLS]
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* my_table = q.table + (size_t)seg * q.nctr;
+    for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) {
+        const uint32_t X = k / B2_NCLS, c = k - X * B2_NCLS;
+        ctr[k] = EMIT ? my_table[(X * (X + 1) / 2 + X) * B2_NCLS + c] : 0u;
+    }
+    const Segment sg = q.segs[seg];
+    const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
+    if (first >= end) return;
+
+    // chain slots of the first node's ancestors: inclusive OR along the root path (the narrow nodes are a prefix of it)
+    {
+        const uint32_t d = q.seg_anc_n[seg];
+        unsigned long long carry = 0;
+        for (uint32_t c0 = 0; c0 < d; c0 += WAVE) {
+            const uint32_t k = c0 + lane;
+            const bool on = k < d;
+            const uint32_t node = on ? q.seg_anc[(size_t)seg * q.chain_cap + k] : 0u;
+            const bool nar = on && !(q.nl[node] >> 31);
+            unsigned long long F = (nar && (q.p0_info[node] >> 8) != 0) ? q.p0_mask[node] : 0ull;
+            if (lane == 0) F |= carry;
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const unsigned long long o = shfl_up64(F, s);
+                if (lane >= (uint32_t)s) F |= o;
+            }
+            if (on) chain[k] = F;
+            carry = shfl64(F, WAVE - 1);
+        }
+        lds_sync();
+    }
+
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_dep = 0;
+    int32_t nx_par = -1;
+    unsigned long long nx_m0 = 0;
+    auto fetch = [&](uint32_t b0) {
+        const uint32_t ii = b0 + lane;
+        const bool v = ii < end;
+        nx_nl = v ? q.nl[ii] : 0x80000000u;
+        nx_w = v ? q.w[ii] : 0u;
+        nx_par = v ? q.parent[ii] : -1;
+        nx_dep = v ? q.depth[ii] : 0xFFFFu;
+        nx_info = v ? q.p0_info[ii] : 0u;
+        nx_m0 = v ? q.p0_mask[ii] : 0ull;
+    };
+    fetch(first);
+    for (uint32_t base = first; base < end; base += WAVE) {
+        const uint32_t idx = base + lane;
+        const uint32_t nl = nx_nl, w = nx_w, info = nx_info, dep = nx_dep;
+        const int32_t par = nx_par;
+        unsigned long long F = nx_m0;
+        if (base + WAVE < end) fetch(base + WAVE);
+        const bool nar = !(nl >> 31);                       // lanes past the end carry the wide flag
+        if (!nar || (info >> 8) == 0) F = 0ull;
+        const uint32_t X = info & 0xFFu;
+        if (nar && par >= 0 && par < (int32_t)base) F |= chain[dep - 2u];
+        int pl = (nar && par >= (int32_t)base) ? (int)(par - (int32_t)base) : -1;
+        while (__ballot(pl >= 0)) {
+            const int src = pl >= 0 ? pl : (int)lane;
+            const unsigned long long o = shfl64(F, src);
+            if (pl >= 0) F |= o;
+            const int npl = __shfl(pl, src, WAVE);
+            pl = pl >= 0 ? npl : -1;
+        }
+        if (nar && ((nl >> 30) & 1u)) q.fnarrow[idx] = F;
+        // ---- records
+        const bool act = nar && w != 0 && (nl & 0xFFFFu) >= 2u && !(q.dbg & 512u);
+        const uint32_t cls = b2_weight_class(w);
+        unsigned long long pend = __ballot(act);
+        while (pend) {
+            const uint32_t X0 = bcast(X, (uint32_t)__builtin_ctzll(pend));
+            const bool mine = act && X == X0;
+            const unsigned long long b0 = __ballot(mine && cls == 0u), b1 = __ballot(mine && cls == 1u), b2 = __ballot(mine && cls == 2u);
+            uint32_t mybase = 0;
+            if (lane < B2_NCLS) {
+                const uint32_t cnt = (uint32_t)__popcll(lane == 0 ? b0 : lane == 1 ? b1 : b2);
+                if (cnt) mybase = atomicAdd(&ctr[X0 * B2_NCLS + lane], cnt);
+            }
+            const uint32_t base0 = bcast(mybase, 0), base1 = bcast(mybase, 1), base2 = bcast(mybase, 2);
+            if (EMIT && mine && !(q.dbg & 256u)) {
+                const uint32_t slot = cls == 0u ? base0 + (uint32_t)__popcll(b0 & lt_mask)
+                                    : cls == 1u ? base1 + (uint32_t)__popcll(b1 & lt_mask) : base2 + (uint32_t)__popcll(b2 & lt_mask);
+                q.rec.rows[slot] = F;
+                if (cls) q.rec.w[slot] = w;
+            }
+            pend &= ~(b0 | b1 | b2);
+        }
+        // ---- chain slots for the next batch: the nodes on the root path of this batch's last node, i.e. the
+        // lanes whose depth is smaller than the depth of every later lane
+        if (base + WAVE < end) {
+            uint32_t m = dep;
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_down((int)m, s, WAVE);
+                if (lane + (uint32_t)s < (uint32_t)WAVE) m = o < m ? o : m;
+            }
+            uint32_t later = (uint32_t)__shfl_down((int)m, 1, WAVE);
+            if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
+            if (nar && dep < later) chain[dep - 1u] = F;
+            lds_sync();
+        }
+    }
+    if (!EMIT) {
+        lds_sync();
+        for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) {
+            const uint32_t X = k / B2_NCLS, c = k - X * B2_NCLS;
+            my_table[(X * (X + 1) / 2 + X) * B2_NCLS + c] = ctr[k];
+        }
+    }
+}
+
 // 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit
 __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, uint32_t lane) {
     const unsigned long long masks[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
@@ -747,7 +943,7 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
     __shared__ unsigned long long rtbuf[4][64];
     const B2Item it = items[blockIdx.x];
     if ((dbg & 64u) && it.cls == 0) return;
-    if ((dbg & 128u) && it.cls == 1) return;
+    if ((dbg & 128u) && it.cls != 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     __syncthreads();
@@ -772,22 +968,33 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
         // lane c: bit j of Ct = record j contains column c
         const unsigned long long Ct = transpose64(C, lane);
         if (dbg & 2048u) { if ((uint32_t)Ct + (uint32_t)R + W == 0x12345u) acc[lane] = 1; continue; }
-        if (it.cls == 0) {
-            // every record has weight 1: cell(r, c) += number of records that contain row r and column c
+        if (it.cls <= 1) {
+            // class 0, every record has weight 1: cell(r, c) += number of records that contain row r and column c.
+            // class 1, weights 2 and 3: twice that number plus the count over the records with an odd weight.
             // R^T goes through LDS: row r's record mask is then a broadcast read instead of a ballot
             // (a ballot writes an SGPR pair that the next VALU must wait for; 64 of them serialise the loop)
             rtbuf[wave][lane] = transpose64(R, lane);
             lds_sync();
-            if (!diag) {
+            if (it.cls == 0) {
+                if (!diag) {
 #pragma unroll 8
-                for (uint32_t r = 0; r < bwidth; ++r) {             // rows >= the block width never occur
-                    const uint32_t c = (uint32_t)__popcll(Ct & rtbuf[wave][r]);
-                    if (c) atomicAdd(&acc[r * 64 + lane], c);
+                    for (uint32_t r = 0; r < bwidth; ++r) {             // rows >= the block width never occur
+                        const uint32_t c = (uint32_t)__popcll(Ct & rtbuf[wave][r]);
+                        if (c) atomicAdd(&acc[r * 64 + lane], c);
+                    }
+                } else {
+#pragma unroll 8
+                    for (uint32_t r = 0; r < bwidth; ++r) {
+                        const uint32_t c = lane < r ? (uint32_t)__popcll(Ct & rtbuf[wave][r]) : 0u;
+                        if (c) atomicAdd(&acc[r * 64 + lane], c);
+                    }
                 }
             } else {
+                const unsigned long long Codd = Ct & __ballot((W & 1u) != 0);
 #pragma unroll 8
                 for (uint32_t r = 0; r < bwidth; ++r) {
-                    const uint32_t c = lane < r ? (uint32_t)__popcll(Ct & rtbuf[wave][r]) : 0u;
+                    const unsigned long long Rr = rtbuf[wave][r];
+                    const uint32_t c = (diag && lane >= r) ? 0u : 2u * (uint32_t)__popcll(Ct & Rr) + (uint32_t)__popcll(Codd & Rr);
                     if (c) atomicAdd(&acc[r * 64 + lane], c);
                 }
             }
@@ -851,40 +1058,62 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
     return 0;
 }
 
-template <int NBW, bool EMIT>
-int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg) {
+template <int NBW, bool EMIT, bool INDIRECT>
+int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg, uint8_t* nwords) {
     B3Params q{};
-    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.segs = db->rsegs;
-    q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
+    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w;
     q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
     q.pair_ofs = db->b3_pair_ofs; q.pair_blk = db->b3_pair_blk; q.pair_mask = db->b3_pair_mask;
-    q.n_segs = db->n_rsegs; q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr; q.chain_cap = db->b3_chain_cap;
+    q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr; q.chain_cap = db->b3_chain_cap;
     q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.dbg = dbg; q.counters = db->counters;
+    q.nwords = nwords;
+    if (INDIRECT) {
+        q.segs = db->b3_wsegs; q.n_segs = db->b3_n_wsegs; q.seg_anc = db->b3_wseg_anc; q.seg_anc_n = db->b3_wseg_anc_n;
+        q.widx = db->b3_widx; q.wparent = db->b3_wparent; q.fnarrow = db->b3_fnarrow; q.seg_np = db->b3_wseg_np;
+        q.seg_row0 = db->n_rsegs;
+    } else {
+        q.segs = db->rsegs; q.n_segs = db->n_rsegs; q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
+    }
     const size_t lds = b3_wave_bytes(NBW, q.maxn_pad, q.nctr, q.chain_cap) * B3_WAVES;
-    HIP_TRY(hipFuncSetAttribute((const void*)b3_emit_kernel<NBW, EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)b3_emit_kernel<NBW, EMIT, INDIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (EMIT && getenv("KMDB_VERBOSE")) {
         static bool once = false;
         if (!once) {
             once = true;
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)b3_emit_kernel<NBW, EMIT>, WAVE * B3_WAVES, lds);
-            fprintf(stderr, "[kmdb] emit kernel: NBW %d, width %u, chain_cap %u, LDS/block %zu B, resident blocks/CU %d, segments %u\n",
-                    NBW, db->b2_width, q.chain_cap, lds, nb, db->n_rsegs);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)b3_emit_kernel<NBW, EMIT, INDIRECT>, WAVE * B3_WAVES, lds);
+            fprintf(stderr, "[kmdb] emit kernel%s: NBW %d, width %u, chain_cap %u, LDS/block %zu B, resident blocks/CU %d, segments %u\n",
+                    INDIRECT ? " (wide list)" : "", NBW, db->b2_width, q.chain_cap, lds, nb, q.n_segs);
         }
     }
-    const uint32_t blocks = (db->n_rsegs + B3_WAVES - 1) / B3_WAVES;
-    if (blocks) hipLaunchKernelGGL((b3_emit_kernel<NBW, EMIT>), dim3(blocks), dim3(WAVE * B3_WAVES), lds, st, q);
+    const uint32_t blocks = (q.n_segs + B3_WAVES - 1) / B3_WAVES;
+    if (blocks) hipLaunchKernelGGL((b3_emit_kernel<NBW, EMIT, INDIRECT>), dim3(blocks), dim3(WAVE * B3_WAVES), lds, st, q);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+template <bool EMIT, bool INDIRECT>
+int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0, uint8_t* nwords = nullptr) {
+    if (db->b3_nbw <= 8) return b3_launch_emit_t<8, EMIT, INDIRECT>(db, st, dbg, nwords);
+    if (db->b3_nbw <= 16) return b3_launch_emit_t<16, EMIT, INDIRECT>(db, st, dbg, nwords);
+    if (db->b3_nbw <= 20) return b3_launch_emit_t<20, EMIT, INDIRECT>(db, st, dbg, nwords);
+    if (db->b3_nbw <= 24) return b3_launch_emit_t<24, EMIT, INDIRECT>(db, st, dbg, nwords);
+    return b3_launch_emit_t<32, EMIT, INDIRECT>(db, st, dbg, nwords);
+}
+
 template <bool EMIT>
-int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0) {
-    if (db->b3_nbw <= 8) return b3_launch_emit_t<8, EMIT>(db, st, dbg);
-    if (db->b3_nbw <= 16) return b3_launch_emit_t<16, EMIT>(db, st, dbg);
-    if (db->b3_nbw <= 20) return b3_launch_emit_t<20, EMIT>(db, st, dbg);
-    if (db->b3_nbw <= 24) return b3_launch_emit_t<24, EMIT>(db, st, dbg);
-    return b3_launch_emit_t<32, EMIT>(db, st, dbg);
+int b3_launch_narrow(kmdb_db* db, hipStream_t st, uint32_t dbg = 0) {
+    B3NParams q{};
+    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.depth = db->b3_depth; q.segs = db->rsegs;
+    q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n; q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
+    q.fnarrow = db->b3_fnarrow; q.n_segs = db->n_rsegs; q.chain_cap = db->b3_chain_cap; q.nctr = db->b2_nctr;
+    q.nb = (uint32_t)((db->N + db->b2_width - 1) / db->b2_width);
+    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.dbg = dbg;
+    const size_t lds = b3n_wave_bytes(q.chain_cap, q.nb) * B3N_WAVES;
+    const uint32_t blocks = (q.n_segs + B3N_WAVES - 1) / B3N_WAVES;
+    if (blocks) hipLaunchKernelGGL((b3_narrow_kernel<EMIT>), dim3(blocks), dim3(WAVE * B3N_WAVES), lds, st, q);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 template <bool COUNT>
@@ -910,8 +1139,12 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
 // the buckets into work items for the apply kernel.
 void b2_release_width(kmdb_db* db) {
     void* ptrs[] = {db->b2_table, db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w, db->b2_items, db->b3_pair_ofs,
-                    db->b3_pair_blk, db->b3_pair_mask, db->b3_p0_mask, db->b3_p0_info};
+                    db->b3_pair_blk, db->b3_pair_mask, db->b3_p0_mask, db->b3_p0_info, db->b3_widx, db->b3_wparent,
+                    db->b3_fnarrow, db->b3_wsegs, db->b3_wseg_anc, db->b3_wseg_anc_n, db->b3_wseg_np};
     for (void* q : ptrs) if (q) (void)hipFree(q);
+    db->b3_widx = nullptr; db->b3_wparent = nullptr; db->b3_fnarrow = nullptr; db->b3_wsegs = nullptr;
+    db->b3_wseg_anc = nullptr; db->b3_wseg_anc_n = nullptr; db->b3_wseg_np = nullptr;
+    db->b3_split = false; db->b3_n_wide = 0; db->b3_n_wsegs = 0;
     db->b2_table = nullptr; db->b2_rec_rows = nullptr; db->b2_rec_rc = nullptr; db->b2_rec_w = nullptr; db->b2_items = nullptr;
     db->b3_pair_ofs = nullptr; db->b3_pair_blk = nullptr; db->b3_pair_mask = nullptr; db->b3_p0_mask = nullptr;
     db->b3_p0_info = nullptr;
@@ -922,7 +1155,9 @@ void b2_release_width(kmdb_db* db) {
 // kernels (layout metadata: a pure function of the database, like CSR row pointers), turn the
 // per-(segment, bucket) record counts into record bases and cut the buckets into work items for the
 // apply kernel.  *fits is false when the width cannot be used.
-int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok, bool* fits) {
+int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, bool* fits) {
+    const uint32_t max_n = h.max_n;
+    const bool chain_ok = h.chain_ok;
     *fits = false;
     const uint64_t N = db->N, P = db->P;
     const uint32_t NB = (uint32_t)((N + width - 1) / width);
@@ -930,9 +1165,10 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
     db->b2_width = width;
     db->b2_maxn_pad = std::max<uint32_t>(64, (max_n + 63) / 64 * 64);
     db->b2_dec_cap = std::max<uint32_t>(512, db->b2_maxn_pad);
-    db->b2_nctr = NB * (NB + 1) / 2 * 2;
+    db->b2_nctr = NB * (NB + 1) / 2 * B2_NCLS;
     if (b2_lds_per_wave(db->b2_maxn_pad, db->b2_dec_cap, db->b2_nctr) * B2_WAVES > 160 * 1024) return 0;
-    const size_t tbl = (size_t)db->n_rsegs * db->b2_nctr;
+    size_t table_rows = db->n_rsegs;
+    size_t tbl = table_rows * db->b2_nctr;
     HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
     HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
     const uint32_t nbw = NB <= 8 ? 8 : NB <= 16 ? 16 : NB <= 20 ? 20 : NB <= 24 ? 24 : 32;
@@ -961,7 +1197,72 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
         HIP_TRY(hipMalloc((void**)&db->b3_pair_blk, std::max<uint32_t>(total_pairs, 1)));
         HIP_TRY(hipMalloc((void**)&db->b3_pair_mask, (size_t)std::max<uint32_t>(total_pairs, 1) * 8));
         if (b3_launch_decode<false>(db, db->stream)) return 1;
-        if (b3_launch_emit<false>(db, db->stream)) return 1;
+        if (getenv("KMDB_K1_SINGLE")) {
+            HIP_TRY(hipMemcpy(db->b3_nl, h.nl->data(), P * 4, hipMemcpyHostToDevice));
+            if (b3_launch_emit<false, false>(db, db->stream)) return 1;
+        } else {
+            // Classify the nodes with the count mode of the all-nodes emit kernel: how many blocks does the full list
+            // touch?  (layout metadata, like the counts.)  Narrow nodes (one block) are handled in the DFS stream by
+            // the narrow kernel; the wide ones get their own list: DFS index, parent position, slices, root paths.
+            uint8_t* d_nw = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_nw, P));
+            HIP_TRY(hipMemcpy(db->b3_nl, h.nl->data(), P * 4, hipMemcpyHostToDevice));
+            if (b3_launch_emit<false, false>(db, db->stream, 0, d_nw)) return 1;
+            HIP_TRY(hipStreamSynchronize(db->stream));
+            std::vector<uint8_t> nw(P);
+            HIP_TRY(hipMemcpy(nw.data(), d_nw, P, hipMemcpyDeviceToHost));
+            (void)hipFree(d_nw);
+            const std::vector<int32_t>& parent = *h.parent;
+            std::vector<uint32_t> nlf(*h.nl), widx;
+            std::vector<int32_t> rank(P, -1), wparent;
+            for (uint64_t i = 0; i < P; ++i)
+                if (nw[i] > 1) { rank[i] = (int32_t)widx.size(); widx.push_back((uint32_t)i); nlf[i] |= 1u << 31; }
+            const size_t nW = widx.size();
+            wparent.resize(nW);
+            for (size_t k = 0; k < nW; ++k) {
+                const int32_t pp = parent[widx[k]];
+                if (pp < 0) wparent[k] = -1;
+                else if (rank[pp] >= 0) wparent[k] = rank[pp];
+                else { wparent[k] = -(pp + 2); nlf[pp] |= 1u << 30; }
+            }
+            const size_t WSEG = 1024;                                  // wide nodes per slice (16 batches)
+            const size_t n_wsegs = (nW + WSEG - 1) / WSEG;
+            std::vector<Segment> wsegs(n_wsegs);
+            const size_t stride = db->b3_chain_cap;
+            std::vector<uint32_t> wanc(std::max<size_t>(n_wsegs, 1) * stride, 0), wanc_n(std::max<size_t>(n_wsegs, 1), 0);
+            std::vector<int32_t> wnp(std::max<size_t>(n_wsegs, 1), -1);
+            std::vector<uint32_t> path;
+            for (size_t sg = 0; sg < n_wsegs; ++sg) {
+                wsegs[sg] = Segment{(uint32_t)(sg * WSEG), (uint32_t)std::min(nW, (sg + 1) * WSEG)};
+                path.clear();
+                int32_t cur = parent[widx[sg * WSEG]];
+                while (cur >= 0 && rank[cur] >= 0) { path.push_back((uint32_t)cur); cur = parent[cur]; }
+                wnp[sg] = cur;                                         // narrow parent of the topmost wide ancestor (or none)
+                wanc_n[sg] = (uint32_t)path.size();
+                for (size_t t = 0; t < path.size(); ++t) wanc[sg * stride + t] = path[path.size() - 1 - t];
+            }
+            HIP_TRY(hipMemcpy(db->b3_nl, nlf.data(), P * 4, hipMemcpyHostToDevice));
+            auto up = [&](auto** dst, const auto& v) -> int {
+                using T = typename std::remove_reference<decltype(v[0])>::type;
+                HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(T)));
+                if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+                return 0;
+            };
+            if (up(&db->b3_widx, widx) || up(&db->b3_wparent, wparent) || up(&db->b3_wsegs, wsegs) || up(&db->b3_wseg_anc, wanc) ||
+                up(&db->b3_wseg_anc_n, wanc_n) || up(&db->b3_wseg_np, wnp)) return 1;
+            HIP_TRY(hipMalloc((void**)&db->b3_fnarrow, P * 8));
+            db->b3_n_wide = (uint32_t)nW; db->b3_n_wsegs = (uint32_t)n_wsegs; db->b3_split = true;
+            // count modes of the two run-time kernels, one table row per slice
+            (void)hipFree(db->b2_table); db->b2_table = nullptr;
+            table_rows = db->n_rsegs + n_wsegs;
+            tbl = table_rows * db->b2_nctr;
+            HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
+            HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
+            if (b3_launch_narrow<false>(db, db->stream)) return 1;
+            if (n_wsegs && b3_launch_emit<false, true>(db, db->stream)) return 1;
+            if (getenv("KMDB_VERBOSE"))
+                fprintf(stderr, "[kmdb] width %u: %zu of %llu nodes are wide (%zu slices)\n", width, nW, (unsigned long long)P, n_wsegs);
+        }
     } else {
         if (b2_launch_emit<false>(db, 0, db->n_rsegs, 0, db->stream)) return 1;
     }
@@ -974,12 +1275,24 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
     uint64_t run = 0;
     for (uint32_t c = 0; c < db->b2_nctr; ++c) {
         cstart[c] = run;
-        for (uint32_t sgi = 0; sgi < db->n_rsegs; ++sgi) {
+        for (size_t sgi = 0; sgi < table_rows; ++sgi) {
             bases[(size_t)sgi * db->b2_nctr + c] = (uint32_t)run;
             run += counts[(size_t)sgi * db->b2_nctr + c];
         }
     }
     cstart[db->b2_nctr] = run;
+    if (getenv("KMDB_VERBOSE")) {
+        uint64_t per_cls[B2_NCLS] = {0}, diag_cls[B2_NCLS] = {0};
+        for (uint32_t X = 0, c = 0; X < NB; ++X)
+            for (uint32_t Y = 0; Y <= X; ++Y)
+                for (uint32_t cls = 0; cls < B2_NCLS; ++cls, ++c) {
+                    per_cls[cls] += cstart[c + 1] - cstart[c];
+                    if (X == Y) diag_cls[cls] += cstart[c + 1] - cstart[c];
+                }
+        fprintf(stderr, "[kmdb] width %u: records per weight class %llu %llu %llu (on the diagonal %llu %llu %llu)\n", width,
+                (unsigned long long)per_cls[0], (unsigned long long)per_cls[1], (unsigned long long)per_cls[2],
+                (unsigned long long)diag_cls[0], (unsigned long long)diag_cls[1], (unsigned long long)diag_cls[2]);
+    }
     if (run >= (1ull << 32)) return 0;                    // record index must fit 32 bits
     db->b2_total = run;
     std::vector<B2Item> items;
@@ -987,7 +1300,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
     if (const char* e = getenv("KMDB_K2_CHUNK")) CH = std::max<uint32_t>(256, (uint32_t)strtoul(e, nullptr, 10));
     for (uint32_t X = 0, c = 0; X < NB; ++X)
         for (uint32_t Y = 0; Y <= X; ++Y)
-            for (uint32_t cls = 0; cls < 2; ++cls, ++c)
+            for (uint32_t cls = 0; cls < B2_NCLS; ++cls, ++c)
                 for (uint64_t b = cstart[c]; b < cstart[c + 1]; b += CH)
                     items.push_back({X, Y, cls, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + CH, cstart[c + 1])});
     HIP_TRY(hipMemcpy(db->b2_table, bases.data(), tbl * 4, hipMemcpyHostToDevice));
@@ -1008,11 +1321,13 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, uint32_t max_n, bool chain_ok,
 // that a 64-id grid would cut in two.  The candidate with the fewest block records wins.
 }  // namespace
 
-int kmdb_records_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uint32_t>& perm, const std::vector<uint32_t>& nl,
-                         const std::vector<uint32_t>& seg_anc, const std::vector<uint32_t>& seg_anc_n) {
+int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h) {
     const uint64_t N = db->N, P = db->P;
+    const uint32_t max_n = h.max_n;
+    const bool chain_ok = h.chain_ok;
     if (N < 2 || P == 0 || N > 2048 || max_n > 1024) return 0;
     if (chain_ok) {
+        const std::vector<uint32_t>&perm = *h.long_nodes, &nl = *h.nl, &seg_anc = *h.seg_anc, &seg_anc_n = *h.seg_anc_n;
         db->b3_n_long = (uint32_t)perm.size();
         HIP_TRY(hipMalloc((void**)&db->b3_perm, std::max<size_t>(perm.size(), 1) * 4));
         if (!perm.empty()) HIP_TRY(hipMemcpy(db->b3_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
@@ -1022,6 +1337,10 @@ int kmdb_records_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::
         HIP_TRY(hipMalloc((void**)&db->b3_seg_anc_n, std::max<size_t>(seg_anc_n.size(), 1) * 4));
         if (!seg_anc.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc, seg_anc.data(), seg_anc.size() * 4, hipMemcpyHostToDevice));
         if (!seg_anc_n.empty()) HIP_TRY(hipMemcpy(db->b3_seg_anc_n, seg_anc_n.data(), seg_anc_n.size() * 4, hipMemcpyHostToDevice));
+        std::vector<uint8_t> depth8(P);
+        for (uint64_t i = 0; i < P; ++i) depth8[i] = (uint8_t)std::min<uint32_t>(255u, (*h.depth)[i]);
+        HIP_TRY(hipMalloc((void**)&db->b3_depth, P));
+        HIP_TRY(hipMemcpy(db->b3_depth, depth8.data(), P, hipMemcpyHostToDevice));
     }
     uint32_t forced = 0;
     if (const char* e = getenv("KMDB_BLOCK_WIDTH")) forced = (uint32_t)strtoul(e, nullptr, 10);
@@ -1031,7 +1350,7 @@ int kmdb_records_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::
     uint64_t best_cost = ~0ull;
     for (uint32_t wd : cands) {
         bool fits = false;
-        if (b2_prepare_width(db, wd, max_n, chain_ok, &fits)) { b2_release_width(db); return 1; }
+        if (b2_prepare_width(db, wd, h, &fits)) { b2_release_width(db); return 1; }
         if (fits) {
             // records dominate K1/K2; wider per-lane register sets (more blocks) make K1 a little dearer
             const uint64_t cost = db->b2_total + P * (db->b3_nbw > 16 ? (db->b3_nbw - 16) : 0) / 64;
@@ -1041,7 +1360,7 @@ int kmdb_records_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::
     }
     if (!best_w) return 0;
     bool fits = false;
-    if (b2_prepare_width(db, best_w, max_n, chain_ok, &fits)) { b2_release_width(db); return 1; }
+    if (b2_prepare_width(db, best_w, h, &fits)) { b2_release_width(db); return 1; }
     if (!fits) b2_release_width(db);
     return 0;
 }
@@ -1049,19 +1368,20 @@ int kmdb_records_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::
 
 void kmdb_records_release(kmdb_db* db) {
     b2_release_width(db);
-    void* ptrs[] = {db->b3_perm, db->b3_seg_anc, db->b3_seg_anc_n, db->b3_nl};
+    void* ptrs[] = {db->b3_perm, db->b3_seg_anc, db->b3_seg_anc_n, db->b3_nl, db->b3_depth};
     for (void* q : ptrs) if (q) (void)hipFree(q);
-    db->b3_perm = nullptr; db->b3_seg_anc = nullptr; db->b3_seg_anc_n = nullptr; db->b3_nl = nullptr;
+    db->b3_perm = nullptr; db->b3_seg_anc = nullptr; db->b3_seg_anc_n = nullptr; db->b3_nl = nullptr; db->b3_depth = nullptr;
 }
 
 uint64_t kmdb_records_device_bytes(const kmdb_db* db) {
-    return db->b2_ready ? db->b2_total * 28 + (uint64_t)db->n_rsegs * db->b2_nctr * 4 + db->P * 14 : 0;
+    return db->b2_ready ? db->b2_total * 28 + (uint64_t)(db->n_rsegs + db->b3_n_wsegs) * db->b2_nctr * 4 + db->P * (db->b3_split ? 23 : 14) +
+                              (uint64_t)db->b3_n_wide * 8 : 0;
 }
 
 int kmdb_records_run(kmdb_db* db, uint32_t* M, uint32_t flags, hipStream_t st) {
     const uint32_t dbg = flags >> 8;
     // emit block records (K0 + K1, or the sequential emit kernel), then ballot/popcount accumulate per block (K2)
-    const bool seq_emit = !db->b3_ready || (flags & KMDB_FLAG_FORCE_SEQ_EMIT);
+    const bool seq_emit = !db->b3_ready;
     if (seq_emit) {
         if (b2_launch_emit<true>(db, 0, db->n_rsegs, dbg, st)) return 1;
         HIP_TRY(hipEventRecord(db->ev_k0, st));
@@ -1069,7 +1389,10 @@ int kmdb_records_run(kmdb_db* db, uint32_t* M, uint32_t flags, hipStream_t st) {
     } else {
         if (b3_launch_decode<false>(db, st)) return 1;
         HIP_TRY(hipEventRecord(db->ev_k0, st));
-        if (b3_launch_emit<true>(db, st, dbg)) return 1;
+        if (db->b3_split) {
+            if (b3_launch_narrow<true>(db, st, dbg)) return 1;
+            if (db->b3_n_wsegs && b3_launch_emit<true, true>(db, st, dbg)) return 1;
+        } else if (b3_launch_emit<true, false>(db, st, dbg)) return 1;
         db->k0_ms = 0;
     }
     HIP_TRY(hipEventRecord(db->ev_k2[0], st));

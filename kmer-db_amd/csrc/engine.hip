@@ -334,7 +334,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
         if (dev_upload(&db->rsegs, rsegs.data(), rsegs.size())) { kmdb_db_free(db); return 1; }
         db->n_rsegs = (uint32_t)rsegs.size();
         std::vector<uint32_t> seg_anc, seg_anc_n(rsegs.size(), 0);
-        const bool chain_ok = max_depth <= (uint32_t)KMDB_CHAIN_MAX;
+        const bool chain_ok = max_depth <= (uint32_t)KMDB_CHAIN_MAX && !(opts && (opts->flags & KMDB_FLAG_FORCE_SEQ_EMIT));
         db->b3_chain_cap = std::min<uint32_t>(KMDB_CHAIN_MAX, std::max<uint32_t>(8, (max_depth + 7) / 8 * 8));
         const size_t anc_stride = db->b3_chain_cap;
         if (chain_ok) {
@@ -347,7 +347,8 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
                 while (cur >= 0) { seg_anc[sidx * anc_stride + (--d)] = (uint32_t)cur; cur = parent[cur]; }
             }
         }
-        if (kmdb_records_prepare(db, max_n, chain_ok, perm, nl, seg_anc, seg_anc_n)) { kmdb_db_free(db); return 1; }
+        const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth};
+        if (kmdb_records_prepare(db, hl)) { kmdb_db_free(db); return 1; }
     }
     db->stats.device_bytes += kmdb_records_device_bytes(db);
     *out = db;

@@ -74,6 +74,17 @@ struct kmdb_db {
     uint32_t* b3_seg_anc = nullptr;     // [n_segs][B3_CHAIN]
     uint32_t* b3_seg_anc_n = nullptr;
     uint64_t b3_total_pairs = 0;
+    // K1 split: narrow nodes (full list inside one block) stay in the DFS stream, wide nodes get their own list
+    bool b3_split = false;
+    uint8_t* b3_depth = nullptr;        // [P] root path length (root = 1)
+    uint32_t* b3_widx = nullptr;        // [n_wide] DFS index of the wide nodes, DFS order
+    int32_t* b3_wparent = nullptr;      // [n_wide] >= 0: position of the (wide) parent in the wide list; -1: none; <= -2: narrow parent -(v + 2)
+    unsigned long long* b3_fnarrow = nullptr;   // [P] full mask of the narrow nodes that have a wide child (written by the narrow kernel)
+    Segment* b3_wsegs = nullptr;        // slices of the wide list
+    uint32_t* b3_wseg_anc = nullptr;    // [n_wsegs][chain_cap] wide ancestors (DFS index) of the slice's first node, root first
+    uint32_t* b3_wseg_anc_n = nullptr;
+    int32_t* b3_wseg_np = nullptr;      // [n_wsegs] narrow parent (DFS index) of the topmost wide ancestor, -1: none
+    uint32_t b3_n_wide = 0, b3_n_wsegs = 0;
     hipEvent_t ev_k0 = nullptr;
     double k0_ms = 0;
 };
@@ -90,8 +101,17 @@ int kmdb_v1_run(kmdb_db* db, uint32_t* M, uint32_t seg_begin, uint32_t seg_end, 
 
 // ---- a2a_records.hip: block-record pipeline
 // upload-time: qualify the database, pick the block width, tabulate record counts (count modes of the kernels)
-int kmdb_records_prepare(kmdb_db* db, uint32_t max_n, bool chain_ok, const std::vector<uint32_t>& long_nodes,
-                         const std::vector<uint32_t>& nl, const std::vector<uint32_t>& seg_anc, const std::vector<uint32_t>& seg_anc_n);
+struct kmdb_host_layout {               // host copies of upload-time arrays the preparation needs
+    uint32_t max_n;
+    bool chain_ok;
+    const std::vector<uint32_t>* long_nodes;
+    const std::vector<uint32_t>* nl;
+    const std::vector<uint32_t>* seg_anc;
+    const std::vector<uint32_t>* seg_anc_n;
+    const std::vector<int32_t>* parent;
+    const std::vector<uint16_t>* depth;
+};
+int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h);
 // per call: decode + emit (+ sequential emit fallback) + apply; records events ev_k0 / ev_k2
 int kmdb_records_run(kmdb_db* db, uint32_t* M, uint32_t flags, hipStream_t st);
 void kmdb_records_release(kmdb_db* db);

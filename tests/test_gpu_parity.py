@@ -41,7 +41,11 @@ def test_all2all_dense_bit_exact(K, O, golden_dir, dev, stem):
     # the other kernels: generic (global stack + HBM atomics), LDS stack + HBM atomics, wave-private LDS tile
     if stem != "synth_k21":
         assert d.stats()["k0_ms"] > 0                    # root paths <= 192 nodes: the batch-parallel front half ran
-    assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_FORCE_SEQ_EMIT), ref)
+    dseq = K.DeviceDB(h, device=dev, flags=K.capi.FLAG_FORCE_SEQ_EMIT)      # laid out for the sequential emit kernel
+    assert np.array_equal(dseq.all2all_dense(), ref)
+    assert dseq.stats()["n_records"] > 0 or d.P <= 1
+    assert dseq.stats()["k0_ms"] == 0                     # no separate decode kernel in this layout
+    dseq.close()
     for fl in (K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT, K.capi.FLAG_FORCE_TILE):
         assert np.array_equal(d.all2all_dense(flags=fl), ref), fl
     assert d.stats()["n_records"] == 0
@@ -162,8 +166,11 @@ def test_synthetic_databases_bit_exact(K, O, dev, tmp_path, N, cs, L, k):
     assert np.array_equal(got, exp)
     st = d.stats()
     assert st["n_records"] > 0 and st["sum_pairs"] == int(exp.astype(np.uint64).sum())
-    for fl in (K.capi.FLAG_FORCE_SEQ_EMIT, K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS):
+    for fl in (K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS):
         assert np.array_equal(d.all2all_dense(flags=fl), exp), fl
+    dseq = K.DeviceDB(view, device=dev, flags=K.capi.FLAG_FORCE_SEQ_EMIT)
+    assert np.array_equal(dseq.all2all_dense(), exp)
+    dseq.close()
     # the same database read back through the front-end's .db reader
     d2 = K.DeviceDB(K.HostDB(path, skip_hashtables=True), device=dev)
     assert np.array_equal(d2.all2all_dense(), exp)
@@ -277,8 +284,11 @@ def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local):
                        arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
     d = K.DeviceDB(view, device=dev)
     assert np.array_equal(d.all2all_dense(), exp)
-    for fl in (K.capi.FLAG_FORCE_SEQ_EMIT, K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT):
+    for fl in (K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT):
         assert np.array_equal(d.all2all_dense(flags=fl), exp), fl
+    dseq = K.DeviceDB(view, device=dev, flags=K.capi.FLAG_FORCE_SEQ_EMIT)
+    assert np.array_equal(dseq.all2all_dense(), exp)
+    dseq.close()
     acc = np.zeros_like(exp)
     for sh in range(3):
         acc += d.all2all_dense(shard=(sh, 3))
