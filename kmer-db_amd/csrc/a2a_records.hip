@@ -269,6 +269,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
 //        non-empty words X >= Y) are written with ballot-ranked, coalesced stores.
 // ------------------------------------------------------------------------------------------
 constexpr int B3_WAVES = 1;
+constexpr int B3_K = 8;            // word registers of the compact path
 constexpr int B3_CHAIN = KMDB_CHAIN_MAX;
 
 template <bool COUNT, bool LONG>
@@ -430,6 +431,8 @@ struct B3Params {
 
 __host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr, uint32_t chain_cap) {
     size_t b = (size_t)chain_cap * nbw * 8 + (size_t)nctr * 4 + (size_t)chain_cap * 4 * 2 + (maxn_pad + 64);
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)B3_K * 64 * 8 + 3 * 64 * 4 + 64 * 4;       // record staging: full masks [B3_K][64], per-lane start / slots / weight, slot -> word
     return (b + 15) & ~(size_t)15;
 }
 
@@ -446,6 +449,11 @@ struct B3Ctx {
     uint32_t* chain_n;             // [B3_CHAIN] list length of the node in the slot
     uint8_t* slot_of_n;            // list length -> slot
     uint32_t* ctr;                 // record cursors per (bucket, class)
+    unsigned long long* fmat;      // record staging: [slot][lane] full masks of the batch
+    uint32_t* st_excl;             // [64] first record of the lane within the batch
+    uint32_t* st_nzs;              // [64] non-empty slots of the lane
+    uint32_t* st_w;                // [64] weight
+    uint32_t* st_word;             // [64] slot -> word
     uint32_t lane;
     unsigned long long lt_mask;
 };
@@ -527,48 +535,74 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
     }
     // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
     const bool act = L.valid && L.w != 0 && L.n >= 2 && !(q.dbg & 512u);
-    const uint32_t cls = b2_weight_class(L.w);
-    const uint32_t l3 = lane / 3u, lc = lane - 3u * l3;      // lane 3 * (sY - y0) + c owns the counter of combo (X, Y, c)
-    if (!__ballot(act)) goto chain_update;
+    // Record-parallel emission: a node with p non-empty words owns p(p+1)/2 records.  The batch's records are
+    // numbered by a prefix sum over the lanes and handed out 64 at a time, one per lane: find the owner (binary
+    // search in the prefix sums), the pair of words (a >= b) from the index within the owner, read the two masks
+    // from the staging area, reserve the slot in the (X, Y, class) stream with one LDS atomic, store.
+    {
+        uint32_t nzs = 0;
 #pragma unroll
-    for (int sX = 0; sX < W; ++sX) {
-        if (!IDENT && (uint32_t)sX >= ku) break;
-        const uint32_t X = IDENT ? (uint32_t)sX : wl[sX];
-        const bool ax = act && F[sX] != 0;
-        if (!__ballot(ax)) continue;
-        // 21 column words (63 counters) per round: one LDS atomic per lane reserves the slots of its combo
+        for (int s = 0; s < W; ++s) nzs |= (F[s] != 0 ? 1u : 0u) << s;
+        const uint32_t pw = (uint32_t)__popc(nzs);
+        const uint32_t myrec = act ? pw * (pw + 1u) / 2u : 0u;
+        const uint32_t incl = wave_incl_scan(myrec, lane);
+        const uint32_t T = bcast(incl, WAVE - 1);
+        if (T == 0) goto chain_update;
+        if (!IDENT) {
 #pragma unroll
-        for (int y0 = 0; y0 <= sX; y0 += 21) {
-            const int y1 = sX < y0 + 20 ? sX : y0 + 20;
-            uint32_t mycnt = 0, mywl = 0;
-#pragma unroll
-            for (int sY = y0; sY <= y1; ++sY) {
-                const bool a = ax && F[sY] != 0;
-                const uint32_t c0 = (uint32_t)__popcll(__ballot(a && cls == 0u));
-                const uint32_t c1 = (uint32_t)__popcll(__ballot(a && cls == 1u));
-                const uint32_t c2 = (uint32_t)__popcll(__ballot(a && cls == 2u));
-                if (l3 == (uint32_t)(sY - y0)) { mycnt = lc == 0u ? c0 : lc == 1u ? c1 : c2; mywl = IDENT ? (uint32_t)sY : wl[sY]; }
+            for (int s = 0; s < W; ++s) {
+                if ((uint32_t)s >= ku) break;
+                C.fmat[s * 64 + lane] = F[s];
             }
-            uint32_t mybase = 0;
-            if (mycnt) mybase = atomicAdd(&C.ctr[(X * (X + 1) / 2 + mywl) * B2_NCLS + lc], mycnt);
-            if (EMIT && !(q.dbg & 256u)) {
+        }
+        C.st_excl[lane] = incl - myrec; C.st_nzs[lane] = nzs; C.st_w[lane] = L.w;
+        if (!IDENT) {
+            uint32_t mw = 0;
 #pragma unroll
-                for (int sY = y0; sY <= y1; ++sY) {
-                    const bool a = ax && F[sY] != 0;
-                    const unsigned long long ba = __ballot(a);
-                    if (!ba) continue;
-                    const unsigned long long b0 = __ballot(a && cls == 0u), b1 = __ballot(a && cls == 1u);
-                    const uint32_t base0 = bcast(mybase, 3 * (sY - y0)), base1 = bcast(mybase, 3 * (sY - y0) + 1),
-                                   base2 = bcast(mybase, 3 * (sY - y0) + 2);
-                    if (a) {
-                        const unsigned long long mine = cls == 0u ? b0 : cls == 1u ? b1 : (ba & ~b0 & ~b1);
-                        const uint32_t slot = (cls == 0u ? base0 : cls == 1u ? base1 : base2) + (uint32_t)__popcll(mine & C.lt_mask);
-                        if (sX != sY) q.rec.rc[slot] = make_ulonglong2(F[sX], F[sY]); else q.rec.rows[slot] = F[sX];
-                        if (cls) q.rec.w[slot] = L.w;
-                    }
+            for (int s = 0; s < W; ++s) mw = lane == (uint32_t)s ? wl[s] : mw;
+            C.st_word[lane] = mw;
+        }
+        lds_sync();
+        for (uint32_t t0 = 0; t0 < T; t0 += WAVE) {
+            const uint32_t t = t0 + lane;
+            const bool on = t < T;
+            uint32_t own = 0;
+#pragma unroll
+            for (uint32_t step = 32; step >= 1; step >>= 1) {
+                const uint32_t cand = own + step;
+                if (C.st_excl[cand & 63u] <= t) own = cand;           // cand <= 63 always: own < 64 - step
+            }
+            const uint32_t qi = on ? t - C.st_excl[own] : 0u;
+            uint32_t a = (uint32_t)((__fsqrt_rn((float)(8u * qi + 1u)) - 1.0f) * 0.5f);
+            a = a * (a + 1u) / 2u > qi ? a - 1u : a;
+            a = (a + 1u) * (a + 2u) / 2u <= qi ? a + 1u : a;
+            const uint32_t b = qi - a * (a + 1u) / 2u;
+            uint32_t ma = C.st_nzs[own], mb = ma;
+            for (uint32_t k = 0; k < a; ++k) ma &= ma - 1u;
+            for (uint32_t k = 0; k < b; ++k) mb &= mb - 1u;
+            const uint32_t sa = on ? (uint32_t)__builtin_ctz(ma | 0x80000000u) : 0u, sb = on ? (uint32_t)__builtin_ctz(mb | 0x80000000u) : 0u;
+            unsigned long long FX = 0, FY = 0;
+            if (IDENT) {
+                // full-width batches (rare) keep the masks in registers: fetch every word from the owner, keep two
+#pragma unroll
+                for (int s = 0; s < W; ++s) {
+                    const unsigned long long v = shfl64(F[s], (int)own);
+                    FX = sa == (uint32_t)s ? v : FX;
+                    FY = sb == (uint32_t)s ? v : FY;
+                }
+            } else { FX = C.fmat[sa * 64 + own]; FY = C.fmat[sb * 64 + own]; }
+            const uint32_t X = IDENT ? sa : C.st_word[sa], Y = IDENT ? sb : C.st_word[sb];
+            const uint32_t wv = C.st_w[own];
+            const uint32_t cls = b2_weight_class(wv);
+            if (on) {
+                const uint32_t slot = atomicAdd(&C.ctr[(X * (X + 1u) / 2u + Y) * B2_NCLS + cls], 1u);
+                if (EMIT && !(q.dbg & 256u)) {
+                    if (X != Y) q.rec.rc[slot] = make_ulonglong2(FX, FY); else q.rec.rows[slot] = FX;
+                    if (cls) q.rec.w[slot] = wv;
                 }
             }
         }
+        lds_sync();
     }
 chain_update:
     // ---- chain table for the next batch: root path of this batch's last node
@@ -599,7 +633,6 @@ chain_update:
     }
 }
 
-constexpr int B3_K = 8;            // word registers of the compact path
 
 template <int NBW, bool EMIT, bool INDIRECT>
 __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
@@ -615,6 +648,9 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     C.chain_n = C.ctr + q.nctr;                                            // [chain_cap]
     C.chain_nz = C.chain_n + q.chain_cap;                                  // [chain_cap]
     C.slot_of_n = (uint8_t*)(C.chain_nz + q.chain_cap);                    // [maxn_pad + 64]
+    C.fmat = (unsigned long long*)(((uintptr_t)(C.slot_of_n + q.maxn_pad + 64) + 7) & ~(uintptr_t)7);   // [B3_K][64]
+    C.st_excl = (uint32_t*)(C.fmat + (size_t)B3_K * 64);
+    C.st_nzs = C.st_excl + 64; C.st_w = C.st_nzs + 64; C.st_word = C.st_w + 64;
     C.lane = lane;
     C.lt_mask = (1ull << lane) - 1ull;
     uint32_t* my_table = q.table + (size_t)(q.seg_row0 + seg) * q.nctr;
@@ -937,17 +973,26 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
-__global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B2Item* __restrict__ items,
-                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t dbg, uint32_t bwidth) {
-    __shared__ uint32_t acc[64 * 64];
-    __shared__ unsigned long long rtbuf[4][64];
-    const B2Item it = items[blockIdx.x];
-    if ((dbg & 64u) && it.cls == 0) return;
-    if ((dbg & 128u) && it.cls != 0) return;
+// K2: one workgroup per (bucket, chunk of records).  A wave takes 64 records per step, one per lane, and turns
+// them into bit matrices over the records: lane c holds Ct = "which of the 64 records contain column c", and
+// Rt_r = "which records contain row r" is a broadcast read from LDS.  cell(r, c) += popcount(Ct & Rt_r): ONE
+// add per cell per 64 records.  The cells live in registers (lane c keeps column c of the 64 x 64 block, one
+// register per row; v_bcnt accumulates for free) and are merged through LDS once per work item.
+// Weights: class 1 (w = 2, 3) = twice the count plus the count over the odd weights; class 2 = one pass per
+// bit plane of w that occurs in the step.
+template <int CLS>
+__device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& it, uint32_t* __restrict__ M, uint32_t dbg, uint32_t bwidth,
+                                              uint32_t* acc, unsigned long long (*rtbuf)[64]) {
+    if ((dbg & 64u) && CLS == 0) return;
+    if ((dbg & 128u) && CLS != 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     __syncthreads();
     const bool diag = it.X == it.Y;
+    uint32_t a[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) a[r] = 0;
+    const unsigned long long* rt = rtbuf[wave];
     // the next group's records are fetched while the current group is reduced
     unsigned long long nR = 0, nC = 0;
     uint32_t nW = 0;
@@ -957,7 +1002,7 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
         if (j < it.end) {
             if (diag) { nR = rec.rows[j]; nC = nR; }
             else { const ulonglong2 rc = rec.rc[j]; nR = rc.x; nC = rc.y; }
-            nW = it.cls ? rec.w[j] : 1u;
+            nW = CLS ? rec.w[j] : 1u;
         }
     };
     fetch(it.begin + wave * 64);
@@ -965,64 +1010,58 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
         if (g0 + 256 < it.end) fetch(g0 + 256);
-        // lane c: bit j of Ct = record j contains column c
         const unsigned long long Ct = transpose64(C, lane);
         if (dbg & 2048u) { if ((uint32_t)Ct + (uint32_t)R + W == 0x12345u) acc[lane] = 1; continue; }
-        if (it.cls <= 1) {
-            // class 0, every record has weight 1: cell(r, c) += number of records that contain row r and column c.
-            // class 1, weights 2 and 3: twice that number plus the count over the records with an odd weight.
-            // R^T goes through LDS: row r's record mask is then a broadcast read instead of a ballot
-            // (a ballot writes an SGPR pair that the next VALU must wait for; 64 of them serialise the loop)
-            rtbuf[wave][lane] = transpose64(R, lane);
-            lds_sync();
-            if (it.cls == 0) {
-                if (!diag) {
-#pragma unroll 8
-                    for (uint32_t r = 0; r < bwidth; ++r) {             // rows >= the block width never occur
-                        const uint32_t c = (uint32_t)__popcll(Ct & rtbuf[wave][r]);
-                        if (c) atomicAdd(&acc[r * 64 + lane], c);
-                    }
-                } else {
-#pragma unroll 8
-                    for (uint32_t r = 0; r < bwidth; ++r) {
-                        const uint32_t c = lane < r ? (uint32_t)__popcll(Ct & rtbuf[wave][r]) : 0u;
-                        if (c) atomicAdd(&acc[r * 64 + lane], c);
-                    }
-                }
-            } else {
-                const unsigned long long Codd = Ct & __ballot((W & 1u) != 0);
-#pragma unroll 8
-                for (uint32_t r = 0; r < bwidth; ++r) {
-                    const unsigned long long Rr = rtbuf[wave][r];
-                    const uint32_t c = (diag && lane >= r) ? 0u : 2u * (uint32_t)__popcll(Ct & Rr) + (uint32_t)__popcll(Codd & Rr);
-                    if (c) atomicAdd(&acc[r * 64 + lane], c);
+        rtbuf[wave][lane] = diag ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
+        lds_sync();
+        if (CLS == 0) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if ((uint32_t)(g * 8) < bwidth) {                     // rows >= the block width never occur
+                    asm volatile("" ::: "memory");    // keep a group's LDS reads together (register pressure)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Ct & rt[r]); }
                 }
             }
-            lds_sync();
+        } else if (CLS == 1) {
+            const unsigned long long Codd = Ct & __ballot((W & 1u) != 0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if ((uint32_t)(g * 8) < bwidth) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = g * 8 + k;
+                        const unsigned long long Rr = rt[r];
+                        a[r] += 2u * (uint32_t)__popcll(Ct & Rr) + (uint32_t)__popcll(Codd & Rr);
+                    }
+                }
+            }
         } else {
-            // general weights: the same count per bit plane of w, scaled by 2^plane.  Planes 0..3 are
-            // kept in scalar registers (weights are usually small); higher planes are rare.
             uint32_t wor = W;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) wor |= (uint32_t)__shfl_xor((int)wor, d, WAVE);
             wor = __builtin_amdgcn_readfirstlane(wor);
-            const unsigned long long W0 = __ballot((W & 1u) != 0), W1 = __ballot((W & 2u) != 0);
-            const unsigned long long W2 = __ballot((W & 4u) != 0), W3 = __ballot((W & 8u) != 0);
-            const uint32_t whigh = wor >> 4;
+            for (uint32_t wb = wor; wb; wb &= wb - 1) {
+                const uint32_t b = (uint32_t)__builtin_ctz(wb);
+                const unsigned long long Cb = Ct & __ballot(((W >> b) & 1u) != 0);
 #pragma unroll
-            for (int r = 0; r < 64; ++r) {
-                const unsigned long long Rr = __ballot(((R >> r) & 1ull) != 0);
-                if (!Rr) continue;
-                const unsigned long long base = Ct & Rr;
-                uint32_t c = (uint32_t)__popcll(base & W0) + ((uint32_t)__popcll(base & W1) << 1) +
-                             ((uint32_t)__popcll(base & W2) << 2) + ((uint32_t)__popcll(base & W3) << 3);
-                for (uint32_t wb = whigh; wb; wb &= wb - 1) {
-                    const uint32_t b = 4u + (uint32_t)__builtin_ctz(wb);
-                    c += (uint32_t)__popcll(base & __ballot(((W >> b) & 1u) != 0)) << b;
+                for (int g = 0; g < 8; ++g) {
+                    if ((uint32_t)(g * 8) < bwidth) {
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Cb & rt[r]) << b; }
+                    }
                 }
-                if (c && !(diag && lane >= (uint32_t)r)) atomicAdd(&acc[r * 64 + lane], c);
             }
         }
+        lds_sync();
+    }
+    // merge the four waves' registers, then one HBM atomic per non-zero cell (on the diagonal only c < r)
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        const uint32_t v = (diag && lane >= (uint32_t)r) ? 0u : a[r];
+        if (v) atomicAdd(&acc[r * 64 + lane], v);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
@@ -1031,6 +1070,16 @@ __global__ __launch_bounds__(256) void b2_apply_kernel(const B2Recs rec, const B
         const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
         if (!(dbg & 1024u)) atomicAdd(&M[tri64(row) + col], v);
     }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void b2_apply_kernel(const B2Recs rec, const B2Item* __restrict__ items,
+                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t dbg, uint32_t bwidth) {
+    __shared__ uint32_t acc[64 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
+    const B2Item it = items[blockIdx.x];
+    if (it.cls == 0) b2_apply_item<0>(rec, it, M, dbg, bwidth, acc, rtbuf);
+    else if (it.cls == 1) b2_apply_item<1>(rec, it, M, dbg, bwidth, acc, rtbuf);
+    else b2_apply_item<2>(rec, it, M, dbg, bwidth, acc, rtbuf);
 }
 
 
@@ -1070,7 +1119,7 @@ int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg, uint8_t* nwords)
     if (INDIRECT) {
         q.segs = db->b3_wsegs; q.n_segs = db->b3_n_wsegs; q.seg_anc = db->b3_wseg_anc; q.seg_anc_n = db->b3_wseg_anc_n;
         q.widx = db->b3_widx; q.wparent = db->b3_wparent; q.fnarrow = db->b3_fnarrow; q.seg_np = db->b3_wseg_np;
-        q.seg_row0 = db->n_rsegs;
+        q.seg_row0 = db->n_rsegs; q.chain_cap = db->b3_wchain_cap;
     } else {
         q.segs = db->rsegs; q.n_segs = db->n_rsegs; q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
     }
@@ -1228,7 +1277,17 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
             const size_t WSEG = 1024;                                  // wide nodes per slice (16 batches)
             const size_t n_wsegs = (nW + WSEG - 1) / WSEG;
             std::vector<Segment> wsegs(n_wsegs);
-            const size_t stride = db->b3_chain_cap;
+            // root paths inside the wide forest are short: the chain table of the wide launch is sized for them
+            uint32_t wmaxd = 0;
+            {
+                std::vector<uint16_t> wd(nW, 0);
+                for (size_t k = 0; k < nW; ++k) {
+                    wd[k] = (uint16_t)(wparent[k] >= 0 ? wd[wparent[k]] + 1 : 1);
+                    wmaxd = std::max<uint32_t>(wmaxd, wd[k]);
+                }
+            }
+            db->b3_wchain_cap = std::min<uint32_t>(db->b3_chain_cap, std::max<uint32_t>(8, (wmaxd + 7) / 8 * 8));
+            const size_t stride = db->b3_wchain_cap;
             std::vector<uint32_t> wanc(std::max<size_t>(n_wsegs, 1) * stride, 0), wanc_n(std::max<size_t>(n_wsegs, 1), 0);
             std::vector<int32_t> wnp(std::max<size_t>(n_wsegs, 1), -1);
             std::vector<uint32_t> path;
@@ -1298,11 +1357,17 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
     std::vector<B2Item> items;
     uint32_t CH = 8192;
     if (const char* e = getenv("KMDB_K2_CHUNK")) CH = std::max<uint32_t>(256, (uint32_t)strtoul(e, nullptr, 10));
-    for (uint32_t X = 0, c = 0; X < NB; ++X)
-        for (uint32_t Y = 0; Y <= X; ++Y)
-            for (uint32_t cls = 0; cls < B2_NCLS; ++cls, ++c)
-                for (uint64_t b = cstart[c]; b < cstart[c + 1]; b += CH)
-                    items.push_back({X, Y, cls, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + CH, cstart[c + 1])});
+    // work items class by class (one launch of the apply kernel per weight class)
+    // the dearest class first, in smaller chunks (a class-2 record costs several class-0 records)
+    for (uint32_t cls = B2_NCLS; cls-- > 0;) {
+        const uint32_t ch = cls == 0 ? CH : cls == 1 ? CH / 2 : CH / 8;
+        for (uint32_t X = 0; X < NB; ++X)
+            for (uint32_t Y = 0; Y <= X; ++Y) {
+                const uint32_t c = (X * (X + 1) / 2 + Y) * B2_NCLS + cls;
+                for (uint64_t b = cstart[c]; b < cstart[c + 1]; b += ch)
+                    items.push_back({X, Y, cls, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + ch, cstart[c + 1])});
+            }
+    }
     HIP_TRY(hipMemcpy(db->b2_table, bases.data(), tbl * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&db->b2_rec_rows, std::max<uint64_t>(run, 1) * 8));
     HIP_TRY(hipMalloc((void**)&db->b2_rec_rc, std::max<uint64_t>(run, 1) * 16));
@@ -1390,8 +1455,8 @@ int kmdb_records_run(kmdb_db* db, uint32_t* M, uint32_t flags, hipStream_t st) {
         if (b3_launch_decode<false>(db, st)) return 1;
         HIP_TRY(hipEventRecord(db->ev_k0, st));
         if (db->b3_split) {
-            if (b3_launch_narrow<true>(db, st, dbg)) return 1;
-            if (db->b3_n_wsegs && b3_launch_emit<true, true>(db, st, dbg)) return 1;
+            if (!getenv("KMDB_SKIP_K1N") && b3_launch_narrow<true>(db, st, dbg)) return 1;
+            if (db->b3_n_wsegs && !getenv("KMDB_SKIP_K1W") && b3_launch_emit<true, true>(db, st, dbg)) return 1;
         } else if (b3_launch_emit<true, false>(db, st, dbg)) return 1;
         db->k0_ms = 0;
     }

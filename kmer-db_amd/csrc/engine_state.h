@@ -56,7 +56,7 @@ struct kmdb_db {
     unsigned long long* b2_rec_rows = nullptr;   // [total]
     ulonglong2* b2_rec_rc = nullptr;    // [total]
     uint32_t* b2_rec_w = nullptr;       // [total]
-    void* b2_items = nullptr;           // B2Item[n_items]
+    void* b2_items = nullptr;           // B2Item[n_items], dearest weight class first
     uint64_t b2_total = 0;
     hipEvent_t ev_k2[2] = {nullptr, nullptr};
     double k1_ms = 0, k2_ms = 0;
@@ -84,7 +84,7 @@ struct kmdb_db {
     uint32_t* b3_wseg_anc = nullptr;    // [n_wsegs][chain_cap] wide ancestors (DFS index) of the slice's first node, root first
     uint32_t* b3_wseg_anc_n = nullptr;
     int32_t* b3_wseg_np = nullptr;      // [n_wsegs] narrow parent (DFS index) of the topmost wide ancestor, -1: none
-    uint32_t b3_n_wide = 0, b3_n_wsegs = 0;
+    uint32_t b3_n_wide = 0, b3_n_wsegs = 0, b3_wchain_cap = 8;
     hipEvent_t ev_k0 = nullptr;
     double k0_ms = 0;
 };

@@ -12,6 +12,9 @@ M = torch.zeros(d.tri_size(), dtype=torch.int32, device=dev)
 for _ in range(3): d.all2all_dense_device(M.data_ptr())
 for fl in sys.argv[2:]:
     f = int(fl) << 8
-    d.all2all_dense_device(M.data_ptr(), flags=f); d.all2all_dense_device(M.data_ptr(), flags=f)
-    st = d.stats()
-    print('dbg', fl, 'k0 %.3f k1 %.3f k2 %.3f records %d' % (st['k0_ms'], st['k1_ms'], st['k2_ms'], st['n_records']), flush=True)
+    for ev in ('', 'KMDB_SKIP_K1N', 'KMDB_SKIP_K1W'):
+        if ev: os.environ[ev] = '1'
+        d.all2all_dense_device(M.data_ptr(), flags=f); d.all2all_dense_device(M.data_ptr(), flags=f)
+        st = d.stats()
+        print('dbg', fl, ev, 'k0 %.3f k1 %.3f k2 %.3f records %d' % (st['k0_ms'], st['k1_ms'], st['k2_ms'], st['n_records']), flush=True)
+        if ev: del os.environ[ev]
