@@ -270,6 +270,7 @@ __global__ __launch_bounds__(WAVE * B2_WAVES) void b2_emit_kernel(B2Params q) {
 // ------------------------------------------------------------------------------------------
 constexpr int B3_WAVES = 1;
 constexpr int B3_K = 8;            // word registers of the compact path
+constexpr uint32_t B3_QCAP = 512;  // record descriptors queued per round
 constexpr int B3_CHAIN = KMDB_CHAIN_MAX;
 
 template <bool COUNT, bool LONG>
@@ -432,7 +433,8 @@ struct B3Params {
 __host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr, uint32_t chain_cap) {
     size_t b = (size_t)chain_cap * nbw * 8 + (size_t)nctr * 4 + (size_t)chain_cap * 4 * 2 + (maxn_pad + 64);
     b = (b + 7) & ~(size_t)7;
-    b += (size_t)B3_K * 64 * 8 + 3 * 64 * 4 + 64 * 4;       // record staging: full masks [B3_K][64], per-lane start / slots / weight, slot -> word
+    b += (size_t)B3_K * 64 * 8 + 3 * 64 * 4 + 64 * 4;       // record staging: masks [B3_K][64], per-lane start / slots / weight, slot -> word
+    b += (size_t)B3_K * 64 + B3_QCAP * 2;                   // word of every staged mask, record queue
     return (b + 15) & ~(size_t)15;
 }
 
@@ -454,6 +456,8 @@ struct B3Ctx {
     uint32_t* st_nzs;              // [64] non-empty slots of the lane
     uint32_t* st_w;                // [64] weight
     uint32_t* st_word;             // [64] slot -> word
+    uint8_t* wsp;                  // [B3_K][64] word of the staged masks (sparse staging)
+    uint16_t* queue;               // [B3_QCAP] record descriptors: owner lane | a << 6 | b << 9
     uint32_t lane;
     unsigned long long lt_mask;
 };
@@ -465,6 +469,8 @@ struct B3Lane {                    // one node per lane
     unsigned long long m0;
     uint32_t npw;                  // wide-list launch: word and full mask of a narrow parent (npm == 0: none)
     unsigned long long npm;
+    uint32_t po, e1blk;            // first entry of the node's extra pairs and the first of them (fetched ahead)
+    unsigned long long e1mask;
 };
 
 // One batch of 64 consecutive DFS nodes.  Every lane keeps the full-list masks of its node in W 64-bit
@@ -473,8 +479,12 @@ struct B3Lane {                    // one node per lane
 // with the number of blocks of the matrix.
 template <int W, bool IDENT, int NBW, bool EMIT>
 __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, const B3Lane& L, uint32_t base, uint32_t end,
-                                         uint32_t U, const uint32_t (&wl)[W], uint32_t ku, uint32_t rootslot, uint32_t inh) {
+                                         uint32_t U, const uint32_t (&wl)[W], uint32_t ku, uint32_t rootslot, uint32_t inh,
+                                         unsigned long long (&tph)[4]) {
     const uint32_t lane = C.lane;
+    const bool prof = (q.dbg & 32u) != 0;
+    unsigned long long tq = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto mark = [&](int k) { if (prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tph[k] += t - tq; tq = t; } };
     auto slot_of_word = [&](uint32_t wd) -> uint32_t { return IDENT ? wd : (uint32_t)__popc(U & ((1u << wd) - 1u)); };
     unsigned long long F[W];
     const uint32_t b0 = L.info & 0xFFu, np = L.info >> 8;
@@ -483,17 +493,25 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
 #pragma unroll
         for (int s = 0; s < W; ++s) F[s] = (np != 0 && s0 == (uint32_t)s) ? L.m0 : 0ull;
         if (__ballot(np > 1)) {
-            const uint32_t po = np > 1 ? q.pair_ofs[L.idx] : 0u;
-            uint32_t mx = np > 1 ? np - 1 : 0u;
+            // the first extra pair came with the node record; further ones (rare) are fetched here
+            {
+                const uint32_t sb = slot_of_word(L.e1blk);
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
-            mx = __builtin_amdgcn_readfirstlane(mx);
-            for (uint32_t t = 0; t < mx; ++t) {
-                if (t + 1 < np) {
-                    const uint32_t sb = slot_of_word(q.pair_blk[po + t]);
-                    const unsigned long long mk = q.pair_mask[po + t];
+                for (int s = 0; s < W; ++s) F[s] |= (np > 1 && sb == (uint32_t)s) ? L.e1mask : 0ull;
+            }
+            if (__ballot(np > 2)) {
+                const uint32_t po = L.po;
+                uint32_t mx = np > 1 ? np - 1 : 0u;
 #pragma unroll
-                    for (int s = 0; s < W; ++s) F[s] |= (sb == (uint32_t)s) ? mk : 0ull;
+                for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
+                mx = __builtin_amdgcn_readfirstlane(mx);
+                for (uint32_t t = 1; t < mx; ++t) {
+                    if (t + 1 < np) {
+                        const uint32_t sb = slot_of_word(q.pair_blk[po + t]);
+                        const unsigned long long mk = q.pair_mask[po + t];
+#pragma unroll
+                        for (int s = 0; s < W; ++s) F[s] |= (sb == (uint32_t)s) ? mk : 0ull;
+                    }
                 }
             }
         }
@@ -515,6 +533,7 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
             if ((inh >> wd) & 1u) F[s] |= C.chain[(size_t)rootslot * NBW + wd];
         }
     }
+    mark(0);
     // ---- pointer doubling over in-batch parents
     while (__ballot(pl >= 0)) {
         const int src = pl >= 0 ? pl : (int)lane;
@@ -527,6 +546,7 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         const int npl = __shfl(pl, src, WAVE);
         pl = pl >= 0 ? npl : -1;
     }
+    mark(1);
     if (!EMIT && q.nwords != nullptr && L.valid) {
         uint32_t nz = 0;
 #pragma unroll
@@ -535,10 +555,11 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
     }
     // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
     const bool act = L.valid && L.w != 0 && L.n >= 2 && !(q.dbg & 512u);
-    // Record-parallel emission: a node with p non-empty words owns p(p+1)/2 records.  The batch's records are
-    // numbered by a prefix sum over the lanes and handed out 64 at a time, one per lane: find the owner (binary
-    // search in the prefix sums), the pair of words (a >= b) from the index within the owner, read the two masks
-    // from the staging area, reserve the slot in the (X, Y, class) stream with one LDS atomic, store.
+    // Record-parallel emission: a node with p non-empty words owns p(p+1)/2 records (word pairs a >= b).  The
+    // batch's records are numbered by a prefix sum over the lanes.  Every owner stages its non-empty masks in LDS
+    // ([k-th non-empty word][lane]) and pushes one 16-bit descriptor (lane, a, b) per record into a queue; then the
+    // wave takes 64 descriptors at a time, one per lane: read the two masks and their words, reserve the slot in
+    // the (X, Y, class) stream with one LDS atomic, store.  No search, three LDS round trips per 64 records.
     {
         uint32_t nzs = 0;
 #pragma unroll
@@ -548,6 +569,50 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         const uint32_t incl = wave_incl_scan(myrec, lane);
         const uint32_t T = bcast(incl, WAVE - 1);
         if (T == 0) goto chain_update;
+        bool fast = true;
+        if (IDENT) fast = !__ballot(act && pw > (uint32_t)B3_K);         // more words than staging rows: the general path below
+        if (fast) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                if (!IDENT && (uint32_t)s >= ku) break;
+                if (act && F[s] != 0) { C.fmat[r * 64 + lane] = F[s]; C.wsp[r * 64 + lane] = (uint8_t)(IDENT ? (uint32_t)s : wl[s]); ++r; }
+            }
+            C.st_w[lane] = L.w;
+            const uint32_t excl = incl - myrec;
+            for (uint32_t q0 = 0; q0 < T; q0 += B3_QCAP) {
+                if (myrec) {
+                    uint32_t a = 0, b = 0;
+                    for (uint32_t i = excl; i < incl; ++i) {
+                        if (i - q0 < B3_QCAP) C.queue[i - q0] = (uint16_t)(lane | a << 6 | b << 9);
+                        if (++b > a) { ++a; b = 0; }
+                    }
+                }
+                lds_sync();
+                const uint32_t tend = T < q0 + B3_QCAP ? T : q0 + B3_QCAP;
+                for (uint32_t t0 = q0; t0 < tend; t0 += WAVE) {
+                    const uint32_t t = t0 + lane;
+                    const bool on = t < tend;
+                    const uint32_t d = on ? C.queue[t - q0] : 0u;
+                    const uint32_t own = d & 63u, a = (d >> 6) & 7u, b = d >> 9;
+                    const unsigned long long FX = C.fmat[a * 64 + own], FY = C.fmat[b * 64 + own];
+                    const uint32_t X = C.wsp[a * 64 + own], Y = C.wsp[b * 64 + own];
+                    const uint32_t wv = C.st_w[own];
+                    const uint32_t cls = b2_weight_class(wv);
+                    if (on) {
+                        const uint32_t slot = atomicAdd(&C.ctr[(X * (X + 1u) / 2u + Y) * B2_NCLS + cls], 1u);
+                        if (EMIT && !(q.dbg & 256u)) {
+                            if (X != Y) q.rec.rc[slot] = make_ulonglong2(FX, FY); else q.rec.rows[slot] = FX;
+                            if (cls) q.rec.w[slot] = wv;
+                        }
+                    }
+                }
+                lds_sync();
+            }
+            goto chain_update;
+        }
+        // general path (a lane with more than B3_K words): owner by binary search in the prefix sums, pair from the
+        // index within the owner, masks fetched from the owner's registers
         if (!IDENT) {
 #pragma unroll
             for (int s = 0; s < W; ++s) {
@@ -605,6 +670,7 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         lds_sync();
     }
 chain_update:
+    mark(2);
     // ---- chain table for the next batch: root path of this batch's last node
     if (base + WAVE < end) {
         const uint32_t nvalid = (end - base) < (uint32_t)WAVE ? (end - base) : (uint32_t)WAVE;
@@ -630,12 +696,12 @@ chain_update:
             C.slot_of_n[L.n] = (uint8_t)slot;
         }
         lds_sync();
-    }
+    }    mark(3);
 }
 
 
 template <int NBW, bool EMIT, bool INDIRECT>
-__global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
+__global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu(3, 8))) void b3_emit_kernel(B3Params q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -651,6 +717,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     C.fmat = (unsigned long long*)(((uintptr_t)(C.slot_of_n + q.maxn_pad + 64) + 7) & ~(uintptr_t)7);   // [B3_K][64]
     C.st_excl = (uint32_t*)(C.fmat + (size_t)B3_K * 64);
     C.st_nzs = C.st_excl + 64; C.st_w = C.st_nzs + 64; C.st_word = C.st_w + 64;
+    C.wsp = (uint8_t*)(C.st_word + 64); C.queue = (uint16_t*)(C.wsp + B3_K * 64);
     C.lane = lane;
     C.lt_mask = (1ull << lane) - 1ull;
     uint32_t* my_table = q.table + (size_t)(q.seg_row0 + seg) * q.nctr;
@@ -728,9 +795,9 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     }
 
     // node records of the NEXT batch are fetched while the current one is processed
-    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_idx = 0, nx_npw = 0;
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_idx = 0, nx_npw = 0, nx_po = 0, nx_e1blk = 0;
     int32_t nx_par = -1;
-    unsigned long long nx_m0 = 0, nx_npm = 0;
+    unsigned long long nx_m0 = 0, nx_npm = 0, nx_e1mask = 0;
     auto fetch = [&](uint32_t b0) {
         const uint32_t k = b0 + lane;
         const bool v = k < end;
@@ -741,6 +808,9 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         nx_par = v ? (INDIRECT ? q.wparent[k] : q.parent[ii]) : -1;
         nx_info = v ? q.p0_info[ii] : 0u;
         nx_m0 = v ? q.p0_mask[ii] : 0ull;
+        nx_po = v ? q.pair_ofs[ii] : 0u;
+        nx_e1blk = 0; nx_e1mask = 0;
+        if ((nx_info >> 8) > 1u) { nx_e1blk = q.pair_blk[nx_po]; nx_e1mask = q.pair_mask[nx_po]; }
         nx_npw = 0; nx_npm = 0;
         if (INDIRECT && nx_par <= -2) {
             const uint32_t np = (uint32_t)(-(nx_par + 2));
@@ -752,6 +822,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     const bool prof = (q.dbg & 32u) != 0;
     unsigned long long t_all = 0, t0 = 0;
     unsigned long long n_compact = 0, n_mid = 0, n_full = 0;
+    unsigned long long tph[4] = {0, 0, 0, 0};
     for (uint32_t base = first; base < end; base += WAVE) {
         if (prof) t0 = __builtin_amdgcn_s_memtime();
         B3Lane L;
@@ -759,14 +830,15 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
         L.valid = base + lane < end;
         L.n = nx_nl & 0xFFFFu; L.l = (nx_nl >> 16) & 0x3FFFu;
         L.w = nx_w; L.par = nx_par; L.info = nx_info; L.m0 = nx_m0; L.npw = nx_npw; L.npm = nx_npm;
+        L.po = nx_po; L.e1blk = nx_e1blk; L.e1mask = nx_e1mask;
         if ((q.dbg & 8192u) && (L.info >> 8) > 1u) L.info = (L.info & 0xFFu) | 0x100u;   // timing experiment: ignore extra pairs
         if (base + WAVE < end) fetch(base + WAVE);
         // words this batch touches: own local words + the words inherited from a parent before the batch
         const uint32_t np = L.info >> 8;
         uint32_t lw = np ? (1u << (L.info & 0xFFu)) : 0u;
-        if (__ballot(np > 1)) {
-            const uint32_t po = np > 1 ? q.pair_ofs[L.idx] : 0u;
-            for (uint32_t t = 0; t + 1 < np; ++t) lw |= 1u << q.pair_blk[po + t];
+        if (np > 1) lw |= 1u << L.e1blk;
+        if (__ballot(np > 2)) {
+            for (uint32_t t = 1; t + 1 < np; ++t) lw |= 1u << q.pair_blk[L.po + t];
         }
         uint32_t rootslot = 0xFFFFFFFFu, inh = 0;
         if (L.valid && L.par >= 0 && L.par < (int32_t)base) {
@@ -784,20 +856,21 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
             uint32_t rest = U;
 #pragma unroll
             for (int s = 0; s < B3_K; ++s) { wl[s] = rest ? (uint32_t)__builtin_ctz(rest) : 0u; rest &= rest - 1; }
-            b3_batch<B3_K, false, NBW, EMIT>(q, C, L, base, end, U, wl, ku, rootslot, inh);
+            b3_batch<B3_K, false, NBW, EMIT>(q, C, L, base, end, U, wl, ku, rootslot, inh, tph);
             ++n_mid;
         } else {
             uint32_t wl[NBW];
 #pragma unroll
             for (int s = 0; s < NBW; ++s) wl[s] = (uint32_t)s;
-            b3_batch<NBW, true, NBW, EMIT>(q, C, L, base, end, U, wl, (uint32_t)NBW, rootslot, inh);
+            b3_batch<NBW, true, NBW, EMIT>(q, C, L, base, end, U, wl, (uint32_t)NBW, rootslot, inh, tph);
             ++n_full;
         }
         if (prof) t_all += __builtin_amdgcn_s_memtime() - t0;
     }
     if (prof && lane == 0) {
-        atomicAdd(&q.counters[1], t_all); atomicAdd(&q.counters[2], n_compact);
+        atomicAdd(&q.counters[1], t_all); atomicAdd(&q.counters[2], tph[0]);       // all, load + inherit
         atomicAdd(&q.counters[3], n_mid); atomicAdd(&q.counters[4], n_full);
+        atomicAdd(&q.counters[5], tph[1]); atomicAdd(&q.counters[6], tph[2]); atomicAdd(&q.counters[7], tph[3]);   // doubling, records, chain
     }
     if (!EMIT) {
         lds_sync();

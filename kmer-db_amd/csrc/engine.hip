@@ -449,7 +449,8 @@ int finish_stats(kmdb_db* db, hipStream_t st) {
     HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));
     db->stats.tile_flushes = c[0];
     if (c[1] | c[2] | c[3] | c[4])
-        fprintf(stderr, "[kmdb prof] K1 wave-cycles (memtime ticks), phases 1..4: %llu %llu %llu %llu\n", c[1], c[2], c[3], c[4]);
+        fprintf(stderr, "[kmdb prof] emit kernel, memtime ticks summed over waves: all %llu = inherit %llu + doubling %llu + records %llu + chain %llu (+ fetch); "
+                        "compact batches %llu, full-width %llu\n", c[1], c[2], c[5], c[6], c[7], c[3], c[4]);
     return 0;
 }
 
