@@ -3,8 +3,8 @@
 
 One "step" = one dense all2all pass (SimilarityCalculator::all2all's job, reference
 src/similarity_calculator.cpp:42-438) over a synthetic clade-mutation database that is already
-resident in HBM: subtree-weight scan + the scatter kernel + (N>1) the RCCL sum of the per-GPU
-partial matrices.  Workload at N=1 is BASELINE.json configs[1]: 1000 synthetic 5 Mbp genomes,
+resident in HBM: the block-record pipeline (gamma decode, narrow / wide emit, apply) + (N>1) the
+RCCL sum of the per-GPU partial matrices.  Workload at N=1 is BASELINE.json configs[1]: 1000 synthetic 5 Mbp genomes,
 k=18, f=1.0.  With --gpus N the k-mer space is sharded by prefix bucket (kmer >> 32, reference
 src/types.h:25-27): the genomes are N x 5 Mbp long and rank r owns the k-mers whose bucket is
 congruent to r mod N, so per-GPU work stays fixed ("weak") and the partial matrices sum exactly.
@@ -198,10 +198,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         stl = db.stats()
         if stl["n_records"]:
-            # block-record pipeline: three kernels share the pass; the roofline is quoted on their SUM
-            # (decode + emit + apply), never on the longest one alone
+            # block-record pipeline: the kernels share the pass; the roofline is quoted on their SUM
+            # (decode + narrow/wide emit + apply), never on the longest one alone
             names_ms = [("b3_decode_kernel" if stl["k0_ms"] > 0 else None, stl["k0_ms"]),
-                        ("b3_emit_kernel" if stl["k0_ms"] > 0 else "b2_emit_kernel", stl["k1_ms"]),
+                        ("b3_narrow_kernel+b3_emit_kernel" if stl["k0_ms"] > 0 else "b2_emit_kernel", stl["k1_ms"]),
                         ("b2_apply_kernel", stl["k2_ms"])]
             kern_ms = float(np.mean(pipe_ms))
             dom_name = "+".join(n for n, _ in names_ms if n)

@@ -9,27 +9,26 @@
 
 namespace {
 // ------------------------------------------------------------------------------------------
-// v2 pipeline: block records + wavefront ballot / popcount accumulation
+// Block records.  The N x N matrix is cut into blocks (X, Y), X >= Y, of `width` <= 64 consecutive
+// sample ids (width chosen per database at upload).  A pattern's ascending id list meets a block in
+// a contiguous run, so all pair updates of a pattern with weight w factor into BLOCK RECORDS
+//        (X, Y, rowmask, colmask, w):   M[width*X + r][width*Y + c] += w   for r in rowmask, c in colmask
+//                                                                            (c < r when X == Y).
+// Flat form (all2all_sp semantics, reference similarity_calculator.cpp:596-638): every pattern with
+// w > 0 adds its on-disk w to all pairs of its FULL list, i.e. one record per pair of non-empty
+// 64-bit words X >= Y of the full list F = F(parent) | local ids.
 //
-// The N x N matrix is cut into 64 x 64 blocks (X, Y), X >= Y, by sample-id range.  Because a
-// pattern's id list is ascending, the ids that fall into one block are a contiguous run of
-// stack positions, so the whole update of a node
-//        for every local id a (row), every earlier id b (column):  M[a][b] += W
-// factors into a few BLOCK RECORDS  (X, Y, rowmask, colmask, W):
-//        M[64X + r][64Y + c] += W   for r in rowmask, c in colmask (and c < r when X == Y).
-// K1 (b2_emit_kernel) walks the DFS stream exactly like the v1 kernels (lane-per-node gamma
-//   decode, one id stack per wave) but keeps, per stack position, the running bit mask of the
-//   ids of the same block ("cum"), and writes records instead of touching the matrix.
-//   Records go straight to their final, bucket-grouped position: the per-(segment, bucket)
-//   record counts are a pure function of the database and are tabulated once at upload
-//   (count mode of the same kernel), so no atomics and no sort are needed at run time.
-// K2 (b2_apply_kernel) gives one workgroup a chunk of one bucket and a 64 x 64 uint32
-//   accumulator in LDS.  Records with W == 1 and many rows (the bulk: unique k-mer patterns)
-//   are reduced 64 at a time with ballots: R_r = ballot(row r in record j), C^T by a 64 x 64
-//   bit transpose across lanes, cell(r, c) += popcount(R_r & C^T_c) — one LDS add per cell per
-//   64 records instead of one per record.  The other records are applied row by row with the
-//   column mask as the lane mask.  The accumulator is written back with one HBM atomic per
-//   non-zero cell.
+// Per call, four kinds of kernels on one stream:
+//   K0  b3_decode_kernel   gamma streams -> local (block, mask) pairs of every node            (thread per node)
+//   K1n b3_narrow_kernel   nodes whose full list lies in ONE block (4 in 5): F is one register; DFS stream,
+//                          64 nodes per wave step, records (X, X, F) straight into the diagonal buckets
+//   K1w b3_emit_kernel     the other nodes, from their own DFS-ordered list; F in up to NBW registers per lane
+//                          (compact: only the words the batch touches), record-parallel emission
+//   K2  b2_apply_kernel    records -> matrix: 64 records per wave step as bit matrices, popcount accumulate
+// Records go straight to their final, bucket-grouped position: the per-(slice, bucket, weight class) record
+// counts are a pure function of the database and are tabulated once at upload with the count modes of the
+// same kernels (like CSR row pointers), so there is no sort and no global atomic at run time.
+// b2_emit_kernel is the sequential (stack replay) front half used when root paths exceed KMDB_CHAIN_MAX.
 // ------------------------------------------------------------------------------------------
 // block records, struct-of-arrays, one slot per record: rows always; cols only for off-diagonal
 // buckets (on the diagonal cols == rows); w only for the classes with w > 1
@@ -274,7 +273,8 @@ constexpr uint32_t B3_QCAP = 512;  // record descriptors queued per round
 constexpr int B3_CHAIN = KMDB_CHAIN_MAX;
 
 template <bool COUNT, bool LONG>
-__global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
+__global__ __launch_bounds__(256) void b3_decode_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ bitrel,
+                                                        const uint64_t* __restrict__ blkbase,
                                                         const uint64_t* __restrict__ bits, const uint32_t* __restrict__ perm,
                                                         uint32_t P, uint32_t short_max, BlockMap bm, unsigned long long* __restrict__ p0_mask, uint16_t* __restrict__ p0_info,
                                                         uint32_t* __restrict__ pair_ofs, uint8_t* __restrict__ pair_blk,
@@ -297,11 +297,12 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
         __shared__ uint16_t order[256];
         if (threadIdx.x < 64) bins[threadIdx.x] = 0;
         __syncthreads();
-        const uint2 lt2 = t < P ? make_uint2(meta[t].y, meta[t].w) : make_uint2(0u, 0u);
+        const uint2 kt = t < P ? k0in[t] : make_uint2(0u, 0u);          // {l | last id << 16, stream bits}
+        const uint2 lt2 = make_uint2(kt.x & 0xFFFFu, kt.y);
         // work of a node ~ number of codes that are not "0" ~ stream bits beyond one per delta
         uint32_t key = 0;                                                // 0: nothing to decode here
         if (t < P && lt2.x > 1 && !kmdb_long_node(lt2.x, lt2.y)) {
-            key = (kdbg & 8u) ? 1u + (lt2.y - (lt2.x - 1u)) / 2u : 1u + (lt2.y - (lt2.x - 1u));
+            key = 1u + (lt2.y - (lt2.x - 1u));
             key = key > 63u ? 63u : key;
         }
         atomicAdd(&bins[63u - key], 1u);                                 // bin 0 = most work
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
         i = blockIdx.x * blockDim.x + ((kdbg & 1u) ? threadIdx.x : order[threadIdx.x]);
         if (i >= P) return;
     }
-    const uint4 m = meta[i];
+    const uint2 km = k0in[i];
+    const uint4 m = make_uint4(0u, km.x & 0xFFFFu, km.x >> 16, km.y);   // {-, l, last id, stream bits}
     const uint32_t l = m.y;
     if (!perm && kmdb_long_node(l, m.w)) return;
     uint32_t npairs = 0, blk0 = 0;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint4* __restrict_
         // bit k of R <=> id_0 + k is in the list.  pattern_t::decodeSamples (reference src/pattern.cpp:99-109)
         // gets id_0 the same way: last id minus the sum of the deltas.
         using Cursor = RunCursor<LONG ? 8 : 3, LONG>;
-        const uint64_t pos = bitpos[i];
+        const uint64_t pos = blkbase[i >> 8] + bitrel[i];
         unsigned long long R = 1ull;
         uint32_t span = 0;
         {
@@ -1244,12 +1246,12 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
     const BlockMap bm{db->b2_width, (uint32_t)((1ull << 32) / db->b2_width) + 1u};
     const uint32_t kdbg = getenv("KMDB_K0_DBG") ? (uint32_t)atoi(getenv("KMDB_K0_DBG")) : 0u;
     if (P && !getenv("KMDB_SKIP_K0A"))
-        hipLaunchKernelGGL((b3_decode_kernel<COUNT, false>), dim3((P + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos, db->bits,
+        hipLaunchKernelGGL((b3_decode_kernel<COUNT, false>), dim3((P + 255) / 256), dim3(256), 0, st, db->b3_k0in, db->b3_bitrel, db->b3_blkbase, db->bits,
                            (const uint32_t*)nullptr, P, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info, db->b3_pair_ofs,
                            db->b3_pair_blk, db->b3_pair_mask, kdbg);
     if (db->b3_n_long && !getenv("KMDB_SKIP_K0B"))
-        hipLaunchKernelGGL((b3_decode_kernel<COUNT, true>), dim3((db->b3_n_long + 255) / 256), dim3(256), 0, st, db->meta, db->bitpos,
-                           db->bits, (const uint32_t*)db->b3_perm, db->b3_n_long, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info,
+        hipLaunchKernelGGL((b3_decode_kernel<COUNT, true>), dim3((db->b3_n_long + 255) / 256), dim3(256), 0, st, db->b3_k0in, db->b3_bitrel,
+                           db->b3_blkbase, db->bits, (const uint32_t*)db->b3_perm, db->b3_n_long, db->b3_short_max, bm, db->b3_p0_mask, db->b3_p0_info,
                            db->b3_pair_ofs, db->b3_pair_blk, db->b3_pair_mask, kdbg);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1479,6 +1481,23 @@ int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h) {
         for (uint64_t i = 0; i < P; ++i) depth8[i] = (uint8_t)std::min<uint32_t>(255u, (*h.depth)[i]);
         HIP_TRY(hipMalloc((void**)&db->b3_depth, P));
         HIP_TRY(hipMemcpy(db->b3_depth, depth8.data(), P, hipMemcpyHostToDevice));
+        // K0 input, 12 bytes per node: {l | last id << 16, stream bits} and the stream position relative to the
+        // first stream of the node's 256-node block
+        std::vector<uint2> k0in(P);
+        std::vector<uint32_t> bitrel(P);
+        std::vector<uint64_t> blkbase((P + 255) / 256);
+        for (uint64_t i = 0; i < P; ++i) {
+            const uint4 m = (*h.meta)[i];
+            if ((i & 255u) == 0) blkbase[i >> 8] = (*h.bitpos)[i];
+            k0in[i] = make_uint2(m.y | (m.z << 16), m.w);
+            bitrel[i] = (uint32_t)((*h.bitpos)[i] - blkbase[i >> 8]);
+        }
+        HIP_TRY(hipMalloc((void**)&db->b3_k0in, P * 8));
+        HIP_TRY(hipMemcpy(db->b3_k0in, k0in.data(), P * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&db->b3_bitrel, P * 4));
+        HIP_TRY(hipMemcpy(db->b3_bitrel, bitrel.data(), P * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&db->b3_blkbase, blkbase.size() * 8));
+        HIP_TRY(hipMemcpy(db->b3_blkbase, blkbase.data(), blkbase.size() * 8, hipMemcpyHostToDevice));
     }
     uint32_t forced = 0;
     if (const char* e = getenv("KMDB_BLOCK_WIDTH")) forced = (uint32_t)strtoul(e, nullptr, 10);
@@ -1506,9 +1525,10 @@ int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h) {
 
 void kmdb_records_release(kmdb_db* db) {
     b2_release_width(db);
-    void* ptrs[] = {db->b3_perm, db->b3_seg_anc, db->b3_seg_anc_n, db->b3_nl, db->b3_depth};
+    void* ptrs[] = {db->b3_perm, db->b3_seg_anc, db->b3_seg_anc_n, db->b3_nl, db->b3_depth, db->b3_k0in, db->b3_bitrel, db->b3_blkbase};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     db->b3_perm = nullptr; db->b3_seg_anc = nullptr; db->b3_seg_anc_n = nullptr; db->b3_nl = nullptr; db->b3_depth = nullptr;
+    db->b3_k0in = nullptr; db->b3_bitrel = nullptr; db->b3_blkbase = nullptr;
 }
 
 uint64_t kmdb_records_device_bytes(const kmdb_db* db) {

@@ -347,7 +347,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
                 while (cur >= 0) { seg_anc[sidx * anc_stride + (--d)] = (uint32_t)cur; cur = parent[cur]; }
             }
         }
-        const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth};
+        const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth, &meta, &bitpos};
         if (kmdb_records_prepare(db, hl)) { kmdb_db_free(db); return 1; }
     }
     db->stats.device_bytes += kmdb_records_device_bytes(db);

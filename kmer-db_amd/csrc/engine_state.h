@@ -77,6 +77,9 @@ struct kmdb_db {
     // K1 split: narrow nodes (full list inside one block) stay in the DFS stream, wide nodes get their own list
     bool b3_split = false;
     uint8_t* b3_depth = nullptr;        // [P] root path length (root = 1)
+    uint2* b3_k0in = nullptr;           // [P] decode kernel input: {l | last id << 16, stream bits}
+    uint32_t* b3_bitrel = nullptr;      // [P] stream position relative to b3_blkbase[i / 256]
+    uint64_t* b3_blkbase = nullptr;
     uint32_t* b3_widx = nullptr;        // [n_wide] DFS index of the wide nodes, DFS order
     int32_t* b3_wparent = nullptr;      // [n_wide] >= 0: position of the (wide) parent in the wide list; -1: none; <= -2: narrow parent -(v + 2)
     unsigned long long* b3_fnarrow = nullptr;   // [P] full mask of the narrow nodes that have a wide child (written by the narrow kernel)
@@ -110,6 +113,8 @@ struct kmdb_host_layout {               // host copies of upload-time arrays the
     const std::vector<uint32_t>* seg_anc_n;
     const std::vector<int32_t>* parent;
     const std::vector<uint16_t>* depth;
+    const std::vector<uint4>* meta;
+    const std::vector<uint64_t>* bitpos;
 };
 int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h);
 // per call: decode + emit (+ sequential emit fallback) + apply; records events ev_k0 / ev_k2
