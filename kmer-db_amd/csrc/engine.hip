@@ -314,19 +314,20 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
             depth[i] = (uint16_t)d;
             max_depth = std::max(max_depth, d);
         }
-        // K0: nodes with long lists or streams (a few percent) are decoded by a second launch, longest list first
+        // K0: nodes with long lists or streams (a few percent) are decoded by a second launch, most work first.
+        // Work of a node ~ number of codes that are not "0" (runs of consecutive ids cost one step) ~ stream bits
+        // beyond one per delta.
         std::vector<uint32_t> perm, nl(P);
         {
-            std::vector<uint32_t> cntl(max_n + 2, 0);
-            uint64_t nlong = 0;
             for (uint64_t i = 0; i < P; ++i) {
                 nl[i] = meta[i].x | (meta[i].y << 16);
-                if (kmdb_long_node(meta[i].y, meta[i].w)) { ++cntl[max_n - meta[i].y + 1]; ++nlong; }
+                if (kmdb_long_node(meta[i].y, meta[i].w)) perm.push_back((uint32_t)i);
             }
-            for (uint32_t b = 1; b < cntl.size(); ++b) cntl[b] += cntl[b - 1];
-            perm.resize(nlong);
-            for (uint64_t i = 0; i < P; ++i)
-                if (kmdb_long_node(meta[i].y, meta[i].w)) perm[cntl[max_n - meta[i].y]++] = (uint32_t)i;
+            auto work = [&](uint32_t i) -> uint32_t { return meta[i].w - (meta[i].y ? meta[i].y - 1u : 0u); };
+            if (!getenv("KMDB_LONG_ORDER_BY_LENGTH"))
+                std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return work(a) > work(b); });
+            else
+                std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return meta[a].y > meta[b].y; });
         }
         // segments of the emit kernels.  Measured: the equal-cost slices of the scatter model (long multi-clade
         // lists weigh more) also balance the emit kernel better than equal node counts do, so they are reused.
