@@ -921,11 +921,8 @@ __global__ __launch_bounds__(WAVE * B3N_WAVES) void b3_narrow_kernel(B3NParams q
     unsigned long long* chain = (unsigned long long*)(lds_raw + b3n_wave_bytes(q.chain_cap, q.nb) * wave);   // [chain_cap]
     uint32_t* ctr = (uint32_t*)(chain + q.chain_cap);                                                        // [nb][B2_NCLS]
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t* my_table = q.table + (size_t)seg * q.nctr;
-    for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) {
-        const uint32_t X = k / B2_NCLS, c = k - X * B2_NCLS;
-        ctr[k] = EMIT ? my_table[(X * (X + 1) / 2 + X) * B2_NCLS + c] : 0u;
-    }
+    uint32_t* my_table = q.table + (size_t)seg * q.nb * B2_NCLS;          // [block][class]: diagonal buckets only
+    for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) ctr[k] = EMIT ? my_table[k] : 0u;
     const Segment sg = q.segs[seg];
     const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
     const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
@@ -1025,10 +1022,7 @@ __global__ __launch_bounds__(WAVE * B3N_WAVES) void b3_narrow_kernel(B3NParams q
     }
     if (!EMIT) {
         lds_sync();
-        for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) {
-            const uint32_t X = k / B2_NCLS, c = k - X * B2_NCLS;
-            my_table[(X * (X + 1) / 2 + X) * B2_NCLS + c] = ctr[k];
-        }
+        for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) my_table[k] = ctr[k];
     }
 }
 
@@ -1194,7 +1188,7 @@ int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg, uint8_t* nwords)
     if (INDIRECT) {
         q.segs = db->b3_wsegs; q.n_segs = db->b3_n_wsegs; q.seg_anc = db->b3_wseg_anc; q.seg_anc_n = db->b3_wseg_anc_n;
         q.widx = db->b3_widx; q.wparent = db->b3_wparent; q.fnarrow = db->b3_fnarrow; q.seg_np = db->b3_wseg_np;
-        q.seg_row0 = db->n_rsegs; q.chain_cap = db->b3_wchain_cap;
+        q.seg_row0 = 0; q.chain_cap = db->b3_wchain_cap;
     } else {
         q.segs = db->rsegs; q.n_segs = db->n_rsegs; q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
     }
@@ -1228,11 +1222,11 @@ int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0, uint8_t* nword
 template <bool EMIT>
 int b3_launch_narrow(kmdb_db* db, hipStream_t st, uint32_t dbg = 0) {
     B3NParams q{};
-    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.depth = db->b3_depth; q.segs = db->rsegs;
-    q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n; q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
-    q.fnarrow = db->b3_fnarrow; q.n_segs = db->n_rsegs; q.chain_cap = db->b3_chain_cap; q.nctr = db->b2_nctr;
+    q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.depth = db->b3_depth; q.segs = db->b3_nsegs;
+    q.seg_anc = db->b3_nseg_anc; q.seg_anc_n = db->b3_nseg_anc_n; q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
+    q.fnarrow = db->b3_fnarrow; q.n_segs = db->b3_n_nsegs; q.chain_cap = db->b3_chain_cap; q.nctr = db->b2_nctr;
     q.nb = (uint32_t)((db->N + db->b2_width - 1) / db->b2_width);
-    q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.dbg = dbg;
+    q.table = db->b3_ntable; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.dbg = dbg;
     const size_t lds = b3n_wave_bytes(q.chain_cap, q.nb) * B3N_WAVES;
     const uint32_t blocks = (q.n_segs + B3N_WAVES - 1) / B3N_WAVES;
     if (blocks) hipLaunchKernelGGL((b3_narrow_kernel<EMIT>), dim3(blocks), dim3(WAVE * B3N_WAVES), lds, st, q);
@@ -1264,10 +1258,10 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
 void b2_release_width(kmdb_db* db) {
     void* ptrs[] = {db->b2_table, db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w, db->b2_items, db->b3_pair_ofs,
                     db->b3_pair_blk, db->b3_pair_mask, db->b3_p0_mask, db->b3_p0_info, db->b3_widx, db->b3_wparent,
-                    db->b3_fnarrow, db->b3_wsegs, db->b3_wseg_anc, db->b3_wseg_anc_n, db->b3_wseg_np};
+                    db->b3_fnarrow, db->b3_wsegs, db->b3_wseg_anc, db->b3_wseg_anc_n, db->b3_wseg_np, db->b3_ntable};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     db->b3_widx = nullptr; db->b3_wparent = nullptr; db->b3_fnarrow = nullptr; db->b3_wsegs = nullptr;
-    db->b3_wseg_anc = nullptr; db->b3_wseg_anc_n = nullptr; db->b3_wseg_np = nullptr;
+    db->b3_wseg_anc = nullptr; db->b3_wseg_anc_n = nullptr; db->b3_wseg_np = nullptr; db->b3_ntable = nullptr;
     db->b3_split = false; db->b3_n_wide = 0; db->b3_n_wsegs = 0;
     db->b2_table = nullptr; db->b2_rec_rows = nullptr; db->b2_rec_rc = nullptr; db->b2_rec_w = nullptr; db->b2_items = nullptr;
     db->b3_pair_ofs = nullptr; db->b3_pair_blk = nullptr; db->b3_pair_mask = nullptr; db->b3_p0_mask = nullptr;
@@ -1293,6 +1287,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
     if (b2_lds_per_wave(db->b2_maxn_pad, db->b2_dec_cap, db->b2_nctr) * B2_WAVES > 160 * 1024) return 0;
     size_t table_rows = db->n_rsegs;
     size_t tbl = table_rows * db->b2_nctr;
+    size_t ntbl = 0;                                       // narrow kernel's own table (split front half only)
     HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
     HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
     const uint32_t nbw = NB <= 8 ? 8 : NB <= 16 ? 16 : NB <= 20 ? 20 : NB <= 24 ? 24 : 32;
@@ -1349,7 +1344,8 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
                 else if (rank[pp] >= 0) wparent[k] = rank[pp];
                 else { wparent[k] = -(pp + 2); nlf[pp] |= 1u << 30; }
             }
-            const size_t WSEG = 1024;                                  // wide nodes per slice (16 batches)
+            size_t WSEG = 512;                                         // wide nodes per slice (8 batches)
+            if (const char* e = getenv("KMDB_WSEG")) WSEG = std::max<size_t>(64, strtoull(e, nullptr, 10));
             const size_t n_wsegs = (nW + WSEG - 1) / WSEG;
             std::vector<Segment> wsegs(n_wsegs);
             // root paths inside the wide forest are short: the chain table of the wide launch is sized for them
@@ -1388,10 +1384,13 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
             db->b3_n_wide = (uint32_t)nW; db->b3_n_wsegs = (uint32_t)n_wsegs; db->b3_split = true;
             // count modes of the two run-time kernels, one table row per slice
             (void)hipFree(db->b2_table); db->b2_table = nullptr;
-            table_rows = db->n_rsegs + n_wsegs;
-            tbl = table_rows * db->b2_nctr;
+            table_rows = n_wsegs;
+            tbl = std::max<size_t>(table_rows, 1) * db->b2_nctr;
             HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
             HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
+            ntbl = (size_t)db->b3_n_nsegs * NB * B2_NCLS;
+            HIP_TRY(hipMalloc((void**)&db->b3_ntable, std::max<size_t>(ntbl, 1) * 4));
+            HIP_TRY(hipMemset(db->b3_ntable, 0, std::max<size_t>(ntbl, 1) * 4));
             if (b3_launch_narrow<false>(db, db->stream)) return 1;
             if (n_wsegs && b3_launch_emit<false, true>(db, db->stream)) return 1;
             if (getenv("KMDB_VERBOSE"))
@@ -1404,11 +1403,26 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
     std::vector<uint32_t> counts(tbl);
     HIP_TRY(hipMemcpy(counts.data(), db->b2_table, tbl * 4, hipMemcpyDeviceToHost));
     // bucket-major record order: all records of (bucket, class) c are contiguous, segment by segment
+    std::vector<uint32_t> ncounts(ntbl), nbases(ntbl);
+    if (ntbl) HIP_TRY(hipMemcpy(ncounts.data(), db->b3_ntable, ntbl * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> bases(tbl);
     std::vector<uint64_t> cstart(db->b2_nctr + 1, 0);
     uint64_t run = 0;
     for (uint32_t c = 0; c < db->b2_nctr; ++c) {
         cstart[c] = run;
+        if (ntbl) {
+            // narrow slices first: they only write to the diagonal buckets
+            const uint32_t bucket = c / B2_NCLS, cls = c % B2_NCLS;
+            uint32_t X = 0;
+            while ((X + 1) * (X + 2) / 2 <= bucket) ++X;
+            if (bucket == X * (X + 1) / 2 + X) {
+                const size_t stride = (size_t)NB * B2_NCLS, col = (size_t)X * B2_NCLS + cls;
+                for (size_t sgi = 0; sgi < db->b3_n_nsegs; ++sgi) {
+                    nbases[sgi * stride + col] = (uint32_t)run;
+                    run += ncounts[sgi * stride + col];
+                }
+            }
+        }
         for (size_t sgi = 0; sgi < table_rows; ++sgi) {
             bases[(size_t)sgi * db->b2_nctr + c] = (uint32_t)run;
             run += counts[(size_t)sgi * db->b2_nctr + c];
@@ -1444,6 +1458,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
             }
     }
     HIP_TRY(hipMemcpy(db->b2_table, bases.data(), tbl * 4, hipMemcpyHostToDevice));
+    if (ntbl) HIP_TRY(hipMemcpy(db->b3_ntable, nbases.data(), ntbl * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&db->b2_rec_rows, std::max<uint64_t>(run, 1) * 8));
     HIP_TRY(hipMalloc((void**)&db->b2_rec_rc, std::max<uint64_t>(run, 1) * 16));
     HIP_TRY(hipMalloc((void**)&db->b2_rec_w, std::max<uint64_t>(run, 1) * 4));
@@ -1481,6 +1496,15 @@ int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h) {
         for (uint64_t i = 0; i < P; ++i) depth8[i] = (uint8_t)std::min<uint32_t>(255u, (*h.depth)[i]);
         HIP_TRY(hipMalloc((void**)&db->b3_depth, P));
         HIP_TRY(hipMemcpy(db->b3_depth, depth8.data(), P, hipMemcpyHostToDevice));
+        db->b3_n_nsegs = (uint32_t)h.nsegs->size();
+        HIP_TRY(hipMalloc((void**)&db->b3_nsegs, std::max<size_t>(h.nsegs->size(), 1) * sizeof(Segment)));
+        HIP_TRY(hipMalloc((void**)&db->b3_nseg_anc, std::max<size_t>(h.nseg_anc->size(), 1) * 4));
+        HIP_TRY(hipMalloc((void**)&db->b3_nseg_anc_n, std::max<size_t>(h.nseg_anc_n->size(), 1) * 4));
+        if (!h.nsegs->empty()) {
+            HIP_TRY(hipMemcpy(db->b3_nsegs, h.nsegs->data(), h.nsegs->size() * sizeof(Segment), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(db->b3_nseg_anc, h.nseg_anc->data(), h.nseg_anc->size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(db->b3_nseg_anc_n, h.nseg_anc_n->data(), h.nseg_anc_n->size() * 4, hipMemcpyHostToDevice));
+        }
         // K0 input, 12 bytes per node: {l | last id << 16, stream bits} and the stream position relative to the
         // first stream of the node's 256-node block
         std::vector<uint2> k0in(P);
@@ -1525,14 +1549,16 @@ int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h) {
 
 void kmdb_records_release(kmdb_db* db) {
     b2_release_width(db);
-    void* ptrs[] = {db->b3_perm, db->b3_seg_anc, db->b3_seg_anc_n, db->b3_nl, db->b3_depth, db->b3_k0in, db->b3_bitrel, db->b3_blkbase};
+    void* ptrs[] = {db->b3_perm, db->b3_seg_anc, db->b3_seg_anc_n, db->b3_nl, db->b3_depth, db->b3_k0in, db->b3_bitrel, db->b3_blkbase,
+                    db->b3_nsegs, db->b3_nseg_anc, db->b3_nseg_anc_n};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     db->b3_perm = nullptr; db->b3_seg_anc = nullptr; db->b3_seg_anc_n = nullptr; db->b3_nl = nullptr; db->b3_depth = nullptr;
     db->b3_k0in = nullptr; db->b3_bitrel = nullptr; db->b3_blkbase = nullptr;
+    db->b3_nsegs = nullptr; db->b3_nseg_anc = nullptr; db->b3_nseg_anc_n = nullptr;
 }
 
 uint64_t kmdb_records_device_bytes(const kmdb_db* db) {
-    return db->b2_ready ? db->b2_total * 28 + (uint64_t)(db->n_rsegs + db->b3_n_wsegs) * db->b2_nctr * 4 + db->P * (db->b3_split ? 23 : 14) +
+    return db->b2_ready ? db->b2_total * 28 + (uint64_t)(db->b3_split ? db->b3_n_wsegs : db->n_rsegs) * db->b2_nctr * 4 + db->P * (db->b3_split ? 35 : 26) +
                               (uint64_t)db->b3_n_wide * 8 : 0;
 }
 

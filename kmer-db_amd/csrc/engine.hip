@@ -348,7 +348,23 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
                 while (cur >= 0) { seg_anc[sidx * anc_stride + (--d)] = (uint32_t)cur; cur = parent[cur]; }
             }
         }
-        const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth, &meta, &bitpos};
+        // the narrow kernel is latency-bound per wave, so it gets many small slices of equal node count
+        std::vector<Segment> nsegs;
+        std::vector<uint32_t> nseg_anc, nseg_anc_n;
+        if (chain_ok) {
+            uint64_t NSEG = 1024;
+            if (const char* e = getenv("KMDB_NSEG")) NSEG = std::max<uint64_t>(64, strtoull(e, nullptr, 10));
+            for (uint64_t f = 0; f < P; f += NSEG) nsegs.push_back(Segment{(uint32_t)f, (uint32_t)std::min<uint64_t>(P, f + NSEG)});
+            nseg_anc.assign(nsegs.size() * anc_stride, 0);
+            nseg_anc_n.assign(nsegs.size(), 0);
+            for (size_t sidx = 0; sidx < nsegs.size(); ++sidx) {
+                int32_t cur = parent[nsegs[sidx].first];
+                uint32_t d = cur < 0 ? 0u : depth[cur];
+                nseg_anc_n[sidx] = d;
+                while (cur >= 0) { nseg_anc[sidx * anc_stride + (--d)] = (uint32_t)cur; cur = parent[cur]; }
+            }
+        }
+        const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth, &meta, &bitpos, &nsegs, &nseg_anc, &nseg_anc_n};
         if (kmdb_records_prepare(db, hl)) { kmdb_db_free(db); return 1; }
     }
     db->stats.device_bytes += kmdb_records_device_bytes(db);

@@ -88,6 +88,11 @@ struct kmdb_db {
     uint32_t* b3_wseg_anc_n = nullptr;
     int32_t* b3_wseg_np = nullptr;      // [n_wsegs] narrow parent (DFS index) of the topmost wide ancestor, -1: none
     uint32_t b3_n_wide = 0, b3_n_wsegs = 0, b3_wchain_cap = 8;
+    Segment* b3_nsegs = nullptr;        // equal-node-count slices of the DFS stream for the narrow kernel
+    uint32_t* b3_nseg_anc = nullptr;    // [n_nsegs][chain_cap] root path of the slice's first node
+    uint32_t* b3_nseg_anc_n = nullptr;
+    uint32_t* b3_ntable = nullptr;      // [n_nsegs][blocks * classes] record bases of the narrow kernel (diagonal buckets)
+    uint32_t b3_n_nsegs = 0;
     hipEvent_t ev_k0 = nullptr;
     double k0_ms = 0;
 };
@@ -115,6 +120,9 @@ struct kmdb_host_layout {               // host copies of upload-time arrays the
     const std::vector<uint16_t>* depth;
     const std::vector<uint4>* meta;
     const std::vector<uint64_t>* bitpos;
+    const std::vector<Segment>* nsegs;            // narrow kernel slices + root paths
+    const std::vector<uint32_t>* nseg_anc;
+    const std::vector<uint32_t>* nseg_anc_n;
 };
 int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h);
 // per call: decode + emit (+ sequential emit fallback) + apply; records events ev_k0 / ev_k2
