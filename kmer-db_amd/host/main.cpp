@@ -4,6 +4,7 @@
 //     kmer-db-amd all2all    [-sparse [-min [m:]v] [-max [m:]v]] <db> <out.csv>
 //     kmer-db-amd all2all-sp [-min [m:]v] [-max [m:]v]           <db> <out.csv>
 //     kmer-db-amd new2all    [-multisample-fasta] [-sparse ...]  <db> <sample-list> <out.csv>
+//     kmer-db-amd one2all    <db> <sample> <out.csv>
 // mirroring the reference consoles (reference src/console_all2all.cpp, console_all2all_sparse.cpp,
 // console_new2all.cpp) around the calls that the C ABI replaces.  Options that only tune the
 // reference's CPU engine (-t, -rt, -buffer, -bubble-size) are accepted; -t also sizes the
@@ -400,12 +401,57 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
     return 0;
 }
 
+// ---- one2all (console_one2all.cpp:12-96): one sample against the database --------------------------
+// Same engine call as new2all with a batch of one; the row is labelled with the path as given on the
+// command line and the file does not end with a newline (console_one2all.cpp:88-93).
+int run_one2all(std::vector<std::string>& args, Common& c) {
+    if (take_switch(args, "-from-kmers") || take_switch(args, "-from-minhash"))
+        throw std::runtime_error("only genome (FASTA) query input is supported by the GPU front-end");
+    if (args.size() != 3) throw usage_error("one2all");
+    std::cerr << "One new sample  (from genomes) versus entire database comparison" << std::endl;
+    Db db;
+    std::cerr << "Loading k-mer database " << args[0] << ":" << std::endl;
+    auto t0 = clk::now();
+    check(kmdbh_db_load(args[0].c_str(), 0, &db.h));
+    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1;
+    check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 1, &db.d));
+    std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    const uint64_t n = kmdbh_db_n_samples(db.h);
+    const uint32_t k = kmdbh_db_kmer_length(db.h);
+    const int preserve = kmdbh_db_alphabet(db.h) == 1;
+    if (kmdbh_db_alphabet(db.h) > 1) throw std::runtime_error("protein alphabets are not supported by the GPU front-end");
+    std::string data;
+    if (!slurp(args[1], data)) throw std::runtime_error("Cannot open sample file: " + args[1]);
+    std::vector<Record> recs;
+    split_fasta(data, recs);
+    size_t total = 0;
+    for (auto& r : recs) total += r.seq.size();
+    std::vector<uint64_t> kmers(total + 1);
+    size_t cnt = 0;
+    for (auto& r : recs)
+        cnt += kmdbh_extract_kmers(r.seq.data(), r.seq.size(), k, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, kmers.data() + cnt);
+    cnt = kmdbh_sort_unique(kmers.data(), cnt);                    // KmerHelper::sortAndUnique (console_one2all.cpp:64-66)
+    std::cerr << "Number of k-mers: " << cnt << std::endl << "Calculating similarity vector..." << std::endl;
+    const uint64_t* ptr = kmers.data();
+    std::vector<uint32_t> sims(n + 1);
+    check(kmdb_new2all_batch(db.d, &ptr, &cnt, 1, sims.data(), &o));
+    std::ofstream ofs(args[2]);
+    write_header(db, ofs);
+    std::vector<char> row(10000 + n * 100 + args[1].size());
+    size_t len = kmdbh_format_dense_row(args[1].c_str(), cnt, sims.data(), n, row.data());
+    if (len && row[len - 1] == '\n') --len;
+    ofs.write(row.data(), (std::streamsize)len);
+    std::cerr << "OK" << std::endl;
+    return 0;
+}
+
 void usage() {
     std::cerr << "kmer-db-amd (MI355X engine for kmer-db's all2all / all2all-sp / new2all)\n"
                  "USAGE\n"
                  "    kmer-db-amd all2all [-sparse [-min [<criterion>:]<v>] [-max [<criterion>:]<v>]] <database> <common_table>\n"
                  "    kmer-db-amd all2all-sp [-min ...] [-max ...] <database> <common_table>\n"
                  "    kmer-db-amd new2all [-multisample-fasta] [-sparse [-min ...] [-max ...]] <database> <sample_list> <common_table>\n"
+                 "    kmer-db-amd one2all <database> <sample> <similarity_vector>\n"
                  "Common options: -t <threads>, -gpu <device>\n";
 }
 
@@ -427,6 +473,7 @@ int main(int argc, char** argv) {
         if (mode == "all2all") return run_all2all(args, c);
         if (mode == "all2all-sp") return run_all2all_sp(args, c);
         if (mode == "new2all") return run_new2all(args, c);
+        if (mode == "one2all") return run_one2all(args, c);
         usage();
         return -1;
     } catch (usage_error&) {

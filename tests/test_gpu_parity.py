@@ -139,6 +139,9 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
         _cli("new2all", "-multisample-fasta", "-sparse", g("synth_k21.db"), t("synth.list"), t("n2a-sp")); _same(t("n2a-sp"), g("synth.n2a-sparse"))
         _cli("new2all", "-multisample-fasta", "-sparse", "-max", "69", "-min", "num-kmers:21", g("synth_k21.db"), t("synth.list"), t("n2a-mm"))
         _same(t("n2a-mm"), g("synth.n2a.sparse.above-below"))
+        # one2all: main.yml:156-160 (k=25, f=0.1 database of part 1, one genome against it)
+        _cli("one2all", g("virus_k25_f01_part1.db"), "./test/virus/data/MT159713", t("MT159713.csv"))
+        _same(t("MT159713.csv"), g("virus.MT159713.csv"))
     finally:
         os.chdir(cwd)
 
