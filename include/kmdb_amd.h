@@ -139,6 +139,15 @@ int  kmdb_new2all_batch(kmdb_db* db, const uint64_t* const* kmers, const size_t*
  * row q = ascending (sample_id, count) pairs with count > 0. */
 int  kmdb_new2all_batch_sparse(kmdb_db* db, const uint64_t* const* kmers, const size_t* counts, size_t nq,
                                kmdb_sparse_rows* out, const kmdb_opts* opts);
+/* The same with the query-side loader on the device: replaces, per query, the k-mer extraction of
+ * GenomeInputFile::load / KmerHelper (kmer_extract.h:13-118), the minhash filter (filter.h:28-115) and
+ * KmerHelper::unique (console_new2all.cpp:73) followed by one2all<false>.  seqs[q] = the query's sequence text
+ * (ASCII, records of one sample joined by any non-ACGTU symbol, e.g. '\n'); fraction / start_fraction /
+ * preserve_strand are the database's filter settings (kmdbh_db_fraction, kmdbh_db_start_fraction,
+ * kmdbh_db_alphabet == 1).  out_kmer_counts[q] = number of unique k-mers of query q (the CSV's total-kmers). */
+int  kmdb_new2all_batch_seq(kmdb_db* db, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
+                            double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                            const kmdb_opts* opts);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side helpers of the front-end (no GPU needed).  They mirror the reference's loader

@@ -387,7 +387,7 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
 }
 
 void kmdb_engine_get(kmdb_db* db, kmdb_engine_view* o) {
-    o->device = db->device; o->N = db->N; o->P = db->P;
+    o->device = db->device; o->N = db->N; o->P = db->P; o->kmer_length = db->kmer_length;
     o->meta = db->meta; o->bitpos = db->bitpos; o->parent = db->parent; o->w = db->w; o->sub_end = db->sub_end;
     o->bits = db->bits; o->n_buckets = db->n_buckets; o->bucket_offset = db->bucket_offset; o->slots = db->slots;
     o->pid2dfs = db->pid2dfs; o->stream = db->stream;

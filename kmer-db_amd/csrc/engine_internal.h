@@ -9,6 +9,7 @@ struct kmdb_db;
 struct kmdb_engine_view {
     int device;
     uint64_t N, P;
+    uint32_t kmer_length;
     const uint4* meta;
     const uint64_t* bitpos;
     const int32_t* parent;

@@ -28,7 +28,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -189,25 +191,12 @@ struct DevBuf {
             return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
-extern "C" int kmdb_new2all_batch(kmdb_db* dbh, const uint64_t* const* kmers, const size_t* counts, size_t nq,
-                                  uint32_t* out_dense, const kmdb_opts* opts) {
-    if (!dbh || (nq && (!kmers || !counts || !out_dense))) return kmdb_set_error("kmdb_new2all_batch: null argument");
-    kmdb_engine_view e;
-    kmdb_engine_get(dbh, &e);
-    if (!e.n_buckets || !e.slots) return kmdb_set_error("kmdb_new2all_batch: database was uploaded without hashtables");
-    if (nq >= (1ull << 31)) return kmdb_set_error("kmdb_new2all_batch: too many queries in one batch");
-    N2_TRY(hipSetDevice(e.device));
-    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : (hipStream_t)e.stream;
+// probe / sort / count / walk over a batch whose k-mers (sorted and unique per query, query by query) and
+// query offsets are already on the device
+static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, const uint64_t* d_kmers, const uint64_t* d_qoff_p,
+                   size_t total, size_t nq, uint32_t* out_dense) {
     const uint64_t N = e.N;
-    std::vector<uint64_t> qoff(nq + 1, 0);
-    for (size_t q = 0; q < nq; ++q) qoff[q + 1] = qoff[q] + counts[q];
-    const size_t total = qoff[nq];
-    if (total >= (1ull << 32) - 2) return kmdb_set_error("kmdb_new2all_batch: more than 2^32 k-mers in one batch; split it");
-    if (!nq) return 0;
-
-    DevBuf d_k, d_qoff, d_keys, d_keys2, d_uniq, d_cnt, d_csum, d_nruns, d_qstart, d_sim, d_tmp;
-    N2_TRY(d_k.alloc(total * 8));
-    N2_TRY(d_qoff.alloc((nq + 1) * 8));
+    DevBuf d_keys, d_keys2, d_uniq, d_cnt, d_csum, d_nruns, d_qstart, d_sim, d_tmp;
     N2_TRY(d_keys.alloc(total * 8));
     N2_TRY(d_keys2.alloc(total * 8));
     N2_TRY(d_uniq.alloc((total + 1) * 8));
@@ -223,10 +212,6 @@ extern "C" int kmdb_new2all_batch(kmdb_db* dbh, const uint64_t* const* kmers, co
                                                  d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)total, st));
     N2_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb_scan, d_cnt.as<uint32_t>(), d_csum.as<uint32_t>(), (int)(total + 1), st));
     N2_TRY(d_tmp.alloc(std::max(tb_sort, std::max(tb_rle, tb_scan))));
-
-    for (size_t q = 0; q < nq; ++q)
-        if (counts[q]) N2_TRY(hipMemcpyAsync(d_k.as<uint64_t>() + qoff[q], kmers[q], counts[q] * 8, hipMemcpyHostToDevice, st));
-    N2_TRY(hipMemcpyAsync(d_qoff.p, qoff.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
     N2_TRY(hipMemsetAsync(d_sim.p, 0, std::max<uint64_t>(nq * N * 4, 4), st));
 
     hipEvent_t ev0 = (hipEvent_t)e.ev[0], ev3 = (hipEvent_t)e.ev[3];
@@ -234,7 +219,7 @@ extern "C" int kmdb_new2all_batch(kmdb_db* dbh, const uint64_t* const* kmers, co
     uint32_t nruns = 0;
     if (total) {
         const unsigned blocks = (unsigned)std::min<size_t>(65535, (total + 255) / 256);
-        hipLaunchKernelGGL(n2a_probe_kernel, dim3(blocks), dim3(256), 0, st, d_k.as<uint64_t>(), d_qoff.as<uint64_t>(), (uint32_t)nq,
+        hipLaunchKernelGGL(n2a_probe_kernel, dim3(blocks), dim3(256), 0, st, d_kmers, d_qoff_p, (uint32_t)nq,
                            total, e.n_buckets, e.bucket_offset, e.slots, e.pid2dfs, e.w, d_keys.as<unsigned long long>());
         N2_TRY(hipGetLastError());
         // queries need 32 - clz(nq) high bits; sorting all 64 is simplest and the key count is small
@@ -268,6 +253,218 @@ extern "C" int kmdb_new2all_batch(kmdb_db* dbh, const uint64_t* const* kmers, co
     kmdb_engine_set_times(dbh, ms, ms);
     if (nq * N) N2_TRY(hipMemcpy(out_dense, d_sim.p, nq * N * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+extern "C" int kmdb_new2all_batch(kmdb_db* dbh, const uint64_t* const* kmers, const size_t* counts, size_t nq,
+                                  uint32_t* out_dense, const kmdb_opts* opts) {
+    if (!dbh || (nq && (!kmers || !counts || !out_dense))) return kmdb_set_error("kmdb_new2all_batch: null argument");
+    kmdb_engine_view e;
+    kmdb_engine_get(dbh, &e);
+    if (!e.n_buckets || !e.slots) return kmdb_set_error("kmdb_new2all_batch: database was uploaded without hashtables");
+    if (nq >= (1ull << 31)) return kmdb_set_error("kmdb_new2all_batch: too many queries in one batch");
+    N2_TRY(hipSetDevice(e.device));
+    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : (hipStream_t)e.stream;
+    std::vector<uint64_t> qoff(nq + 1, 0);
+    for (size_t q = 0; q < nq; ++q) qoff[q + 1] = qoff[q] + counts[q];
+    const size_t total = qoff[nq];
+    if (total >= (1ull << 32) - 2) return kmdb_set_error("kmdb_new2all_batch: more than 2^32 k-mers in one batch; split it");
+    if (!nq) return 0;
+    DevBuf d_k, d_qoff;
+    N2_TRY(d_k.alloc(total * 8));
+    N2_TRY(d_qoff.alloc((nq + 1) * 8));
+    for (size_t q = 0; q < nq; ++q)
+        if (counts[q]) N2_TRY(hipMemcpyAsync(d_k.as<uint64_t>() + qoff[q], kmers[q], counts[q] * 8, hipMemcpyHostToDevice, st));
+    N2_TRY(hipMemcpyAsync(d_qoff.p, qoff.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
+    return n2a_run(dbh, e, st, d_k.as<uint64_t>(), d_qoff.as<uint64_t>(), total, nq, out_dense);
+}
+
+// ------------------------------------------------------------------------------------------
+// Query-side k-mer extraction on the device: what the reference's loader + KmerHelper::unique do on
+// the host for every query (src/kmer_extract.h:13-118, src/filter.h:28-115, src/console_new2all.cpp:73).
+//   extract  one thread per sequence position: 2 bits per base (A,C,G,T/U = 0..3, either case), canonical k-mer =
+//            min(forward, reverse complement) unless the strand is preserved, a window with any other symbol or
+//            one that crosses a query boundary is dropped, word widened when 2k-32 < 8 (k=18: 40-bit words),
+//            optional minhash subsampling (MurmurHash3-derived 64-bit hash in [lo, hi))
+//   sort     radix sort by k-mer, then (stable) by query: dropped positions carry query ~0 and end up last
+//   unique   head flags + scan: the flat list of sorted unique k-mers query by query, and the per-query counts
+// ------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ uint64_t n2_mix64(uint64_t v) {
+    v ^= v >> 33; v *= 0xff51afd7ed558ccdull;
+    v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ull;
+    v ^= v >> 33;
+    return v;
+}
+
+__device__ __forceinline__ int n2_base(unsigned char c) {
+    switch (c | 0x20) {
+        case 'a': return 0;
+        case 'c': return 1;
+        case 'g': return 2;
+        case 't': case 'u': return 3;
+        default: return -1;
+    }
+}
+
+struct ExtractParams {
+    const char* seq; const uint64_t* soff; uint32_t nq; uint64_t total_len;
+    uint32_t k, widen; int preserve, subsample; uint64_t lo, hi, quarter_len;
+    unsigned long long* kmer; uint32_t* qid;
+};
+
+__global__ __launch_bounds__(256) void n2a_extract_kernel(ExtractParams p) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.total_len) return;
+    // query of this position
+    uint32_t lo = 0, hi = p.nq;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (p.soff[mid] <= i) lo = mid; else hi = mid; }
+    unsigned long long word = 0;
+    uint32_t q = 0xFFFFFFFFu;
+    if (i + p.k <= p.soff[lo + 1]) {
+        uint64_t fwd = 0, rc = 0;
+        bool ok = true;
+        const unsigned top = 2 * (p.k - 1);
+        for (uint32_t t = 0; t < p.k; ++t) {
+            const int c = n2_base((unsigned char)p.seq[i + t]);
+            if (c < 0) { ok = false; break; }
+            fwd = (fwd << 2) | (uint64_t)c;
+            rc = (rc >> 2) | ((uint64_t)(3 - c) << top);
+        }
+        if (ok) {
+            uint64_t w = (p.preserve || fwd < rc) ? fwd : rc;
+            w = (w << p.widen) | (w & ((1ull << p.widen) - 1ull));
+            bool keep = true;
+            if (p.subsample) {
+                uint64_t a = w * 0x87c37b91114253d5ull;
+                a = (a << 31) | (a >> 33);
+                a *= 0x4cf5ad432745937full;
+                uint64_t h1 = (42ull ^ a) ^ p.quarter_len, h2 = 42ull ^ p.quarter_len;
+                h1 += h2; h2 += h1;
+                h1 = n2_mix64(h1); h2 = n2_mix64(h2);
+                h1 += h2; h2 += h1;
+                const uint64_t h = h1 ^ h2;
+                keep = h >= p.lo && h < p.hi;
+            }
+            if (keep) { word = w; q = lo; }
+        }
+    }
+    p.kmer[i] = word;
+    p.qid[i] = q;
+}
+
+// head of a run of equal (query, k-mer) among the sorted positions
+__global__ void n2a_heads_kernel(const unsigned long long* __restrict__ kmer, const uint32_t* __restrict__ qid, uint64_t n,
+                                 uint32_t* __restrict__ head) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t q = qid[i];
+    head[i] = (q != 0xFFFFFFFFu && (i == 0 || qid[i - 1] != q || kmer[i - 1] != kmer[i])) ? 1u : 0u;
+}
+
+__global__ void n2a_compact_kernel(const unsigned long long* __restrict__ kmer, const uint32_t* __restrict__ head,
+                                   const uint32_t* __restrict__ hscan, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && head[i]) out[hscan[i]] = kmer[i];
+}
+
+// qoff[q] = number of unique k-mers of the queries before q = scanned heads at the first sorted position of query >= q
+__global__ void n2a_query_offsets_kernel(const uint32_t* __restrict__ qid, const uint32_t* __restrict__ hscan, uint64_t n, uint32_t nq,
+                                         uint64_t* __restrict__ qoff) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nq) return;
+    uint64_t lo = 0, hi = n;                       // first position with qid >= q (dropped positions carry ~0: they sort last)
+    while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (qid[mid] < q) lo = mid + 1; else hi = mid; }
+    qoff[q] = hscan[lo];                           // hscan has n + 1 entries
+}
+
+}  // namespace
+
+extern "C" int kmdb_new2all_batch_seq(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
+                                      double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                                      const kmdb_opts* opts) {
+    if (!dbh || (nq && (!seqs || !seq_lens || !out_dense || !out_kmer_counts))) return kmdb_set_error("kmdb_new2all_batch_seq: null argument");
+    kmdb_engine_view e;
+    kmdb_engine_get(dbh, &e);
+    if (!e.n_buckets || !e.slots) return kmdb_set_error("kmdb_new2all_batch_seq: database was uploaded without hashtables");
+    const uint32_t k = e.kmer_length;
+    if (k == 0 || k > 31) return kmdb_set_error("kmdb_new2all_batch_seq: k-mer length must be 1..31");
+    if (!nq) return 0;
+    N2_TRY(hipSetDevice(e.device));
+    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : (hipStream_t)e.stream;
+    std::vector<uint64_t> soff(nq + 1, 0);
+    for (size_t q = 0; q < nq; ++q) soff[q + 1] = soff[q] + seq_lens[q];
+    const uint64_t L = soff[nq];
+    if (L >= (1ull << 31) - 2) return kmdb_set_error("kmdb_new2all_batch_seq: more than 2^31 bases in one batch; split it");
+    if (nq >= (1ull << 31)) return kmdb_set_error("kmdb_new2all_batch_seq: too many queries in one batch");
+    DevBuf d_seq, d_soff, d_kmer, d_kmer2, d_qid, d_qid2, d_head, d_hscan, d_k, d_qoff, d_tmp;
+    N2_TRY(d_seq.alloc(L + 32));
+    N2_TRY(d_soff.alloc((nq + 1) * 8));
+    N2_TRY(d_kmer.alloc(L * 8)); N2_TRY(d_kmer2.alloc(L * 8));
+    N2_TRY(d_qid.alloc(L * 4)); N2_TRY(d_qid2.alloc(L * 4));
+    N2_TRY(d_head.alloc((L + 1) * 4)); N2_TRY(d_hscan.alloc((L + 1) * 4));
+    N2_TRY(d_qoff.alloc((nq + 1) * 8));
+    for (size_t q = 0; q < nq; ++q)
+        if (seq_lens[q]) N2_TRY(hipMemcpyAsync(d_seq.as<char>() + soff[q], seqs[q], seq_lens[q], hipMemcpyHostToDevice, st));
+    N2_TRY(hipMemcpyAsync(d_soff.p, soff.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
+    std::vector<uint64_t> qoff(nq + 1, 0);
+    size_t total = 0;
+    if (L) {
+        const int prefix_bits = 2 * (int)k - 32;
+        ExtractParams p{};
+        p.seq = d_seq.as<char>(); p.soff = d_soff.as<uint64_t>(); p.nq = (uint32_t)nq; p.total_len = L; p.k = k;
+        p.widen = prefix_bits < 8 ? (uint32_t)(8 - prefix_bits) : 0u;
+        p.preserve = preserve_strand; p.subsample = fraction < 1.0;
+        const double u64max = (double)std::numeric_limits<uint64_t>::max();          // src/filter.h:38-51
+        p.lo = (uint64_t)(u64max * start_fraction);
+        p.hi = (uint64_t)(u64max * (start_fraction + fraction));
+        p.quarter_len = (uint64_t)std::ceil((double)k / 4.0);
+        p.kmer = d_kmer.as<unsigned long long>(); p.qid = d_qid.as<uint32_t>();
+        const unsigned blocks = (unsigned)((L + 255) / 256);
+        hipLaunchKernelGGL(n2a_extract_kernel, dim3(blocks), dim3(256), 0, st, p);
+        N2_TRY(hipGetLastError());
+        const int kbits = (int)std::min<uint32_t>(64u, 2 * k + p.widen);
+        int qbits = 1;
+        while ((1ull << qbits) < nq) ++qbits;
+        size_t tb1 = 0, tb2 = 0, tb3 = 0;
+        N2_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_kmer.as<unsigned long long>(), d_kmer2.as<unsigned long long>(),
+                                                  d_qid.as<uint32_t>(), d_qid2.as<uint32_t>(), (int)L, 0, kbits, st));
+        N2_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, d_qid2.as<uint32_t>(), d_qid.as<uint32_t>(),
+                                                  d_kmer2.as<unsigned long long>(), d_kmer.as<unsigned long long>(), (int)L, 0, 32, st));
+        N2_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, d_head.as<uint32_t>(), d_hscan.as<uint32_t>(), (int)(L + 1), st));
+        N2_TRY(d_tmp.alloc(std::max(tb1, std::max(tb2, tb3))));
+        N2_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tb1, d_kmer.as<unsigned long long>(), d_kmer2.as<unsigned long long>(),
+                                                  d_qid.as<uint32_t>(), d_qid2.as<uint32_t>(), (int)L, 0, kbits, st));
+        // dropped positions carry query ~0: all 32 bits take part so that they sort behind every query
+        (void)qbits;
+        N2_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tb2, d_qid2.as<uint32_t>(), d_qid.as<uint32_t>(),
+                                                  d_kmer2.as<unsigned long long>(), d_kmer.as<unsigned long long>(), (int)L, 0, 32, st));
+        N2_TRY(hipMemsetAsync(d_head.p, 0, (L + 1) * 4, st));
+        hipLaunchKernelGGL(n2a_heads_kernel, dim3(blocks), dim3(256), 0, st, d_kmer.as<unsigned long long>(), d_qid.as<uint32_t>(), L,
+                           d_head.as<uint32_t>());
+        N2_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb3, d_head.as<uint32_t>(), d_hscan.as<uint32_t>(), (int)(L + 1), st));
+        uint32_t n_unique = 0;
+        N2_TRY(hipMemcpyAsync(&n_unique, d_hscan.as<uint32_t>() + L, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(n2a_query_offsets_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st, d_qid.as<uint32_t>(),
+                           d_hscan.as<uint32_t>(), L, (uint32_t)nq, d_qoff.as<uint64_t>());
+        N2_TRY(hipGetLastError());
+        N2_TRY(hipStreamSynchronize(st));
+        total = n_unique;
+        N2_TRY(d_k.alloc(total * 8));
+        hipLaunchKernelGGL(n2a_compact_kernel, dim3(blocks), dim3(256), 0, st, d_kmer.as<unsigned long long>(), d_head.as<uint32_t>(),
+                           d_hscan.as<uint32_t>(), L, d_k.as<uint64_t>());
+        N2_TRY(hipGetLastError());
+        N2_TRY(hipMemcpyAsync(qoff.data(), d_qoff.p, (nq + 1) * 8, hipMemcpyDeviceToHost, st));
+        N2_TRY(hipStreamSynchronize(st));
+    } else {
+        N2_TRY(d_k.alloc(16));
+        N2_TRY(hipMemsetAsync(d_qoff.p, 0, (nq + 1) * 8, st));
+    }
+    for (size_t q = 0; q < nq; ++q) out_kmer_counts[q] = qoff[q + 1] - qoff[q];
+    // the sort buffers are not needed any more: release them before the probe pipeline allocates its own
+    d_kmer.~DevBuf(); d_kmer.p = nullptr; d_kmer2.~DevBuf(); d_kmer2.p = nullptr; d_qid2.~DevBuf(); d_qid2.p = nullptr;
+    d_head.~DevBuf(); d_head.p = nullptr; d_hscan.~DevBuf(); d_hscan.p = nullptr; d_qid.~DevBuf(); d_qid.p = nullptr;
+    return n2a_run(dbh, e, st, d_k.as<uint64_t>(), d_qoff.as<uint64_t>(), total, nq, out_dense);
 }
 
 extern "C" int kmdb_new2all_batch_sparse(kmdb_db* dbh, const uint64_t* const* kmers, const size_t* counts, size_t nq,

@@ -270,7 +270,7 @@ void split_fasta(const std::string& data, std::vector<Record>& recs) {
     }
 }
 
-struct Query { std::string name; std::vector<uint64_t> kmers; };
+struct Query { std::string name; std::vector<uint64_t> kmers; std::string text; };   // text: records joined by '\n' (device-side extraction)
 
 std::string basename_of(const std::string& p) {
     size_t s = p.find_last_of('/');
@@ -282,6 +282,7 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
     if (take_switch(args, "-from-kmers") || take_switch(args, "-from-minhash"))
         throw std::runtime_error("only genome (FASTA) query input is supported by the GPU front-end");
     const bool multi = take_switch(args, "-multisample-fasta");
+    const bool host_extract = take_switch(args, "-host-extract");   // k-mer extraction on the host instead of the device
     c.sparse = take_switch(args, "-sparse");
     if (c.sparse) c.filters.parse(args);
     if (args.size() != 3) throw usage_error("new2all");
@@ -318,11 +319,21 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
     std::vector<Query> batch;
     auto flush = [&]() {
         if (batch.empty()) return;
-        std::vector<const uint64_t*> ptrs(batch.size());
         std::vector<size_t> cnts(batch.size());
-        for (size_t q = 0; q < batch.size(); ++q) { ptrs[q] = batch[q].kmers.data(); cnts[q] = batch[q].kmers.size(); }
         std::vector<uint32_t> out(batch.size() * n + 1);
-        check(kmdb_new2all_batch(db.d, ptrs.data(), cnts.data(), batch.size(), out.data(), &o));
+        if (host_extract) {
+            std::vector<const uint64_t*> ptrs(batch.size());
+            for (size_t q = 0; q < batch.size(); ++q) { ptrs[q] = batch[q].kmers.data(); cnts[q] = batch[q].kmers.size(); }
+            check(kmdb_new2all_batch(db.d, ptrs.data(), cnts.data(), batch.size(), out.data(), &o));
+        } else {
+            // loader + KmerHelper::unique + one2all on the device (kmdb_new2all_batch_seq)
+            std::vector<const char*> ptrs(batch.size());
+            std::vector<size_t> lens(batch.size());
+            std::vector<uint64_t> uniq(batch.size());
+            for (size_t q = 0; q < batch.size(); ++q) { ptrs[q] = batch[q].text.data(); lens[q] = batch[q].text.size(); }
+            check(kmdb_new2all_batch_seq(db.d, ptrs.data(), lens.data(), batch.size(), fraction, fstart, preserve, out.data(), uniq.data(), &o));
+            for (size_t q = 0; q < batch.size(); ++q) cnts[q] = (size_t)uniq[q];
+        }
         std::vector<uint32_t> cols, vals;
         for (size_t q = 0; q < batch.size(); ++q) {
             const uint32_t* r = out.data() + q * n;
@@ -346,6 +357,13 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
     auto make_query = [&](const std::string& name, const std::vector<const std::string*>& seqs) {
         Query q;
         q.name = name;
+        if (!host_extract) {
+            size_t bytes = 0;
+            for (auto* s : seqs) bytes += s->size() + 1;
+            q.text.reserve(bytes);
+            for (auto* s : seqs) { q.text += *s; q.text += '\n'; }
+            return q;
+        }
         size_t total = 0;
         for (auto* s : seqs) total += s->size();
         q.kmers.resize(total + 1);
@@ -424,17 +442,16 @@ int run_one2all(std::vector<std::string>& args, Common& c) {
     if (!slurp(args[1], data)) throw std::runtime_error("Cannot open sample file: " + args[1]);
     std::vector<Record> recs;
     split_fasta(data, recs);
-    size_t total = 0;
-    for (auto& r : recs) total += r.seq.size();
-    std::vector<uint64_t> kmers(total + 1);
-    size_t cnt = 0;
-    for (auto& r : recs)
-        cnt += kmdbh_extract_kmers(r.seq.data(), r.seq.size(), k, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, kmers.data() + cnt);
-    cnt = kmdbh_sort_unique(kmers.data(), cnt);                    // KmerHelper::sortAndUnique (console_one2all.cpp:64-66)
-    std::cerr << "Number of k-mers: " << cnt << std::endl << "Calculating similarity vector..." << std::endl;
-    const uint64_t* ptr = kmers.data();
+    // loader (kmer_extract.h, filter.h), KmerHelper::sortAndUnique (console_one2all.cpp:64-66) and one2all on the device
+    std::string text;
+    for (auto& r : recs) { text += r.seq; text += '\n'; }
+    const char* tp = text.data();
+    size_t tl = text.size();
+    uint64_t cnt = 0;
     std::vector<uint32_t> sims(n + 1);
-    check(kmdb_new2all_batch(db.d, &ptr, &cnt, 1, sims.data(), &o));
+    std::cerr << "Calculating similarity vector..." << std::endl;
+    check(kmdb_new2all_batch_seq(db.d, &tp, &tl, 1, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, sims.data(), &cnt, &o));
+    std::cerr << "Number of k-mers: " << cnt << std::endl;
     std::ofstream ofs(args[2]);
     write_header(db, ofs);
     std::vector<char> row(10000 + n * 100 + args[1].size());

@@ -63,4 +63,20 @@ with tempfile.TemporaryDirectory() as td:
                       "gpu_queries_per_s": NQ / (st["kernel_ms"] * 1e-3),
                       "reference_one2all_seconds_per_query_1_thread": info["seconds"] / 8,
                       "reference_queries_per_s_per_thread": 8 / info["seconds"], "rows_checked_identical": 8}
+    # ---- new2all from sequence text: host loader (kmdbh_extract_kmers + kmdbh_sort_unique, one thread) + kmdb_new2all_batch
+    #      against kmdb_new2all_batch_seq (extraction, sort and unique on the device)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    texts = [acgt[g_more.sample(N + i).cpu().numpy()].tobytes() for i in range(NQ)]
+    t0 = time.perf_counter()
+    host_q = [K.sort_unique(K.extract_kmers(t, k)) for t in texts]
+    t_host_loader = time.perf_counter() - t0
+    assert all(np.array_equal(a, b) for a, b in zip(host_q, qs))
+    got2, cnt = d.new2all_seq(texts)
+    t0 = time.perf_counter(); got2, cnt = d.new2all_seq(texts); wall_seq = time.perf_counter() - t0
+    assert np.array_equal(got2, got) and [int(c) for c in cnt] == [q.size for q in qs]
+    out["new2all_from_sequences"] = {"queries": NQ, "bases_per_query": len(texts[0]),
+                                     "host_loader_seconds_total_1_thread": t_host_loader,
+                                     "gpu_wall_ms_host_loader_path": t_host_loader * 1e3 + wall * 1e3,
+                                     "gpu_wall_ms_device_loader_path": wall_seq * 1e3,
+                                     "queries_per_s_device_loader_wall": NQ / wall_seq, "rows_checked_identical": NQ}
 print(json.dumps(out, indent=1))

@@ -100,6 +100,40 @@ def test_new2all_bit_exact(K, O, golden_dir, dev):
         K.DeviceDB(K.HostDB(path, skip_hashtables=True), device=dev).new2all(qs[:1])
 
 
+def _virus_texts(golden_dir, list_name, limit):
+    """sequence text of the genomes of a sample list: the records of one file joined by a newline"""
+    texts = []
+    with open(os.path.join(golden_dir, list_name)) as f:
+        entries = [ln.strip() for ln in f if ln.strip()]
+    for e in entries[:limit]:
+        raw = open(os.path.join(golden_dir, e + ".fasta")).read()
+        recs = [r.split("\n", 1)[1] if "\n" in r else "" for r in raw.split(">") if r]
+        texts.append("\n".join(r.replace("\n", "").replace("\r", "") for r in recs))
+    return texts
+
+
+@pytest.mark.parametrize("stem,k,fraction", [("virus_k18_part1", 18, 1.0), ("virus_k25_f01_part1", 25, 0.1)])
+def test_new2all_device_side_kmer_extraction(K, O, golden_dir, dev, stem, k, fraction):
+    """kmdb_new2all_batch_seq (extraction + minhash filter + sort/unique on the device) against the host loader
+    (kmdbh_extract_kmers + kmdbh_sort_unique = the reference's loader, pinned by the CLI goldens) and the oracle."""
+    path = os.path.join(golden_dir, stem + ".db")
+    d = K.DeviceDB(K.HostDB(path), device=dev, with_hashtables=True)
+    texts = _virus_texts(golden_dir, "virus.seqs.part2.list", 12)
+    # edge cases: lower case + U, an invalid symbol inside, shorter than k, empty, a record boundary right at a window
+    texts += [texts[0].lower().replace("t", "u"), texts[1][:500] + "N" + texts[1][500:], "ACGT", "", "A" * (k - 1) + "\n" + "C" * (k - 1)]
+    host = []
+    for t in texts:
+        parts = [K.extract_kmers(rec, k, fraction) for rec in t.split("\n")] if t else []
+        host.append(K.sort_unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64))
+    got, cnt = d.new2all_seq(texts, fraction=fraction)
+    assert [int(c) for c in cnt] == [h.size for h in host]
+    exp = d.new2all(host)
+    assert np.array_equal(got, exp)
+    o = O.OracleDB(path)
+    assert np.array_equal(got[:3], np.stack([o.one2all(h) for h in host[:3]]))
+    assert cnt[-1] == 0 and cnt[-2] == 0 and not got[-1].any()
+
+
 def _cli(*args):
     exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
     r = subprocess.run([exe] + list(args), capture_output=True, text=True)
@@ -133,6 +167,8 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
         _cli("new2all", g("virus_k18_part1.db"), g("virus.seqs.part2.list"), t("n2a.csv")); _same(t("n2a.csv"), g("virus.k18.n2a.csv"))
         _cli("new2all", "-sparse", g("virus_k18_part1.db"), g("virus.seqs.part2.list"), t("n2a.sp.csv")); _same(t("n2a.sp.csv"), g("virus.k18.n2a.sparse.csv"))
         _cli("new2all", g("virus_k18.db"), g("virus.seqs.list"), t("n2a.it.csv")); _same(t("n2a.it.csv"), g("virus.k18.n2a.itself.csv"))
+        # the same with the loader on the host (-host-extract): kmdb_new2all_batch instead of kmdb_new2all_batch_seq
+        _cli("new2all", "-host-extract", g("virus_k18_part1.db"), g("virus.seqs.part2.list"), t("n2a.h.csv")); _same(t("n2a.h.csv"), g("virus.k18.n2a.csv"))
         with open(t("synth.list"), "w") as f:
             f.write(g("synth.synth") + "\n")
         _cli("new2all", "-multisample-fasta", g("synth_k21.db"), t("synth.list"), t("n2a")); _same(t("n2a"), g("synth.n2a"))
