@@ -149,6 +149,12 @@ int  kmdb_new2all_batch_seq(kmdb_db* db, const char* const* seqs, const size_t* 
                             double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
                             const kmdb_opts* opts);
 
+/* Replaces SimilarityCalculator::db2db_sp(db_row, db_col, SparseMatrix&, bubbles) (similarity_calculator.cpp:1225-1540),
+ * the off-diagonal cell of the all2all-parts grid (call sites console_all2all_parts.cpp:180,226): both databases
+ * resident with hashtables on the same device.  out: n_samples(db_row) x n_samples(db_col) uint32, row-major, host
+ * memory: out[r][c] = number of k-mers shared by sample r of db_row and sample c of db_col. */
+int  kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmdb_opts* opts);
+
 /* ---------------------------------------------------------------------------------------
  * Host-side helpers of the front-end (no GPU needed).  They mirror the reference's loader
  * and writer so that the CLI stays byte-compatible; exported so tests can drive them.

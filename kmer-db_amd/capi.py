@@ -58,7 +58,7 @@ FLAG_FORCE_SEQ_EMIT = 8
 EXPORTS = [
     "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_free", "kmdb_db_stats",
     "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_sparse_free",
-    "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq",
+    "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
     "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
     "kmdbh_db_start_fraction", "kmdbh_db_alphabet", "kmdbh_db_n_samples", "kmdbh_db_sample_name",
     "kmdbh_db_sample_kmers", "kmdbh_db_pattern_section_bytes", "kmdbh_extract_kmers", "kmdbh_sort_unique",
@@ -92,6 +92,7 @@ def lib():
     L.kmdb_sparse_free.argtypes = [C.POINTER(_Sparse)]
     L.kmdb_new2all_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_new2all_batch_sparse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(_Sparse), C.POINTER(_Opts)]
+    L.kmdb_db2db_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_new2all_batch_seq.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_double, C.c_double, C.c_int,
                                          C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdbh_db_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -296,6 +297,14 @@ class DeviceDB:
         out = np.zeros((nq, self.N), dtype=np.uint32)
         o = _opts(self.device)
         _check(lib().kmdb_new2all_batch(self._d, ptrs, cnts, nq, out.ctypes.data if out.size else None, C.byref(o)))
+        return out
+
+    def db2db(self, col):
+        """shared k-mers between every sample of this database (rows) and every sample of `col` (columns)"""
+        out = np.zeros((self.N, col.N), dtype=np.uint32)
+        buf = out if out.size else np.zeros(1, np.uint32)
+        o = _opts(self.device)
+        _check(lib().kmdb_db2db_dense(self._d, col._d, buf.ctypes.data, C.byref(o)))
         return out
 
     def new2all_seq(self, seqs, fraction=1.0, start_fraction=0.0, preserve_strand=False):

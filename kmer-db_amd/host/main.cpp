@@ -5,6 +5,7 @@
 //     kmer-db-amd all2all-sp [-min [m:]v] [-max [m:]v]           <db> <out.csv>
 //     kmer-db-amd new2all    [-multisample-fasta] [-sparse ...]  <db> <sample-list> <out.csv>
 //     kmer-db-amd one2all    <db> <sample> <out.csv>
+//     kmer-db-amd all2all-parts [-min ...] [-max ...] <db-list> <out.csv>
 // mirroring the reference consoles (reference src/console_all2all.cpp, console_all2all_sparse.cpp,
 // console_new2all.cpp) around the calls that the C ABI replaces.  Options that only tune the
 // reference's CPU engine (-t, -rt, -buffer, -bubble-size) are accepted; -t also sizes the
@@ -222,6 +223,106 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     }
     kmdb_sparse_free(&sp);
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    std::cerr << "No. saved pairs: " << saved << std::endl;
+    return 0;
+}
+
+// ---- all2all-parts (console_all2all_parts.cpp:21-399): a collection split into several databases --------------
+// Grid of cells (row part, column part <= row part): the diagonal cells are all2all_sp of one database, the others
+// db2db_sp of two (similarity_calculator.cpp:1225-1540 -> kmdb_db2db_dense).  Row k of row part i is written as the
+// concatenation of its cells' sparse rows with the column index shifted by the samples of the earlier parts
+// (:292-310), which is the sparse lower-triangular matrix of the whole collection.
+int run_all2all_parts(std::vector<std::string>& args, Common& c) {
+    std::string v;
+    take_option(args, "-buffer", v);
+    take_option(args, "-bubble-size", v);
+    take_switch(args, "-sparse");
+    c.filters.parse(args);
+    if (take_option(args, "-sample-rows", v)) throw std::runtime_error("-sample-rows is not supported by the GPU front-end");
+    if (args.size() != 2) throw usage_error("all2all-parts");
+    std::cerr << "All versus all comparison (parts)" << std::endl;
+    std::ifstream lst(args[0]);
+    if (!lst) throw std::runtime_error("Cannot open file with list of database files " + args[0]);
+    std::vector<std::string> files;
+    for (std::string ln; std::getline(lst, ln);) {
+        while (!ln.empty() && (ln.back() == '\r' || ln.back() == ' ')) ln.pop_back();
+        if (!ln.empty()) files.push_back(ln);
+    }
+    if (files.empty()) throw std::runtime_error("Empty list of database files");
+    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1;
+    // names and k-mer counts of the whole collection (:60-100): every database is read once up front
+    std::vector<std::string> names;
+    std::vector<uint64_t> counts, part_n;
+    uint32_t k = 0;
+    double fraction = 0;
+    for (size_t i = 0; i < files.size(); ++i) {
+        Db d;
+        if (kmdbh_db_load(files[i].c_str(), 2, &d.h)) throw std::runtime_error("Cannot open k-mer database " + files[i]);
+        if (i == 0) { k = kmdbh_db_kmer_length(d.h); fraction = kmdbh_db_fraction(d.h); }
+        else if (k != kmdbh_db_kmer_length(d.h) || fraction != kmdbh_db_fraction(d.h))
+            throw std::runtime_error("Databases have different k-mer lengths or fractions");
+        const uint64_t n = kmdbh_db_n_samples(d.h);
+        part_n.push_back(n);
+        for (uint64_t s = 0; s < n; ++s) { names.push_back(kmdbh_db_sample_name(d.h, s)); counts.push_back(kmdbh_db_sample_kmers(d.h, s)); }
+    }
+    std::ofstream ofs(args[1], std::ios::binary);
+    {
+        char head[128];
+        std::snprintf(head, sizeof head, "kmer-length: %u fraction: %g ,db-samples ,", k, fraction);
+        ofs << head;
+        for (auto& nm : names) ofs << nm << ",";
+        ofs << "\nquery-samples,total-kmers,";
+        for (auto cnt : counts) ofs << cnt << ",";
+        ofs << "\n";
+    }
+    std::vector<char> row(10000 + names.size() * 100);
+    std::vector<uint32_t> cols, vals;
+    size_t saved = 0;
+    uint64_t row_shift = 0;
+    auto load = [&](size_t i, Db& d) {
+        check(kmdbh_db_load(files[i].c_str(), 0, &d.h));
+        check(kmdb_db_upload(kmdbh_db_view(d.h), &o, 1, &d.d));
+    };
+    for (size_t i = 0; i < files.size(); ++i) {
+        Db drow;
+        load(i, drow);
+        const uint64_t nr = part_n[i];
+        std::vector<std::vector<uint32_t>> cross(i);              // cross[j]: nr x part_n[j]
+        for (size_t j = 0; j < i; ++j) {
+            std::cerr << "Processing cell (" << i + 1 << "," << j + 1 << ")" << std::endl;
+            Db dcol;
+            load(j, dcol);
+            cross[j].resize(nr * part_n[j] + 1);
+            check(kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &o));
+        }
+        std::cerr << "Processing cell (" << i + 1 << "," << i + 1 << ")" << std::endl;
+        kmdb_sparse_rows sp{};
+        check(kmdb_all2all_sparse(drow.d, &sp, &o));
+        for (uint64_t r = 0; r < nr; ++r) {
+            cols.clear(); vals.clear();
+            const uint32_t cr = (uint32_t)counts[row_shift + r];
+            uint64_t shift = 0;
+            for (size_t j = 0; j < i; ++j) {
+                const uint32_t* m = cross[j].data() + r * part_n[j];
+                for (uint64_t cidx = 0; cidx < part_n[j]; ++cidx)
+                    if (m[cidx] && c.filters.pass(m[cidx], cr, (uint32_t)counts[shift + cidx], (int)k)) {
+                        cols.push_back((uint32_t)(shift + cidx)); vals.push_back(m[cidx]);
+                    }
+                shift += part_n[j];
+            }
+            for (uint64_t e = sp.row_ptr[r]; e < sp.row_ptr[r + 1]; ++e)
+                if (c.filters.pass(sp.val[e], cr, (uint32_t)counts[shift + sp.col[e]], (int)k)) {
+                    cols.push_back((uint32_t)(shift + sp.col[e])); vals.push_back(sp.val[e]);
+                }
+            const std::string& name = names[row_shift + r];
+            if (row.size() < 10000 + names.size() * 100 + name.size()) row.resize(10000 + names.size() * 100 + name.size());
+            size_t len = kmdbh_format_sparse_row(name.c_str(), counts[row_shift + r], cols.data(), vals.data(), cols.size(), row.data());
+            ofs.write(row.data(), (std::streamsize)len);
+            saved += cols.size();
+        }
+        kmdb_sparse_free(&sp);
+        row_shift += nr;
+    }
     std::cerr << "No. saved pairs: " << saved << std::endl;
     return 0;
 }
@@ -469,6 +570,7 @@ void usage() {
                  "    kmer-db-amd all2all-sp [-min ...] [-max ...] <database> <common_table>\n"
                  "    kmer-db-amd new2all [-multisample-fasta] [-sparse [-min ...] [-max ...]] <database> <sample_list> <common_table>\n"
                  "    kmer-db-amd one2all <database> <sample> <similarity_vector>\n"
+                 "    kmer-db-amd all2all-parts [-min ...] [-max ...] <db_list> <common_table>\n"
                  "Common options: -t <threads>, -gpu <device>\n";
 }
 
@@ -491,6 +593,7 @@ int main(int argc, char** argv) {
         if (mode == "all2all-sp") return run_all2all_sp(args, c);
         if (mode == "new2all") return run_new2all(args, c);
         if (mode == "one2all") return run_one2all(args, c);
+        if (mode == "all2all-parts") return run_all2all_parts(args, c);
         usage();
         return -1;
     } catch (usage_error&) {

@@ -7,6 +7,7 @@
 #define _FILE_OFFSET_BITS 64
 #include "kmdb_oracle.h"
 
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -307,6 +308,33 @@ int kmo_one2all(const kmo_db* db, const uint64_t* kmers, size_t n, uint32_t* out
         for (uint32_t i = 0; i < ns; ++i) out[buf[i]] += (uint32_t)hits[pid];   /* :896-917 */
     }
     free(buf); free(hits);
+    return 0;
+}
+
+/* db2db_sp (similarity_calculator.cpp:1225-1540) restated densely: out[r * n_col + c] = number of k-mers shared by
+ * sample r of db_row and sample c of db_col.  The reference merge-joins the sorted (suffix, pattern) lists of every
+ * prefix (:1252-1285), counts equal (pattern_row, pattern_col) pairs (:1300-1330) and adds the count to every pair of
+ * samples of the two patterns' full lists (:1340-1500).  Here: look every k-mer of db_col up in db_row's tables. */
+int kmo_db2db_dense(const kmo_db* db_row, const kmo_db* db_col, uint32_t* out) {
+    const uint64_t nr = db_row->n_samples, nc = db_col->n_samples;
+    memset(out, 0, 4 * (size_t)(nr * nc ? nr * nc : 1));
+    if (db_row->kmer_length != db_col->kmer_length) return 1;
+    uint32_t* br = (uint32_t*)malloc(4 * (nr ? nr : 1));
+    uint32_t* bc = (uint32_t*)malloc(4 * (nc ? nc : 1));
+    for (uint64_t b = 0; b < db_col->n_buckets && b < db_row->n_buckets; ++b) {
+        const kmo_hashtable* t = &db_col->tables[b];
+        if (!t->slots) continue;
+        for (uint64_t s = 0; s < t->allocated; ++s) {
+            const int32_t pc = (int32_t)(t->slots[s] >> 32);
+            if (pc == INT32_MAX) continue;                     /* empty slot (hashmap_lp.h:78) */
+            const int32_t pr = kmo_ht_find(&db_row->tables[b], (uint32_t)t->slots[s]);
+            if (pr < 0) continue;
+            const uint32_t n1 = kmo_decode_chain(db_row, pr, br), n2 = kmo_decode_chain(db_col, pc, bc);
+            for (uint32_t i = 0; i < n1; ++i)
+                for (uint32_t j = 0; j < n2; ++j) out[(size_t)br[i] * nc + bc[j]] += 1u;
+        }
+    }
+    free(br); free(bc);
     return 0;
 }
 

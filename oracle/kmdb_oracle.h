@@ -87,6 +87,8 @@ void kmo_update_counts(const kmo_db* db, uint64_t* tree_updates, uint64_t* flat_
 int32_t kmo_ht_find(const kmo_hashtable* ht, uint32_t key);
 /* SimilarityCalculator::one2all<false> (:809-925): out[N] zeroed here */
 int kmo_one2all(const kmo_db* db, const uint64_t* kmers, size_t n, uint32_t* out);
+/* db2db_sp (similarity_calculator.cpp:1225-1540), dense: out[r * db_col->n_samples + c] = shared k-mers of row sample r and column sample c */
+int kmo_db2db_dense(const kmo_db* db_row, const kmo_db* db_col, uint32_t* out);
 
 /* KmerHelper::extract (kmer_extract.h:13-97) for the nt alphabet (alphabet.h:80), with
  * MinHashFilter (filter.h:28-115).  Returns number of k-mers written. */

@@ -71,6 +71,7 @@ def lib():
         L.kmo_all2all_flat.argtypes = [C.POINTER(_Db), C.c_void_p]
         L.kmo_update_counts.argtypes = [C.POINTER(_Db), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.kmo_one2all.argtypes = [C.POINTER(_Db), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.kmo_db2db_dense.argtypes = [C.POINTER(_Db), C.POINTER(_Db), C.c_void_p]
         L.kmo_extract_kmers.restype = C.c_size_t
         L.kmo_extract_kmers.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.kmo_sort_unique.restype = C.c_size_t
@@ -155,6 +156,14 @@ class OracleDB:
         out = np.zeros(max(1, self.N), dtype=np.uint32)
         lib().kmo_one2all(self._p, q.ctypes.data, q.size, out.ctypes.data)
         return out[: self.N]
+
+    def db2db(self, col):
+        """shared k-mers between every sample of this database (rows) and every sample of `col` (columns)"""
+        out = np.zeros((self.N, col.N), dtype=np.uint32)
+        buf = out if out.size else np.zeros(1, np.uint32)
+        rc = lib().kmo_db2db_dense(self._p, col._p, buf.ctypes.data)
+        assert rc == 0, "k-mer lengths differ"
+        return out
 
     def decode_chain(self, pid):
         n = self._p.contents.patterns[pid].num_samples
@@ -276,6 +285,13 @@ def ref_all2all(db_path, out_path, threads=1, buffer_mb=8):
 
 def ref_all2all_sp(db_path, out_path, threads=1, buffer_mb=8, bubble=8000):
     info = _run_ref(["all2all_sp", db_path, out_path, threads, buffer_mb, bubble])
+    with open(out_path, "rb") as f:
+        return f.read(), info
+
+
+def ref_db2db_sp(db_row, db_col, out_path, threads=1):
+    """the reference's db2db_sp + compact2 on two databases: sparse rows 'col1based:val,' of the cell"""
+    info = _run_ref(["db2db_sp", db_row, db_col, out_path, threads])
     with open(out_path, "rb") as f:
         return f.read(), info
 

@@ -7,7 +7,7 @@
 // oracle/_ref/ref_driver.  No reference source is copied into this repository; this file
 // only CALLS the reference's public C++ interface:
 //   PrefixKmerDb::addKmers / serialize / deserialize      (prefix_kmer_db.h:89-129)
-//   SimilarityCalculator::all2all / all2all_sp / one2all<false> / one2all_sp
+//   SimilarityCalculator::all2all / all2all_sp / one2all<false> / one2all_sp / db2db_sp
 //                                                          (similarity_calculator.h:4-16)
 //   SparseMatrix::compact2 / saveRowSparse                 (array.h:391-446, 625-637)
 //
@@ -17,6 +17,7 @@
 //   ref_driver all2all_sp <db> <out.txt> [threads] [bufferMb] [bubbleSize]
 //   ref_driver one2all  <db> <queries.bin> <out.u32> [threads]   nq x N dense rows
 //   ref_driver one2all_sp <db> <queries.bin> <out.txt> [threads]
+//   ref_driver db2db_sp <db_row> <db_col> <out.txt> [threads]    sparse rows of the cell (row part, column part)
 //
 // kmers.bin / queries.bin (little endian): u32 magic 'KMRS', u32 k, f64 fraction,
 //   u64 n_samples, then per sample: u64 name_len, name bytes, u64 count, count x u64 k-mers
@@ -132,6 +133,37 @@ int main(int argc, char** argv) {
             }
             fclose(o);
             printf("{\"cmd\":\"all2all_sp\",\"samples\":%zu,\"threads\":%d,\"seconds\":%.6f}\n", db.getSamplesCount(), threads, t1 - t0);
+            return 0;
+        }
+        if (cmd == "db2db_sp") {
+            // ref_driver db2db_sp <db_row> <db_col> <out.txt> [threads]: the off-diagonal cell of all2all-parts
+            // (console_all2all_parts.cpp:159-226): rows of db_row against the samples of db_col
+            if (argc < 5) return 2;
+            if (argc > 5) threads = atoi(argv[5]);
+            PrefixKmerDb db_row(threads), db_col(threads);
+            std::ifstream f2(argv[3], std::ios::binary);
+            if (!db_row.deserialize(dbFile, AbstractKmerDb::DeserializationMode::CompactedHashtables)) return 1;
+            if (!f2 || !db_col.deserialize(f2, AbstractKmerDb::DeserializationMode::CompactedHashtables)) return 1;
+            SimilarityCalculator calc(threads, bufferMb);
+            SparseMatrix<uint32_t> m;
+            CBubbleHelper bubbles(8000);
+            double t0 = now_s();
+            calc.db2db_sp(db_row, db_col, m, bubbles);      // console_all2all_parts.cpp:180
+            double t1 = now_s();
+            std::map<std::string, MetricFilter> noMetric;
+            KmerFilter kf;
+            CombinedFilter<uint32_t> filter(noMetric, kf, db_row.getSampleKmersCount(), db_col.getSampleKmersCount(), db_row.getKmerLength());
+            m.compact2(filter, threads, bubbles);           // console_all2all_parts.cpp:196
+            std::vector<char> row(10000 + db_col.getSamplesCount() * 100);
+            FILE* o = fopen(argv[4], "wb");
+            for (size_t sid = 0; sid < db_row.getSamplesCount(); ++sid) {
+                int n = m.saveRowSparse(sid, row.data(), 0);
+                fwrite(row.data(), 1, n, o);
+                fputc('\n', o);
+            }
+            fclose(o);
+            printf("{\"cmd\":\"db2db_sp\",\"rows\":%zu,\"cols\":%zu,\"threads\":%d,\"seconds\":%.6f}\n", db_row.getSamplesCount(),
+                   db_col.getSamplesCount(), threads, t1 - t0);
             return 0;
         }
         if (cmd == "one2all" || cmd == "one2all_sp") {

@@ -134,6 +134,69 @@ def test_new2all_device_side_kmer_extraction(K, O, golden_dir, dev, stem, k, fra
     assert cnt[-1] == 0 and cnt[-2] == 0 and not got[-1].any()
 
 
+def test_db2db_bit_exact(K, O, golden_dir, dev):
+    """kmdb_db2db_dense (db2db_sp, the off-diagonal cell of all2all-parts) against the oracle, whose db2db is pinned to
+    the reference's all2all matrix of the union database (tests/test_oracle_golden.py)."""
+    p1, p2 = os.path.join(golden_dir, "virus_k18_part1.db"), os.path.join(golden_dir, "virus_k18_part2.db")
+    d1 = K.DeviceDB(K.HostDB(p1), device=dev, with_hashtables=True)
+    d2 = K.DeviceDB(K.HostDB(p2), device=dev, with_hashtables=True)
+    o1, o2 = O.OracleDB(p1), O.OracleDB(p2)
+    got = d2.db2db(d1)
+    assert got.shape == (65, 100) and np.array_equal(got, o2.db2db(o1))
+    assert np.array_equal(d1.db2db(d2), got.T)
+    # a database against itself: the diagonal holds the samples' k-mer counts, the rest is the all2all matrix
+    self_m = d1.db2db(d1)
+    ref = np.fromfile(os.path.join(golden_dir, "virus_k18_part1.a2a.ref.u32"), dtype=np.uint32)
+    for i in (1, 17, 99):
+        assert np.array_equal(self_m[i, :i], O.tri_row(ref, i))
+    h1 = K.HostDB(p1)
+    assert [int(self_m[i, i]) for i in range(5)] == [int(K.capi.lib().kmdbh_db_sample_kmers(h1._h, i)) for i in range(5)]
+    with pytest.raises(K.KmdbError, match="hashtables"):
+        d1.db2db(K.DeviceDB(K.HostDB(p2, skip_hashtables=True), device=dev))
+    with pytest.raises(K.KmdbError, match="k-mer lengths"):
+        d1.db2db(K.DeviceDB(K.HostDB(os.path.join(golden_dir, "virus_k25_f01_part1.db")), device=dev, with_hashtables=True))
+
+
+def _synth_part(S, g, ids, k, path, device):
+    """database (with hashtables) of the samples `ids` of the genome model g, written in kmer-db's format"""
+    pat = S.build_patterns(lambda i: S.kmers_of(g.sample(ids[i]), k), len(ids), device)
+    arr = S.to_view_arrays(pat)
+    tables = S.build_hashtables(pat["dictionary"], pat["kmer_pid"], k)
+    S.write_db(path, k, 1.0, [g.name(i) for i in ids], pat["sample_counts"], arr, kmers_count=int(pat["dictionary"].numel()), tables=tables)
+
+
+@pytest.mark.parametrize("split", ["halves", "interleaved"])
+def test_db2db_synthetic_parts(K, O, dev, tmp_path, split):
+    """db2db on two parts of one clade-structured collection: GPU == oracle == the real reference's db2db_sp, and the
+    cell equals the corresponding block of the all2all matrix of the whole collection."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    N, cs, L, k = 120, 20, 6000, 18
+    device = torch.device("cuda", dev)
+    g = S.CladeGenomes(N, cs, L, seed=5, device=device)
+    ids_a = list(range(N // 2)) if split == "halves" else list(range(0, N, 2))
+    ids_b = list(range(N // 2, N)) if split == "halves" else list(range(1, N, 2))
+    pa, pb, pall = str(tmp_path / "a.db"), str(tmp_path / "b.db"), str(tmp_path / "all.db")
+    _synth_part(S, g, ids_a, k, pa, device)
+    _synth_part(S, g, ids_b, k, pb, device)
+    _synth_part(S, g, ids_a + ids_b, k, pall, device)
+    da = K.DeviceDB(K.HostDB(pa), device=dev, with_hashtables=True)
+    db_ = K.DeviceDB(K.HostDB(pb), device=dev, with_hashtables=True)
+    got = db_.db2db(da)
+    exp = O.OracleDB(pb).db2db(O.OracleDB(pa))
+    assert np.array_equal(got, exp) and got.any()
+    full = K.DeviceDB(K.HostDB(pall, skip_hashtables=True), device=dev).all2all_dense()
+    na = len(ids_a)
+    for r in (0, 7, len(ids_b) - 1):
+        assert np.array_equal(got[r], O.tri_row(full, na + r)[:na])
+    if O.have_ref():
+        txt, _ = O.ref_db2db_sp(pb, pa, str(tmp_path / "ref.txt"), threads=2)
+        lines = txt.split(b"\n")
+        for r in range(len(ids_b)):
+            assert "".join("%d:%d," % (c + 1, v) for c, v in enumerate(got[r]) if v).encode() == lines[r]
+
+
 def _cli(*args):
     exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
     r = subprocess.run([exe] + list(args), capture_output=True, text=True)
@@ -175,6 +238,10 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
         _cli("new2all", "-multisample-fasta", "-sparse", g("synth_k21.db"), t("synth.list"), t("n2a-sp")); _same(t("n2a-sp"), g("synth.n2a-sparse"))
         _cli("new2all", "-multisample-fasta", "-sparse", "-max", "69", "-min", "num-kmers:21", g("synth_k21.db"), t("synth.list"), t("n2a-mm"))
         _same(t("n2a-mm"), g("synth.n2a.sparse.above-below"))
+        # all2all-parts: self-hosted.yml:355-362 (two part databases, output = sparse all2all of the whole collection)
+        with open(t("db.list"), "w") as f:
+            f.write(g("virus_k18_part1.db") + "\n" + g("virus_k18_part2.db") + "\n")
+        _cli("all2all-parts", t("db.list"), t("k18.parts.csv")); _same(t("k18.parts.csv"), g("virus.k18.sparse.csv"))
         # one2all: main.yml:156-160 (k=25, f=0.1 database of part 1, one genome against it)
         _cli("one2all", g("virus_k25_f01_part1.db"), "./test/virus/data/MT159713", t("MT159713.csv"))
         _same(t("MT159713.csv"), g("virus.MT159713.csv"))

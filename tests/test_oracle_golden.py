@@ -112,3 +112,31 @@ def test_chain_lists_strictly_increasing(O, golden_dir):
     for pid in range(0, db.P, 97):
         ids = db.decode_chain(pid).astype(np.int64)
         assert np.all(np.diff(ids) > 0)
+
+
+def test_db2db_restatement_pinned_to_the_reference_matrix(O, golden_dir):
+    """oracle db2db (db2db_sp restated) of part 2 x part 1 == the corresponding block of the reference's own all2all
+    matrix of the union database (samples of seqs.list = part 1 followed by part 2)."""
+    import os
+    import numpy as np
+    p1 = O.OracleDB(os.path.join(golden_dir, "virus_k18_part1.db"))
+    p2 = O.OracleDB(os.path.join(golden_dir, "virus_k18_part2.db"))
+    ref = np.fromfile(os.path.join(golden_dir, "virus_k18.a2a.ref.u32"), dtype=np.uint32)
+    cross = p2.db2db(p1)
+    for r in range(p2.N):
+        assert np.array_equal(cross[r], O.tri_row(ref, p1.N + r)[: p1.N]), r
+    assert np.array_equal(p1.db2db(p2), cross.T)
+
+
+def test_db2db_restatement_equals_the_real_reference(O, golden_dir, tmp_path):
+    """when oracle/_ref is built: the reference's own db2db_sp + compact2 (ref_driver db2db_sp) on the two virus parts"""
+    import os
+    import pytest
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    a, b = os.path.join(golden_dir, "virus_k18_part2.db"), os.path.join(golden_dir, "virus_k18_part1.db")
+    txt, _ = O.ref_db2db_sp(a, b, str(tmp_path / "o.txt"), threads=2)
+    m = O.OracleDB(a).db2db(O.OracleDB(b))
+    lines = txt.split(b"\n")
+    for r in range(m.shape[0]):
+        assert "".join("%d:%d," % (c + 1, v) for c, v in enumerate(m[r]) if v).encode() == lines[r]
