@@ -79,4 +79,33 @@ with tempfile.TemporaryDirectory() as td:
                                      "gpu_wall_ms_host_loader_path": t_host_loader * 1e3 + wall * 1e3,
                                      "gpu_wall_ms_device_loader_path": wall_seq * 1e3,
                                      "queries_per_s_device_loader_wall": NQ / wall_seq, "rows_checked_identical": NQ}
+# ---- db2db (all2all-parts cell): the collection split into two databases of 500 samples (even / odd sample ids)
+def part_db(ids, path):
+    pat_p = S.build_patterns(lambda i: S.kmers_of(g.sample(ids[i]), k), len(ids), dev)
+    arr_p = S.to_view_arrays(pat_p)
+    tab_p = S.build_hashtables(pat_p["dictionary"], pat_p["kmer_pid"], k)
+    S.write_db(path, k, 1.0, [g.name(i) for i in ids], pat_p["sample_counts"], arr_p, kmers_count=int(pat_p["dictionary"].numel()), tables=tab_p)
+    return int(arr_p["num_kmers"].size)
+
+
+with tempfile.TemporaryDirectory() as td:
+    pa, pb = os.path.join(td, "a.db"), os.path.join(td, "b.db")
+    n_pa = part_db(list(range(0, N, 2)), pa)
+    n_pb = part_db(list(range(1, N, 2)), pb)
+    da = K.DeviceDB(K.HostDB(pa), device=0, with_hashtables=True)
+    db_ = K.DeviceDB(K.HostDB(pb), device=0, with_hashtables=True)
+    got = db_.db2db(da)
+    t0 = time.perf_counter(); got = db_.db2db(da); wall = time.perf_counter() - t0
+    st = db_.stats()
+    best = None
+    for thr in (16, 32):
+        txt, info = O.ref_db2db_sp(pb, pa, os.path.join(td, "o.txt"), threads=thr)
+        if best is None or info["seconds"] < best[1]["seconds"]:
+            best = (txt, info)
+    lines = best[0].split(b"\n")
+    for r in (0, 123, 499):
+        assert "".join("%d:%d," % (c + 1, v) for c, v in enumerate(got[r]) if v).encode() == lines[r]
+    out["db2db"] = {"rows": int(got.shape[0]), "cols": int(got.shape[1]), "patterns": [n_pb, n_pa], "shared_kmer_pairs": int(got.astype(np.uint64).sum()),
+                    "gpu_device_ms": st["kernel_ms"], "gpu_wall_ms_incl_d2h": wall * 1e3,
+                    "reference_seconds": best[1]["seconds"], "reference_threads": best[1]["threads"], "rows_checked_identical": 3}
 print(json.dumps(out, indent=1))
