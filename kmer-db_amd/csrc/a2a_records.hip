@@ -1049,7 +1049,11 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
 // register per row; v_bcnt accumulates for free) and are merged through LDS once per work item.
 // Weights: class 1 (w = 2, 3) = twice the count plus the count over the odd weights; class 2 = one pass per
 // bit plane of w that occurs in the step.
-template <int CLS>
+// DIAG (X == Y, rows == cols): the block is symmetric and only c < r is wanted.  Lane c then takes the rows
+// (c + d) mod width for d = 1 .. width/2 instead of all rows: every unordered pair of samples exactly once (for an even
+// width the distance width/2 is kept by the lower half of the lanes) — half the row loop; the row mask is a per-lane
+// LDS read instead of a broadcast.
+template <int CLS, bool DIAG>
 __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& it, uint32_t* __restrict__ M, uint32_t dbg, uint32_t bwidth,
                                               uint32_t* acc, unsigned long long (*rtbuf)[64]) {
     if ((dbg & 64u) && CLS == 0) return;
@@ -1057,11 +1061,14 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     __syncthreads();
-    const bool diag = it.X == it.Y;
+    const bool diag = DIAG;
+    const uint32_t njs = DIAG ? bwidth / 2u : bwidth;                    // accumulators in use
+    const uint32_t wrapd = bwidth - lane;                                 // DIAG: row of accumulator j = lane + j + 1 (mod width)
     uint32_t a[64];
 #pragma unroll
     for (int r = 0; r < 64; ++r) a[r] = 0;
     const unsigned long long* rt = rtbuf[wave];
+#define ROWMASK(j) (DIAG ? rt[((uint32_t)(j) + 1u < wrapd ? lane + (uint32_t)(j) + 1u : lane + (uint32_t)(j) + 1u - bwidth) & 63u] : rt[(j)])
     // the next group's records are fetched while the current group is reduced
     unsigned long long nR = 0, nC = 0;
     uint32_t nW = 0;
@@ -1086,22 +1093,22 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
         if (CLS == 0) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                if ((uint32_t)(g * 8) < bwidth) {                     // rows >= the block width never occur
+                if ((uint32_t)(g * 8) < njs) {                        // rows >= the block width never occur
                     asm volatile("" ::: "memory");    // keep a group's LDS reads together (register pressure)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Ct & rt[r]); }
+                    for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Ct & ROWMASK(r)); }
                 }
             }
         } else if (CLS == 1) {
             const unsigned long long Codd = Ct & __ballot((W & 1u) != 0);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                if ((uint32_t)(g * 8) < bwidth) {
+                if ((uint32_t)(g * 8) < njs) {
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int r = g * 8 + k;
-                        const unsigned long long Rr = rt[r];
+                        const unsigned long long Rr = ROWMASK(r);
                         a[r] += 2u * (uint32_t)__popcll(Ct & Rr) + (uint32_t)__popcll(Codd & Rr);
                     }
                 }
@@ -1116,10 +1123,10 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
                 const unsigned long long Cb = Ct & __ballot(((W >> b) & 1u) != 0);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    if ((uint32_t)(g * 8) < bwidth) {
+                    if ((uint32_t)(g * 8) < njs) {
                         asm volatile("" ::: "memory");
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Cb & rt[r]) << b; }
+                        for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Cb & ROWMASK(r)) << b; }
                     }
                 }
             }
@@ -1127,10 +1134,21 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
         lds_sync();
     }
     // merge the four waves' registers, then one HBM atomic per non-zero cell (on the diagonal only c < r)
+#undef ROWMASK
+    if (DIAG) {
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
-        const uint32_t v = (diag && lane >= (uint32_t)r) ? 0u : a[r];
-        if (v) atomicAdd(&acc[r * 64 + lane], v);
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t d = (uint32_t)j + 1u;
+            if (d > njs || lane >= bwidth) continue;
+            if (2u * d == bwidth && lane >= d) continue;                 // even width: the opposite sample, once
+            const uint32_t r2 = d < wrapd ? lane + d : lane + d - bwidth;
+            const uint32_t row = r2 > lane ? r2 : lane, col = r2 > lane ? lane : r2;
+            if (a[j]) atomicAdd(&acc[row * 64 + col], a[j]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            if (a[r]) atomicAdd(&acc[r * 64 + lane], a[r]);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
@@ -1146,9 +1164,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
     const B2Item it = items[blockIdx.x];
-    if (it.cls == 0) b2_apply_item<0>(rec, it, M, dbg, bwidth, acc, rtbuf);
-    else if (it.cls == 1) b2_apply_item<1>(rec, it, M, dbg, bwidth, acc, rtbuf);
-    else b2_apply_item<2>(rec, it, M, dbg, bwidth, acc, rtbuf);
+    if (it.X == it.Y) {
+        if (it.cls == 0) b2_apply_item<0, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
+        else if (it.cls == 1) b2_apply_item<1, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
+        else b2_apply_item<2, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
+    } else {
+        if (it.cls == 0) b2_apply_item<0, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
+        else if (it.cls == 1) b2_apply_item<1, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
+        else b2_apply_item<2, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
+    }
 }
 
 
