@@ -337,12 +337,14 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint2* __restrict_
             Cursor c(bits, pos);
             uint32_t rem = l - 1;
             while (rem) {
-                const uint32_t z = c.zeros(rem);
+                uint32_t z, v;
+                c.step(rem, z, v);                                     // a run of z consecutive ids, then a gap of v
                 if (z) {
                     if (span + z < 64u) R |= ((2ull << (z - 1)) - 1ull) << (span + 1);
                     span += z; rem -= z;
-                } else {
-                    span += c.big(); --rem;
+                }
+                if (v) {
+                    span += v; --rem;
                     if (span < 64u) R |= 1ull << span;
                 }
             }
@@ -378,7 +380,8 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint2* __restrict_
                 ++npairs;
             };
             while (rem) {
-                uint32_t z = c.zeros(rem);
+                uint32_t z, v;
+                c.step(rem, z, v);
                 if (z) {
                     rem -= z;
                     while (z) {
@@ -387,8 +390,9 @@ __global__ __launch_bounds__(256) void b3_decode_kernel(const uint2* __restrict_
                         if (t) { acc |= ((2ull << (t - 1)) - 1ull) << (bit + 1); bit += t; z -= t; }
                         if (z) { flush(); ++curblk; acc = 1ull; bit = 0; --z; }
                     }
-                } else {
-                    const uint32_t id = curblk * bm.width + bit + c.big();
+                }
+                if (v) {
+                    const uint32_t id = curblk * bm.width + bit + v;
                     --rem;
                     const uint32_t blk = bm.blk(id);
                     if (blk != curblk) { flush(); curblk = blk; acc = 0; }

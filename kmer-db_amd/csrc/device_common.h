@@ -154,6 +154,27 @@ struct RunCursor {
         if (z) advance(z);
         return z;
     }
+    // One step of the run-aware decoder: z consecutive "0" codes (deltas of 1, at most `limit`) and, when it is
+    // complete inside the 64-bit window, the code that follows them (value >= 2; 0 = none taken).  One window
+    // extraction serves both.
+    __device__ __forceinline__ void step(uint32_t limit, uint32_t& z, uint32_t& v) {
+        const uint64_t win = window();
+        z = win ? (uint32_t)__clzll((long long)win) : 64u;
+        z = z < limit ? z : limit;
+        v = 0;
+        uint32_t used = z;
+        if (z < limit && z < 64u) {
+            const uint64_t rest = win << z;                          // starts with a 1 bit
+            uint32_t ones = (uint32_t)__clzll((long long)~rest);
+            ones = ones > 31u ? 31u : ones;
+            const uint32_t len = 2u * ones + 1u;
+            if (z + len <= 64u) {
+                v = (uint32_t)((rest << ones) >> (63u - ones)) | (1u << ones);
+                used += len;
+            }
+        }
+        advance(used);
+    }
     // one code that is known to start with a 1 bit (value >= 2)
     __device__ __forceinline__ uint32_t big() {
         const uint64_t win = window();
