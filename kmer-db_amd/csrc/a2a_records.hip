@@ -430,10 +430,11 @@ struct B3Params {
     // wide-list launch (INDIRECT): lane k of a batch handles node widx[base + k]; parents are positions in the list
     const uint32_t* widx;
     const int32_t* wparent;
-    const unsigned long long* fnarrow;
+    const ulonglong2* fnarrow;     // (F0, F1) of the <= 2-block nodes that have a wider child
+    const uint16_t* wd01;          // their blocks: first | second << 8 (0xFF: none)
     const int32_t* seg_np;
     uint32_t seg_row0;             // first row of this launch in the count / base table
-    uint8_t* nwords;               // count mode of the all-nodes launch: non-empty words of every node's full list
+    uint32_t* fwords;              // count mode of the all-nodes launch: which words (blocks) every node's full list touches
 };
 
 __host__ __device__ inline size_t b3_wave_bytes(uint32_t nbw, uint32_t maxn_pad, uint32_t nctr, uint32_t chain_cap) {
@@ -473,8 +474,8 @@ struct B3Lane {                    // one node per lane
     uint32_t n, l, w, info, idx;
     int32_t par;
     unsigned long long m0;
-    uint32_t npw;                  // wide-list launch: word and full mask of a narrow parent (npm == 0: none)
-    unsigned long long npm;
+    uint32_t npw, npw1;            // wide-list launch: blocks and full masks of a parent with <= 2 blocks (mask 0: none)
+    unsigned long long npm, npm1;
     uint32_t po, e1blk;            // first entry of the node's extra pairs and the first of them (fetched ahead)
     unsigned long long e1mask;
 };
@@ -523,9 +524,10 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         }
     }
     if (__ballot(L.npm != 0)) {
-        const uint32_t sp = slot_of_word(L.npw);
+        const uint32_t sp = slot_of_word(L.npw), sp1 = slot_of_word(L.npw1 & 31u);
 #pragma unroll
-        for (int s = 0; s < W; ++s) F[s] |= (L.npm != 0 && sp == (uint32_t)s) ? L.npm : 0ull;
+        for (int s = 0; s < W; ++s)
+            F[s] |= ((L.npm != 0 && sp == (uint32_t)s) ? L.npm : 0ull) | ((L.npm1 != 0 && sp1 == (uint32_t)s) ? L.npm1 : 0ull);
     }
     const bool inb = L.valid && L.par >= (int32_t)base;
     int pl = inb ? (int)(L.par - (int32_t)base) : -1;
@@ -553,11 +555,11 @@ __device__ __forceinline__ void b3_batch(const B3Params& q, const B3Ctx& C, cons
         pl = pl >= 0 ? npl : -1;
     }
     mark(1);
-    if (!EMIT && q.nwords != nullptr && L.valid) {
-        uint32_t nz = 0;
+    if (!EMIT && q.fwords != nullptr && L.valid) {
+        uint32_t fw = 0;
 #pragma unroll
-        for (int s = 0; s < W; ++s) nz += F[s] != 0 ? 1u : 0u;
-        q.nwords[L.idx] = (uint8_t)nz;
+        for (int s = 0; s < W; ++s) fw |= F[s] != 0 ? 1u << (IDENT ? (uint32_t)s : wl[s]) : 0u;
+        q.fwords[L.idx] = fw;
     }
     // ---- records: flat form, one per pair of non-empty words X >= Y of patterns with w > 0
     const bool act = L.valid && L.w != 0 && L.n >= 2 && !(q.dbg & 512u);
@@ -769,10 +771,11 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu
             if (INDIRECT && c0 == 0 && lane == 0) {
                 const int32_t np0 = q.seg_np[seg];
                 if (np0 >= 0) {
-                    const uint32_t wd = q.p0_info[np0] & 0xFFu;
-                    const unsigned long long mk = q.fnarrow[np0];
+                    const uint32_t wd = q.wd01[np0];
+                    const ulonglong2 mk = q.fnarrow[np0];
 #pragma unroll
-                    for (int w = 0; w < NBW; ++w) F[w] |= (wd == (uint32_t)w) ? mk : 0ull;
+                    for (int w = 0; w < NBW; ++w)
+                        F[w] |= (((wd & 0xFFu) == (uint32_t)w) ? mk.x : 0ull) | (((wd >> 8) == (uint32_t)w) ? mk.y : 0ull);
                 }
             }
 #pragma unroll
@@ -801,9 +804,9 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu
     }
 
     // node records of the NEXT batch are fetched while the current one is processed
-    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_idx = 0, nx_npw = 0, nx_po = 0, nx_e1blk = 0;
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_idx = 0, nx_npw = 0, nx_npw1 = 0, nx_po = 0, nx_e1blk = 0;
     int32_t nx_par = -1;
-    unsigned long long nx_m0 = 0, nx_npm = 0, nx_e1mask = 0;
+    unsigned long long nx_m0 = 0, nx_npm = 0, nx_npm1 = 0, nx_e1mask = 0;
     auto fetch = [&](uint32_t b0) {
         const uint32_t k = b0 + lane;
         const bool v = k < end;
@@ -817,11 +820,13 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu
         nx_po = v ? q.pair_ofs[ii] : 0u;
         nx_e1blk = 0; nx_e1mask = 0;
         if ((nx_info >> 8) > 1u) { nx_e1blk = q.pair_blk[nx_po]; nx_e1mask = q.pair_mask[nx_po]; }
-        nx_npw = 0; nx_npm = 0;
+        nx_npw = 0; nx_npm = 0; nx_npw1 = 0; nx_npm1 = 0;
         if (INDIRECT && nx_par <= -2) {
             const uint32_t np = (uint32_t)(-(nx_par + 2));
-            nx_npw = q.p0_info[np] & 0xFFu;
-            nx_npm = q.fnarrow[np];
+            const uint32_t wd = q.wd01[np];
+            const ulonglong2 pm = q.fnarrow[np];
+            nx_npw = wd & 0xFFu; nx_npm = pm.x;
+            nx_npw1 = wd >> 8; nx_npm1 = (wd >> 8) != 0xFFu ? pm.y : 0ull;
         }
     };
     fetch(first);
@@ -835,7 +840,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu
         L.idx = nx_idx;
         L.valid = base + lane < end;
         L.n = nx_nl & 0xFFFFu; L.l = (nx_nl >> 16) & 0x3FFFu;
-        L.w = nx_w; L.par = nx_par; L.info = nx_info; L.m0 = nx_m0; L.npw = nx_npw; L.npm = nx_npm;
+        L.w = nx_w; L.par = nx_par; L.info = nx_info; L.m0 = nx_m0; L.npw = nx_npw; L.npm = nx_npm; L.npw1 = nx_npw1; L.npm1 = nx_npm1;
         L.po = nx_po; L.e1blk = nx_e1blk; L.e1mask = nx_e1mask;
         if ((q.dbg & 8192u) && (L.info >> 8) > 1u) L.info = (L.info & 0xFFu) | 0x100u;   // timing experiment: ignore extra pairs
         if (base + WAVE < end) fetch(base + WAVE);
@@ -851,7 +856,7 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu
             rootslot = C.slot_of_n[L.n - L.l];
             inh = C.chain_nz[rootslot];
         }
-        uint32_t U = L.valid ? (lw | inh | (L.npm != 0 ? 1u << L.npw : 0u)) : 0u;
+        uint32_t U = L.valid ? (lw | inh | (L.npm != 0 ? 1u << L.npw : 0u) | (L.npm1 != 0 ? 1u << L.npw1 : 0u)) : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) U |= (uint32_t)__shfl_xor((int)U, d, WAVE);
         U = __builtin_amdgcn_readfirstlane(U);
@@ -885,34 +890,39 @@ __global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu
 }
 
 // ------------------------------------------------------------------------------------------
-// K1 for NARROW nodes: full list inside one block (about 4 nodes in 5).  Their ancestors are narrow too, so
-// a full list is ONE 64-bit mask and a record is (X, X, F, F, w).  The kernel walks the whole DFS stream,
-// 64 nodes per step, one per lane (lanes of wide nodes idle):
-//   F = local mask | F(parent): parents inside the batch by pointer doubling over one register, parents
-//   before the batch from chain[depth - 2] in LDS (one 64-bit slot per depth: the latest node of every depth
-//   on the current root path); records go straight to the diagonal bucket of their block.
-// Narrow nodes that have a wide child also leave their mask in HBM (fnarrow) for the wide-list launch.
+// K1 for the nodes whose full list touches at most TWO blocks (9 nodes in 10).  Lists are ascending and a child only
+// appends, so a child's first block is its parent's first block and a second block, once there, stays: the ancestors of
+// such a node are of the same kind and a full list is two registers (F0 for block w0, F1 for block w1 > w0 or none).
+// The kernel walks the whole DFS stream, 64 nodes per step, one per lane (lanes of wider nodes idle):
+//   F = local masks | F(parent), register by register: parents inside the batch by pointer doubling, parents before
+//   the batch from chain[depth - 2] in LDS (one slot per depth = the latest node of that depth on the current root
+//   path).  Records (w0, w0, F0) for every pattern with k-mers, plus (w1, w0, F1, F0) and (w1, w1, F1) when there
+//   is a second block, straight into their streams.
+// Nodes that have a wider child also leave (F0, F1) in HBM (fnarrow) for the wide-list launch.
 // ------------------------------------------------------------------------------------------
 struct B3NParams {
-    const uint32_t* nl;            // n | l << 16 | has-wide-child << 30 | wide << 31
+    const uint32_t* nl;            // n | l << 16 | has-wider-child << 30 | wide (more than two blocks) << 31
     const int32_t* parent;
     const uint32_t* w;
     const uint8_t* depth;
+    const uint16_t* wd01;          // first block | second block << 8 (0xFF: none)
     const Segment* segs;
     const uint32_t* seg_anc;       // [n_segs][chain_cap] root-first ancestors of the segment's first node
     const uint32_t* seg_anc_n;
     const unsigned long long* p0_mask;
     const uint16_t* p0_info;
-    unsigned long long* fnarrow;
-    uint32_t n_segs, chain_cap, nctr, nb;
-    uint32_t* table;
+    const uint32_t* pair_ofs;
+    const unsigned long long* pair_mask;
+    ulonglong2* fnarrow;
+    uint32_t n_segs, chain_cap, nctr;
+    uint32_t* table;               // [n_segs][nctr]
     B2Recs rec;
     uint32_t dbg;
 };
 constexpr int B3N_WAVES = 4;
 
-__host__ __device__ inline size_t b3n_wave_bytes(uint32_t chain_cap, uint32_t nb) {
-    return ((size_t)chain_cap * 8 + (size_t)nb * B2_NCLS * 4 + 15) & ~(size_t)15;
+__host__ __device__ inline size_t b3n_wave_bytes(uint32_t chain_cap, uint32_t nctr) {
+    return ((size_t)chain_cap * 16 + (size_t)nctr * 4 + 15) & ~(size_t)15;
 }
 
 template <bool EMIT>
@@ -922,41 +932,50 @@ __global__ __launch_bounds__(WAVE * B3N_WAVES) void b3_narrow_kernel(B3NParams q
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg = blockIdx.x * B3N_WAVES + wave;
     if (seg >= q.n_segs) return;
-    unsigned long long* chain = (unsigned long long*)(lds_raw + b3n_wave_bytes(q.chain_cap, q.nb) * wave);   // [chain_cap]
-    uint32_t* ctr = (uint32_t*)(chain + q.chain_cap);                                                        // [nb][B2_NCLS]
+    ulonglong2* chain = (ulonglong2*)(lds_raw + b3n_wave_bytes(q.chain_cap, q.nctr) * wave);                 // [chain_cap]
+    uint32_t* ctr = (uint32_t*)(chain + q.chain_cap);                                                        // [nctr]
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t* my_table = q.table + (size_t)seg * q.nb * B2_NCLS;          // [block][class]: diagonal buckets only
-    for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) ctr[k] = EMIT ? my_table[k] : 0u;
+    uint32_t* my_table = q.table + (size_t)seg * q.nctr;
+    for (uint32_t k = lane; k < q.nctr; k += WAVE) ctr[k] = EMIT ? my_table[k] : 0u;
     const Segment sg = q.segs[seg];
     const uint32_t first = __builtin_amdgcn_readfirstlane(sg.first);
     const uint32_t end = __builtin_amdgcn_readfirstlane(sg.end);
     if (first >= end) return;
 
-    // chain slots of the first node's ancestors: inclusive OR along the root path (the narrow nodes are a prefix of it)
+    // local masks of a node, sorted into the two registers
+    auto locals = [&](uint32_t node, uint32_t info, unsigned long long m0, uint32_t wd, unsigned long long& f0, unsigned long long& f1) {
+        f0 = 0; f1 = 0;
+        const uint32_t np = info >> 8;
+        if (np == 0) return;
+        if ((info & 0xFFu) == (wd & 0xFFu)) f0 = m0; else f1 = m0;
+        if (np > 1) f1 |= q.pair_mask[q.pair_ofs[node]];             // the second pair can only lie in the second block
+    };
+
+    // chain slots of the first node's ancestors: inclusive OR along the root path (the nodes of this kind are a prefix of it)
     {
         const uint32_t d = q.seg_anc_n[seg];
-        unsigned long long carry = 0;
-        for (uint32_t c0 = 0; c0 < d; c0 += WAVE) {
-            const uint32_t k = c0 + lane;
+        unsigned long long c0 = 0, c1 = 0;
+        for (uint32_t cb = 0; cb < d; cb += WAVE) {
+            const uint32_t k = cb + lane;
             const bool on = k < d;
             const uint32_t node = on ? q.seg_anc[(size_t)seg * q.chain_cap + k] : 0u;
-            const bool nar = on && !(q.nl[node] >> 31);
-            unsigned long long F = (nar && (q.p0_info[node] >> 8) != 0) ? q.p0_mask[node] : 0ull;
-            if (lane == 0) F |= carry;
+            unsigned long long F0 = 0, F1 = 0;
+            if (on && !(q.nl[node] >> 31)) locals(node, q.p0_info[node], q.p0_mask[node], q.wd01[node], F0, F1);
+            if (lane == 0) { F0 |= c0; F1 |= c1; }
 #pragma unroll
             for (int s = 1; s < WAVE; s <<= 1) {
-                const unsigned long long o = shfl_up64(F, s);
-                if (lane >= (uint32_t)s) F |= o;
+                const unsigned long long o0 = shfl_up64(F0, s), o1 = shfl_up64(F1, s);
+                if (lane >= (uint32_t)s) { F0 |= o0; F1 |= o1; }
             }
-            if (on) chain[k] = F;
-            carry = shfl64(F, WAVE - 1);
+            if (on) chain[k] = make_ulonglong2(F0, F1);
+            c0 = shfl64(F0, WAVE - 1); c1 = shfl64(F1, WAVE - 1);
         }
         lds_sync();
     }
 
-    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_dep = 0;
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_dep = 0, nx_wd = 0;
     int32_t nx_par = -1;
-    unsigned long long nx_m0 = 0;
+    unsigned long long nx_m0 = 0, nx_e1 = 0;
     auto fetch = [&](uint32_t b0) {
         const uint32_t ii = b0 + lane;
         const bool v = ii < end;
@@ -966,48 +985,66 @@ __global__ __launch_bounds__(WAVE * B3N_WAVES) void b3_narrow_kernel(B3NParams q
         nx_dep = v ? q.depth[ii] : 0xFFFFu;
         nx_info = v ? q.p0_info[ii] : 0u;
         nx_m0 = v ? q.p0_mask[ii] : 0ull;
+        nx_wd = v ? q.wd01[ii] : 0xFFFFu;
+        nx_e1 = 0;
+        if (v && !(nx_nl >> 31) && (nx_info >> 8) > 1u) nx_e1 = q.pair_mask[q.pair_ofs[ii]];
     };
     fetch(first);
     for (uint32_t base = first; base < end; base += WAVE) {
         const uint32_t idx = base + lane;
-        const uint32_t nl = nx_nl, w = nx_w, info = nx_info, dep = nx_dep;
+        const uint32_t nl = nx_nl, w = nx_w, info = nx_info, dep = nx_dep, wd = nx_wd;
         const int32_t par = nx_par;
-        unsigned long long F = nx_m0;
+        const unsigned long long m0 = nx_m0, e1 = nx_e1;
         if (base + WAVE < end) fetch(base + WAVE);
         const bool nar = !(nl >> 31);                       // lanes past the end carry the wide flag
-        if (!nar || (info >> 8) == 0) F = 0ull;
-        const uint32_t X = info & 0xFFu;
-        if (nar && par >= 0 && par < (int32_t)base) F |= chain[dep - 2u];
+        const uint32_t w0 = wd & 0xFFu, w1 = wd >> 8;
+        unsigned long long F0 = 0, F1 = 0;
+        if (nar && (info >> 8) != 0) {
+            if ((info & 0xFFu) == w0) F0 = m0; else F1 = m0;
+            F1 |= e1;
+        }
+        if (nar && par >= 0 && par < (int32_t)base) { const ulonglong2 c = chain[dep - 2u]; F0 |= c.x; F1 |= c.y; }
         int pl = (nar && par >= (int32_t)base) ? (int)(par - (int32_t)base) : -1;
         while (__ballot(pl >= 0)) {
             const int src = pl >= 0 ? pl : (int)lane;
-            const unsigned long long o = shfl64(F, src);
-            if (pl >= 0) F |= o;
+            const unsigned long long o0 = shfl64(F0, src), o1 = shfl64(F1, src);
+            if (pl >= 0) { F0 |= o0; F1 |= o1; }
             const int npl = __shfl(pl, src, WAVE);
             pl = pl >= 0 ? npl : -1;
         }
-        if (nar && ((nl >> 30) & 1u)) q.fnarrow[idx] = F;
+        if (nar && ((nl >> 30) & 1u)) q.fnarrow[idx] = make_ulonglong2(F0, F1);
         // ---- records
         const bool act = nar && w != 0 && (nl & 0xFFFFu) >= 2u && !(q.dbg & 512u);
         const uint32_t cls = b2_weight_class(w);
-        unsigned long long pend = __ballot(act);
+        // (w0, w0): the lanes of a batch mostly share the block, so one reservation per block and weight class
+        unsigned long long pend = __ballot(act && F0 != 0);
         while (pend) {
-            const uint32_t X0 = bcast(X, (uint32_t)__builtin_ctzll(pend));
-            const bool mine = act && X == X0;
+            const uint32_t X0 = bcast(w0, (uint32_t)__builtin_ctzll(pend));
+            const bool mine = act && F0 != 0 && w0 == X0;
             const unsigned long long b0 = __ballot(mine && cls == 0u), b1 = __ballot(mine && cls == 1u), b2 = __ballot(mine && cls == 2u);
             uint32_t mybase = 0;
             if (lane < B2_NCLS) {
                 const uint32_t cnt = (uint32_t)__popcll(lane == 0 ? b0 : lane == 1 ? b1 : b2);
-                if (cnt) mybase = atomicAdd(&ctr[X0 * B2_NCLS + lane], cnt);
+                if (cnt) mybase = atomicAdd(&ctr[(X0 * (X0 + 1u) / 2u + X0) * B2_NCLS + lane], cnt);
             }
             const uint32_t base0 = bcast(mybase, 0), base1 = bcast(mybase, 1), base2 = bcast(mybase, 2);
             if (EMIT && mine && !(q.dbg & 256u)) {
                 const uint32_t slot = cls == 0u ? base0 + (uint32_t)__popcll(b0 & lt_mask)
                                     : cls == 1u ? base1 + (uint32_t)__popcll(b1 & lt_mask) : base2 + (uint32_t)__popcll(b2 & lt_mask);
-                q.rec.rows[slot] = F;
+                q.rec.rows[slot] = F0;
                 if (cls) q.rec.w[slot] = w;
             }
             pend &= ~(b0 | b1 | b2);
+        }
+        // (w1, w0) and (w1, w1): the second blocks differ from lane to lane, one LDS atomic per record
+        if (act && F1 != 0) {
+            const uint32_t t1 = w1 * (w1 + 1u) / 2u;
+            if (F0 != 0) {
+                const uint32_t s1 = atomicAdd(&ctr[(t1 + w0) * B2_NCLS + cls], 1u);
+                if (EMIT && !(q.dbg & 256u)) { q.rec.rc[s1] = make_ulonglong2(F1, F0); if (cls) q.rec.w[s1] = w; }
+            }
+            const uint32_t s2 = atomicAdd(&ctr[(t1 + w1) * B2_NCLS + cls], 1u);
+            if (EMIT && !(q.dbg & 256u)) { q.rec.rows[s2] = F1; if (cls) q.rec.w[s2] = w; }
         }
         // ---- chain slots for the next batch: the nodes on the root path of this batch's last node, i.e. the
         // lanes whose depth is smaller than the depth of every later lane
@@ -1020,13 +1057,13 @@ __global__ __launch_bounds__(WAVE * B3N_WAVES) void b3_narrow_kernel(B3NParams q
             }
             uint32_t later = (uint32_t)__shfl_down((int)m, 1, WAVE);
             if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
-            if (nar && dep < later) chain[dep - 1u] = F;
+            if (nar && dep < later) chain[dep - 1u] = make_ulonglong2(F0, F1);
             lds_sync();
         }
     }
     if (!EMIT) {
         lds_sync();
-        for (uint32_t k = lane; k < q.nb * B2_NCLS; k += WAVE) my_table[k] = ctr[k];
+        for (uint32_t k = lane; k < q.nctr; k += WAVE) my_table[k] = ctr[k];
     }
 }
 
@@ -1205,17 +1242,17 @@ int b2_launch_emit(kmdb_db* db, uint32_t seg_begin, uint32_t seg_end, uint32_t d
 }
 
 template <int NBW, bool EMIT, bool INDIRECT>
-int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg, uint8_t* nwords) {
+int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg, uint32_t* fwords) {
     B3Params q{};
     q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w;
     q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
     q.pair_ofs = db->b3_pair_ofs; q.pair_blk = db->b3_pair_blk; q.pair_mask = db->b3_pair_mask;
     q.maxn_pad = db->b2_maxn_pad; q.nctr = db->b2_nctr; q.chain_cap = db->b3_chain_cap;
     q.table = db->b2_table; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.dbg = dbg; q.counters = db->counters;
-    q.nwords = nwords;
+    q.fwords = fwords;
     if (INDIRECT) {
         q.segs = db->b3_wsegs; q.n_segs = db->b3_n_wsegs; q.seg_anc = db->b3_wseg_anc; q.seg_anc_n = db->b3_wseg_anc_n;
-        q.widx = db->b3_widx; q.wparent = db->b3_wparent; q.fnarrow = db->b3_fnarrow; q.seg_np = db->b3_wseg_np;
+        q.widx = db->b3_widx; q.wparent = db->b3_wparent; q.fnarrow = db->b3_fnarrow; q.wd01 = db->b3_wd01; q.seg_np = db->b3_wseg_np;
         q.seg_row0 = 0; q.chain_cap = db->b3_wchain_cap;
     } else {
         q.segs = db->rsegs; q.n_segs = db->n_rsegs; q.seg_anc = db->b3_seg_anc; q.seg_anc_n = db->b3_seg_anc_n;
@@ -1239,12 +1276,12 @@ int b3_launch_emit_t(kmdb_db* db, hipStream_t st, uint32_t dbg, uint8_t* nwords)
 }
 
 template <bool EMIT, bool INDIRECT>
-int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0, uint8_t* nwords = nullptr) {
-    if (db->b3_nbw <= 8) return b3_launch_emit_t<8, EMIT, INDIRECT>(db, st, dbg, nwords);
-    if (db->b3_nbw <= 16) return b3_launch_emit_t<16, EMIT, INDIRECT>(db, st, dbg, nwords);
-    if (db->b3_nbw <= 20) return b3_launch_emit_t<20, EMIT, INDIRECT>(db, st, dbg, nwords);
-    if (db->b3_nbw <= 24) return b3_launch_emit_t<24, EMIT, INDIRECT>(db, st, dbg, nwords);
-    return b3_launch_emit_t<32, EMIT, INDIRECT>(db, st, dbg, nwords);
+int b3_launch_emit(kmdb_db* db, hipStream_t st, uint32_t dbg = 0, uint32_t* fwords = nullptr) {
+    if (db->b3_nbw <= 8) return b3_launch_emit_t<8, EMIT, INDIRECT>(db, st, dbg, fwords);
+    if (db->b3_nbw <= 16) return b3_launch_emit_t<16, EMIT, INDIRECT>(db, st, dbg, fwords);
+    if (db->b3_nbw <= 20) return b3_launch_emit_t<20, EMIT, INDIRECT>(db, st, dbg, fwords);
+    if (db->b3_nbw <= 24) return b3_launch_emit_t<24, EMIT, INDIRECT>(db, st, dbg, fwords);
+    return b3_launch_emit_t<32, EMIT, INDIRECT>(db, st, dbg, fwords);
 }
 
 template <bool EMIT>
@@ -1253,9 +1290,10 @@ int b3_launch_narrow(kmdb_db* db, hipStream_t st, uint32_t dbg = 0) {
     q.nl = db->b3_nl; q.parent = db->parent; q.w = db->w; q.depth = db->b3_depth; q.segs = db->b3_nsegs;
     q.seg_anc = db->b3_nseg_anc; q.seg_anc_n = db->b3_nseg_anc_n; q.p0_mask = db->b3_p0_mask; q.p0_info = db->b3_p0_info;
     q.fnarrow = db->b3_fnarrow; q.n_segs = db->b3_n_nsegs; q.chain_cap = db->b3_chain_cap; q.nctr = db->b2_nctr;
-    q.nb = (uint32_t)((db->N + db->b2_width - 1) / db->b2_width);
+    q.wd01 = db->b3_wd01; q.pair_ofs = db->b3_pair_ofs; q.pair_mask = db->b3_pair_mask;
     q.table = db->b3_ntable; q.rec = B2Recs{db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w}; q.dbg = dbg;
-    const size_t lds = b3n_wave_bytes(q.chain_cap, q.nb) * B3N_WAVES;
+    const size_t lds = b3n_wave_bytes(q.chain_cap, q.nctr) * B3N_WAVES;
+    HIP_TRY(hipFuncSetAttribute((const void*)b3_narrow_kernel<EMIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t blocks = (q.n_segs + B3N_WAVES - 1) / B3N_WAVES;
     if (blocks) hipLaunchKernelGGL((b3_narrow_kernel<EMIT>), dim3(blocks), dim3(WAVE * B3N_WAVES), lds, st, q);
     HIP_TRY(hipGetLastError());
@@ -1286,10 +1324,10 @@ int b3_launch_decode(kmdb_db* db, hipStream_t st) {
 void b2_release_width(kmdb_db* db) {
     void* ptrs[] = {db->b2_table, db->b2_rec_rows, db->b2_rec_rc, db->b2_rec_w, db->b2_items, db->b3_pair_ofs,
                     db->b3_pair_blk, db->b3_pair_mask, db->b3_p0_mask, db->b3_p0_info, db->b3_widx, db->b3_wparent,
-                    db->b3_fnarrow, db->b3_wsegs, db->b3_wseg_anc, db->b3_wseg_anc_n, db->b3_wseg_np, db->b3_ntable};
+                    db->b3_fnarrow, db->b3_wsegs, db->b3_wseg_anc, db->b3_wseg_anc_n, db->b3_wseg_np, db->b3_ntable, db->b3_wd01};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     db->b3_widx = nullptr; db->b3_wparent = nullptr; db->b3_fnarrow = nullptr; db->b3_wsegs = nullptr;
-    db->b3_wseg_anc = nullptr; db->b3_wseg_anc_n = nullptr; db->b3_wseg_np = nullptr; db->b3_ntable = nullptr;
+    db->b3_wseg_anc = nullptr; db->b3_wseg_anc_n = nullptr; db->b3_wseg_np = nullptr; db->b3_ntable = nullptr; db->b3_wd01 = nullptr;
     db->b3_split = false; db->b3_n_wide = 0; db->b3_n_wsegs = 0;
     db->b2_table = nullptr; db->b2_rec_rows = nullptr; db->b2_rec_rc = nullptr; db->b2_rec_w = nullptr; db->b2_items = nullptr;
     db->b3_pair_ofs = nullptr; db->b3_pair_blk = nullptr; db->b3_pair_mask = nullptr; db->b3_p0_mask = nullptr;
@@ -1351,19 +1389,23 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
             // Classify the nodes with the count mode of the all-nodes emit kernel: how many blocks does the full list
             // touch?  (layout metadata, like the counts.)  Narrow nodes (one block) are handled in the DFS stream by
             // the narrow kernel; the wide ones get their own list: DFS index, parent position, slices, root paths.
-            uint8_t* d_nw = nullptr;
-            HIP_TRY(hipMalloc((void**)&d_nw, P));
+            uint32_t* d_fw = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_fw, P * 4));
             HIP_TRY(hipMemcpy(db->b3_nl, h.nl->data(), P * 4, hipMemcpyHostToDevice));
-            if (b3_launch_emit<false, false>(db, db->stream, 0, d_nw)) return 1;
+            if (b3_launch_emit<false, false>(db, db->stream, 0, d_fw)) return 1;
             HIP_TRY(hipStreamSynchronize(db->stream));
-            std::vector<uint8_t> nw(P);
-            HIP_TRY(hipMemcpy(nw.data(), d_nw, P, hipMemcpyDeviceToHost));
-            (void)hipFree(d_nw);
+            std::vector<uint32_t> fw(P);
+            HIP_TRY(hipMemcpy(fw.data(), d_fw, P * 4, hipMemcpyDeviceToHost));
+            (void)hipFree(d_fw);
             const std::vector<int32_t>& parent = *h.parent;
             std::vector<uint32_t> nlf(*h.nl), widx;
             std::vector<int32_t> rank(P, -1), wparent;
-            for (uint64_t i = 0; i < P; ++i)
-                if (nw[i] > 1) { rank[i] = (int32_t)widx.size(); widx.push_back((uint32_t)i); nlf[i] |= 1u << 31; }
+            std::vector<uint16_t> wd01(P, 0xFFFFu);
+            for (uint64_t i = 0; i < P; ++i) {
+                const uint32_t f = fw[i], f2 = f & (f - 1u);                   // f2: without the lowest block
+                if (f2 & (f2 - 1u)) { rank[i] = (int32_t)widx.size(); widx.push_back((uint32_t)i); nlf[i] |= 1u << 31; }   // > 2 blocks
+                else if (f) wd01[i] = (uint16_t)((uint32_t)__builtin_ctz(f) | (f2 ? (uint32_t)__builtin_ctz(f2) << 8 : 0xFF00u));
+            }
             const size_t nW = widx.size();
             wparent.resize(nW);
             for (size_t k = 0; k < nW; ++k) {
@@ -1406,9 +1448,9 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
                 if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
                 return 0;
             };
-            if (up(&db->b3_widx, widx) || up(&db->b3_wparent, wparent) || up(&db->b3_wsegs, wsegs) || up(&db->b3_wseg_anc, wanc) ||
+            if (up(&db->b3_wd01, wd01) || up(&db->b3_widx, widx) || up(&db->b3_wparent, wparent) || up(&db->b3_wsegs, wsegs) || up(&db->b3_wseg_anc, wanc) ||
                 up(&db->b3_wseg_anc_n, wanc_n) || up(&db->b3_wseg_np, wnp)) return 1;
-            HIP_TRY(hipMalloc((void**)&db->b3_fnarrow, P * 8));
+            HIP_TRY(hipMalloc((void**)&db->b3_fnarrow, P * 16));
             db->b3_n_wide = (uint32_t)nW; db->b3_n_wsegs = (uint32_t)n_wsegs; db->b3_split = true;
             // count modes of the two run-time kernels, one table row per slice
             (void)hipFree(db->b2_table); db->b2_table = nullptr;
@@ -1416,7 +1458,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
             tbl = std::max<size_t>(table_rows, 1) * db->b2_nctr;
             HIP_TRY(hipMalloc((void**)&db->b2_table, tbl * 4));
             HIP_TRY(hipMemset(db->b2_table, 0, tbl * 4));
-            ntbl = (size_t)db->b3_n_nsegs * NB * B2_NCLS;
+            ntbl = (size_t)db->b3_n_nsegs * db->b2_nctr;
             HIP_TRY(hipMalloc((void**)&db->b3_ntable, std::max<size_t>(ntbl, 1) * 4));
             HIP_TRY(hipMemset(db->b3_ntable, 0, std::max<size_t>(ntbl, 1) * 4));
             if (b3_launch_narrow<false>(db, db->stream)) return 1;
@@ -1438,18 +1480,9 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
     uint64_t run = 0;
     for (uint32_t c = 0; c < db->b2_nctr; ++c) {
         cstart[c] = run;
-        if (ntbl) {
-            // narrow slices first: they only write to the diagonal buckets
-            const uint32_t bucket = c / B2_NCLS, cls = c % B2_NCLS;
-            uint32_t X = 0;
-            while ((X + 1) * (X + 2) / 2 <= bucket) ++X;
-            if (bucket == X * (X + 1) / 2 + X) {
-                const size_t stride = (size_t)NB * B2_NCLS, col = (size_t)X * B2_NCLS + cls;
-                for (size_t sgi = 0; sgi < db->b3_n_nsegs; ++sgi) {
-                    nbases[sgi * stride + col] = (uint32_t)run;
-                    run += ncounts[sgi * stride + col];
-                }
-            }
+        for (size_t sgi = 0; ntbl && sgi < db->b3_n_nsegs; ++sgi) {        // the slices of the <= 2-block kernel first
+            nbases[sgi * db->b2_nctr + c] = (uint32_t)run;
+            run += ncounts[sgi * db->b2_nctr + c];
         }
         for (size_t sgi = 0; sgi < table_rows; ++sgi) {
             bases[(size_t)sgi * db->b2_nctr + c] = (uint32_t)run;

@@ -82,7 +82,8 @@ struct kmdb_db {
     uint64_t* b3_blkbase = nullptr;
     uint32_t* b3_widx = nullptr;        // [n_wide] DFS index of the wide nodes, DFS order
     int32_t* b3_wparent = nullptr;      // [n_wide] >= 0: position of the (wide) parent in the wide list; -1: none; <= -2: narrow parent -(v + 2)
-    unsigned long long* b3_fnarrow = nullptr;   // [P] full mask of the narrow nodes that have a wide child (written by the narrow kernel)
+    ulonglong2* b3_fnarrow = nullptr;   // [P] (F0, F1) of the <= 2-block nodes that have a wider child (written by the narrow kernel)
+    uint16_t* b3_wd01 = nullptr;        // [P] blocks of a <= 2-block node: first | second << 8 (0xFF: none)
     Segment* b3_wsegs = nullptr;        // slices of the wide list
     uint32_t* b3_wseg_anc = nullptr;    // [n_wsegs][chain_cap] wide ancestors (DFS index) of the slice's first node, root first
     uint32_t* b3_wseg_anc_n = nullptr;
