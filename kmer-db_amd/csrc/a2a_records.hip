@@ -1069,14 +1069,42 @@ __global__ __launch_bounds__(WAVE * B3N_WAVES) void b3_narrow_kernel(B3NParams q
 
 // 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit
 __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, uint32_t lane) {
-    const unsigned long long masks[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
-                                         0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
-    int s = 32;
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    // stage 32: the upper half of the wave swaps its low words with the high words of the lower half — one
+    // v_permlane32_swap on gfx950
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    }
+    // stage 16: 16-bit halves of every word between the lanes that differ in bit 4: v_permlane16_swap brings the
+    // partner's word, v_perm_b32 splices the halves
+    {
+        const bool up = (lane & 16u) != 0;
+        const uint32_t sel = up ? 0x03020706u : 0x05040100u;
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const uint32_t plo = up ? a[0] : a[1];
+        lo = __builtin_amdgcn_perm(plo, lo, sel);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const uint32_t phi = up ? b[0] : b[1];
+        hi = __builtin_amdgcn_perm(phi, hi, sel);
+    }
+    x = ((unsigned long long)hi << 32) | lo;
+    const unsigned long long masks[4] = {0x00FF00FF00FF00FFull, 0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
+    int s = 8;
 #pragma unroll
-    for (int k = 0; k < 6; ++k, s >>= 1) {
+    for (int k = 0; k < 4; ++k, s >>= 1) {
         const unsigned long long m = masks[k];
-        const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)x, s, WAVE);
-        const uint32_t phi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), s, WAVE);
+        uint32_t plo, phi;
+        if (s == 2) {               // quad_perm [2,3,0,1]
+            plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0x4E, 0xF, 0xF, false);
+            phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0x4E, 0xF, 0xF, false);
+        } else if (s == 1) {        // quad_perm [1,0,3,2]
+            plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0xB1, 0xF, 0xF, false);
+            phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0xB1, 0xF, 0xF, false);
+        } else {
+            plo = (uint32_t)__shfl_xor((int)(uint32_t)x, s, WAVE);
+            phi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), s, WAVE);
+        }
         const unsigned long long pv = ((unsigned long long)phi << 32) | plo;
         x = (lane & (uint32_t)s) ? ((x & ~m) | ((pv >> s) & m)) : ((x & m) | ((pv & m) << s));
     }
