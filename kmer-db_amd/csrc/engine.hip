@@ -352,7 +352,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
         std::vector<Segment> nsegs;
         std::vector<uint32_t> nseg_anc, nseg_anc_n;
         if (chain_ok) {
-            uint64_t NSEG = 4096;
+            uint64_t NSEG = 2048;
             if (const char* e = getenv("KMDB_NSEG")) NSEG = std::max<uint64_t>(64, strtoull(e, nullptr, 10));
             for (uint64_t f = 0; f < P; f += NSEG) nsegs.push_back(Segment{(uint32_t)f, (uint32_t)std::min<uint64_t>(P, f + NSEG)});
             nseg_anc.assign(nsegs.size() * anc_stride, 0);
