@@ -1367,7 +1367,7 @@ void b2_release_width(kmdb_db* db) {
 // kernels (layout metadata: a pure function of the database, like CSR row pointers), turn the
 // per-(segment, bucket) record counts into record bases and cut the buckets into work items for the
 // apply kernel.  *fits is false when the width cannot be used.
-int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, bool* fits) {
+int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, bool* fits, bool estimate_only = false) {
     const uint32_t max_n = h.max_n;
     const bool chain_ok = h.chain_ok;
     *fits = false;
@@ -1410,6 +1410,20 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
         HIP_TRY(hipMalloc((void**)&db->b3_pair_blk, std::max<uint32_t>(total_pairs, 1)));
         HIP_TRY(hipMalloc((void**)&db->b3_pair_mask, (size_t)std::max<uint32_t>(total_pairs, 1) * 8));
         if (b3_launch_decode<false>(db, db->stream)) return 1;
+        if (estimate_only) {
+            // ranking the candidate widths only needs the number of records: the count mode of the all-nodes emit kernel
+            HIP_TRY(hipMemcpy(db->b3_nl, h.nl->data(), P * 4, hipMemcpyHostToDevice));
+            if (b3_launch_emit<false, false>(db, db->stream)) return 1;
+            HIP_TRY(hipStreamSynchronize(db->stream));
+            std::vector<uint32_t> counts(tbl);
+            HIP_TRY(hipMemcpy(counts.data(), db->b2_table, tbl * 4, hipMemcpyDeviceToHost));
+            uint64_t total = 0;
+            for (uint32_t v : counts) total += v;
+            if (total >= (1ull << 32)) return 0;
+            db->b2_total = total;
+            *fits = true;
+            return 0;
+        }
         if (getenv("KMDB_K1_SINGLE")) {
             HIP_TRY(hipMemcpy(db->b3_nl, h.nl->data(), P * 4, hipMemcpyHostToDevice));
             if (b3_launch_emit<false, false>(db, db->stream)) return 1;
@@ -1620,7 +1634,8 @@ int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h) {
     uint64_t best_cost = ~0ull;
     for (uint32_t wd : cands) {
         bool fits = false;
-        if (b2_prepare_width(db, wd, h, &fits)) { b2_release_width(db); return 1; }
+        if (cands.size() == 1) { best_w = wd; break; }
+        if (b2_prepare_width(db, wd, h, &fits, /*estimate_only=*/true)) { b2_release_width(db); return 1; }
         if (fits) {
             // records dominate K1/K2; wider per-lane register sets (more blocks) make K1 a little dearer
             const uint64_t cost = db->b2_total + P * (db->b3_nbw > 16 ? (db->b3_nbw - 16) : 0) / 64;
