@@ -32,6 +32,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -158,6 +159,14 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
     const int device = opts ? opts->device : 0;
     HIP_TRY(hipSetDevice(device));
 
+    const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
+    auto tphase0 = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kmdb] upload: %-28s %.2f s\n", what, std::chrono::duration<double>(now - tphase0).count());
+        tphase0 = now;
+    };
     // ---- children lists (parent_id[p] < p, SURVEY §7 invariants) ------------------------------
     std::vector<uint32_t> child_count(P + 1, 0), order(P), dfs_of(P);
     std::vector<uint32_t> roots;
@@ -200,6 +209,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
     }
     std::vector<uint32_t>().swap(children);
 
+    phase("DFS order");
     // ---- DFS-ordered arrays, bit-packed streams, cost model ----------------------------------
     std::vector<uint4> meta(P);
     std::vector<uint64_t> bitpos(P);
@@ -240,6 +250,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
     bits.resize((bw.pos + 63) / 64 + 16, 0);           // zero padding words for the cursors' look-ahead
     alg_bytes += 4ull * (N ? N * (N - 1) / 2 : 0);
 
+    phase("node arrays + bit packing");
     // ---- equal-cost segments -------------------------------------------------------------------
     uint32_t want = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1, P / 48));
     want = (want + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
@@ -266,6 +277,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
     db->n_bit_words = bits.size();
     db->n_segs = (uint32_t)segs.size();
     int rc = 0;
+    phase("segments");
     rc |= dev_upload(&db->meta, meta.data(), P);
     rc |= dev_upload(&db->bitpos, bitpos.data(), P);
     rc |= dev_upload(&db->parent, parent.data(), P);
@@ -365,7 +377,9 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
             }
         }
         const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth, &meta, &bitpos, &nsegs, &nseg_anc, &nseg_anc_n};
+        phase("copies + emit metadata");
         if (kmdb_records_prepare(db, hl)) { kmdb_db_free(db); return 1; }
+        phase("block-record preparation");
     }
     db->stats.device_bytes += kmdb_records_device_bytes(db);
     *out = db;
