@@ -32,6 +32,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -112,28 +113,6 @@ __global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t N, c
 // ------------------------------------------------------------------------------------------
 namespace {
 
-struct BitWriter {
-    std::vector<uint64_t>& words;
-    uint64_t pos = 0;
-    explicit BitWriter(std::vector<uint64_t>& w) : words(w) {}
-    // append the first `nbits` bits (MSB-first) of src
-    void append(const uint64_t* src, uint32_t nbits) {
-        uint64_t need = (pos + nbits + 63) / 64 + 1;
-        if (words.size() < need) words.resize(std::max<uint64_t>(need, words.size() * 2), 0);
-        uint32_t done = 0;
-        while (done < nbits) {
-            uint32_t take = std::min<uint32_t>(64, nbits - done);
-            uint64_t chunk = src[done >> 6];                     // done is always a multiple of 64 here
-            if (take < 64) chunk &= ~0ull << (64 - take);
-            uint32_t s = (uint32_t)(pos & 63);
-            words[pos >> 6] |= chunk >> s;
-            if (s && take > 64 - s) words[(pos >> 6) + 1] |= chunk << (64 - s);
-            pos += take;
-            done += take;
-        }
-    }
-};
-
 template <class T>
 int dev_upload(T** dst, const T* src, size_t n) {
     size_t bytes = std::max<size_t>(1, n) * sizeof(T);
@@ -211,43 +190,77 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
 
     phase("DFS order");
     // ---- DFS-ordered arrays, bit-packed streams, cost model ----------------------------------
+    // (host threads over contiguous DFS ranges: the gathers through `order` are random reads of the view)
     std::vector<uint4> meta(P);
-    std::vector<uint64_t> bitpos(P);
+    std::vector<uint64_t> bitpos(P + 1, 0);
     std::vector<int32_t> parent(P);
     std::vector<uint32_t> w(P + 1, 0);
-    std::vector<uint64_t> bits;
-    bits.reserve(v->n_data_words / 4 + 16);
-    BitWriter bw(bits);
     std::vector<uint64_t> cost_prefix(P + 1, 0);
     uint64_t alg_bytes = 0, tree_updates = 0, sum_pairs = 0;
     uint32_t max_n = 0;
-    for (uint64_t i = 0; i < P; ++i) {
-        const uint32_t pid = order[i];
-        const uint32_t n = v->num_samples[pid], l = v->num_local[pid], nb = v->num_bits[pid];
-        if (l > n || n > N) return kmdb_set_error("kmdb_db_upload: inconsistent pattern header");
-        meta[i] = make_uint4(n, l, v->last_sample_id[pid], nb);
-        max_n = std::max(max_n, n);
-        bitpos[i] = bw.pos;
-        if (nb) bw.append(v->data + v->data_offset[pid], nb);
-        const int64_t par = v->parent_id[pid];
-        parent[i] = par < 0 ? -1 : (int32_t)dfs_of[par];
-        w[i] = (uint32_t)v->num_kmers[pid];
-        const uint64_t upd = (uint64_t)(n - l) * l + (uint64_t)l * (l ? l - 1 : 0) / 2;
-        tree_updates += upd;
-        sum_pairs += (uint64_t)v->num_kmers[pid] * ((uint64_t)n * (n ? n - 1 : 0) / 2);
-        alg_bytes += 40 + (uint64_t)((nb + 127) / 128) * 16;
-        // per-node cost in "wave instructions": decode share + one scatter instruction per 64 columns per row
-        uint64_t rows_cost = 0;
-        if (l) {
-            // sum over t in [n-l, n) of (t/64 + 1)
-            for (uint32_t blk = (n - l) / 64; blk <= (n - 1) / 64; ++blk) {
-                uint32_t lo = std::max<uint32_t>(n - l, blk * 64), hi = std::min<uint32_t>(n, blk * 64 + 64);
-                rows_cost += (uint64_t)(hi - lo) * (blk + 1);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::min<uint64_t>(std::min(32u, hw), std::max<uint64_t>(1, P / 65536));
+    struct Part { uint64_t alg = 0, upd = 0, pairs = 0; uint32_t max_n = 0; bool bad = false; };
+    std::vector<Part> parts(T);
+    auto run_parts = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back([&, t] { fn(t, P * t / T, P * (t + 1) / T); });
+        fn(0u, (uint64_t)0, P / T);
+        for (auto& th : pool) th.join();
+    };
+    run_parts([&](unsigned t, uint64_t lo, uint64_t hi) {
+        Part& pt = parts[t];
+        for (uint64_t i = lo; i < hi; ++i) {
+            const uint32_t pid = order[i];
+            const uint32_t n = v->num_samples[pid], l = v->num_local[pid], nb = v->num_bits[pid];
+            if (l > n || n > N) { pt.bad = true; continue; }
+            meta[i] = make_uint4(n, l, v->last_sample_id[pid], nb);
+            pt.max_n = std::max(pt.max_n, n);
+            bitpos[i + 1] = nb;                               // scanned below
+            const int64_t par = v->parent_id[pid];
+            parent[i] = par < 0 ? -1 : (int32_t)dfs_of[par];
+            w[i] = (uint32_t)v->num_kmers[pid];
+            pt.upd += (uint64_t)(n - l) * l + (uint64_t)l * (l ? l - 1 : 0) / 2;
+            pt.pairs += (uint64_t)v->num_kmers[pid] * ((uint64_t)n * (n ? n - 1 : 0) / 2);
+            pt.alg += 40 + (uint64_t)((nb + 127) / 128) * 16;
+            // per-node cost in "wave instructions": decode share + one scatter instruction per 64 columns per row
+            uint64_t rows_cost = 0;
+            if (l) {
+                // sum over t in [n-l, n) of (t/64 + 1)
+                for (uint32_t blk = (n - l) / 64; blk <= (n - 1) / 64; ++blk) {
+                    uint32_t lo2 = std::max<uint32_t>(n - l, blk * 64), hi2 = std::min<uint32_t>(n, blk * 64 + 64);
+                    rows_cost += (uint64_t)(hi2 - lo2) * (blk + 1);
+                }
+            }
+            cost_prefix[i + 1] = 4 + l / 2 + rows_cost * 2;   // scanned below
+        }
+    });
+    for (const Part& pt : parts) {
+        if (pt.bad) return kmdb_set_error("kmdb_db_upload: inconsistent pattern header");
+        alg_bytes += pt.alg; tree_updates += pt.upd; sum_pairs += pt.pairs; max_n = std::max(max_n, pt.max_n);
+    }
+    for (uint64_t i = 0; i < P; ++i) { bitpos[i + 1] += bitpos[i]; cost_prefix[i + 1] += cost_prefix[i]; }
+    const uint64_t total_bits = bitpos[P];
+    std::vector<uint64_t> bits((total_bits + 63) / 64 + 16, 0);    // zero padding words for the cursors' look-ahead
+    run_parts([&](unsigned, uint64_t lo, uint64_t hi) {
+        // streams of different threads can share a word at the range boundaries: OR the words in atomically
+        for (uint64_t i = lo; i < hi; ++i) {
+            const uint32_t nb = meta[i].w;
+            if (!nb) continue;
+            const uint64_t* src = v->data + v->data_offset[order[i]];
+            uint64_t pos = bitpos[i];
+            for (uint32_t done = 0; done < nb; done += 64) {
+                const uint32_t take = std::min<uint32_t>(64, nb - done);
+                uint64_t chunk = src[done >> 6];
+                if (take < 64) chunk &= ~0ull << (64 - take);
+                const uint32_t sh = (uint32_t)(pos & 63);
+                __atomic_fetch_or(&bits[pos >> 6], chunk >> sh, __ATOMIC_RELAXED);
+                if (sh && take > 64 - sh) __atomic_fetch_or(&bits[(pos >> 6) + 1], chunk << (64 - sh), __ATOMIC_RELAXED);
+                pos += take;
             }
         }
-        cost_prefix[i + 1] = cost_prefix[i] + 4 + l / 2 + rows_cost * 2;
-    }
-    bits.resize((bw.pos + 63) / 64 + 16, 0);           // zero padding words for the cursors' look-ahead
+    });
+    bitpos.pop_back();
     alg_bytes += 4ull * (N ? N * (N - 1) / 2 : 0);
 
     phase("node arrays + bit packing");
