@@ -1456,7 +1456,7 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
                 else if (rank[pp] >= 0) wparent[k] = rank[pp];
                 else { wparent[k] = -(pp + 2); nlf[pp] |= 1u << 30; }
             }
-            size_t WSEG = 512;                                         // wide nodes per slice (8 batches)
+            size_t WSEG = 256;                                         // wide nodes per slice (4 batches)
             if (const char* e = getenv("KMDB_WSEG")) WSEG = std::max<size_t>(64, strtoull(e, nullptr, 10));
             const size_t n_wsegs = (nW + WSEG - 1) / WSEG;
             std::vector<Segment> wsegs(n_wsegs);
