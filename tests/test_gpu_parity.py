@@ -2,6 +2,7 @@
 the committed outputs of the real reference, bit-exact (all arithmetic is uint32 / integer)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -506,3 +507,13 @@ def test_new2all_synthetic_scale(K, O, dev, tmp_path):
         assert np.array_equal(rows.reshape(len(qs), N), exp)
     # all2all of the same upload still works (hashtables do not disturb it)
     assert np.array_equal(d.all2all_dense(), o.all2all_dense())
+
+
+@pytest.mark.gpu
+def test_randomised_stress_of_the_block_record_pipeline(dev):
+    """profiles/r01_fuzz_stress.py: random forests x random block widths (odd ones too, which the width search never
+    picks) x both front halves, against the v1 kernels that the tests above pin to the oracle."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "r01_fuzz_stress.py"), "60", "2026"], capture_output=True,
+                       text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "60 cases, 0 mismatches" in r.stdout
