@@ -517,3 +517,40 @@ def test_randomised_stress_of_the_block_record_pipeline(dev):
                        text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60 cases, 0 mismatches" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stem,k,fraction", [("virus_k18", 18, 1.0), ("synth_k21", 21, 1.0), ("virus_k24", 24, 1.0),
+                                              ("virus_k25_f01_part1", 25, 0.1), ("virus_k18_f01", 18, 0.1)])
+def test_device_side_extraction_fuzz(K, golden_dir, dev, stem, k, fraction):
+    """random sequences (both cases, U, invalid symbols, record breaks, homopolymers) through kmdb_new2all_batch_seq and
+    through the host loader + kmdb_new2all_batch: same unique k-mer counts, same similarity rows, for several k and with
+    the minhash filter."""
+    path = os.path.join(golden_dir, stem + ".db")
+    d = K.DeviceDB(K.HostDB(path), device=dev, with_hashtables=True)
+    rng = np.random.default_rng(k * 1000 + int(fraction * 10))
+    genome = open(os.path.join(golden_dir, "test/virus/data/MT159713.fasta")).read().split("\n", 1)[1].replace("\n", "")
+    alphabet = np.frombuffer(b"ACGTacgtUuNn-\n", dtype=np.uint8)
+    texts = []
+    for q in range(24):
+        n = int(rng.integers(0, 4000))
+        if q % 3 == 0:                                   # pieces of a real genome (hits in the virus databases) with noise
+            a = int(rng.integers(0, len(genome) - n - 1))
+            b = bytearray(genome[a:a + n].encode())
+            for pos in rng.integers(0, max(1, n), size=n // 200):
+                if n:
+                    b[int(pos)] = int(alphabet[int(rng.integers(0, len(alphabet)))])
+            texts.append(bytes(b))
+        elif q % 3 == 1:
+            p = np.array([8, 8, 8, 8, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1], dtype=float)
+            texts.append(alphabet[rng.choice(len(alphabet), size=n, p=p / p.sum())].tobytes())
+        else:
+            texts.append((b"A" * int(rng.integers(0, 3 * k))) + b"\n" + (b"ACGT" * int(rng.integers(0, 40))))
+    host = []
+    for t in texts:
+        parts = [K.extract_kmers(rec, k, fraction) for rec in t.split(b"\n")] if t else []
+        host.append(K.sort_unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64))
+    got, cnt = d.new2all_seq(texts, fraction=fraction)
+    assert [int(c) for c in cnt] == [h.size for h in host]
+    assert np.array_equal(got, d.new2all(host))
+    assert got.any() or not stem.startswith("virus")          # the genome pieces hit the virus databases
