@@ -1161,22 +1161,22 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
         lds_sync();
         if (CLS == 0) {
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                if ((uint32_t)(g * 8) < njs) {                        // rows >= the block width never occur
+            for (int g = 0; g < 16; ++g) {
+                if ((uint32_t)(g * 4) < njs) {                        // rows >= the block width never occur
                     asm volatile("" ::: "memory");    // keep a group's LDS reads together (register pressure)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Ct & ROWMASK(r)); }
+                    for (int k = 0; k < 4; ++k) { const int r = g * 4 + k; a[r] += (uint32_t)__popcll(Ct & ROWMASK(r)); }
                 }
             }
         } else if (CLS == 1) {
             const unsigned long long Codd = Ct & __ballot((W & 1u) != 0);
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                if ((uint32_t)(g * 8) < njs) {
+            for (int g = 0; g < 16; ++g) {
+                if ((uint32_t)(g * 4) < njs) {
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int r = g * 8 + k;
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = g * 4 + k;
                         const unsigned long long Rr = ROWMASK(r);
                         a[r] += 2u * (uint32_t)__popcll(Ct & Rr) + (uint32_t)__popcll(Codd & Rr);
                     }
@@ -1191,11 +1191,11 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
                 const uint32_t b = (uint32_t)__builtin_ctz(wb);
                 const unsigned long long Cb = Ct & __ballot(((W >> b) & 1u) != 0);
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    if ((uint32_t)(g * 8) < njs) {
+                for (int g = 0; g < 16; ++g) {
+                    if ((uint32_t)(g * 4) < njs) {
                         asm volatile("" ::: "memory");
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) { const int r = g * 8 + k; a[r] += (uint32_t)__popcll(Cb & ROWMASK(r)) << b; }
+                        for (int k = 0; k < 4; ++k) { const int r = g * 4 + k; a[r] += (uint32_t)__popcll(Cb & ROWMASK(r)) << b; }
                     }
                 }
             }
