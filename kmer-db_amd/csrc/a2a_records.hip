@@ -34,10 +34,11 @@ namespace {
 // buckets (on the diagonal cols == rows); w only for the classes with w > 1
 struct B2Recs { unsigned long long* rows; ulonglong2* rc; uint32_t* w; };   // rows: diagonal buckets; rc = {rows, cols}: others
 struct B2Item { uint32_t X, Y, cls, begin, end; };
-// Records are grouped by weight class so that the apply kernel runs a fixed number of bit planes per group:
-// class 0: w == 1 (no weight stored), class 1: w in {2, 3} (two planes), class 2: w >= 4 (all planes).
+// Records are grouped by weight class: class 0: w == 1 (no weight stored; popcounts, or unit bytes on the matrix
+// cores), class 1: 2 <= w < 128 (the weight is one signed byte of an int8 MFMA operand), class 2: w >= 128 (rare:
+// one popcount pass per bit plane).
 constexpr uint32_t B2_NCLS = 3;
-__host__ __device__ __forceinline__ uint32_t b2_weight_class(uint32_t w) { return w == 1u ? 0u : w < 4u ? 1u : 2u; }
+__host__ __device__ __forceinline__ uint32_t b2_weight_class(uint32_t w) { return w == 1u ? 0u : w < 128u ? 1u : 2u; }
 
 constexpr int B2_WAVES = 4;
 
@@ -709,7 +710,7 @@ chain_update:
 
 
 template <int NBW, bool EMIT, bool INDIRECT>
-__global__ __launch_bounds__(WAVE * B3_WAVES) __attribute__((amdgpu_waves_per_eu(3, 8))) void b3_emit_kernel(B3Params q) {
+__global__ __launch_bounds__(WAVE * B3_WAVES) void b3_emit_kernel(B3Params q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -1128,8 +1129,6 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
     if ((dbg & 64u) && CLS == 0) return;
     if ((dbg & 128u) && CLS != 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
-    __syncthreads();
     const bool diag = DIAG;
     const uint32_t njs = DIAG ? bwidth / 2u : bwidth;                    // accumulators in use
     const uint32_t wrapd = bwidth - lane;                                 // DIAG: row of accumulator j = lane + j + 1 (mod width)
@@ -1166,20 +1165,6 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
                     asm volatile("" ::: "memory");    // keep a group's LDS reads together (register pressure)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { const int r = g * 4 + k; a[r] += (uint32_t)__popcll(Ct & ROWMASK(r)); }
-                }
-            }
-        } else if (CLS == 1) {
-            const unsigned long long Codd = Ct & __ballot((W & 1u) != 0);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                if ((uint32_t)(g * 4) < njs) {
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int r = g * 4 + k;
-                        const unsigned long long Rr = ROWMASK(r);
-                        a[r] += 2u * (uint32_t)__popcll(Ct & Rr) + (uint32_t)__popcll(Codd & Rr);
-                    }
                 }
             }
         } else {
@@ -1228,18 +1213,119 @@ __device__ __forceinline__ void b2_apply_item(const B2Recs& rec, const B2Item& i
     }
 }
 
+// The same accumulation on the matrix cores: over the 64 records of a step,
+//     cell(r, c) += sum_k  w_k [r in rows_k] * [c in cols_k]    =  (A B)(r, c),   A = 64 x 64 int8 (rows x records, weighted),
+//                                                                                B = 64 x 64 int8 (records x cols, 0/1)
+// as eight v_mfma_i32_32x32x32_i8 (operand layout probed in profiles/r01_mfma_i8_layout_probe.hip: lane l holds
+// A[l & 31][16 (l >> 5) + j], B[16 (l >> 5) + j][l & 31], j < 16; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).
+// The bit matrices R^T / C^T of the step are parked in LDS; a lane turns 16 of their bits into 16 operand bytes with two
+// reads of a 256-entry byte-spreading table and ANDs the weights in.  The work does not depend on the weights, so
+// every weight below 128 costs the same as 1 — this path takes class 1 and the off-diagonal part of class 0 (on the
+// diagonal of class 0 the folded popcount loop is cheaper).
+typedef int b2_v4i __attribute__((ext_vector_type(4)));
+typedef int b2_v16i __attribute__((ext_vector_type(16)));
+
+template <bool WEIGHTED, bool DIAG>
+__device__ __forceinline__ void b2_apply_item_mfma(const B2Recs& rec, const B2Item& it, uint32_t* __restrict__ M, uint32_t dbg, uint32_t bwidth,
+                                                   uint32_t* acc, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
+                                                   unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01) {
+    if ((dbg & 64u) && !WEIGHTED) return;
+    if ((dbg & 128u) && WEIGHTED) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t half = lane >> 5, l31 = lane & 31u;
+    b2_v16i c00 = {}, c01 = {}, c10 = {}, c11 = {};
+    const unsigned long long* lut_a = WEIGHTED ? lut_ff : lut_01;
+    auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> b2_v4i {
+        const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
+        const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
+        b2_v4i r;
+        r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
+        return r;
+    };
+    unsigned long long nR = 0, nC = 0;
+    uint32_t nW = 0;
+    auto fetch = [&](uint32_t g) {
+        const uint32_t j = g + lane;
+        nR = 0; nC = 0; nW = 0;
+        if (j < it.end) {
+            if (DIAG) { nR = rec.rows[j]; nC = nR; }
+            else { const ulonglong2 rc = rec.rc[j]; nR = rc.x; nC = rc.y; }
+            nW = WEIGHTED ? rec.w[j] : 1u;
+        }
+    };
+    fetch(it.begin + wave * 64);
+    for (uint32_t g0 = it.begin + wave * 64; g0 < it.end; g0 += 256) {
+        const unsigned long long R = nR, C = nC;
+        const uint32_t W = nW;
+        if (g0 + 256 < it.end) fetch(g0 + 256);
+        const unsigned long long Ct = transpose64(C, lane);
+        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);
+        if (!DIAG) ctbuf[wave][lane] = Ct;
+        if (WEIGHTED) wbuf[wave][lane] = (unsigned char)W;
+        lds_sync();
+        const unsigned long long* rtp = rtbuf[wave];
+        const unsigned long long* ctp = DIAG ? rtbuf[wave] : ctbuf[wave];
+        const unsigned long long ra0 = rtp[l31], ra1 = rtp[32u + l31], cb0 = ctp[l31], cb1 = ctp[32u + l31];
+#pragma unroll
+        for (uint32_t kh = 0; kh < 2; ++kh) {
+            const uint32_t shift = 32u * kh + 16u * half;            // records 32 kh + 16 half .. + 15 of the step
+            b2_v4i a0 = spread(ra0, shift, lut_a), a1 = spread(ra1, shift, lut_a);
+            if (WEIGHTED) {
+                const b2_v4i wv = *(const b2_v4i*)(wbuf[wave] + shift);
+                a0 &= wv; a1 &= wv;
+            }
+            const b2_v4i b0 = spread(cb0, shift, lut_01), b1 = spread(cb1, shift, lut_01);
+            c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c11, 0, 0, 0);
+        }
+        lds_sync();
+    }
+    // merge the four waves' tiles through the LDS block (on the diagonal only c < r), then one HBM atomic per non-zero cell
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
+        const uint32_t v00 = (uint32_t)c00[r], v01 = (uint32_t)c01[r], v10 = (uint32_t)c10[r], v11 = (uint32_t)c11[r];
+        if (v00 && (!DIAG || l31 < row0)) atomicAdd(&acc[row0 * 64 + l31], v00);
+        if (v01 && (!DIAG || 32u + l31 < row0)) atomicAdd(&acc[row0 * 64 + 32u + l31], v01);
+        if (v10 && (!DIAG || l31 < 32u + row0)) atomicAdd(&acc[(32u + row0) * 64 + l31], v10);
+        if (v11 && (!DIAG || l31 < row0)) atomicAdd(&acc[(32u + row0) * 64 + 32u + l31], v11);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
+        const uint32_t v = acc[k];
+        if (!v) continue;
+        const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
+        if (!(dbg & 1024u)) atomicAdd(&M[tri64(row) + col], v);
+    }
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void b2_apply_kernel(const B2Recs rec, const B2Item* __restrict__ items,
                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t dbg, uint32_t bwidth) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
+    __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
+    __shared__ unsigned long long lut_ff[256], lut_01[256];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
     const B2Item it = items[blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
+    {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= ((threadIdx.x >> i) & 1u) ? 0xFFull << (8 * i) : 0ull;
+        lut_ff[threadIdx.x] = v;
+        lut_01[threadIdx.x] = v & 0x0101010101010101ull;
+    }
+    __syncthreads();
     if (it.X == it.Y) {
         if (it.cls == 0) b2_apply_item<0, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
-        else if (it.cls == 1) b2_apply_item<1, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
+        else if (it.cls == 1 && !(dbg & 65536u)) b2_apply_item_mfma<true, true>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
         else b2_apply_item<2, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
     } else {
-        if (it.cls == 0) b2_apply_item<0, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
-        else if (it.cls == 1) b2_apply_item<1, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
+        if (it.cls == 0 && (dbg & 4096u)) b2_apply_item<0, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
+        else if (it.cls == 0) b2_apply_item_mfma<false, false>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        else if (it.cls == 1 && !(dbg & 131072u)) b2_apply_item_mfma<true, false>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
         else b2_apply_item<2, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
     }
 }
@@ -1505,8 +1591,16 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
             HIP_TRY(hipMemset(db->b3_ntable, 0, std::max<size_t>(ntbl, 1) * 4));
             if (b3_launch_narrow<false>(db, db->stream)) return 1;
             if (n_wsegs && b3_launch_emit<false, true>(db, db->stream)) return 1;
-            if (getenv("KMDB_VERBOSE"))
-                fprintf(stderr, "[kmdb] width %u: %zu of %llu nodes are wide (%zu slices)\n", width, nW, (unsigned long long)P, n_wsegs);
+            if (getenv("KMDB_VERBOSE")) {
+                uint64_t expect = 0, expect_wide = 0;                  // records the block masks imply: p (p + 1) / 2 per pattern with k-mers
+                for (uint64_t i = 0; i < P; ++i) {
+                    const uint32_t pw = (uint32_t)__builtin_popcount(fw[i]);
+                    if (((*h.nl)[i] & 0xFFFFu) >= 2u && h.w && (*h.w)[i]) { expect += (uint64_t)pw * (pw + 1) / 2; if (pw > 2) expect_wide += (uint64_t)pw * (pw + 1) / 2; }
+                }
+                fprintf(stderr, "[kmdb] width %u: of which %llu from nodes with more than two blocks\n", width, (unsigned long long)expect_wide);
+                fprintf(stderr, "[kmdb] width %u: %zu of %llu nodes are wide (%zu slices), %llu records expected\n", width, nW,
+                        (unsigned long long)P, n_wsegs, (unsigned long long)expect);
+            }
         }
     } else {
         if (b2_launch_emit<false>(db, 0, db->n_rsegs, 0, db->stream)) return 1;
@@ -1517,6 +1611,13 @@ int b2_prepare_width(kmdb_db* db, uint32_t width, const kmdb_host_layout& h, boo
     // bucket-major record order: all records of (bucket, class) c are contiguous, segment by segment
     std::vector<uint32_t> ncounts(ntbl), nbases(ntbl);
     if (ntbl) HIP_TRY(hipMemcpy(ncounts.data(), db->b3_ntable, ntbl * 4, hipMemcpyDeviceToHost));
+    if (getenv("KMDB_VERBOSE") && ntbl) {
+        uint64_t sn = 0, sw = 0;
+        for (uint32_t v : ncounts) sn += v;
+        for (uint32_t v : counts) sw += v;
+        fprintf(stderr, "[kmdb] width %u: count mode: %llu records from the slim kernel, %llu from the wide list\n", width,
+                (unsigned long long)sn, (unsigned long long)sw);
+    }
     std::vector<uint32_t> bases(tbl);
     std::vector<uint64_t> cstart(db->b2_nctr + 1, 0);
     uint64_t run = 0;

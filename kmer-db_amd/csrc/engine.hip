@@ -389,7 +389,7 @@ extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int 
                 while (cur >= 0) { nseg_anc[sidx * anc_stride + (--d)] = (uint32_t)cur; cur = parent[cur]; }
             }
         }
-        const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth, &meta, &bitpos, &nsegs, &nseg_anc, &nseg_anc_n};
+        const kmdb_host_layout hl{max_n, chain_ok, &perm, &nl, &seg_anc, &seg_anc_n, &parent, &depth, &meta, &bitpos, &nsegs, &nseg_anc, &nseg_anc_n, &w};
         phase("copies + emit metadata");
         if (kmdb_records_prepare(db, hl)) { kmdb_db_free(db); return 1; }
         phase("block-record preparation");

@@ -124,6 +124,7 @@ struct kmdb_host_layout {               // host copies of upload-time arrays the
     const std::vector<Segment>* nsegs;            // narrow kernel slices + root paths
     const std::vector<uint32_t>* nseg_anc;
     const std::vector<uint32_t>* nseg_anc_n;
+    const std::vector<uint32_t>* w;               // on-disk weights, DFS order
 };
 int kmdb_records_prepare(kmdb_db* db, const kmdb_host_layout& h);
 // per call: decode + emit (+ sequential emit fallback) + apply; records events ev_k0 / ev_k2

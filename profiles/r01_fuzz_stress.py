@@ -34,7 +34,7 @@ for c in range(cases):
         os.environ.pop("KMDB_BLOCK_WIDTH", None)
     d = K.DeviceDB(view, device=0)
     ref = d.all2all_dense(flags=K.capi.FLAG_FORCE_GLOBAL_ATOMICS)
-    got = d.all2all_dense()
+    got = d.all2all_dense(flags=int(os.environ.get('FUZZ_FLAGS', '0')))
     ok = np.array_equal(got, ref) and (d.stats()["n_records"] > 0 or arr["num_samples"].max() > 1024 or P < 3)
     dseq = K.DeviceDB(view, device=0, flags=K.capi.FLAG_FORCE_SEQ_EMIT)
     ok2 = np.array_equal(dseq.all2all_dense(), ref)
