@@ -1319,13 +1319,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     __syncthreads();
     if (it.X == it.Y) {
-        if (it.cls == 0) b2_apply_item<0, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
-        else if (it.cls == 1 && !(dbg & 65536u)) b2_apply_item_mfma<true, true>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        if (it.cls == 0) b2_apply_item_mfma<false, true>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        else if (it.cls == 1) b2_apply_item_mfma<true, true>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
         else b2_apply_item<2, true>(rec, it, M, dbg, bwidth, acc, rtbuf);
     } else {
-        if (it.cls == 0 && (dbg & 4096u)) b2_apply_item<0, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
-        else if (it.cls == 0) b2_apply_item_mfma<false, false>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-        else if (it.cls == 1 && !(dbg & 131072u)) b2_apply_item_mfma<true, false>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        if (it.cls == 0) b2_apply_item_mfma<false, false>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        else if (it.cls == 1) b2_apply_item_mfma<true, false>(rec, it, M, dbg, bwidth, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
         else b2_apply_item<2, false>(rec, it, M, dbg, bwidth, acc, rtbuf);
     }
 }
