@@ -24,7 +24,8 @@ namespace {
 //                          64 nodes per wave step, records (X, X, F) straight into the diagonal buckets
 //   K1w b3_emit_kernel     the other nodes, from their own DFS-ordered list; F in up to NBW registers per lane
 //                          (compact: only the words the batch touches), record-parallel emission
-//   K2  b2_apply_kernel    records -> matrix: 64 records per wave step as bit matrices, popcount accumulate
+//   K2  b2_apply_kernel    records -> matrix: 64 records per wave step as bit matrices, int8 MFMA accumulate
+//                          (popcount passes per bit plane for the rare weights >= 128)
 // Records go straight to their final, bucket-grouped position: the per-(slice, bucket, weight class) record
 // counts are a pure function of the database and are tabulated once at upload with the count modes of the
 // same kernels (like CSR row pointers), so there is no sort and no global atomic at run time.
@@ -1112,13 +1113,12 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
-// K2: one workgroup per (bucket, chunk of records).  A wave takes 64 records per step, one per lane, and turns
-// them into bit matrices over the records: lane c holds Ct = "which of the 64 records contain column c", and
-// Rt_r = "which records contain row r" is a broadcast read from LDS.  cell(r, c) += popcount(Ct & Rt_r): ONE
-// add per cell per 64 records.  The cells live in registers (lane c keeps column c of the 64 x 64 block, one
-// register per row; v_bcnt accumulates for free) and are merged through LDS once per work item.
-// Weights: class 1 (w = 2, 3) = twice the count plus the count over the odd weights; class 2 = one pass per
-// bit plane of w that occurs in the step.
+// K2, popcount form (weights >= 128 only; everything else goes through b2_apply_item_mfma below): one workgroup per
+// (bucket, chunk of records).  A wave takes 64 records per step, one per lane, and turns them into bit matrices over
+// the records: lane c holds Ct = "which of the 64 records contain column c", and Rt_r = "which records contain row r"
+// is read from LDS.  cell(r, c) += popcount(Ct & Rt_r & plane_b) << b for every bit plane b of the weights that occurs
+// in the step.  The cells live in registers (lane c keeps column c of the 64 x 64 block, one register per row) and are
+// merged through LDS once per work item.
 // DIAG (X == Y, rows == cols): the block is symmetric and only c < r is wanted.  Lane c then takes the rows
 // (c + d) mod width for d = 1 .. width/2 instead of all rows: every unordered pair of samples exactly once (for an even
 // width the distance width/2 is kept by the lower half of the lanes) — half the row loop; the row mask is a per-lane
