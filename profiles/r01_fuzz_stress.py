@@ -1,6 +1,6 @@
 """Randomised stress of the block-record pipeline against the v1 kernels (which the test-suite pins to the oracle):
 random pattern forests, random block widths (even and odd), both front halves.
-usage: python profiles/r01_fuzz_stress.py [cases=60] [seed=1]"""
+usage: python profiles/r01_fuzz_stress.py [cases=60] [seed=1] [max_patterns=30000]"""
 import importlib
 import os
 import sys
@@ -16,10 +16,11 @@ K = import_kmerdb_amd()
 S = importlib.import_module("kmerdb_amd.synth")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MAXP = int(sys.argv[3]) if len(sys.argv) > 3 else 30000
 bad = 0
 for c in range(cases):
     N = int(rng.choice([2, 3, 31, 64, 65, 100, 257, 600, 1000, 1500, 2048]))
-    P = int(rng.integers(5, 30000))
+    P = int(rng.integers(5, MAXP))
     max_local = int(rng.choice([1, 2, 5, 40, 200]))
     width = int(rng.choice([0, 0, 32, 33, 47, 50, 63, 64]))
     if width and (N + width - 1) // width > 32:
