@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py — all2all common-k-mer counting throughput on MI355X.
+"""bench.py — all2all common-k-mer counting on MI355X: throughput AND wall-clock.
 
-One "step" = one dense all2all pass (SimilarityCalculator::all2all's job, reference
-src/similarity_calculator.cpp:42-438) over a synthetic clade-mutation database that is already
-resident in HBM: the block-record pipeline (gamma decode, narrow / wide emit, apply) + (N>1) the
-RCCL sum of the per-GPU partial matrices.  Workload at N=1 is BASELINE.json configs[1]: 1000 synthetic 5 Mbp genomes,
-k=18, f=1.0.  With --gpus N the k-mer space is sharded by prefix bucket (kmer >> 32, reference
-src/types.h:25-27): the genomes are N x 5 Mbp long and rank r owns the k-mers whose bucket is
-congruent to r mod N, so per-GPU work stays fixed ("weak") and the partial matrices sum exactly.
+One "step" = one dense all2all call (SimilarityCalculator::all2all's job, reference
+src/similarity_calculator.cpp:42-438, called once per run at console_all2all.cpp:31-36) on a synthetic
+clade-mutation database resident in HBM.  The call is self-contained: gamma decode, block placement, record
+emission and accumulation all happen inside it; upload only converts the on-disk format (DFS order, packed streams).
+Reported:
+  value / ms_per_step   warm calls (the timed K steps)
+  wall.upload_s         kmdb_db_upload: host conversion + H2D + device layout   (the reference's deserialize)
+  wall.cold_call_ms     first call after upload, host matrix out (H2D/D2H inclusive)
+  wall.cold_total_s     upload + first call = what one `all2all` run costs end to end, next to cpu_baseline.seconds
+Workloads (--workload): c2 = BASELINE.json configs[1], 1000 x 5 Mbp; c3shard = the per-GPU share of configs[2],
+10 000 samples x 625 kbp.  With --gpus N the k-mer space is sharded by prefix bucket (kmer >> 32, reference
+src/types.h:25-27): --scaling weak (default) keeps per-GPU work fixed (genomes N x longer, rank r owns the buckets
+congruent to r mod N); --scaling strong shards ONE database of the workload's size (kmdb_db_upload_shard).  The
+partial matrices are summed with one RCCL reduce.  `python bench.py --gpus N` starts its own N ranks.
 
 Prints ONE JSON line on stdout (rank 0); progress goes to stderr.
 """
@@ -28,13 +35,18 @@ from _kmerdb_loader import import_kmerdb_amd  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
+WORKLOADS = {
+    "c2": dict(samples=1000, clade_size=50, length=5_000_000),
+    "c3shard": dict(samples=10000, clade_size=50, length=625_000),
+}
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_shard_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, progress=None):
-    """patterns of the k-mers whose prefix bucket is owned by `rank`"""
+def build_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, progress=None, with_items=False):
+    """patterns of the k-mers whose prefix bucket is owned by `rank` (world == 1: all of them)"""
     g = S.CladeGenomes(n_samples, clade_size, length, seed=seed, device=device)
 
     def kmers(i):
@@ -45,62 +57,84 @@ def build_shard_db(K, S, n_samples, clade_size, length, k, seed, device, rank, w
     t0 = time.time()
     pat = S.build_patterns(kmers, n_samples, device, progress=progress)
     arr = S.to_view_arrays(pat)
+    items = S.shard_item_lists(pat["dictionary"], pat["kmer_pid"], k) if with_items else None
     log("[rank %d] synth db: %d samples x %d bp, %d k-mers, %d patterns in %.1f s" % (
         rank, n_samples, length, pat["dictionary"].numel(), arr["num_kmers"].size, time.time() - t0))
     names = [g.name(i) for i in range(n_samples)]
-    return arr, names, pat["sample_counts"], int(pat["dictionary"].numel())
+    return arr, names, pat["sample_counts"], int(pat["dictionary"].numel()), items
 
 
-def upload(K, arr, n_samples, k, device_index):
-    t0 = time.time()
+def upload(K, arr, n_samples, k, device_index, items=None, prefix_shard=None):
     view = K.make_view(k, n_samples, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
-                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
-    d = K.DeviceDB(view, device=device_index)
-    log("  layout + upload to HBM: %.1f s" % (time.time() - t0))
-    return d
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"],
+                       bucket_offset=None if items is None else items[0], slots=None if items is None else items[1])
+    t0 = time.perf_counter()
+    d = K.DeviceDB(view, device=device_index, prefix_shard=prefix_shard)
+    return d, time.perf_counter() - t0
 
 
-def cpu_baseline(K, S, args, device):
-    """The real reference hot path (oracle/_ref) — or the oracle's C restatement — timed on the
-    host cores on a bounded sample: the same 1000-sample model at a shorter genome length."""
-    from oracle import oracle as O
-    L = args.cpu_sample_length
-    arr, names, counts, nk = build_shard_db(K, S, args.samples, args.clade_size, L, args.k, args.seed, device, 0, 1)
+def cpu_baseline(K, S, O, args, device, arr, names, counts, nk, gpu_matrix):
+    """The real reference hot path (oracle/_ref) on the host cores, on the FULL database of the timed workload:
+    (threads, bufferMb) picked by a sweep on a 1/50-length sample, then one run on the full .db; the interval is the
+    reference's own "Calculating matrix of common k-mers" (console_all2all.cpp:31-36).  Without oracle/_ref: the
+    oracle's C restatement on the sample only (kind "port")."""
     cores = os.cpu_count() or 1
-    with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "sample.db")
-        S.write_db(path, args.k, 1.0, names, counts, arr, kmers_count=nk)
-        odb = O.OracleDB(path, skip_hashtables=True)
-        uc = odb.update_counts()
-        d = upload(K, arr, args.samples, args.k, device.index or 0)
-        gpu = d.all2all_dense()
-        if O.have_ref():
-            # the reference's 4-stage pipeline does not scale to hundreds of threads on inputs of this
-            # size; sweep -t / -buffer (README.md:185 of the reference) and report its best run
-            best, tried = None, []
-            for thr in sorted({min(cores, t) for t in (8, 16, 32, 64, 128)}):
-                for buf in (8, 32):
-                    m, info = O.ref_all2all(path, os.path.join(td, "m.u32"), threads=thr, buffer_mb=buf)
-                    tried.append((thr, buf, round(info["seconds"], 3)))
-                    if best is None or info["seconds"] < best[1]["seconds"]:
-                        best = (m, info)
-                    if info["seconds"] > 20:
-                        break
-            m, info = best
-            log("  reference sweep (threads, bufferMb, s):", tried)
-            kind, secs, used = "reference", info["seconds"], info["threads"]
-        else:
+    L = args.cpu_sample_length
+    sarr, snames, scounts, snk, _ = build_db(K, S, args.samples, args.clade_size, L, args.k, args.seed, device, 0, 1)
+    with tempfile.TemporaryDirectory(dir=args.tmp) as td:
+        spath = os.path.join(td, "sample.db")
+        S.write_db(spath, args.k, 1.0, snames, scounts, sarr, kmers_count=snk)
+        odb = O.OracleDB(spath, skip_hashtables=True)
+        d, _ = upload(K, sarr, args.samples, args.k, device.index or 0)
+        gpu_s = d.all2all_dense()
+        d.close()
+        if not O.have_ref():
             t0 = time.time()
             m = odb.all2all_dense()
-            kind, secs, used = "port", time.time() - t0, 1
-        assert np.array_equal(m, gpu), "GPU result differs from the CPU baseline on the sample database"
-        d.close()
-    return {
-        "value": uc["sum_matrix"] / secs, "unit": "kmer-pair-comparisons/s", "cores": used, "host_cores": cores, "kind": kind,
-        "seconds": secs, "cell_updates_per_s": uc["tree_updates"] / secs,
-        "sample": "same %d-sample clade model at genome length %d bp (1/%d of the timed workload), %d patterns; "
-                  "GPU matrix on this sample verified bit-identical" % (args.samples, L, max(1, args.length // L), odb.P),
-    }
+            secs = time.time() - t0
+            assert np.array_equal(m, gpu_s), "GPU result differs from the CPU baseline on the sample database"
+            uc = odb.update_counts()
+            return {"value": uc["sum_matrix"] / secs, "unit": "kmer-pair-comparisons/s", "cores": 1, "host_cores": cores, "kind": "port",
+                    "seconds": secs, "sample": "oracle C restatement on the same %d-sample model at genome length %d bp (oracle/_ref not built)"
+                    % (args.samples, L)}
+        # the reference's 4-stage pipeline does not scale to hundreds of threads; sweep -t / -buffer (README.md:185 of
+        # the reference) on the sample and keep the best pair
+        best, tried = None, []
+        for thr in sorted({min(cores, t) for t in (8, 16, 32, 64)}):
+            for buf in (8, 32):
+                m, info = O.ref_all2all(spath, os.path.join(td, "m.u32"), threads=thr, buffer_mb=buf)
+                tried.append((thr, buf, round(info["seconds"], 3)))
+                if best is None or info["seconds"] < best[1]["seconds"]:
+                    best = (m, info, thr, buf)
+        assert np.array_equal(best[0], gpu_s), "GPU result differs from the reference on the sample database"
+        log("  reference sweep on the sample (threads, bufferMb, s):", tried)
+        thr, buf = best[2], best[3]
+        # the full database: written once in the reference's format, one run
+        t0 = time.time()
+        path = os.path.join(td, "full.db")
+        S.write_db_fast(path, args.k, 1.0, names, counts, arr, kmers_count=nk, device=device)
+        log("  full .db written: %.1f GB in %.1f s" % (os.path.getsize(path) / 1e9, time.time() - t0))
+        t0 = time.time()
+        m, info = O.ref_all2all(path, os.path.join(td, "full.u32"), threads=thr, buffer_mb=buf)
+        log("  reference on the full database: compute %.2f s (whole process incl. deserialize %.1f s)" % (info["seconds"], time.time() - t0))
+        assert np.array_equal(m, gpu_matrix), "GPU matrix differs from the reference's on the full database"
+        sum_pairs = float(m.astype(np.uint64).sum())
+        return {"value": sum_pairs / info["seconds"], "unit": "kmer-pair-comparisons/s", "cores": thr, "host_cores": cores, "kind": "reference",
+                "seconds": info["seconds"], "process_seconds": time.time() - t0, "buffer_mb": buf,
+                "sample": "full %s database (%d patterns), reference SimilarityCalculator::all2all compute interval, -t %d -buffer %d "
+                          "(best of a %d-point sweep on a 1/%d-length sample); the whole %d-cell GPU matrix compared equal"
+                          % (args.workload, arr["num_kmers"].size, thr, buf, len(tried), max(1, args.length // L), m.size)}
+
+
+def respawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run"""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -108,44 +142,71 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--samples", type=int, default=1000)
-    ap.add_argument("--clade-size", type=int, default=50)
-    ap.add_argument("--length", type=int, default=5_000_000, help="genome length per GPU (bp)")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--clade-size", type=int, default=None)
+    ap.add_argument("--length", type=int, default=None, help="genome length (bp); per GPU with --scaling weak")
     ap.add_argument("--k", type=int, default=18)
     ap.add_argument("--seed", type=int, default=20260928 + 1)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample-length", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tmp", default=None, help="directory for the reference's .db files (default: the system temp dir)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the matrix reduce goes through host memory); never used for reported numbers")
     args = ap.parse_args()
+    for key, val in WORKLOADS[args.workload].items():
+        if getattr(args, key) is None:
+            setattr(args, key, val)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU path to time")
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    rccl = None
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
         else:
             dist.init_process_group("gloo")
     K = import_kmerdb_amd()
     import importlib
     S = importlib.import_module("kmerdb_amd.synth")
 
-    total_len = args.length * world
-    arr, names, counts, nk = build_shard_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device,
-                                            rank, world, progress=100 if rank == 0 else None)
-    torch.cuda.empty_cache()
-    db = upload(K, arr, args.samples, args.k, dev_index)
-    del arr
+    strong = world > 1 and args.scaling == "strong"
+    total_len = args.length if (world == 1 or strong) else args.length * world
+    if strong:
+        # every rank derives the same database and keeps its prefix shard of it
+        arr, names, counts, nk, items = build_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device, rank, 1,
+                                                 progress=100 if rank == 0 else None, with_items=True)
+        torch.cuda.empty_cache()
+        db, upload_s = upload(K, arr, args.samples, args.k, dev_index, items=items, prefix_shard=(rank, world))
+    else:
+        arr, names, counts, nk, items = build_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device, rank, world,
+                                                 progress=100 if rank == 0 else None)
+        torch.cuda.empty_cache()
+        db, upload_s = upload(K, arr, args.samples, args.k, dev_index)
     st0 = db.stats()
+    log("[rank %d] upload %.2f s; block width %d" % (rank, upload_s, st0["width"]))
     cells = db.tri_size()
+    # the first call: host matrix out, as the front-end uses it (H2D / D2H inclusive, grid sizes measured on the way)
+    t0 = time.perf_counter()
+    first = db.all2all_dense()
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    stc = db.stats()
+    log("[rank %d] cold call %.1f ms (device pipeline %.2f ms, path %d)" % (rank, cold_ms, stc["kernel_ms"], stc["path"]))
+
     M = torch.zeros(max(cells, 1), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -169,55 +230,50 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    dom_ms, pipe_ms = [], []
+    call_ms, parts = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         _s = db.stats()
-        dom_ms.append(_s["dominant_kernel_ms"])
-        pipe_ms.append(_s["k0_ms"] + _s["k1_ms"] + _s["k2_ms"])
+        call_ms.append(_s["kernel_ms"])
+        parts.append((_s["k0_ms"], _s["k1n_ms"], _s["k1g_ms"], _s["k2_ms"]))
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         cdev = device if args.backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        t = torch.tensor([elapsed, upload_s, cold_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, upload_s, cold_ms = float(t[0]), float(t[1]), float(t[2])
         tot = torch.tensor([st0["sum_pairs"], st0["tree_updates"], st0["algorithmic_bytes"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         sum_pairs, tree_updates = float(tot[0]), float(tot[1])
     else:
         sum_pairs, tree_updates = float(st0["sum_pairs"]), float(st0["tree_updates"])
 
-    # size-independent check of the timed result: sum of the matrix == sum_p w_p C(n_p,2)
+    # size-independent check of the timed result: sum of the matrix == sum_p w_p C(n_p,2); and warm == cold
     if rank == 0:
         got = int(M[:cells].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) if cells else 0
         assert got == int(sum_pairs), "matrix checksum mismatch: %d vs %d" % (got, int(sum_pairs))
+        if world == 1:
+            assert np.array_equal(M[:cells].cpu().numpy().view(np.uint32), first), "warm call differs from the first call"
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         stl = db.stats()
-        if stl["n_records"]:
-            # block-record pipeline: the kernels share the pass; the roofline is quoted on their SUM
-            # (decode + narrow/wide emit + apply), never on the longest one alone
-            names_ms = [("b3_decode_kernel" if stl["k0_ms"] > 0 else None, stl["k0_ms"]),
-                        ("b3_narrow_kernel+b3_emit_kernel" if stl["k0_ms"] > 0 else "b2_emit_kernel", stl["k1_ms"]),
-                        ("b2_apply_kernel", stl["k2_ms"])]
-            kern_ms = float(np.mean(pipe_ms))
-            dom_name = "+".join(n for n, _ in names_ms if n)
-        else:
-            kern_ms = float(np.mean(dom_ms))
-            dom_name = "a2a_tile_kernel"
+        path_name = {1: "block-record pipeline", 2: "v1 tile kernel", 3: "v1 HBM-atomics kernel"}.get(stl["path"], "none")
+        kern_ms = float(np.mean(call_ms))                  # HIP events around the WHOLE call on its stream: zeroing, decode, emit, apply
+        pk = np.mean(np.array(parts), axis=0)
         alg = st0["algorithmic_bytes"]
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        # HBM bytes per pass come from separate rocprofv3 --pmc runs of this same command (profiles/): they
+        # HBM bytes per call come from separate rocprofv3 --pmc runs of this same command (profiles/): they
         # cannot be collected from inside the timed process; quoted only for the default workload
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.length == 5_000_000 and args.samples == 1000:
+        if os.path.exists(tpath) and world == 1 and args.workload == "c2" and args.length == 5_000_000 and args.samples == 1000:
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic, traffic_src = tj["traffic_bytes_per_pass"], "profiles/latest_traffic.json: " + tj["source"]
+            if tj.get("pipeline") == "r02":
+                traffic, traffic_src = tj["traffic_bytes_per_pass"], "REPLAYED from profiles/latest_traffic.json (not measured in this run): " + tj["source"]
         out = {
             "metric": "all2all k-mer pair-comparisons/sec",
             "value": sum_pairs / (elapsed / args.steps),
@@ -225,29 +281,45 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "%d synthetic %g Mbp genomes (clade-mutation model, clades of %d, r1=0.10 r2=0.01), k=%d f=1.0, "
-                            "dense all2all%s" % (args.samples, total_len / 1e6, args.clade_size, args.k,
-                                                 "" if world == 1 else ", k-mer space sharded by prefix bucket over %d GPUs + RCCL reduce" % world),
+                "workload": "%s: %d synthetic %g Mbp genomes (clade-mutation model, clades of %d, r1=0.10 r2=0.01), k=%d f=1.0, "
+                            "dense all2all%s" % (args.workload, args.samples, total_len / 1e6, args.clade_size, args.k,
+                                                 "" if world == 1 else ", k-mer space sharded by prefix bucket over %d GPUs (%s) + RCCL reduce"
+                                                 % (world, "one database, kmdb_db_upload_shard" if strong else "per-rank databases")),
                 "samples": args.samples, "genome_length_bp": total_len, "k": args.k, "fraction": 1.0,
-                "patterns_rank0": db.P, "distinct_kmers_rank0": nk, "parallelism": "prefix-shard x%d" % world,
+                "patterns_rank0": db.P, "distinct_kmers_rank0": nk, "parallelism": "prefix-shard x%d" % world, "rccl": rccl,
                 "sample_pairs_per_s": args.samples * (args.samples - 1) / 2 / (elapsed / args.steps),
                 "cell_updates_per_s": tree_updates / (elapsed / args.steps),
-                "tile_flushes": db.stats()["tile_flushes"],
+                "path": path_name, "block_width": stl["width"],
+            },
+            "wall": {
+                "upload_s": upload_s, "cold_call_ms": cold_ms, "cold_total_s": upload_s + cold_ms * 1e-3, "warm_ms": ms_per_step,
+                "note": "upload = kmdb_db_upload (format conversion: host narrowing + H2D + device DFS layout; no sample id decoded except "
+                        "the 1-in-%d sample of the block-width estimate); cold call = first kmdb_all2all_dense incl. D2H of the matrix; every "
+                        "call, warm or cold, decodes, places and accumulates everything itself" % max(1, min(1024, db.P // 65536)),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
-                "per_kernel_ms": {"decode": stl["k0_ms"], "emit": stl["k1_ms"], "apply": stl["k2_ms"], "whole_call": stl["kernel_ms"]},
-                "block_records_per_launch": stl["n_records"],
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "whole call: k0_decode_kernel + k1n_kernel + wide list + k1g_kernel + k2_apply_kernel (+ zeroing, pool init)",
+                "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
+                "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3]),
+                                  "whole_call": kern_ms},
+                "cold_call_frac": alg / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "block_records_per_launch": stl["n_records"], "wide_nodes": stl["n_wide"], "record_chunks": stl["n_chunks"],
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(K, S, args, device)
+            from oracle import oracle as O
+            db.close()
+            out["cpu_baseline"] = cpu_baseline(K, S, O, args, device, arr, names, counts, nk, first)
+            cb = out["cpu_baseline"]
+            if cb["kind"] == "reference":
+                out["wall"]["reference_compute_s"] = cb["seconds"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

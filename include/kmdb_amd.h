@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KMDB_ABI_VERSION 1
+#define KMDB_ABI_VERSION 2
 
 /* ---------------------------------------------------------------------------------------
  * Host-side view of a loaded database = what the reference hands to SimilarityCalculator:
@@ -59,9 +59,10 @@ typedef struct kmdb_db_view {
 typedef struct kmdb_opts {
     uint32_t abi_version;          /* KMDB_ABI_VERSION */
     int32_t  device;               /* HIP device ordinal */
-    /* pattern-stream sharding for multi-GPU runs: this call processes shard `shard_index`
-     * of `shard_count` equal-cost slices of the pattern stream; partial matrices from all
-     * shards sum (uint32, wrap-around) to the full result.  {0,1} = everything. */
+    /* pattern-stream sharding of ONE resident database: this call adds the pairs of the patterns in
+     * slice `shard_index` of `shard_count` equal slices of the (DFS-ordered) pattern stream; partial
+     * matrices from all slices sum (uint32, wrap-around) to the full result.  {0,1} = everything.
+     * (Prefix-bucket shards, one per GPU, are made at upload: kmdb_db_upload_shard.) */
     uint32_t shard_index;
     uint32_t shard_count;
     uint32_t bubble_size;          /* all2all-sp: -bubble-size (params.h:78), kept for CLI compat; 0 = default 8000 */
@@ -69,11 +70,18 @@ typedef struct kmdb_opts {
     void*    stream;               /* hipStream_t to run on, NULL = the engine's own stream */
 } kmdb_opts;
 
-#define KMDB_FLAG_FORCE_GLOBAL_ATOMICS 1u   /* debugging: generic kernel, stack in global scratch, HBM atomics */
-#define KMDB_FLAG_FORCE_DIRECT         2u   /* debugging: LDS stack, HBM atomics */
-#define KMDB_FLAG_FORCE_TILE           4u   /* v1 wave-private LDS tile kernel instead of the block-record pipeline */
-#define KMDB_FLAG_FORCE_SEQ_EMIT       8u   /* kmdb_db_upload only: lay the block-record pipeline out for the sequential (stack-replay)
-                                              emit kernel, the one used when root paths exceed 192 nodes */
+#define KMDB_FLAG_FORCE_GLOBAL_ATOMICS 1u   /* A/B reference: tree-form walk, id stack in global scratch, HBM atomics (any N, any depth) */
+#define KMDB_FLAG_FORCE_DIRECT         2u   /* A/B reference: tree-form walk, id stack in LDS, HBM atomics */
+#define KMDB_FLAG_FORCE_TILE           4u   /* A/B reference: tree-form walk, wave-private LDS tile */
+#define KMDB_FLAG_NO_FALLBACK          8u   /* fail instead of taking the HBM-atomics kernel when the block-record pipeline cannot
+                                              take the database (kmdb_stats.path tells which one ran) */
+#define KMDB_FLAG_ALL                  15u  /* any other bit in kmdb_opts.flags is rejected */
+
+/* kmdb_stats.path */
+#define KMDB_PATH_NONE     0u
+#define KMDB_PATH_RECORDS  1u   /* block-record pipeline (default) */
+#define KMDB_PATH_TILE     2u   /* v1 LDS tile / direct kernels (forced by a flag) */
+#define KMDB_PATH_GLOBAL   3u   /* v1 HBM-atomics kernel (forced, or fallback: a note goes to stderr) */
 
 typedef struct kmdb_db kmdb_db;    /* database resident in HBM */
 
@@ -100,7 +108,16 @@ typedef struct kmdb_stats {        /* measurements of the LAST call on this db h
     double   k1_ms;                /* block-record pipeline: emit kernel */
     double   k2_ms;                /* block-record pipeline: apply kernel */
     uint64_t n_records;            /* block records per pass (0 when the v1 kernels ran) */
-    double   k0_ms;                /* block-record pipeline: gamma decode kernel (0 when the sequential emit ran) */
+    double   k0_ms;                /* block-record pipeline: gamma decode kernels */
+    double   k1n_ms;               /* ... emit, nodes with at most two blocks (DFS stream) */
+    double   k1g_ms;               /* ... wide list + emit, nodes with more blocks */
+    double   upload_ms;            /* wall-clock of kmdb_db_upload for this handle (host conversion + H2D + device layout) */
+    uint64_t n_wide;               /* nodes with more than two blocks */
+    uint64_t n_chunks;             /* record chunks = work items of the apply kernel */
+    uint32_t path;                 /* KMDB_PATH_* of the last all2all call */
+    uint32_t width;                /* sample ids per block */
+    uint32_t sized_call;           /* 1: the last call measured its own grid sizes (first call on a handle, two host syncs more) */
+    uint32_t reserved;
 } kmdb_stats;
 
 const char* kmdb_last_error(void);
@@ -112,6 +129,13 @@ int  kmdb_device_count(void);
  * deserialize, prefix_kmer_db.cpp:578-748).  with_hashtables != 0 also uploads the
  * bucket tables (DeserializationMode::Everything vs SkipHashtables, kmer_db.h:55-60). */
 int  kmdb_db_upload(const kmdb_db_view* view, const kmdb_opts* opts, int with_hashtables, kmdb_db** out);
+/* One prefix-bucket shard of the database (bucket = kmer >> 32, reference src/types.h:25-27, items
+ * src/hashmap_lp.h:71-78): the pattern tree stays whole and every pattern keeps only the k-mers of the buckets b with
+ * b % shard_count == shard_index, w_s[p] = #{items of those buckets with val == p}.  Partial matrices of the shards sum
+ * (uint32, wrap-around) to the matrix of the whole database: one shard per GPU + one RCCL reduce.  The view must carry the
+ * hashtables (load mode Everything). */
+int  kmdb_db_upload_shard(const kmdb_db_view* view, const kmdb_opts* opts, int with_hashtables, uint32_t shard_index,
+                          uint32_t shard_count, kmdb_db** out);
 void kmdb_db_free(kmdb_db* db);
 int  kmdb_db_stats(const kmdb_db* db, kmdb_stats* out);
 

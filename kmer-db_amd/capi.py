@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -46,17 +46,21 @@ class _Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
                 ("algorithmic_bytes", C.c_uint64), ("tree_updates", C.c_uint64), ("sum_pairs", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("n_segments", C.c_uint64), ("tile_flushes", C.c_uint64),
-                ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64), ("k0_ms", C.c_double)]
+                ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64), ("k0_ms", C.c_double),
+                ("k1n_ms", C.c_double), ("k1g_ms", C.c_double), ("upload_ms", C.c_double), ("n_wide", C.c_uint64),
+                ("n_chunks", C.c_uint64), ("path", C.c_uint32), ("width", C.c_uint32), ("sized_call", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 FLAG_FORCE_GLOBAL_ATOMICS = 1
 FLAG_FORCE_DIRECT = 2
 FLAG_FORCE_TILE = 4
-FLAG_FORCE_SEQ_EMIT = 8
+FLAG_NO_FALLBACK = 8
+PATH_NONE, PATH_RECORDS, PATH_TILE, PATH_GLOBAL = 0, 1, 2, 3
 
 # every symbol include/kmdb_amd.h declares
 EXPORTS = [
-    "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_free", "kmdb_db_stats",
+    "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_stats",
     "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_sparse_free",
     "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
     "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
@@ -84,6 +88,7 @@ def lib():
     L = C.CDLL(p)
     L.kmdb_last_error.restype = C.c_char_p
     L.kmdb_db_upload.argtypes = [C.POINTER(_View), C.POINTER(_Opts), C.c_int, C.POINTER(C.c_void_p)]
+    L.kmdb_db_upload_shard.argtypes = [C.POINTER(_View), C.POINTER(_Opts), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.kmdb_db_free.argtypes = [C.c_void_p]
     L.kmdb_db_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
     L.kmdb_all2all_dense.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
@@ -250,7 +255,9 @@ class SparseRows:
 class DeviceDB:
     """A database resident in HBM (kmdb_db_upload)."""
 
-    def __init__(self, src, device=0, with_hashtables=False, flags=0):
+    def __init__(self, src, device=0, with_hashtables=False, flags=0, prefix_shard=None):
+        """prefix_shard=(index, count): keep only the k-mers of the prefix buckets b with b % count == index
+        (kmdb_db_upload_shard; the source must carry the hashtables)."""
         self._keep = None
         if isinstance(src, HostDB):
             view = src.view
@@ -262,7 +269,11 @@ class DeviceDB:
         self.device = device
         self._d = C.c_void_p()
         o = _opts(device, (0, 1), flags)
-        _check(lib().kmdb_db_upload(view, C.byref(o), int(with_hashtables), C.byref(self._d)))
+        if prefix_shard is None:
+            _check(lib().kmdb_db_upload(view, C.byref(o), int(with_hashtables), C.byref(self._d)))
+        else:
+            _check(lib().kmdb_db_upload_shard(view, C.byref(o), int(with_hashtables), int(prefix_shard[0]), int(prefix_shard[1]),
+                                              C.byref(self._d)))
         self.N = int(view.contents.n_samples)
         self.P = int(view.contents.n_patterns)
 

@@ -1,0 +1,1299 @@
+// a2a_blocks.hip — the block-record pipeline of the dense all2all path (any N up to 65535).
+//
+// Replaces SimilarityCalculator::all2all (reference src/similarity_calculator.cpp:42-438, inner loop row_add
+// src/simd/row_add_avx2.cpp:30-124) with a design for gfx950.  The N x N matrix is cut into blocks (X, Y), X >= Y,
+// of `width` <= 64 consecutive sample ids.  A pattern's ascending id list meets a block in a contiguous run, so
+// all pair updates of a pattern with weight w factor into BLOCK RECORDS
+//        (X, Y, rowmask, colmask, w):   M[width*X + r][width*Y + c] += w   for r in rowmask, c in colmask
+//                                                                            (c < r when X == Y).
+// Flat form (all2all_sp semantics, reference similarity_calculator.cpp:596-638): every pattern with w > 0 adds its
+// on-disk w to all pairs of its FULL list, i.e. one record per pair of blocks X >= Y the full list touches.
+//
+// Everything that depends on a decoded sample id happens inside the call (kmdb_blocks_run), on one stream:
+//   K0  k0_decode_kernel   gamma streams -> the LOCAL ids of every node as (block, 64-bit mask) pairs   (thread per node)
+//   K1n k1n_kernel         walks the DFS stream, 64 nodes per wave step, one lane each.  A full list is the union of
+//                          the local lists on the root path and ids ascend along it, so the list of a node with at most
+//                          TWO blocks is two registers; in-batch parents by pointer doubling across lanes, earlier ones
+//                          from a chain table in LDS (one slot per depth).  Emits the records of those nodes, leaves
+//                          (blocks, masks) of the ones with children in HBM, and flags the nodes with more blocks.
+//       wide list          the flagged nodes, compacted (popcount + scan + expand)
+//   K1g k1g_kernel         one lane per wide node: climbs to the nearest ancestor with at most two blocks, collecting
+//                          the (block, mask) pairs on the way into a per-wave entry pool in LDS; records of the batch are
+//                          numbered by a prefix sum and emitted one per lane from a descriptor queue.
+//   K2  k2_apply_kernel    one workgroup per record chunk: 64 records per wave step as bit matrices, int8 MFMA
+//                          accumulate into a 64 x 64 LDS tile (popcount passes per bit plane for weights >= 128),
+//                          one HBM atomic per non-zero cell.
+// Records are grouped by (block pair, weight class) WITHOUT a counting pass: every stream owns a current chunk of the
+// record pool; a wave reserves slots for a whole group of lanes with one 64-bit atomic on the stream's state
+// (chunk << 32 | used), and the reservation that crosses the end of a chunk takes a fresh chunk from the pool and
+// publishes it.  K2's work items are the chunks.
+#include "device_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+constexpr uint32_t NCLS = 3;
+// weight classes: 0: w == 1 (no weight stored), 1: 2 <= w < 128 (one signed byte of an int8 MFMA operand),
+// 2: w >= 128 (rare: one popcount pass per bit plane)
+__host__ __device__ __forceinline__ uint32_t weight_class(uint32_t w) { return w == 1u ? 0u : w < 128u ? 1u : 2u; }
+__host__ __device__ __forceinline__ uint32_t tri32(uint32_t x) { return x * (x + 1u) / 2u; }
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, WAVE);
+    const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, WAVE);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// record pool
+// ------------------------------------------------------------------------------------------
+struct PoolView {
+    unsigned long long* state;     // [n_states] chunk << 32 | used
+    uint32_t* counters;            // KCTR_*
+    uint32_t* chunk_key;           // [pool_cap]
+    unsigned char* rec;            // record slots, 16 bytes each
+    uint32_t* recw;
+    uint32_t c_shift;              // records per chunk = 1 << c_shift
+    uint32_t pool_cap;             // chunks
+};
+struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
+
+// cnt (<= 64) slots of stream s, for ONE lane to call.  Slots of a reservation are consecutive inside a chunk; the
+// reservation that crosses the end of the current chunk (or finds the stream without one) takes the next chunk of the
+// pool and publishes it; reservations that arrive between its atomic and the publication try again.
+__device__ __forceinline__ Resv pool_reserve(const PoolView& pv, uint32_t s, uint32_t cnt) {
+    const uint32_t C = 1u << pv.c_shift;
+    for (;;) {
+        const unsigned long long old = atomicAdd(&pv.state[s], (unsigned long long)cnt);
+        const uint32_t u = (uint32_t)old, ch = (uint32_t)(old >> 32);
+        if (u + cnt <= C) return Resv{(ch << pv.c_shift) + u, cnt, 0u};
+        if (u <= C) {
+            uint32_t nc = atomicAdd(&pv.counters[KCTR_CHUNKS], 1u);
+            if (nc >= pv.pool_cap) { atomicOr(&pv.counters[KCTR_POOL_OVERFLOW], 1u); nc = pv.pool_cap - 1u; }   // in range; the call is repeated
+            pv.chunk_key[nc] = s;
+            const uint32_t n1 = C - u;
+            atomicExch(&pv.state[s], ((unsigned long long)nc << 32) | (unsigned long long)(cnt - n1));
+            return Resv{(ch << pv.c_shift) + u, n1, nc << pv.c_shift};
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+__device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
+
+// diagonal streams (X == Y, cols == rows) pack 8-byte rows into the first half of their chunks
+__device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t cls, uint32_t w) {
+    const uint32_t ch = slot >> pv.c_shift, r = slot & ((1u << pv.c_shift) - 1u);
+    ((unsigned long long*)(pv.rec + ((size_t)ch << (pv.c_shift + 4))))[r] = rows;
+    if (cls) pv.recw[slot] = w;
+}
+__device__ __forceinline__ void rec_store_off(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t cls, uint32_t w) {
+    ((ulonglong2*)pv.rec)[slot] = make_ulonglong2(rows, cols);
+    if (cls) pv.recw[slot] = w;
+}
+
+__global__ void pool_init_kernel(unsigned long long* __restrict__ state, uint32_t n_states, uint32_t c_shift) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_states) state[i] = (0xFFFFFFFFull << 32) | (unsigned long long)(1u << c_shift);     // no chunk yet: the first reservation takes one
+}
+
+// the last chunk of every stream is partly filled
+__global__ void pool_finalize_kernel(const unsigned long long* __restrict__ state, uint32_t n_states, uint32_t c_shift, uint32_t pool_cap,
+                                     uint32_t* __restrict__ chunk_fill) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states) return;
+    const unsigned long long st = state[i];
+    const uint32_t ch = (uint32_t)(st >> 32), used = (uint32_t)st, C = 1u << c_shift;
+    if (ch < pool_cap && used < C) chunk_fill[ch] = used;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: gamma streams -> local (block, mask) pairs
+// ------------------------------------------------------------------------------------------
+struct K0Params {
+    const uint2* k0in;
+    const uint32_t* bitrel;
+    const uint64_t* blkbase;
+    const uint64_t* bits;
+    const uint32_t* perm;          // nullptr: all nodes in DFS order, long ones skipped; else: the long nodes
+    uint32_t P;                    // nodes of this launch
+    BlockMap bm;
+    unsigned long long* p0_mask;   // first pair inline
+    uint32_t* p0_info;             // block | npairs << 16
+    uint32_t* pair_ofs;            // further pairs: first entry in the pair pool
+    uint16_t* pair_blk;
+    unsigned long long* pair_mask;
+    uint32_t* pair_cursor;         // [KMDB_PAIR_REGIONS * 16]
+    uint32_t region_cap;
+    uint32_t* counters;
+};
+
+template <bool LONG>
+__global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
+    // two launches cover the nodes: perm == nullptr walks ALL nodes in DFS order (coalesced) and skips the ones whose
+    // stream does not fit three registers; those few are listed in perm, most work first, and decoded by the second
+    // launch so that no wave waits on one long stream
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t i = 0;
+    bool live;
+    if (q.perm) {
+        live = t < q.P;
+        if (live) i = q.perm[t];
+    } else {
+        // DFS-order launch: the 256 nodes of the block are re-dealt to its threads by decreasing amount of work
+        // (counting sort in LDS), so every wave runs decode loops of similar length while all global accesses
+        // of the block stay inside its own 256-node window
+        __shared__ uint32_t bins[64];
+        __shared__ uint16_t order[256];
+        if (threadIdx.x < 64) bins[threadIdx.x] = 0;
+        __syncthreads();
+        const uint2 kt = t < q.P ? q.k0in[t] : make_uint2(0u, 0u);          // {l | last id << 16, stream bits}
+        const uint32_t tl = kt.x & 0xFFFFu;
+        // work of a node ~ number of codes that are not "0" ~ stream bits beyond one per delta
+        uint32_t key = 0;                                                    // 0: nothing to decode here
+        if (t < q.P && tl > 1 && !kmdb_long_node(tl, kt.y)) {
+            key = 1u + (kt.y - (tl - 1u));
+            key = key > 63u ? 63u : key;
+        }
+        atomicAdd(&bins[63u - key], 1u);                                     // bin 0 = most work
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t c = bins[threadIdx.x];
+            bins[threadIdx.x] = wave_incl_scan(c, threadIdx.x) - c;
+        }
+        __syncthreads();
+        order[atomicAdd(&bins[63u - key], 1u)] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        i = blockIdx.x * blockDim.x + order[threadIdx.x];
+        live = i < q.P;
+    }
+    const BlockMap bm = q.bm;
+    const uint2 km = live ? q.k0in[i] : make_uint2(0u, 0u);
+    const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16, nbits = km.y;
+    if (!q.perm && kmdb_long_node(l, nbits)) live = false;
+    using Cursor = RunCursor<LONG ? 8 : 3, LONG>;
+    uint32_t npairs = 0, blk0 = 0, need = 0, span = 0, bit0 = 0;
+    unsigned long long mask0 = 0, m1 = 0, m2 = 0;
+    bool second_pass = false;
+    uint64_t pos = 0;
+    if (live && l == 1) {
+        blk0 = bm.blk(last); mask0 = 1ull << bm.bit(last, blk0); npairs = 1;
+    } else if (live && l) {
+        // Pass 1 walks the stream run by run and builds the list RELATIVE to its (still unknown) first id:
+        // bit k of R <=> id_0 + k is in the list.  pattern_t::decodeSamples (reference src/pattern.cpp:99-109)
+        // gets id_0 the same way: last id minus the sum of the deltas.
+        pos = q.blkbase[i >> 8] + q.bitrel[i];
+        unsigned long long R = 1ull;
+        {
+            Cursor c(q.bits, pos);
+            uint32_t rem = l - 1;
+            while (rem) {
+                uint32_t z, v;
+                c.step(rem, z, v);                                     // a run of z consecutive ids, then a gap of v
+                if (z) {
+                    if (span + z < 64u) R |= ((2ull << (z - 1)) - 1ull) << (span + 1);
+                    span += z; rem -= z;
+                }
+                if (v) {
+                    span += v; --rem;
+                    if (span < 64u) R |= 1ull << span;
+                }
+            }
+        }
+        const uint32_t id0 = last - span;
+        blk0 = bm.blk(id0);
+        bit0 = bm.bit(id0, blk0);
+        const unsigned long long wm = bm.width == 64 ? ~0ull : (1ull << bm.width) - 1ull;
+        if (span < 64u) {
+            // the whole list fits the relative mask: cut it at the block boundaries (at most 3 blocks: width >= 32)
+            const unsigned long long lo = R << bit0, hi = bit0 ? R >> (64u - bit0) : 0ull;
+            auto ext = [&](uint32_t sh) -> unsigned long long {
+                return sh == 0 ? lo : sh < 64u ? ((lo >> sh) | (hi << (64u - sh))) : sh == 64u ? hi : sh < 128u ? (hi >> (sh - 64u)) : 0ull;
+            };
+            mask0 = lo & wm;
+            m1 = ext(bm.width) & wm; m2 = ext(2 * bm.width) & wm;
+            npairs = 1u + (m1 != 0) + (m2 != 0);
+            need = npairs - 1u;
+        } else {
+            // wide list: second pass with absolute ids; the blocks it can touch bound the reservation
+            second_pass = true;
+            need = bm.blk(last) - blk0;
+        }
+    }
+    // extra pairs: one reservation per wave in the wave's region of the pair pool
+    uint32_t out = 0;
+    {
+        const uint32_t incl = wave_incl_scan(need, lane);
+        const uint32_t total = bcast(incl, WAVE - 1);
+        if (total) {
+            const uint32_t region = (blockIdx.x * 4u + (threadIdx.x >> 6)) % KMDB_PAIR_REGIONS;
+            uint32_t base = 0;
+            if (lane == WAVE - 1) base = atomicAdd(&q.pair_cursor[region * 16u], total);
+            base = bcast(base, WAVE - 1);
+            if (base + total > q.region_cap) {
+                if (lane == 0) atomicOr(&q.counters[KCTR_PAIR_OVERFLOW], 1u);
+                need = 0; second_pass = false; npairs = npairs ? 1u : 0u; m1 = m2 = 0;        // results invalid; the call is repeated with a larger pool
+            } else out = region * q.region_cap + base + (incl - need);
+        }
+    }
+    if (!live) return;
+    if (!second_pass) {
+        if (m1) { q.pair_blk[out] = (uint16_t)(blk0 + 1); q.pair_mask[out] = m1; }
+        if (m2) { const uint32_t o2 = out + (m1 != 0); q.pair_blk[o2] = (uint16_t)(blk0 + 2); q.pair_mask[o2] = m2; }
+    } else {
+        Cursor c(q.bits, pos);
+        uint32_t o = out;
+        uint32_t curblk = blk0, bit = bit0, rem = l - 1;
+        unsigned long long acc = 1ull << bit0;
+        auto flush = [&]() {
+            if (npairs == 0) mask0 = acc;
+            else { q.pair_blk[o] = (uint16_t)curblk; q.pair_mask[o] = acc; ++o; }
+            ++npairs;
+        };
+        while (rem) {
+            uint32_t z, v;
+            c.step(rem, z, v);
+            if (z) {
+                rem -= z;
+                while (z) {
+                    const uint32_t room = bm.width - 1u - bit;
+                    const uint32_t tk = z < room ? z : room;
+                    if (tk) { acc |= ((2ull << (tk - 1)) - 1ull) << (bit + 1); bit += tk; z -= tk; }
+                    if (z) { flush(); ++curblk; acc = 1ull; bit = 0; --z; }
+                }
+            }
+            if (v) {
+                const uint32_t id = curblk * bm.width + bit + v;
+                --rem;
+                const uint32_t blk = bm.blk(id);
+                if (blk != curblk) { flush(); curblk = blk; acc = 0; }
+                bit = bm.bit(id, blk);
+                acc |= 1ull << bit;
+            }
+        }
+        flush();
+    }
+    q.p0_mask[i] = mask0;
+    q.p0_info[i] = blk0 | (npairs << 16);
+    if (npairs > 1) q.pair_ofs[i] = out;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1n: the DFS stream, nodes with at most two blocks
+// ------------------------------------------------------------------------------------------
+// Summary of a stretch of a root path: the first block and its mask, the second block and its mask, and whether
+// there is a third one.  Ids ascend along a root path, so "the ancestors' stretch" always holds the smaller blocks.
+constexpr uint32_t BNONE = 0x7FFFu;
+struct NSum { unsigned long long m0, m1; uint32_t bw; };        // bw = b0 | b1 << 15 | wide << 30
+
+__device__ __forceinline__ NSum nsum_make(uint32_t b0, unsigned long long m0, uint32_t b1, unsigned long long m1, bool wide) {
+    return NSum{m0, m1, b0 | (b1 << 15) | ((wide ? 1u : 0u) << 30)};
+}
+// T = the stretch closer to the root, S = the stretch below it
+__device__ __forceinline__ NSum nsum_merge(const NSum& T, const NSum& S) {
+    const uint32_t Tb0 = T.bw & 0x7FFFu, Tb1 = (T.bw >> 15) & 0x7FFFu, Sb0 = S.bw & 0x7FFFu, Sb1 = (S.bw >> 15) & 0x7FFFu;
+    bool wide = (((T.bw | S.bw) >> 30) & 1u) != 0;
+    if (Tb0 == BNONE) return S;
+    if (Sb0 == BNONE) return T;
+    if (Sb0 == Tb0) return nsum_make(Sb0, S.m0 | T.m0, Sb1, S.m1, wide || Tb1 != BNONE);
+    if (Tb1 == BNONE) return nsum_make(Tb0, T.m0, Sb0, S.m0, wide || Sb1 != BNONE);
+    if (Tb1 == Sb0) return nsum_make(Tb0, T.m0, Sb0, T.m1 | S.m0, wide || Sb1 != BNONE);
+    return nsum_make(Tb0, T.m0, Tb1, T.m1, true);
+}
+__device__ __forceinline__ NSum nsum_shfl(const NSum& s, int src) {
+    return NSum{shfl64(s.m0, src), shfl64(s.m1, src), (uint32_t)__shfl((int)s.bw, src, WAVE)};
+}
+__device__ __forceinline__ NSum nsum_shfl_up(const NSum& s, int d) {
+    return NSum{shfl_up64(s.m0, d), shfl_up64(s.m1, d), (uint32_t)__shfl_up((int)s.bw, d, WAVE)};
+}
+
+struct NParams {
+    const uint32_t* nl;            // n | l << 16
+    const int32_t* parent;
+    const uint32_t* w;
+    const uint16_t* dflag;         // depth | has-child << 15
+    const uint32_t* seg_anc;       // [n_segs][chain_cap] root-first ancestors of the slice's first node
+    const uint32_t* seg_anc_n;
+    const unsigned long long* p0_mask;
+    const uint32_t* p0_info;
+    const uint32_t* pair_ofs;
+    const uint16_t* pair_blk;
+    const unsigned long long* pair_mask;
+    ulonglong2* fn_mask;
+    uint32_t* fn_blk;
+    unsigned long long* widebits;
+    uint32_t P, nseg_nodes, n_segs, chain_cap;
+    uint32_t emit_lo, emit_hi;
+    PoolView pool;
+};
+constexpr int K1N_WAVES = 4;
+__host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap) { return ((size_t)chain_cap * 20 + 15) & ~(size_t)15; }
+
+__global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t seg = blockIdx.x * K1N_WAVES + wave;
+    if (seg >= q.n_segs) return;
+    ulonglong2* chain_m = (ulonglong2*)(lds_raw + k1n_wave_bytes(q.chain_cap) * wave);       // [chain_cap] one slot per depth:
+    uint32_t* chain_b = (uint32_t*)(chain_m + q.chain_cap);                                  // the latest node of that depth on the current root path
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t first = seg * q.nseg_nodes;
+    const uint32_t end = (q.P - first) < q.nseg_nodes ? q.P : first + q.nseg_nodes;
+
+    auto locals = [&](uint32_t info, unsigned long long m0, uint32_t e1blk, unsigned long long e1mask) -> NSum {
+        const uint32_t np = info >> 16;
+        if (np == 0) return nsum_make(BNONE, 0ull, BNONE, 0ull, false);
+        if (np == 1) return nsum_make(info & 0xFFFFu, m0, BNONE, 0ull, false);
+        return nsum_make(info & 0xFFFFu, m0, e1blk, e1mask, np > 2);
+    };
+
+    // chain slots of the first node's ancestors: inclusive merge along the root path
+    {
+        const uint32_t d = q.seg_anc_n[seg];
+        NSum carry = nsum_make(BNONE, 0ull, BNONE, 0ull, false);
+        for (uint32_t cb = 0; cb < d; cb += WAVE) {
+            const uint32_t k = cb + lane;
+            const bool on = k < d;
+            NSum S = nsum_make(BNONE, 0ull, BNONE, 0ull, false);
+            if (on) {
+                const uint32_t node = q.seg_anc[(size_t)seg * q.chain_cap + k];
+                const uint32_t info = q.p0_info[node];
+                uint32_t e1b = BNONE; unsigned long long e1m = 0;
+                if ((info >> 16) > 1u) { const uint32_t po = q.pair_ofs[node]; e1b = q.pair_blk[po]; e1m = q.pair_mask[po]; }
+                S = locals(info, q.p0_mask[node], e1b, e1m);
+            }
+            if (lane == 0) S = nsum_merge(carry, S);
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const NSum o = nsum_shfl_up(S, s);
+                if (lane >= (uint32_t)s) S = nsum_merge(o, S);
+            }
+            if (on) { chain_m[k] = make_ulonglong2(S.m0, S.m1); chain_b[k] = S.bw; }
+            carry = nsum_shfl(S, WAVE - 1);
+        }
+        lds_sync();
+    }
+
+    // node records of the NEXT batch are fetched while the current one is processed
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_df = 0, nx_e1b = BNONE;
+    int32_t nx_par = -1;
+    unsigned long long nx_m0 = 0, nx_e1m = 0;
+    auto fetch = [&](uint32_t b0) {
+        const uint32_t ii = b0 + lane;
+        const bool v = ii < end;
+        nx_nl = v ? q.nl[ii] : 0u;
+        nx_w = v ? q.w[ii] : 0u;
+        nx_par = v ? q.parent[ii] : -1;
+        nx_df = v ? q.dflag[ii] : 0x7FFFu;
+        nx_info = v ? q.p0_info[ii] : 0u;
+        nx_m0 = v ? q.p0_mask[ii] : 0ull;
+        nx_e1b = BNONE; nx_e1m = 0;
+        if ((nx_info >> 16) > 1u) { const uint32_t po = q.pair_ofs[ii]; nx_e1b = q.pair_blk[po]; nx_e1m = q.pair_mask[po]; }
+    };
+    fetch(first);
+    unsigned long long n_rec = 0;
+    for (uint32_t base = first; base < end; base += WAVE) {
+        const uint32_t idx = base + lane;
+        const bool valid = idx < end;
+        const uint32_t nl = nx_nl, w = nx_w, info = nx_info, df = nx_df, e1b = nx_e1b;
+        const int32_t par = nx_par;
+        const unsigned long long m0 = nx_m0, e1m = nx_e1m;
+        if (base + WAVE < end) fetch(base + WAVE);
+        const uint32_t dep = df & 0x7FFFu;
+        NSum S = locals(info, m0, e1b, e1m);
+        if (valid && par >= 0 && par < (int32_t)base) {
+            const ulonglong2 cm = chain_m[dep - 2u];
+            S = nsum_merge(NSum{cm.x, cm.y, chain_b[dep - 2u]}, S);
+        }
+        // pointer doubling over the in-batch parents
+        int pl = (valid && par >= (int32_t)base) ? (int)(par - (int32_t)base) : -1;
+        while (__ballot(pl >= 0)) {
+            const int src = pl >= 0 ? pl : (int)lane;
+            const NSum o = nsum_shfl(S, src);
+            if (pl >= 0) S = nsum_merge(o, S);
+            const int npl = __shfl(pl, src, WAVE);
+            pl = pl >= 0 ? npl : -1;
+        }
+        const bool wide = valid && ((S.bw >> 30) & 1u);
+        const uint32_t w0 = S.bw & 0x7FFFu, w1 = (S.bw >> 15) & 0x7FFFu;
+        const unsigned long long F0 = S.m0, F1 = w1 != BNONE ? S.m1 : 0ull;
+        {
+            const unsigned long long wb = __ballot(wide);
+            if (lane == 0) q.widebits[base >> 6] = wb;
+        }
+        if (valid && !wide && (df >> 15)) {                       // a child with more blocks will start from here
+            q.fn_mask[idx] = make_ulonglong2(F0, F1);
+            q.fn_blk[idx] = (w0 == BNONE ? 0xFFFFu : w0) | ((w1 == BNONE ? 0xFFFFu : w1) << 16);
+        }
+        // ---- records (flat form): (w0, w0, F0), and with a second block (w1, w0, F1, F0) and (w1, w1, F1).  A diagonal
+        // record needs two ids to have a pair.
+        const bool act = valid && !wide && w != 0 && (nl & 0xFFFFu) >= 2u && w0 != BNONE && idx >= q.emit_lo && idx < q.emit_hi;
+        const uint32_t cls = weight_class(w);
+        // the lanes of a batch mostly share the block: one reservation per block and weight class
+        unsigned long long pend = __ballot(act && __popcll(F0) >= 2);
+        while (pend) {
+            const uint32_t X0 = bcast(w0, (uint32_t)__builtin_ctzll(pend));
+            const bool mine = act && __popcll(F0) >= 2 && w0 == X0;
+            const unsigned long long b0 = __ballot(mine && cls == 0u), b1 = __ballot(mine && cls == 1u), b2 = __ballot(mine && cls == 2u);
+            Resv r{0u, 0u, 0u};
+            if (lane < NCLS) {
+                const uint32_t cnt = (uint32_t)__popcll(lane == 0 ? b0 : lane == 1 ? b1 : b2);
+                if (cnt) r = pool_reserve(q.pool, (tri32(X0) + X0) * NCLS + lane, cnt);
+            }
+            const uint32_t src = cls;                            // lane that holds this class's reservation
+            const Resv mr{(uint32_t)__shfl((int)r.base1, (int)src, WAVE), (uint32_t)__shfl((int)r.n1, (int)src, WAVE), (uint32_t)__shfl((int)r.base2, (int)src, WAVE)};
+            if (mine) {
+                const unsigned long long mb = cls == 0u ? b0 : cls == 1u ? b1 : b2;
+                rec_store_diag(q.pool, resv_slot(mr, (uint32_t)__popcll(mb & lt_mask)), F0, cls, w);
+            }
+            n_rec += (unsigned long long)__popcll(b0 | b1 | b2);
+            pend &= ~(b0 | b1 | b2);
+        }
+        // second blocks: one round per distinct (w0, w1) of the batch
+        const bool act2 = act && F1 != 0;
+        unsigned long long pend2 = __ballot(act2);
+        while (pend2) {
+            const uint32_t key = bcast(S.bw & 0x3FFFFFFFu, (uint32_t)__builtin_ctzll(pend2));
+            const uint32_t Y0 = key & 0x7FFFu, X1 = key >> 15;
+            const bool mine = act2 && (S.bw & 0x3FFFFFFFu) == key;
+            const bool dg = mine && __popcll(F1) >= 2;
+            const unsigned long long a0 = __ballot(mine && cls == 0u), a1 = __ballot(mine && cls == 1u), a2 = __ballot(mine && cls == 2u);
+            const unsigned long long d0 = __ballot(dg && cls == 0u), d1 = __ballot(dg && cls == 1u), d2 = __ballot(dg && cls == 2u);
+            Resv r{0u, 0u, 0u};
+            if (lane < 2 * NCLS) {
+                const uint32_t c3 = lane % NCLS;
+                const bool isd = lane >= NCLS;
+                const unsigned long long bl = isd ? (c3 == 0 ? d0 : c3 == 1 ? d1 : d2) : (c3 == 0 ? a0 : c3 == 1 ? a1 : a2);
+                const uint32_t cnt = (uint32_t)__popcll(bl);
+                if (cnt) r = pool_reserve(q.pool, (tri32(X1) + (isd ? X1 : Y0)) * NCLS + c3, cnt);
+            }
+            {
+                const Resv mr{(uint32_t)__shfl((int)r.base1, (int)cls, WAVE), (uint32_t)__shfl((int)r.n1, (int)cls, WAVE), (uint32_t)__shfl((int)r.base2, (int)cls, WAVE)};
+                if (mine) {
+                    const unsigned long long mb = cls == 0u ? a0 : cls == 1u ? a1 : a2;
+                    rec_store_off(q.pool, resv_slot(mr, (uint32_t)__popcll(mb & lt_mask)), F1, F0, cls, w);
+                }
+            }
+            {
+                const int src = (int)(cls + NCLS);
+                const Resv mr{(uint32_t)__shfl((int)r.base1, src, WAVE), (uint32_t)__shfl((int)r.n1, src, WAVE), (uint32_t)__shfl((int)r.base2, src, WAVE)};
+                if (dg) {
+                    const unsigned long long mb = cls == 0u ? d0 : cls == 1u ? d1 : d2;
+                    rec_store_diag(q.pool, resv_slot(mr, (uint32_t)__popcll(mb & lt_mask)), F1, cls, w);
+                }
+            }
+            n_rec += (unsigned long long)(__popcll(a0 | a1 | a2) + __popcll(d0 | d1 | d2));
+            pend2 &= ~(a0 | a1 | a2);
+        }
+        // ---- chain slots for the next batch: the nodes on the root path of this batch's last node, i.e. the
+        // lanes whose depth is smaller than the depth of every later lane
+        if (base + WAVE < end) {
+            uint32_t m = dep;
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_down((int)m, s, WAVE);
+                if (lane + (uint32_t)s < (uint32_t)WAVE) m = o < m ? o : m;
+            }
+            uint32_t later = (uint32_t)__shfl_down((int)m, 1, WAVE);
+            if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
+            if (valid && dep < later) { chain_m[dep - 1u] = make_ulonglong2(S.m0, S.m1); chain_b[dep - 1u] = S.bw; }
+            lds_sync();
+        }
+    }
+    if (lane == 0 && n_rec) atomicAdd((unsigned long long*)&q.pool.counters[KCTR_RECORDS], n_rec);
+}
+
+// ------------------------------------------------------------------------------------------
+// wide list: compaction of the flagged nodes
+// ------------------------------------------------------------------------------------------
+__global__ void wide_count_kernel(const unsigned long long* __restrict__ bits, uint32_t n_words, uint32_t* __restrict__ cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) cnt[i] = (uint32_t)__popcll(bits[i]);
+    else if (i == n_words) cnt[i] = 0;
+}
+__global__ void wide_expand_kernel(const unsigned long long* __restrict__ bits, const uint32_t* __restrict__ base, uint32_t n_words,
+                                   uint32_t* __restrict__ widx, uint32_t cap, uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) counters[KCTR_NWIDE] = base[n_words];
+    if (i >= n_words) return;
+    unsigned long long b = bits[i];
+    uint32_t o = base[i];
+    while (b) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(b);
+        b &= b - 1;
+        if (o < cap) widx[o] = i * 64u + k;
+        ++o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1g: nodes with more than two blocks
+// ------------------------------------------------------------------------------------------
+struct GParams {
+    const uint32_t* widx;
+    uint32_t n_wide;
+    const uint32_t* nl;
+    const int32_t* parent;
+    const uint32_t* w;
+    const unsigned long long* widebits;
+    const unsigned long long* p0_mask;
+    const uint32_t* p0_info;
+    const uint32_t* pair_ofs;
+    const uint16_t* pair_blk;
+    const unsigned long long* pair_mask;
+    const ulonglong2* fn_mask;
+    const uint32_t* fn_blk;
+    uint32_t emit_lo, emit_hi;
+    PoolView pool;
+};
+constexpr int K1G_WAVES = 4;
+constexpr uint32_t K1G_ENT = 768;          // entries of the per-wave pool
+constexpr uint32_t K1G_QCAP = 256;         // record descriptors queued per round
+struct K1GWave {
+    unsigned long long ent_mask[K1G_ENT];
+    uint32_t queue[K1G_QCAP];               // owner lane | a << 6 | b << 19
+    uint32_t st_w[64];
+    uint16_t ent_blk[K1G_ENT];
+    uint16_t st_start[64];
+};
+
+__global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) {
+    __shared__ K1GWave lds[K1G_WAVES];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    K1GWave& L = lds[wave];
+    const uint32_t batch = blockIdx.x * K1G_WAVES + wave;
+    const uint32_t k = batch * WAVE + lane;
+    const bool valid = k < q.n_wide;
+    if (batch * WAVE >= q.n_wide) return;
+    const uint32_t node = valid ? q.widx[k] : 0u;
+    auto iswide = [&](uint32_t y) -> bool { return (q.widebits[y >> 6] >> (y & 63u)) & 1ull; };
+    // pass 1: how many (block, mask) pairs lie between the node and its nearest ancestor with at most two blocks
+    uint32_t cnt = 0;
+    if (valid) {
+        cnt = q.p0_info[node] >> 16;
+        int32_t y = q.parent[node];
+        while (y >= 0 && iswide((uint32_t)y)) { cnt += q.p0_info[y] >> 16; y = q.parent[y]; }
+        if (y >= 0) cnt += 2;
+        if (cnt > K1G_ENT) { atomicOr(&q.pool.counters[KCTR_LIST_OVERFLOW], 1u); cnt = 0; }      // the engine falls back
+    }
+    const uint32_t nlv = valid ? q.nl[node] : 0u;
+    const uint32_t wv = valid ? q.w[node] : 0u;
+    const bool act = valid && cnt != 0 && wv != 0 && (nlv & 0xFFFFu) >= 2u && node >= q.emit_lo && node < q.emit_hi;
+    const uint32_t cls = weight_class(wv);
+    unsigned long long n_rec = 0;
+    uint32_t done = 0;                                         // lanes below `done` are finished
+    while (done < (uint32_t)WAVE) {
+        // the lanes [done, hi) whose pairs fit the entry pool together
+        const uint32_t c = lane >= done ? cnt : 0u;
+        const uint32_t incl = wave_incl_scan(c, lane);
+        const unsigned long long over = __ballot(incl > K1G_ENT);
+        const uint32_t hi = over ? (uint32_t)__builtin_ctzll(over) : (uint32_t)WAVE;      // > done: a single list fits
+        const bool on = lane >= done && lane < hi && cnt != 0;
+        const uint32_t off = incl - c;
+        // pass 2: fill the lane's region right to left (the climb meets the blocks in descending order)
+        uint32_t m = 0, start = 0;
+        if (on) {
+            uint32_t pos = off + cnt, cur = 0xFFFFFFFFu;
+            auto push = [&](uint32_t blk, unsigned long long mask) {
+                if (blk == cur) L.ent_mask[pos] |= mask;
+                else { --pos; L.ent_blk[pos] = (uint16_t)blk; L.ent_mask[pos] = mask; cur = blk; }
+            };
+            int32_t y = (int32_t)node;
+            for (;;) {
+                const uint32_t info = q.p0_info[y];
+                const uint32_t np = info >> 16;
+                if (np > 1) {
+                    const uint32_t po = q.pair_ofs[y];
+                    for (uint32_t t = np - 1; t-- > 0;) push(q.pair_blk[po + t], q.pair_mask[po + t]);
+                }
+                if (np) push(info & 0xFFFFu, q.p0_mask[y]);
+                y = q.parent[y];
+                if (y < 0) break;
+                if (!iswide((uint32_t)y)) {
+                    const uint32_t fb = q.fn_blk[y];
+                    const ulonglong2 fm = q.fn_mask[y];
+                    if ((fb >> 16) != 0xFFFFu) push(fb >> 16, fm.y);
+                    if ((fb & 0xFFFFu) != 0xFFFFu) push(fb & 0xFFFFu, fm.x);
+                    break;
+                }
+            }
+            m = off + cnt - pos; start = pos;
+        }
+        L.st_start[lane] = (uint16_t)start;
+        L.st_w[lane] = wv;
+        // record-parallel emission: a node with m blocks owns m (m + 1) / 2 records (block pairs a >= b); the records of
+        // the round are numbered by a prefix sum, every owner pushes one descriptor per record into a queue, then
+        // the wave takes 64 descriptors at a time, one record per lane
+        const uint32_t myrec = (on && act) ? m * (m + 1u) / 2u : 0u;
+        const uint32_t rincl = wave_incl_scan(myrec, lane);
+        const uint32_t T = bcast(rincl, WAVE - 1);
+        const uint32_t rexcl = rincl - myrec;
+        lds_sync();
+        for (uint32_t q0 = 0; q0 < T; q0 += K1G_QCAP) {
+            if (myrec) {
+                const uint32_t lo = rexcl > q0 ? rexcl : q0;
+                const uint32_t hi2 = rincl < q0 + K1G_QCAP ? rincl : q0 + K1G_QCAP;
+                if (lo < hi2) {
+                    const uint32_t r0 = lo - rexcl;
+                    uint32_t a = (uint32_t)((__fsqrt_rn(8.0f * (float)r0 + 1.0f) - 1.0f) * 0.5f);
+                    while (tri32(a) > r0) --a;
+                    while (tri32(a + 1u) <= r0) ++a;
+                    uint32_t b = r0 - tri32(a);
+                    for (uint32_t i = lo; i < hi2; ++i) {
+                        L.queue[i - q0] = lane | (a << 6) | (b << 19);
+                        if (++b > a) { ++a; b = 0; }
+                    }
+                }
+            }
+            lds_sync();
+            const uint32_t tend = T < q0 + K1G_QCAP ? T : q0 + K1G_QCAP;
+            for (uint32_t t0 = q0; t0 < tend; t0 += WAVE) {
+                const uint32_t t = t0 + lane;
+                if (t < tend) {
+                    const uint32_t d = L.queue[t - q0];
+                    const uint32_t own = d & 63u, a = (d >> 6) & 0x1FFFu, b = d >> 19;
+                    const uint32_t st = L.st_start[own];
+                    const unsigned long long FX = L.ent_mask[st + a], FY = L.ent_mask[st + b];
+                    const uint32_t X = L.ent_blk[st + a], Y = L.ent_blk[st + b];
+                    const uint32_t ww = L.st_w[own];
+                    const uint32_t cl = weight_class(ww);
+                    if (a != b || __popcll(FX) >= 2) {
+                        const Resv r = pool_reserve(q.pool, (tri32(X) + Y) * NCLS + cl, 1u);
+                        if (a != b) rec_store_off(q.pool, r.n1 ? r.base1 : r.base2, FX, FY, cl, ww);
+                        else rec_store_diag(q.pool, r.n1 ? r.base1 : r.base2, FX, cl, ww);
+                        ++n_rec;
+                    }
+                }
+            }
+            lds_sync();
+        }
+        done = hi;
+    }
+    (void)cls;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_rec += shfl64(n_rec, (int)(lane ^ (uint32_t)d));
+    if (lane == 0 && n_rec) atomicAdd((unsigned long long*)&q.pool.counters[KCTR_RECORDS], n_rec);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: records -> matrix
+// ------------------------------------------------------------------------------------------
+// 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit
+__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, uint32_t lane) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    // stage 32: the upper half of the wave swaps its low words with the high words of the lower half — one
+    // v_permlane32_swap on gfx950
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    }
+    // stage 16: 16-bit halves of every word between the lanes that differ in bit 4: v_permlane16_swap brings the
+    // partner's word, v_perm_b32 splices the halves
+    {
+        const bool up = (lane & 16u) != 0;
+        const uint32_t sel = up ? 0x03020706u : 0x05040100u;
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const uint32_t plo = up ? a[0] : a[1];
+        lo = __builtin_amdgcn_perm(plo, lo, sel);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const uint32_t phi = up ? b[0] : b[1];
+        hi = __builtin_amdgcn_perm(phi, hi, sel);
+    }
+    x = ((unsigned long long)hi << 32) | lo;
+    const unsigned long long masks[4] = {0x00FF00FF00FF00FFull, 0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
+    int s = 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k, s >>= 1) {
+        const unsigned long long m = masks[k];
+        uint32_t plo, phi;
+        if (s == 2) {               // quad_perm [2,3,0,1]
+            plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0x4E, 0xF, 0xF, false);
+            phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0x4E, 0xF, 0xF, false);
+        } else if (s == 1) {        // quad_perm [1,0,3,2]
+            plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0xB1, 0xF, 0xF, false);
+            phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0xB1, 0xF, 0xF, false);
+        } else {
+            plo = (uint32_t)__shfl_xor((int)(uint32_t)x, s, WAVE);
+            phi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), s, WAVE);
+        }
+        const unsigned long long pv = ((unsigned long long)phi << 32) | plo;
+        x = (lane & (uint32_t)s) ? ((x & ~m) | ((pv >> s) & m)) : ((x & m) | ((pv & m) << s));
+    }
+    return x;
+}
+
+struct K2Item {
+    uint32_t X, Y, cls, n;                 // block pair, weight class, records in the chunk
+    const unsigned char* rec;              // the chunk's record slots
+    const uint32_t* w;                     // the chunk's weights
+};
+__device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t j, bool weighted, unsigned long long& R, unsigned long long& Cc, uint32_t& W) {
+    R = 0; Cc = 0; W = 0;
+    if (j < it.n) {
+        if (diag) { R = ((const unsigned long long*)it.rec)[j]; Cc = R; }
+        else { const ulonglong2 rc = ((const ulonglong2*)it.rec)[j]; R = rc.x; Cc = rc.y; }
+        W = weighted ? it.w[j] : 1u;
+    }
+}
+
+// Popcount form (weights >= 128 only).  A wave takes 64 records per step, one per lane, and turns them into bit
+// matrices over the records: lane c holds Ct = "which of the 64 records contain column c", and Rt_r = "which records
+// contain row r" is read from LDS.  cell(r, c) += popcount(Ct & Rt_r & plane_b) << b for every bit plane b of the
+// weights that occurs in the step.  The cells live in registers (lane c keeps column c of the 64 x 64 block, one
+// register per row) and are merged through LDS once per work item.
+// DIAG (X == Y, rows == cols): the block is symmetric and only c < r is wanted.  Lane c then takes the rows
+// (c + d) mod width for d = 1 .. width/2 instead of all rows: every unordered pair of samples exactly once (for an even
+// width the distance width/2 is kept by the lower half of the lanes) — half the row loop; the row mask is a per-lane
+// LDS read instead of a broadcast.
+template <bool DIAG>
+__device__ __forceinline__ void k2_apply_popc(const K2Item& it, uint32_t* __restrict__ M, uint32_t bwidth, uint32_t* acc, unsigned long long (*rtbuf)[64]) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t njs = DIAG ? bwidth / 2u : bwidth;                    // accumulators in use
+    const uint32_t wrapd = bwidth - lane;                                 // DIAG: row of accumulator j = lane + j + 1 (mod width)
+    uint32_t a[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) a[r] = 0;
+    const unsigned long long* rt = rtbuf[wave];
+#define ROWMASK(j) (DIAG ? rt[((uint32_t)(j) + 1u < wrapd ? lane + (uint32_t)(j) + 1u : lane + (uint32_t)(j) + 1u - bwidth) & 63u] : rt[(j)])
+    unsigned long long nR = 0, nC = 0;
+    uint32_t nW = 0;
+    k2_fetch(it, DIAG, wave * 64 + lane, true, nR, nC, nW);
+    for (uint32_t g0 = wave * 64; g0 < it.n; g0 += 256) {
+        const unsigned long long R = nR, C = nC;
+        const uint32_t W = nW;
+        if (g0 + 256 < it.n) k2_fetch(it, DIAG, g0 + 256 + lane, true, nR, nC, nW);
+        const unsigned long long Ct = transpose64(C, lane);
+        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
+        lds_sync();
+        uint32_t wor = W;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wor |= (uint32_t)__shfl_xor((int)wor, d, WAVE);
+        wor = __builtin_amdgcn_readfirstlane(wor);
+        for (uint32_t wb = wor; wb; wb &= wb - 1) {
+            const uint32_t b = (uint32_t)__builtin_ctz(wb);
+            const unsigned long long Cb = Ct & __ballot(((W >> b) & 1u) != 0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                if ((uint32_t)(g * 4) < njs) {
+                    asm volatile("" ::: "memory");    // keep a group's LDS reads together (register pressure)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const int r = g * 4 + k; a[r] += (uint32_t)__popcll(Cb & ROWMASK(r)) << b; }
+                }
+            }
+        }
+        lds_sync();
+    }
+#undef ROWMASK
+    if (DIAG) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t d = (uint32_t)j + 1u;
+            if (d > njs || lane >= bwidth) continue;
+            if (2u * d == bwidth && lane >= d) continue;                 // even width: the opposite sample, once
+            const uint32_t r2 = d < wrapd ? lane + d : lane + d - bwidth;
+            const uint32_t row = r2 > lane ? r2 : lane, col = r2 > lane ? lane : r2;
+            if (a[j]) atomicAdd(&acc[row * 64 + col], a[j]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            if (a[r]) atomicAdd(&acc[r * 64 + lane], a[r]);
+    }
+}
+
+// The same accumulation on the matrix cores: over the 64 records of a step,
+//     cell(r, c) += sum_k  w_k [r in rows_k] * [c in cols_k]    =  (A B)(r, c),   A = 64 x 64 int8 (rows x records, weighted),
+//                                                                                B = 64 x 64 int8 (records x cols, 0/1)
+// as eight v_mfma_i32_32x32x32_i8 (operand layout probed in profiles/r01_mfma_i8_layout_probe.hip: lane l holds
+// A[l & 31][16 (l >> 5) + j], B[16 (l >> 5) + j][l & 31], j < 16; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).
+// The bit matrices R^T / C^T of the step are parked in LDS; a lane turns 16 of their bits into 16 operand bytes with two
+// reads of a 256-entry byte-spreading table and ANDs the weights in.  The work does not depend on the weights, so
+// every weight below 128 costs the same as 1.  Exact: integer MACs, no rounding anywhere.
+typedef int k2_v4i __attribute__((ext_vector_type(4)));
+typedef int k2_v16i __attribute__((ext_vector_type(16)));
+
+template <bool WEIGHTED, bool DIAG>
+__device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
+                                              unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t half = lane >> 5, l31 = lane & 31u;
+    k2_v16i c00 = {}, c01 = {}, c10 = {}, c11 = {};
+    const unsigned long long* lut_a = WEIGHTED ? lut_ff : lut_01;
+    auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> k2_v4i {
+        const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
+        const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
+        k2_v4i r;
+        r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
+        return r;
+    };
+    unsigned long long nR = 0, nC = 0;
+    uint32_t nW = 0;
+    k2_fetch(it, DIAG, wave * 64 + lane, WEIGHTED, nR, nC, nW);
+    for (uint32_t g0 = wave * 64; g0 < it.n; g0 += 256) {
+        const unsigned long long R = nR, C = nC;
+        const uint32_t W = nW;
+        if (g0 + 256 < it.n) k2_fetch(it, DIAG, g0 + 256 + lane, WEIGHTED, nR, nC, nW);
+        const unsigned long long Ct = transpose64(C, lane);
+        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);
+        if (!DIAG) ctbuf[wave][lane] = Ct;
+        if (WEIGHTED) wbuf[wave][lane] = (unsigned char)W;
+        lds_sync();
+        const unsigned long long* rtp = rtbuf[wave];
+        const unsigned long long* ctp = DIAG ? rtbuf[wave] : ctbuf[wave];
+        const unsigned long long ra0 = rtp[l31], ra1 = rtp[32u + l31], cb0 = ctp[l31], cb1 = ctp[32u + l31];
+#pragma unroll
+        for (uint32_t kh = 0; kh < 2; ++kh) {
+            const uint32_t shift = 32u * kh + 16u * half;            // records 32 kh + 16 half .. + 15 of the step
+            k2_v4i a0 = spread(ra0, shift, lut_a), a1 = spread(ra1, shift, lut_a);
+            if (WEIGHTED) {
+                const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
+                a0 &= wv; a1 &= wv;
+            }
+            const k2_v4i b0 = spread(cb0, shift, lut_01), b1 = spread(cb1, shift, lut_01);
+            c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c11, 0, 0, 0);
+        }
+        lds_sync();
+    }
+    // merge the four waves' tiles through the LDS block (on the diagonal only c < r)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
+        const uint32_t v00 = (uint32_t)c00[r], v01 = (uint32_t)c01[r], v10 = (uint32_t)c10[r], v11 = (uint32_t)c11[r];
+        if (v00 && (!DIAG || l31 < row0)) atomicAdd(&acc[row0 * 64 + l31], v00);
+        if (v01 && (!DIAG || 32u + l31 < row0)) atomicAdd(&acc[row0 * 64 + 32u + l31], v01);
+        if (v10 && (!DIAG || l31 < 32u + row0)) atomicAdd(&acc[(32u + row0) * 64 + l31], v10);
+        if (v11 && (!DIAG || l31 < row0)) atomicAdd(&acc[(32u + row0) * 64 + 32u + l31], v11);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
+                                                       const uint32_t* __restrict__ chunk_key, const uint32_t* __restrict__ chunk_fill,
+                                                       const uint32_t* __restrict__ counters, uint32_t c_shift,
+                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+    __shared__ uint32_t acc[64 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
+    __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
+    __shared__ unsigned long long lut_ff[256], lut_01[256];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= counters[KCTR_CHUNKS]) return;
+    K2Item it;
+    {
+        const uint32_t key = chunk_key[chunk];
+        const uint32_t bucket = key / NCLS;
+        it.cls = key - bucket * NCLS;
+        uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)bucket + 1.0f) - 1.0f) * 0.5f);
+        while (tri32(X) > bucket) --X;
+        while (tri32(X + 1u) <= bucket) ++X;
+        it.X = X; it.Y = bucket - tri32(X);
+        const uint32_t f = chunk_fill[chunk];
+        it.n = f ? f : (1u << c_shift);
+        it.rec = rec + ((size_t)chunk << (c_shift + 4));
+        it.w = recw + ((size_t)chunk << c_shift);
+    }
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
+    {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= ((threadIdx.x >> i) & 1u) ? 0xFFull << (8 * i) : 0ull;
+        lut_ff[threadIdx.x] = v;
+        lut_01[threadIdx.x] = v & 0x0101010101010101ull;
+    }
+    __syncthreads();
+    if (it.X == it.Y) {
+        if (it.cls == 0) k2_apply_mfma<false, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        else if (it.cls == 1) k2_apply_mfma<true, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        else k2_apply_popc<true>(it, M, bwidth, acc, rtbuf);
+    } else {
+        if (it.cls == 0) k2_apply_mfma<false, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        else if (it.cls == 1) k2_apply_mfma<true, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        else k2_apply_popc<false>(it, M, bwidth, acc, rtbuf);
+    }
+    // one HBM atomic per non-zero cell of the block
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
+        const uint32_t v = acc[k];
+        if (!v) continue;
+        const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
+        if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// upload-time: sampled estimate of the number of block records per candidate width
+// ------------------------------------------------------------------------------------------
+constexpr int EST_NW = 10;
+struct EstParams {
+    const uint2* k0in;
+    const uint32_t* bitrel;
+    const uint64_t* blkbase;
+    const uint64_t* bits;
+    const int32_t* parent;
+    const uint32_t* nl;
+    const uint32_t* w;
+    uint32_t P, stride;
+    uint32_t widths[EST_NW];
+    uint32_t magics[EST_NW];
+    unsigned long long* out;       // [EST_NW] records of the sampled nodes, + [EST_NW] nodes sampled
+};
+// One thread per sampled node: climbs the root path, decodes every node's local ids (the only decoder run outside the
+// call: it looks at one node in `stride`) and counts the blocks of the full list for every candidate width.
+__global__ void width_estimate_kernel(const EstParams q) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i0 = (uint64_t)t * q.stride + (t * 2654435761u) % q.stride;
+    if (i0 >= q.P) return;
+    const uint32_t node = (uint32_t)i0;
+    if (q.w[node] == 0 || (q.nl[node] & 0xFFFFu) < 2u) return;
+    uint32_t nblk[EST_NW], lower_first[EST_NW];
+#pragma unroll
+    for (int c = 0; c < EST_NW; ++c) { nblk[c] = 0; lower_first[c] = 0xFFFFFFFFu; }
+    int32_t y = (int32_t)node;
+    while (y >= 0) {
+        const uint2 km = q.k0in[y];
+        const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16;
+        if (l) {
+            const uint64_t pos = q.blkbase[(uint32_t)y >> 8] + q.bitrel[y];
+            uint32_t sum = 0;
+            if (l > 1) { BitCursor c(q.bits, pos); for (uint32_t k = 0; k + 1 < l; ++k) sum += c.next(); }
+            uint32_t id = last - sum;
+            uint32_t fb[EST_NW], cb[EST_NW];
+#pragma unroll
+            for (int c = 0; c < EST_NW; ++c) { fb[c] = __umulhi(id, q.magics[c]); cb[c] = fb[c]; nblk[c] += 1; }
+            if (l > 1) {
+                BitCursor c2(q.bits, pos);
+                for (uint32_t k = 0; k + 1 < l; ++k) {
+                    id += c2.next();
+#pragma unroll
+                    for (int c = 0; c < EST_NW; ++c) { const uint32_t b = __umulhi(id, q.magics[c]); nblk[c] += b != cb[c]; cb[c] = b; }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < EST_NW; ++c) { nblk[c] -= cb[c] == lower_first[c]; lower_first[c] = fb[c]; }
+        }
+        y = q.parent[y];
+    }
+#pragma unroll
+    for (int c = 0; c < EST_NW; ++c) atomicAdd(&q.out[c], (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u);
+    atomicAdd(&q.out[EST_NW], 1ull);
+}
+
+// v1 / new2all node arrays from the compact layout
+__global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ bitrel, const uint64_t* __restrict__ blkbase,
+                                 const uint32_t* __restrict__ nl, uint32_t P, uint4* __restrict__ meta, uint64_t* __restrict__ bitpos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint2 km = k0in[i];
+    const uint32_t v = nl[i];
+    meta[i] = make_uint4(v & 0xFFFFu, km.x & 0xFFFFu, km.x >> 16, km.y);
+    bitpos[i] = blkbase[i >> 8] + bitrel[i];
+}
+
+PoolView pool_view(const kmdb_db* db) {
+    return PoolView{db->state, db->counters, db->chunk_key, db->rec, db->recw, db->c_shift, (uint32_t)db->pool_cap};
+}
+
+void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+#define FREE_NULL(x) free_and_null((void**)&(x))
+
+int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
+    FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->rec); FREE_NULL(db->recw);
+    db->pool_cap = 0;
+    if (chunks >= (1ull << 32) >> db->c_shift) return kmdb_set_error("kmdb: record pool would exceed 2^32 record slots");
+    HIP_TRY(hipMalloc((void**)&db->chunk_key, chunks * 4));
+    HIP_TRY(hipMalloc((void**)&db->chunk_fill, chunks * 4));
+    HIP_TRY(hipMalloc((void**)&db->rec, (chunks << db->c_shift) * 16));
+    HIP_TRY(hipMalloc((void**)&db->recw, (chunks << db->c_shift) * 4));
+    db->pool_cap = chunks;
+    return 0;
+}
+int alloc_pair_pool(kmdb_db* db, uint64_t entries) {
+    FREE_NULL(db->pair_blk); FREE_NULL(db->pair_mask);
+    entries = (entries + KMDB_PAIR_REGIONS - 1) / KMDB_PAIR_REGIONS * KMDB_PAIR_REGIONS;
+    if (entries >= (1ull << 32)) return kmdb_set_error("kmdb: pair pool would exceed 2^32 entries");
+    HIP_TRY(hipMalloc((void**)&db->pair_blk, entries * 2 + 64));
+    HIP_TRY(hipMalloc((void**)&db->pair_mask, entries * 8 + 64));
+    db->pair_cap = entries;
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int kmdb_ensure_v1_arrays(kmdb_db* db) {
+    if (db->meta) return 0;
+    const uint64_t P = db->P;
+    HIP_TRY(hipMalloc((void**)&db->meta, std::max<uint64_t>(P, 1) * sizeof(uint4)));
+    HIP_TRY(hipMalloc((void**)&db->bitpos, std::max<uint64_t>(P, 1) * 8));
+    HIP_TRY(hipMalloc((void**)&db->wprefix, (P + 1) * 4));
+    HIP_TRY(hipMalloc((void**)&db->v1_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(db->v1_counters, 0, 8 * sizeof(unsigned long long)));
+    if (P) hipLaunchKernelGGL(v1_arrays_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, db->stream, db->k0in, db->bitrel, db->blkbase, db->nl,
+                              (uint32_t)P, db->meta, db->bitpos);
+    HIP_TRY(hipGetLastError());
+    std::vector<Segment> segs;
+    for (uint64_t f = 0; f < P; f += db->nseg_nodes) segs.push_back(Segment{(uint32_t)f, (uint32_t)std::min<uint64_t>(P, f + db->nseg_nodes)});
+    while (segs.size() % WAVES_PER_BLOCK) segs.push_back(Segment{(uint32_t)P, (uint32_t)P});
+    HIP_TRY(hipMalloc((void**)&db->segs, std::max<size_t>(segs.size(), 1) * sizeof(Segment)));
+    if (!segs.empty()) HIP_TRY(hipMemcpy(db->segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
+    db->n_segs = (uint32_t)segs.size();
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1)));
+    HIP_TRY(hipMalloc(&db->v1_scan_tmp, std::max<size_t>(db->v1_scan_tmp_bytes, 16)));
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    return 0;
+}
+
+int kmdb_blocks_prepare(kmdb_db* db) {
+    const uint64_t N = db->N, P = db->P;
+    db->fallback_reason.clear();
+    db->blocks_prepared = true;
+    if (N < 2 || P == 0) { db->fallback_reason = "fewer than two samples"; return 0; }
+    if (!db->chain_ok) {
+        db->fallback_reason = "a root path of " + std::to_string(db->max_depth) + " nodes exceeds the chain table (" + std::to_string(KMDB_CHAIN_MAX) + ")";
+        return 0;
+    }
+    const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
+    // ---- block width: fewer sample ids per block than 64 pay off when the samples cluster (clades, species) in id
+    // ranges that a 64-id grid would cut in two.  One node in `stride` is decoded along its whole root path and its
+    // blocks are counted for every candidate at once; the candidate with the fewest records wins.
+    const uint32_t cands[EST_NW] = {64, 60, 56, 52, 50, 48, 44, 40, 36, 32};
+    uint32_t forced = 0;
+    if (const char* e = getenv("KMDB_BLOCK_WIDTH")) forced = (uint32_t)strtoul(e, nullptr, 10);
+    const uint32_t stride = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, P / 65536));
+    {
+        EstParams q{};
+        q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.parent = db->parent; q.nl = db->nl; q.w = db->w;
+        q.P = (uint32_t)P; q.stride = stride;
+        for (int c = 0; c < EST_NW; ++c) { q.widths[c] = cands[c]; q.magics[c] = (uint32_t)((1ull << 32) / cands[c]) + 1u; }
+        HIP_TRY(hipMalloc((void**)&q.out, (EST_NW + 1) * 8));
+        HIP_TRY(hipMemsetAsync(q.out, 0, (EST_NW + 1) * 8, db->stream));
+        const uint64_t nthreads = (P + stride - 1) / stride;
+        hipLaunchKernelGGL(width_estimate_kernel, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, db->stream, q);
+        HIP_TRY(hipGetLastError());
+        unsigned long long h[EST_NW + 1];
+        HIP_TRY(hipMemcpyAsync(h, q.out, sizeof h, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        (void)hipFree(q.out);
+        int best = 0;
+        for (int c = 1; c < EST_NW; ++c) if (h[c] < h[best]) best = c;
+        if (forced >= 32 && forced <= 64) {
+            db->width = forced;
+            best = 0;
+            for (int c = 0; c < EST_NW; ++c) if (cands[c] >= forced) best = c;
+        } else db->width = cands[best];
+        db->est_records = h[best] * stride;
+        if (verbose) {
+            fprintf(stderr, "[kmdb] width estimate (1 node in %u, %llu sampled):", stride, h[EST_NW]);
+            for (int c = 0; c < EST_NW; ++c) fprintf(stderr, " %u:%llu", cands[c], h[c] * stride);
+            fprintf(stderr, " -> width %u\n", db->width);
+        }
+    }
+    db->NB = (uint32_t)((N + db->width - 1) / db->width);
+    const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2 * NCLS;
+    if (n_states >= (1ull << 31)) { db->fallback_reason = "too many block pairs"; return 0; }
+    db->n_states = (uint32_t)n_states;
+    // chunk size: every stream ends in a partly filled chunk, so many streams want small chunks
+    {
+        uint64_t budget = 2ull << 30;                              // bytes of partly filled chunks at most
+        uint32_t sh = 13;
+        while (sh > 6 && (n_states << sh) * 20 > budget) --sh;
+        db->c_shift = sh;
+        if (const char* e = getenv("KMDB_CHUNK_SHIFT")) db->c_shift = std::min(16u, std::max(6u, (uint32_t)strtoul(e, nullptr, 10)));
+    }
+    // ---- working set
+    HIP_TRY(hipMalloc((void**)&db->p0_mask, P * 8));
+    HIP_TRY(hipMalloc((void**)&db->p0_info, P * 4));
+    HIP_TRY(hipMalloc((void**)&db->pair_ofs, P * 4));
+    HIP_TRY(hipMalloc((void**)&db->pair_cursor, KMDB_PAIR_REGIONS * 16 * 4));
+    HIP_TRY(hipMalloc((void**)&db->fn_mask, P * 16));
+    HIP_TRY(hipMalloc((void**)&db->fn_blk, P * 4));
+    const uint64_t n_words = (P + 63) / 64;
+    HIP_TRY(hipMalloc((void**)&db->widebits, n_words * 8));
+    HIP_TRY(hipMalloc((void**)&db->wide_cnt, (n_words + 1) * 4));
+    HIP_TRY(hipMalloc((void**)&db->wide_base, (n_words + 1) * 4));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1)));
+    HIP_TRY(hipMalloc(&db->scan_tmp, std::max<size_t>(db->scan_tmp_bytes, 16)));
+    HIP_TRY(hipMalloc((void**)&db->state, n_states * 8));
+    HIP_TRY(hipMalloc((void**)&db->counters, KCTR_COUNT * 4));
+    HIP_TRY(hipHostMalloc((void**)&db->h_counters, KCTR_COUNT * 4));
+    if (alloc_pair_pool(db, std::max<uint64_t>(P / 3, 1u << 16))) return 1;
+    const uint64_t C = 1ull << db->c_shift;
+    uint64_t chunks = (db->est_records + db->est_records / 4) / C + std::min<uint64_t>(n_states, db->est_records / 8 + 1024) + 64;
+    if (alloc_record_pool(db, chunks)) return 1;
+    return 0;
+}
+
+void kmdb_blocks_release(kmdb_db* db) {
+    FREE_NULL(db->p0_mask); FREE_NULL(db->p0_info); FREE_NULL(db->pair_ofs); FREE_NULL(db->pair_blk); FREE_NULL(db->pair_mask);
+    FREE_NULL(db->pair_cursor); FREE_NULL(db->fn_mask); FREE_NULL(db->fn_blk); FREE_NULL(db->widebits); FREE_NULL(db->wide_cnt);
+    FREE_NULL(db->wide_base); FREE_NULL(db->widx); FREE_NULL(db->state); FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill);
+    FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp);
+    if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
+    db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
+}
+
+uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
+    if (!db->state) return 0;
+    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << db->c_shift) * 20) + db->pool_cap * 8 + (uint64_t)db->n_states * 8 +
+           db->wide_cap * 4 + (db->P / 64) * 16;
+}
+
+namespace {
+
+// one attempt of the whole pipeline; *retry is set when a pool was too small (it has been enlarged)
+int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, hipStream_t st, bool* retry) {
+    *retry = false;
+    // KMDB_SYNC_DEBUG: wait after every stage and name the one that failed (debugging aid, no effect on results)
+    static const bool sync_debug = getenv("KMDB_SYNC_DEBUG") != nullptr;
+    auto stage = [&](const char* name) -> int {
+        if (!sync_debug) return 0;
+        const hipError_t e = hipStreamSynchronize(st);
+        fprintf(stderr, "[kmdb] stage %-14s %s\n", name, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        return e == hipSuccess ? 0 : kmdb_set_error(std::string("stage ") + name + ": " + hipGetErrorString(e));
+    };
+    const uint32_t P = (uint32_t)db->P;
+    const BlockMap bm{db->width, (uint32_t)((1ull << 32) / db->width) + 1u};
+    const uint32_t n_words = (P + 63) / 64;
+    HIP_TRY(hipMemsetAsync(db->counters, 0, KCTR_COUNT * 4, st));
+    HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, KMDB_PAIR_REGIONS * 16 * 4, st));
+    HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, db->pool_cap * 4, st));
+    hipLaunchKernelGGL(pool_init_kernel, dim3((db->n_states + 255) / 256), dim3(256), 0, st, db->state, db->n_states, db->c_shift);
+    if (stage("init")) return 1;
+    // ---- K0
+    {
+        K0Params q{};
+        q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.perm = nullptr; q.P = P; q.bm = bm;
+        q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
+        q.pair_cursor = db->pair_cursor; q.region_cap = (uint32_t)(db->pair_cap / KMDB_PAIR_REGIONS); q.counters = db->counters;
+        hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
+        if (db->n_long) {
+            q.perm = db->long_nodes; q.P = db->n_long;
+            hipLaunchKernelGGL((k0_decode_kernel<true>), dim3((db->n_long + 255) / 256), dim3(256), 0, st, q);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (stage("decode")) return 1;
+    HIP_TRY(hipEventRecord(db->ev_k[0], st));
+    // ---- K1n
+    {
+        NParams q{};
+        q.nl = db->nl; q.parent = db->parent; q.w = db->w; q.dflag = db->dflag; q.seg_anc = db->nseg_anc; q.seg_anc_n = db->nseg_anc_n;
+        q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
+        q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.widebits = db->widebits;
+        q.P = P; q.nseg_nodes = db->nseg_nodes; q.n_segs = db->n_nsegs; q.chain_cap = db->chain_cap;
+        q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db);
+        const size_t lds = k1n_wave_bytes(q.chain_cap) * K1N_WAVES;
+        HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + K1N_WAVES - 1) / K1N_WAVES), dim3(WAVE * K1N_WAVES), lds, st, q);
+        HIP_TRY(hipGetLastError());
+    }
+    if (stage("narrow emit")) return 1;
+    HIP_TRY(hipEventRecord(db->ev_k[1], st));
+    // ---- wide list
+    hipLaunchKernelGGL(wide_count_kernel, dim3((n_words + 1 + 255) / 256), dim3(256), 0, st, db->widebits, n_words, db->wide_cnt);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->scan_tmp, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1), st));
+    uint32_t n_wide;
+    if (db->have_counts && db->wide_cap >= db->last_n_wide) n_wide = db->last_n_wide;     // deterministic per database; checked at the end of the call
+    else {
+        HIP_TRY(hipMemcpyAsync(db->h_counters, db->wide_base + n_words, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_wide = db->h_counters[0];
+        if (n_wide > db->wide_cap) {
+            FREE_NULL(db->widx);
+            HIP_TRY(hipMalloc((void**)&db->widx, (size_t)n_wide * 4));
+            db->wide_cap = n_wide;
+        }
+    }
+    if (!db->widx) { HIP_TRY(hipMalloc((void**)&db->widx, 4)); db->wide_cap = std::max<uint64_t>(db->wide_cap, 1); }
+    hipLaunchKernelGGL(wide_expand_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, db->widebits, db->wide_base, n_words, db->widx,
+                       (uint32_t)db->wide_cap, db->counters);
+    // ---- K1g
+    if (n_wide) {
+        GParams q{};
+        q.widx = db->widx; q.n_wide = n_wide; q.nl = db->nl; q.parent = db->parent; q.w = db->w; q.widebits = db->widebits;
+        q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
+        q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db);
+        const uint32_t batches = (n_wide + WAVE - 1) / WAVE;
+        hipLaunchKernelGGL(k1g_kernel, dim3((batches + K1G_WAVES - 1) / K1G_WAVES), dim3(WAVE * K1G_WAVES), 0, st, q);
+    }
+    HIP_TRY(hipGetLastError());
+    if (stage("wide emit")) return 1;
+    HIP_TRY(hipEventRecord(db->ev_k[2], st));
+    // ---- K2 over the chunks
+    hipLaunchKernelGGL(pool_finalize_kernel, dim3((db->n_states + 255) / 256), dim3(256), 0, st, db->state, db->n_states, db->c_shift,
+                       (uint32_t)db->pool_cap, db->chunk_fill);
+    uint32_t grid;
+    if (db->have_counts) grid = db->last_n_chunks;
+    else {
+        HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        grid = std::min<uint32_t>(db->h_counters[KCTR_CHUNKS], (uint32_t)db->pool_cap);
+    }
+    if (grid)
+        hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, st, db->rec, db->recw, db->chunk_key, db->chunk_fill, db->counters, db->c_shift,
+                           M, (uint32_t)db->N, db->width);
+    HIP_TRY(hipGetLastError());
+    if (stage("apply")) return 1;
+    HIP_TRY(hipEventRecord(db->ev_k[3], st));
+    // ---- what the call found
+    HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t* c = db->h_counters;
+    if (c[KCTR_LIST_OVERFLOW]) {
+        db->fallback_reason = "a chain of more-than-two-block nodes does not fit the entry pool of the wide-node kernel";
+        return 0;
+    }
+    if (c[KCTR_PAIR_OVERFLOW]) {
+        if (alloc_pair_pool(db, db->pair_cap * 2)) return 1;
+        db->have_counts = false; *retry = true;
+        return 0;
+    }
+    if (c[KCTR_POOL_OVERFLOW]) {
+        if (alloc_record_pool(db, std::max<uint64_t>(db->pool_cap * 2, (uint64_t)c[KCTR_CHUNKS] + 64))) return 1;
+        db->have_counts = false; *retry = true;
+        return 0;
+    }
+    if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks)) {
+        // cannot happen for an unchanged database and emit range; redo the call with measured sizes
+        db->have_counts = false; *retry = true;
+        return 0;
+    }
+    db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS];
+    db->last_records = (uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32);
+    return 0;
+}
+
+}  // namespace
+
+int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, hipStream_t st) {
+    if (db->last_emit_lo != emit_lo || db->last_emit_hi != emit_hi) db->have_counts = false;   // grid sizes belong to one emit range
+    db->last_emit_lo = emit_lo; db->last_emit_hi = emit_hi;
+    const uint64_t cells = db->N * (db->N - 1) / 2;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        bool retry = false;
+        if (attempt) HIP_TRY(hipMemsetAsync(M, 0, cells * 4, st));
+        if (blocks_attempt(db, M, emit_lo, emit_hi, st, &retry)) return 1;
+        if (!db->fallback_reason.empty()) return 0;
+        if (!retry) { db->have_counts = true; return 0; }
+        if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] pools enlarged (pairs %llu, chunks %llu), repeating the call\n",
+                                            (unsigned long long)db->pair_cap, (unsigned long long)db->pool_cap);
+    }
+    return kmdb_set_error("kmdb_blocks_run: the record pools did not converge");
+}

@@ -1,6 +1,6 @@
-// a2a_v1.hip — tree-form scatter kernels (the first generation of the dense all2all path; today the
-// fallback for N > 2048 / lists > 1024 ids, for pattern-stream sharded calls, and the A/B reference of
-// the block-record pipeline).
+// a2a_v1.hip — tree-form scatter kernels (the first generation of the dense all2all path; today the A/B
+// reference of the block-record pipeline behind KMDB_FLAG_FORCE_*, and the announced fallback for the
+// databases it cannot take: root paths beyond its chain table).
 //
 // All three walk the DFS stream like the reference walks its pattern blocks
 // (reference src/similarity_calculator.cpp:110-241) — lanes decode 64 nodes' gamma streams in parallel
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(WAVE * DIRECT_WAVES) void a2a_direct_kernel(A2APara
             if (cnt != 0)
                 for (uint32_t k = lane; k < lj; k += WAVE) stack[top + k] = dec[oj + k];
             wave_sync();
-            if (Wj != 0 && nj > 1 && !(p.dbg & 2)) {
+            if (Wj != 0 && nj > 1) {
                 for (uint32_t t = top; t < nj; ++t) {
                     const uint64_t rb = tri64(stack[t]);
                     for (uint32_t u = lane; u < t; u += WAVE) atomicAdd(&p.M[rb + stack[u]], Wj);
@@ -227,9 +227,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
             cvalid = cvalid < top ? cvalid : top;
             wave_sync();
             if (Wj == 0 || nj < 2) continue;
-            if (p.dbg & 8) continue;
             if (nj > (uint32_t)S) {
-                if (p.dbg & 16) continue;
                 // list longer than the tile side: straight to HBM
                 for (uint32_t t = top; t < nj; ++t) {
                     const uint64_t rb = tri64(L.rstack[t]);
@@ -246,7 +244,6 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
                 need += (uint32_t)__popcll(__ballot(isnew));
             }
             if (ns + need > (uint32_t)S) {
-                if (p.dbg & 4) { for (uint32_t k = lane; k < ns; k += WAVE) L.map[L.rid[k]] = 0xFF; ns = 0; wave_sync(); } else
                 tile_flush<S, NCAP>(L, ns, p.M, lane, p.counters);
                 cvalid = 0;
             }
@@ -273,7 +270,6 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void a2a_tile_kernel(A2APar
             const uint32_t c1v = (S > 64 && lane + 64 < nj) ? L.cstack[lane + 64] : 0u;
             const uint32_t t0v = c0v * (c0v - 1) / 2;       // garbage for c=0 is never used as a base with c<r false... guarded below
             const uint32_t t1v = c1v * (c1v - 1) / 2;
-            if (!(p.dbg & 2))
             for (uint32_t t = top; t < nj; ++t) {
                 const uint32_t r = t < 64 ? bcast(c0v, t) : bcast(c1v, t - 64);
                 const uint32_t rr = r * (r - 1) / 2;
@@ -312,8 +308,7 @@ int kmdb_v1_run(kmdb_db* db, uint32_t* M, uint32_t seg_begin, uint32_t seg_end, 
     A2AParams p{};
     p.meta = db->meta; p.bitpos = db->bitpos; p.parent = db->parent; p.sub_end = db->sub_end;
     p.wprefix = db->wprefix; p.bits = db->bits; p.segs = db->segs;
-    p.seg_begin = seg_begin; p.seg_end = seg_end; p.M = M; p.counters = db->counters;
-    p.dbg = flags >> 8;
+    p.seg_begin = seg_begin; p.seg_end = seg_end; p.M = M; p.counters = db->v1_counters;
     const uint32_t nseg = seg_end - seg_begin;
     const uint32_t blocks = (nseg + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     const bool force_global = (flags & KMDB_FLAG_FORCE_GLOBAL_ATOMICS) != 0;

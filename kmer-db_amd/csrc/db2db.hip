@@ -59,7 +59,7 @@ __global__ void d2_probe_kernel(D2Db row, D2Db col, uint64_t n_col_slots, unsign
                 const uint64_t mask = cap - 1;
                 const uint32_t kk = (uint32_t)it;
                 uint64_t h = (uint64_t)d2_fmix32(kk) & mask;
-                for (;;) {
+                for (uint64_t step = 0; step < cap; ++step) {        // a full table (corrupt file) ends the probe too
                     const uint64_t r = row.slots[off + h];
                     const int32_t pr = (int32_t)(r >> 32);
                     if (pr == 0x7fffffff) break;
@@ -167,8 +167,8 @@ D2Db view_of(const kmdb_engine_view& e) {
 extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmdb_opts* opts) {
     if (!db_row || !db_col || !out) return kmdb_set_error("kmdb_db2db_dense: null argument");
     kmdb_engine_view er, ec;
-    kmdb_engine_get(db_row, &er);
-    kmdb_engine_get(db_col, &ec);
+    if (kmdb_engine_get(db_row, &er)) return 1;
+    if (kmdb_engine_get(db_col, &ec)) return 1;
     if (!er.n_buckets || !er.slots || !ec.n_buckets || !ec.slots)
         return kmdb_set_error("kmdb_db2db_dense: both databases must be uploaded with hashtables");
     if (er.kmer_length != ec.kmer_length) return kmdb_set_error("kmdb_db2db_dense: the databases have different k-mer lengths");

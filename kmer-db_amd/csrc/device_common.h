@@ -267,7 +267,6 @@ struct A2AParams {
     uint32_t* stack_scratch;        // global kernel only
     uint32_t stack_stride;          // words per wave
     unsigned long long* counters;
-    uint32_t dbg;                   // timing experiments only: 2 = skip scatter, 4 = skip flush, 8 = skip mapping+scatter
 };
 
 // rebuild the id stack for the ancestors of `first` by walking parent links

@@ -24,5 +24,6 @@ struct kmdb_engine_view {
     void* ev[4];
 };
 
-void kmdb_engine_get(kmdb_db* db, kmdb_engine_view* out);
+// also builds the v1 / new2all node arrays on first use; non-zero on failure
+int kmdb_engine_get(kmdb_db* db, kmdb_engine_view* out);
 void kmdb_engine_set_times(kmdb_db* db, double kernel_ms, double dominant_ms);

@@ -112,6 +112,9 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
         uint64_t allocated = c.get<uint64_t>();
         c.take(8 * 5);                               // size_when_restruct, mask, ht_memory, ht_total, ht_match
         if (!c.ok) return fail("bad hashtable header");
+        // hashmap_lp invariants (reference src/hashmap_lp.h:150,427-437): power-of-two capacity with at least one empty slot —
+        // the device probes rely on both
+        if (allocated == 0 || (allocated & (allocated - 1)) || filled >= allocated || allocated > (1ull << 40)) return fail("bad hashtable header");
         if (!c.take(8 * ((allocated + 63) / 64)) || !c.take(8 * filled)) return fail("bad hashtable body");
         if (want_ht) { db->bucket_offset[b] = total_slots; total_slots += allocated; }
     }
@@ -134,16 +137,21 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
                 while (word) {                        // slot-exact restore (hashmap_lp.h:580-600)
                     int bit = __builtin_ctzll(word);
                     word &= word - 1;
-                    if (it >= filled) return fail("hashtable fill vector overflow");
+                    if (it >= filled || w * 64 + (uint64_t)bit >= allocated) return fail("hashtable fill vector overflow");
                     std::memcpy(&dst[w * 64 + bit], items + 8 * it, 8);
                     ++it;
                 }
             }
+            if (it != filled) return fail("hashtable fill vector does not match the item count");
         }
     }
 
     uint64_t P = c.get<uint64_t>();
     if (!c.ok || P > (uint64_t)st.st_size) return fail("bad pattern count");
+    for (uint64_t sl : db->slots) {                     // every stored pattern id must exist (the device indexes with it)
+        const int32_t val = (int32_t)(sl >> 32);
+        if (val != INT32_MAX && (val < 0 || (uint64_t)val >= P)) return fail("hashtable item points past the pattern table");
+    }
     db->num_kmers.resize(P); db->parent_id.resize(P);
     db->num_samples.resize(P); db->num_local.resize(P);
     db->last_id.resize(P); db->num_bits.resize(P); db->data_offset.resize(P);

@@ -1,0 +1,520 @@
+// layout.hip — kmdb_db_upload: the on-disk pattern section (pid order, parent links) becomes the HBM layout of the
+// engine (DFS pre-order, bit-packed streams).  A pure format conversion: nothing here decodes a sample id.
+//
+//   host   (threads)  narrow the header fields, validate them, pack the 128-bit padded gamma streams back to back
+//                     in pid order (reference layout: src/pattern.cpp:15-46, streams src/elias_gamma.h:113-125)
+//   device            subtree sizes (leaf climb with child counters), children grouped by parent (stable radix sort:
+//                     pid order inside a family), pre-order offsets among siblings (scan), pre-order index / depth of
+//                     every node by pointer doubling along the parent links, then one gather into DFS order and a
+//                     bit-exact re-pack of the streams
+// parent_id[p] < p (patterns are appended, reference src/prefix_kmer_db.cpp:219,357); children keep pid order.
+#include "device_common.h"
+#include "engine_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace {
+
+struct U32toU64 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
+
+__global__ void lay_child_count_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* __restrict__ cnt /*[P+1], index = parent + 1*/) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) atomicAdd(&cnt[parent[i] + 1], 1u);
+}
+
+// subtree sizes: every leaf climbs; a node continues upwards only as the LAST of its siblings to arrive
+__global__ void lay_sizes_kernel(const int32_t* __restrict__ parent, const uint32_t* __restrict__ cnt, uint32_t P, uint32_t* __restrict__ size,
+                                 uint32_t* __restrict__ pending) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P || cnt[i + 1] != 0) return;
+    uint32_t v = i, sz = 1;
+    for (;;) {
+        const int32_t p = parent[v];
+        if (p < 0) break;
+        atomicAdd(&size[p], sz);
+        __threadfence();
+        if (atomicSub(&pending[p], 1u) != 1u) break;
+        __threadfence();
+        sz = atomicAdd(&size[p], 0u);
+        v = (uint32_t)p;
+    }
+}
+
+__global__ void lay_keys_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) { keys[i] = (uint32_t)(parent[i] + 1); vals[i] = i; }
+}
+__global__ void lay_fill_kernel(uint32_t* __restrict__ dst, uint32_t n, uint32_t val) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = val;
+}
+__global__ void lay_pid2dfs_kernel(const uint32_t* __restrict__ acc, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = acc[i] - 1u;
+}
+__global__ void lay_gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// offset of a child inside its parent's subtree: 1 + sizes of the earlier siblings
+__global__ void lay_rel_kernel(const uint32_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_child, const uint32_t* __restrict__ S,
+                               const uint32_t* __restrict__ child_begin, uint32_t P, uint32_t* __restrict__ acc, uint32_t* __restrict__ dep,
+                               int32_t* __restrict__ anc, const int32_t* __restrict__ parent) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const uint32_t c = sorted_child[j];
+    acc[c] = 1u + S[j] - S[child_begin[sorted_keys[j]]];
+    dep[c] = 1u;
+    anc[c] = parent[c];
+}
+// one round of pointer doubling: (sum of offsets, number of nodes) along the path to the current ancestor pointer
+__global__ void lay_jump_kernel(const uint32_t* __restrict__ acc_in, const uint32_t* __restrict__ dep_in, const int32_t* __restrict__ anc_in, uint32_t P,
+                                uint32_t* __restrict__ acc_out, uint32_t* __restrict__ dep_out, int32_t* __restrict__ anc_out, uint32_t* __restrict__ active) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int32_t a = anc_in[i];
+    uint32_t ac = acc_in[i], dp = dep_in[i];
+    int32_t na = -1;
+    if (a >= 0) {
+        ac += acc_in[a]; dp += dep_in[a]; na = anc_in[a];
+        if (na >= 0) *active = 1u;
+    }
+    acc_out[i] = ac; dep_out[i] = dp; anc_out[i] = na;
+}
+__global__ void lay_order_kernel(const uint32_t* __restrict__ acc, uint32_t P, uint32_t* __restrict__ order, uint32_t* __restrict__ bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t pre = acc[i] - 1u;                       // the virtual root sits at -1
+    if (pre >= P) { *bad = 1u; return; }
+    order[pre] = i;
+}
+struct LayStats { unsigned long long alg, upd, pairs; uint32_t max_n, max_depth, bad, n_long; };
+__global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ acc, const uint32_t* __restrict__ dep,
+                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ size, const int32_t* __restrict__ parent,
+                                  const uint32_t* __restrict__ h_ll, const uint32_t* __restrict__ h_n, const uint32_t* __restrict__ h_nbits,
+                                  const uint32_t* __restrict__ h_w, const unsigned long long* __restrict__ h_wfull, uint32_t P,
+                                  uint2* __restrict__ k0in, uint32_t* __restrict__ nl, int32_t* __restrict__ dparent, uint32_t* __restrict__ w,
+                                  uint16_t* __restrict__ dflag, uint32_t* __restrict__ sub_end, LayStats* __restrict__ st) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long alg = 0, upd = 0, pairs = 0;
+    uint32_t mn = 0, md = 0, nlong = 0;
+    if (i < P) {
+        const uint32_t pid = order[i];
+        const uint32_t ll = h_ll[pid], n = h_n[pid], nb = h_nbits[pid], l = ll & 0xFFFFu;
+        k0in[i] = make_uint2(ll, nb);
+        nl[i] = n | (l << 16);
+        const int32_t par = parent[pid];
+        dparent[i] = par < 0 ? -1 : (int32_t)(acc[par] - 1u);
+        w[i] = h_w[pid];
+        const uint32_t d = dep[pid];
+        dflag[i] = (uint16_t)((d > 0x7FFFu ? 0x7FFFu : d) | (cnt[pid + 1] ? 0x8000u : 0u));
+        sub_end[i] = i + size[pid];
+        alg = 40ull + (unsigned long long)((nb + 127u) / 128u) * 16ull;
+        upd = (unsigned long long)(n - l) * l + (unsigned long long)l * (l ? l - 1 : 0) / 2;
+        pairs = (h_wfull ? h_wfull[pid] : (unsigned long long)h_w[pid]) * ((unsigned long long)n * (n ? n - 1 : 0) / 2);
+        mn = n; md = d; nlong = kmdb_long_node(l, nb) ? 1u : 0u;
+    } else if (i == P) w[P] = 0;
+    // block reduction of the statistics
+    __shared__ unsigned long long s_alg[256], s_upd[256], s_pairs[256];
+    __shared__ uint32_t s_mn[256], s_md[256], s_nl[256];
+    s_alg[threadIdx.x] = alg; s_upd[threadIdx.x] = upd; s_pairs[threadIdx.x] = pairs; s_mn[threadIdx.x] = mn; s_md[threadIdx.x] = md; s_nl[threadIdx.x] = nlong;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_alg[threadIdx.x] += s_alg[threadIdx.x + s]; s_upd[threadIdx.x] += s_upd[threadIdx.x + s]; s_pairs[threadIdx.x] += s_pairs[threadIdx.x + s];
+            s_mn[threadIdx.x] = max(s_mn[threadIdx.x], s_mn[threadIdx.x + s]); s_md[threadIdx.x] = max(s_md[threadIdx.x], s_md[threadIdx.x + s]);
+            s_nl[threadIdx.x] += s_nl[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&st->alg, s_alg[0]); atomicAdd(&st->upd, s_upd[0]); atomicAdd(&st->pairs, s_pairs[0]);
+        atomicMax(&st->max_n, s_mn[0]); atomicMax(&st->max_depth, s_md[0]); atomicAdd(&st->n_long, s_nl[0]);
+    }
+}
+__global__ void lay_nbits_dfs_kernel(const uint2* __restrict__ k0in, uint32_t P, uint32_t* __restrict__ nb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) nb[i] = k0in[i].y;
+}
+__global__ void lay_blkbase_kernel(const uint64_t* __restrict__ dstpos, uint32_t P, uint64_t* __restrict__ blkbase, uint32_t* __restrict__ bitrel) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint64_t b = dstpos[i & ~255u];
+    if ((i & 255u) == 0) blkbase[i >> 8] = b;
+    bitrel[i] = (uint32_t)(dstpos[i] - b);
+}
+// re-pack: the stream of DFS node i moves from its pid-order position to its DFS-order position (both bit-granular,
+// MSB-first inside little-endian uint64 words)
+__global__ void lay_copy_bits_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ srcpos, const uint64_t* __restrict__ dstpos,
+                                     const uint2* __restrict__ k0in, const uint64_t* __restrict__ src, uint32_t P, unsigned long long* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t nb = k0in[i].y;
+    if (!nb) return;
+    uint64_t sp = srcpos[order[i]], dp = dstpos[i];
+    for (uint32_t done = 0; done < nb; done += 64) {
+        const uint32_t take = nb - done < 64u ? nb - done : 64u;
+        const uint32_t ss = (uint32_t)(sp & 63u);
+        uint64_t chunk = src[sp >> 6] << ss;
+        if (ss && take > 64u - ss) chunk |= src[(sp >> 6) + 1] >> (64u - ss);
+        if (take < 64u) chunk &= ~0ull << (64u - take);
+        const uint32_t ds = (uint32_t)(dp & 63u);
+        atomicOr(&dst[dp >> 6], (unsigned long long)(chunk >> ds));
+        if (ds && take > 64u - ds) atomicOr(&dst[(dp >> 6) + 1], (unsigned long long)(chunk << (64u - ds)));
+        sp += take; dp += take;
+    }
+}
+// long nodes: (work key, DFS index), compacted with a block-aggregated cursor
+__global__ void lay_long_kernel(const uint2* __restrict__ k0in, uint32_t P, uint32_t* __restrict__ cursor, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is = false;
+    uint32_t work = 0;
+    if (i < P) {
+        const uint2 km = k0in[i];
+        const uint32_t l = km.x & 0xFFFFu;
+        is = kmdb_long_node(l, km.y);
+        work = km.y - (l ? l - 1u : 0u);
+    }
+    const unsigned long long bal = __ballot(is);
+    if (!bal) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (uint32_t)__popcll(bal));
+    base = (uint32_t)__shfl((int)base, 0, WAVE);
+    if (is) {
+        const uint32_t o = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        keys[o] = work; vals[o] = i;
+    }
+}
+// root path of the first node of every slice, root first
+__global__ void lay_seg_anc_kernel(const int32_t* __restrict__ parent, const uint16_t* __restrict__ dflag, uint32_t P, uint32_t nseg_nodes, uint32_t n_segs,
+                                   uint32_t chain_cap, uint32_t* __restrict__ anc, uint32_t* __restrict__ anc_n) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    int32_t cur = parent[(size_t)s * nseg_nodes];
+    uint32_t d = cur < 0 ? 0u : (uint32_t)(dflag[cur] & 0x7FFFu);
+    if (d > chain_cap) d = 0;                                  // deeper than the chain table: the pipeline is not used
+    anc_n[s] = d;
+    while (cur >= 0 && d) { anc[(size_t)s * chain_cap + (--d)] = (uint32_t)cur; cur = parent[cur]; }
+}
+// a prefix shard keeps only its own k-mers: w_s[p] = #{slots of the shard's buckets that point to p}
+__global__ void lay_shard_weights_kernel(const uint64_t* __restrict__ slots, const uint64_t* __restrict__ bucket_offset, uint64_t n_buckets,
+                                         uint32_t shard_index, uint32_t shard_count, uint32_t P, uint32_t* __restrict__ w_pid) {
+    const uint64_t b = blockIdx.x;
+    if (b >= n_buckets || b % shard_count != shard_index) return;
+    for (uint64_t j = bucket_offset[b] + threadIdx.x; j < bucket_offset[b + 1]; j += blockDim.x) {
+        const int32_t val = (int32_t)(slots[j] >> 32);
+        if (val != INT32_MAX && val >= 0 && (uint32_t)val < P) atomicAdd(&w_pid[val], 1u);
+    }
+}
+
+template <class T>
+struct HostBuf {
+    T* p = nullptr;
+    explicit HostBuf(size_t n, bool zero = false) { p = (T*)(zero ? std::calloc(std::max<size_t>(n, 1), sizeof(T)) : std::malloc(std::max<size_t>(n, 1) * sizeof(T))); }
+    ~HostBuf() { std::free(p); }
+    void reset() { std::free(p); p = nullptr; }
+    T& operator[](size_t i) { return p[i]; }
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+};
+
+template <class T>
+struct DevTmp {
+    T* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { HIP_TRY(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return 0; }
+    void reset() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+}  // namespace
+
+int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count) {
+    const uint64_t P = v->n_patterns, N = v->n_samples;
+    const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
+    auto tphase0 = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!verbose) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kmdb] upload: %-34s %.3f s\n", what, std::chrono::duration<double>(now - tphase0).count());
+        tphase0 = now;
+    };
+    hipStream_t st = db->stream;
+    const unsigned B = 256;
+    const unsigned G = (unsigned)((P + B - 1) / B), G1 = (unsigned)((P + 1 + B - 1) / B);
+
+    // ---- host: narrow + validate the header fields, pack the streams in pid order
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::min<uint64_t>(std::min(64u, hw), std::max<uint64_t>(1, P / 65536));
+    HostBuf<int32_t> h_parent(P);                             // not zero-filled: the pages are first touched by the worker threads
+    HostBuf<uint32_t> h_ll(P), h_n(P), h_nbits(P), h_w(P);
+    if (!h_parent.p || !h_ll.p || !h_n.p || !h_nbits.p || !h_w.p) return kmdb_set_error("kmdb_db_upload: out of host memory");
+    std::vector<uint64_t> part_bits(T + 1, 0);
+    std::atomic<int> bad{0};
+    auto run_parts = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back([&, t] { fn(t, P * t / T, P * (t + 1) / T); });
+        fn(0u, (uint64_t)0, P / T);
+        for (auto& th : pool) th.join();
+    };
+    run_parts([&](unsigned t, uint64_t lo, uint64_t hi) {
+        uint64_t nbsum = 0;
+        for (uint64_t p = lo; p < hi; ++p) {
+            const int64_t par = v->parent_id[p];
+            const uint32_t n = v->num_samples[p], l = v->num_local[p], nb = v->num_bits[p], last = v->last_sample_id[p];
+            if (par >= (int64_t)p) bad = 1;
+            if (l > n || n > N || l > 0xFFFFu || (l && last >= N) || n > 0xFFFFu) bad = 2;
+            h_parent[p] = par < 0 ? -1 : (int32_t)par;
+            h_ll[p] = l | (last << 16);
+            h_n[p] = n;
+            h_nbits[p] = nb;
+            h_w[p] = (uint32_t)v->num_kmers[p];                // truncated exactly like the reference's to_add (similarity_calculator.cpp:222)
+            nbsum += nb;
+        }
+        part_bits[t + 1] = nbsum;
+    });
+    if (bad == 1) return kmdb_set_error("kmdb_db_upload: parent_id >= pattern id");
+    if (bad) return kmdb_set_error("kmdb_db_upload: inconsistent pattern header");
+    for (unsigned t = 0; t < T; ++t) part_bits[t + 1] += part_bits[t];
+    const uint64_t total_bits = part_bits[T];
+    const uint64_t n_bit_words = (total_bits + 63) / 64 + 16;       // zero padding words for the cursors' look-ahead
+    HostBuf<uint64_t> h_bits(n_bit_words, /*zero=*/true);
+    if (!h_bits.p) return kmdb_set_error("kmdb_db_upload: out of host memory");
+    run_parts([&](unsigned t, uint64_t lo, uint64_t hi) {
+        // streams of different threads can share a word at the range boundaries: OR the words in atomically
+        uint64_t pos = part_bits[t];
+        for (uint64_t p = lo; p < hi; ++p) {
+            const uint32_t nb = h_nbits[p];
+            if (!nb) continue;
+            const uint64_t* src = v->data + v->data_offset[p];
+            for (uint32_t done = 0; done < nb; done += 64) {
+                const uint32_t take = std::min<uint32_t>(64, nb - done);
+                uint64_t chunk = src[done >> 6];
+                if (take < 64) chunk &= ~0ull << (64 - take);
+                const uint32_t sh = (uint32_t)(pos & 63);
+                __atomic_fetch_or(&h_bits[pos >> 6], chunk >> sh, __ATOMIC_RELAXED);
+                if (sh && take > 64 - sh) __atomic_fetch_or(&h_bits[(pos >> 6) + 1], chunk << (64 - sh), __ATOMIC_RELAXED);
+                pos += take;
+            }
+        }
+    });
+    phase("host: narrow fields + pack streams");
+
+    // ---- H2D
+    DevTmp<int32_t> d_parent;
+    DevTmp<uint32_t> d_ll, d_n, d_nbits, d_w;
+    DevTmp<uint64_t> d_src;
+    if (d_parent.alloc(P) || d_ll.alloc(P) || d_n.alloc(P) || d_nbits.alloc(P) || d_w.alloc(P) || d_src.alloc(n_bit_words)) return 1;
+    HIP_TRY(hipMemcpyAsync(d_parent.p, h_parent.p, P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ll.p, h_ll.p, P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_n.p, h_n.p, P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_nbits.p, h_nbits.p, P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_w.p, h_w.p, P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_src.p, h_bits.p, n_bit_words * 8, hipMemcpyHostToDevice, st));
+    DevTmp<unsigned long long> d_wfull;                       // sum_pairs uses the untruncated counts
+    uint64_t dev_ht_bytes = 0;
+    if (with_hashtables && v->n_buckets) {
+        const uint64_t n_slots = v->bucket_offset[v->n_buckets];
+        db->n_buckets = v->n_buckets;
+        HIP_TRY(hipMalloc((void**)&db->bucket_offset, (v->n_buckets + 1) * 8));
+        HIP_TRY(hipMalloc((void**)&db->slots, std::max<uint64_t>(n_slots, 1) * 8));
+        HIP_TRY(hipMemcpyAsync(db->bucket_offset, v->bucket_offset, (v->n_buckets + 1) * 8, hipMemcpyHostToDevice, st));
+        if (n_slots) HIP_TRY(hipMemcpyAsync(db->slots, v->slots, n_slots * 8, hipMemcpyHostToDevice, st));
+        dev_ht_bytes = (v->n_buckets + 1) * 8 + n_slots * 8 + P * 4;
+    }
+    if (shard_count > 1) {
+        // prefix-bucket shard (bucket = kmer >> 32, reference src/types.h:25-27): the tree stays whole, the weights become
+        // the shard's own k-mer counts — partial matrices of all shards sum to the full one
+        if (!v->n_buckets) return kmdb_set_error("kmdb_db_upload_shard: the view carries no hashtables (load the database with mode Everything)");
+        const uint64_t n_slots = v->bucket_offset[v->n_buckets];
+        DevTmp<uint64_t> t_off, t_slots;
+        const uint64_t* bo = db->bucket_offset;
+        const uint64_t* sl = db->slots;
+        if (!bo) {
+            if (t_off.alloc(v->n_buckets + 1) || t_slots.alloc(n_slots)) return 1;
+            HIP_TRY(hipMemcpyAsync(t_off.p, v->bucket_offset, (v->n_buckets + 1) * 8, hipMemcpyHostToDevice, st));
+            if (n_slots) HIP_TRY(hipMemcpyAsync(t_slots.p, v->slots, n_slots * 8, hipMemcpyHostToDevice, st));
+            bo = t_off.p; sl = t_slots.p;
+        }
+        HIP_TRY(hipMemsetAsync(d_w.p, 0, P * 4, st));
+        hipLaunchKernelGGL(lay_shard_weights_kernel, dim3((unsigned)v->n_buckets), dim3(256), 0, st, sl, bo, v->n_buckets, shard_index, shard_count, (uint32_t)P, d_w.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    phase("H2D");
+    h_parent.reset(); h_ll.reset(); h_n.reset(); h_nbits.reset(); h_w.reset(); h_bits.reset();
+
+    // ---- device: DFS pre-order
+    DevTmp<uint32_t> cnt, size, pending, keys, vals, skeys, schild, ssz, S, child_begin, acc[2], dep[2], order, flags;
+    DevTmp<int32_t> anc[2];
+    if (cnt.alloc(P + 2) || size.alloc(P) || pending.alloc(P) || flags.alloc(4)) return 1;
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, (P + 2) * 4, st));
+    HIP_TRY(hipMemsetAsync(flags.p, 0, 16, st));
+    hipLaunchKernelGGL(lay_child_count_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, cnt.p);
+    // size = 1, pending = children
+    HIP_TRY(hipMemcpyAsync(pending.p, cnt.p + 1, P * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(lay_fill_kernel, dim3(G), dim3(B), 0, st, size.p, (uint32_t)P, 1u);
+    hipLaunchKernelGGL(lay_sizes_kernel, dim3(G), dim3(B), 0, st, d_parent.p, cnt.p, (uint32_t)P, size.p, pending.p);
+    HIP_TRY(hipGetLastError());
+    pending.reset();
+    // children grouped by parent, pid order inside a family
+    if (keys.alloc(P) || vals.alloc(P) || skeys.alloc(P) || schild.alloc(P)) return 1;
+    hipLaunchKernelGGL(lay_keys_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, keys.p, vals.p);
+    {
+        int end_bit = 1;
+        while ((1ull << end_bit) <= P) ++end_bit;
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
+        DevTmp<unsigned char> tmp;
+        if (tmp.alloc(tb)) return 1;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    keys.reset(); vals.reset();
+    if (ssz.alloc(P) || S.alloc(P + 1) || child_begin.alloc(P + 2)) return 1;
+    hipLaunchKernelGGL(lay_gather_u32_kernel, dim3(G), dim3(B), 0, st, size.p, schild.p, (uint32_t)P, ssz.p);
+    {
+        size_t tb1 = 0, tb2 = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, ssz.p, S.p, (int)P, st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, cnt.p, child_begin.p, (int)(P + 1), st));
+        DevTmp<unsigned char> tmp;
+        if (tmp.alloc(std::max(tb1, tb2))) return 1;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb1, ssz.p, S.p, (int)P, st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, cnt.p, child_begin.p, (int)(P + 1), st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    ssz.reset();
+    for (int k = 0; k < 2; ++k) if (acc[k].alloc(P) || dep[k].alloc(P) || anc[k].alloc(P)) return 1;
+    hipLaunchKernelGGL(lay_rel_kernel, dim3(G), dim3(B), 0, st, skeys.p, schild.p, S.p, child_begin.p, (uint32_t)P, acc[0].p, dep[0].p, anc[0].p, d_parent.p);
+    HIP_TRY(hipGetLastError());
+    skeys.reset(); schild.reset(); S.reset(); child_begin.reset();
+    int cur = 0;
+    for (int round = 0; round < 40; ++round) {
+        HIP_TRY(hipMemsetAsync(flags.p, 0, 4, st));
+        hipLaunchKernelGGL(lay_jump_kernel, dim3(G), dim3(B), 0, st, acc[cur].p, dep[cur].p, anc[cur].p, (uint32_t)P, acc[cur ^ 1].p, dep[cur ^ 1].p,
+                           anc[cur ^ 1].p, flags.p);
+        uint32_t active = 0;
+        HIP_TRY(hipMemcpyAsync(&active, flags.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        cur ^= 1;
+        if (!active) break;
+    }
+    anc[0].reset(); anc[1].reset(); acc[cur ^ 1].reset(); dep[cur ^ 1].reset();
+    if (order.alloc(P)) return 1;
+    HIP_TRY(hipMemsetAsync(order.p, 0xFF, P * 4, st));
+    hipLaunchKernelGGL(lay_order_kernel, dim3(G), dim3(B), 0, st, acc[cur].p, (uint32_t)P, order.p, flags.p + 1);
+    phase("device: DFS pre-order");
+
+    // ---- DFS-ordered node arrays
+    HIP_TRY(hipMalloc((void**)&db->k0in, std::max<uint64_t>(P, 1) * 8));
+    HIP_TRY(hipMalloc((void**)&db->nl, std::max<uint64_t>(P, 1) * 4));
+    HIP_TRY(hipMalloc((void**)&db->parent, std::max<uint64_t>(P, 1) * 4));
+    HIP_TRY(hipMalloc((void**)&db->w, (P + 1) * 4));
+    HIP_TRY(hipMalloc((void**)&db->dflag, std::max<uint64_t>(P, 1) * 2));
+    HIP_TRY(hipMalloc((void**)&db->sub_end, std::max<uint64_t>(P, 1) * 4));
+    DevTmp<LayStats> d_stats;
+    if (d_stats.alloc(1)) return 1;
+    HIP_TRY(hipMemsetAsync(d_stats.p, 0, sizeof(LayStats), st));
+    if (shard_count <= 1) {
+        // the checksum sum_p w_p C(n_p, 2) is defined on the full 64-bit counts
+        if (d_wfull.alloc(P)) return 1;
+        HIP_TRY(hipMemcpyAsync(d_wfull.p, v->num_kmers, P * 8, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(lay_gather_kernel, dim3(G1), dim3(B), 0, st, order.p, acc[cur].p, dep[cur].p, cnt.p, size.p, d_parent.p, d_ll.p, d_n.p, d_nbits.p, d_w.p,
+                       d_wfull.p, (uint32_t)P, db->k0in, db->nl, db->parent, db->w, db->dflag, db->sub_end, d_stats.p);
+    HIP_TRY(hipGetLastError());
+    LayStats hs{};
+    uint32_t hflags[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(&hs, d_stats.p, sizeof hs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hflags, flags.p, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hflags[1]) return kmdb_set_error("kmdb_db_upload: pattern tree is not a forest");
+    if (with_hashtables && v->n_buckets) {
+        // pid -> DFS index for the hash lookups of new2all
+        HIP_TRY(hipMalloc((void**)&db->pid2dfs, std::max<uint64_t>(P, 1) * 4));
+        hipLaunchKernelGGL(lay_pid2dfs_kernel, dim3(G), dim3(B), 0, st, acc[cur].p, (uint32_t)P, db->pid2dfs);
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    d_wfull.reset(); d_ll.reset(); d_n.reset(); d_w.reset(); size.reset(); cnt.reset(); dep[cur].reset(); d_parent.reset();
+    phase("device: node arrays");
+
+    // ---- streams re-packed in DFS order
+    {
+        DevTmp<uint32_t> nb_dfs;
+        DevTmp<uint64_t> srcpos, dstpos;
+        if (nb_dfs.alloc(P) || srcpos.alloc(P + 1) || dstpos.alloc(P + 1)) return 1;
+        hipLaunchKernelGGL(lay_nbits_dfs_kernel, dim3(G), dim3(B), 0, st, db->k0in, (uint32_t)P, nb_dfs.p);
+        hipcub::TransformInputIterator<uint64_t, U32toU64, uint32_t*> it_src(d_nbits.p, U32toU64()), it_dst(nb_dfs.p, U32toU64());
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it_src, srcpos.p, (int)P, st));
+        DevTmp<unsigned char> tmp;
+        if (tmp.alloc(tb)) return 1;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, it_src, srcpos.p, (int)P, st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, it_dst, dstpos.p, (int)P, st));
+        HIP_TRY(hipMalloc((void**)&db->bits, n_bit_words * 8));
+        HIP_TRY(hipMemsetAsync(db->bits, 0, n_bit_words * 8, st));
+        db->n_bit_words = n_bit_words;
+        HIP_TRY(hipMalloc((void**)&db->blkbase, ((P + 255) / 256 + 1) * 8));
+        HIP_TRY(hipMalloc((void**)&db->bitrel, std::max<uint64_t>(P, 1) * 4));
+        hipLaunchKernelGGL(lay_blkbase_kernel, dim3(G), dim3(B), 0, st, dstpos.p, (uint32_t)P, db->blkbase, db->bitrel);
+        hipLaunchKernelGGL(lay_copy_bits_kernel, dim3(G), dim3(B), 0, st, order.p, srcpos.p, dstpos.p, db->k0in, d_src.p, (uint32_t)P,
+                           (unsigned long long*)db->bits);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    d_src.reset(); d_nbits.reset(); order.reset();
+    phase("device: stream re-pack");
+
+    // ---- per-slice root paths, long nodes
+    db->max_n = hs.max_n; db->max_depth = hs.max_depth;
+    db->chain_ok = hs.max_depth <= (uint32_t)KMDB_CHAIN_MAX;
+    db->chain_cap = std::min<uint32_t>(KMDB_CHAIN_MAX, std::max<uint32_t>(8, (hs.max_depth + 7) / 8 * 8));
+    if (const char* e = getenv("KMDB_NSEG")) db->nseg_nodes = (uint32_t)std::max<uint64_t>(64, strtoull(e, nullptr, 10) / 64 * 64);
+    db->n_nsegs = (uint32_t)((P + db->nseg_nodes - 1) / db->nseg_nodes);
+    HIP_TRY(hipMalloc((void**)&db->nseg_anc, std::max<size_t>((size_t)db->n_nsegs * db->chain_cap, 1) * 4));
+    HIP_TRY(hipMalloc((void**)&db->nseg_anc_n, std::max<size_t>(db->n_nsegs, 1) * 4));
+    if (db->n_nsegs)
+        hipLaunchKernelGGL(lay_seg_anc_kernel, dim3((db->n_nsegs + 63) / 64), dim3(64), 0, st, db->parent, db->dflag, (uint32_t)P, db->nseg_nodes, db->n_nsegs,
+                           db->chain_cap, db->nseg_anc, db->nseg_anc_n);
+    db->n_long = hs.n_long;
+    if (hs.n_long) {
+        DevTmp<uint32_t> lk, lv, lk2, cursor;
+        if (lk.alloc(hs.n_long) || lv.alloc(hs.n_long) || lk2.alloc(hs.n_long) || cursor.alloc(1)) return 1;
+        HIP_TRY(hipMalloc((void**)&db->long_nodes, (size_t)hs.n_long * 4));
+        HIP_TRY(hipMemsetAsync(cursor.p, 0, 4, st));
+        hipLaunchKernelGGL(lay_long_kernel, dim3(G), dim3(B), 0, st, db->k0in, (uint32_t)P, cursor.p, lk.p, lv.p);
+        // most work first; equal work in ascending DFS order needs a stable sort on (work desc) of DFS-ordered input:
+        // the compaction above is not ordered across waves, so sort by DFS index first
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lv.p, db->long_nodes, lk.p, lk2.p, (int)hs.n_long, 0, 32, st));
+        DevTmp<unsigned char> tmp;
+        if (tmp.alloc(tb)) return 1;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, lv.p, db->long_nodes, lk.p, lk2.p, (int)hs.n_long, 0, 32, st));
+        size_t tb2 = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb2, lk2.p, lk.p, db->long_nodes, lv.p, (int)hs.n_long, 0, 32, st));
+        DevTmp<unsigned char> tmp2;
+        if (tmp2.alloc(tb2)) return 1;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2.p, tb2, lk2.p, lk.p, db->long_nodes, lv.p, (int)hs.n_long, 0, 32, st));
+        HIP_TRY(hipMemcpyAsync(db->long_nodes, lv.p, (size_t)hs.n_long * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    phase("device: slices + long nodes");
+
+    db->stats.algorithmic_bytes = hs.alg + 4ull * (N ? N * (N - 1) / 2 : 0);
+    db->stats.tree_updates = hs.upd;
+    db->stats.sum_pairs = hs.pairs;
+    db->stats.n_segments = db->n_nsegs;
+    db->stats.device_bytes = P * (8 + 4 + 4 + 4 + 4 + 2 + 4) + n_bit_words * 8 + (uint64_t)db->n_nsegs * db->chain_cap * 4 + dev_ht_bytes;
+    return 0;
+}

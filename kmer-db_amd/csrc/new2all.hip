@@ -61,7 +61,7 @@ __global__ void n2a_probe_kernel(const uint64_t* __restrict__ kmers, const uint6
                 const uint64_t mask = cap - 1;
                 const uint32_t kk = (uint32_t)k;
                 uint64_t h = (uint64_t)fmix32(kk) & mask;
-                for (;;) {
+                for (uint64_t step = 0; step < cap; ++step) {        // a full table (corrupt file) ends the probe too
                     const uint64_t it = slots[off + h];
                     const int32_t val = (int32_t)(it >> 32);
                     if (val == 0x7fffffff) break;                // empty slot ends the probe (src/hashmap_lp.h:78)
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long*
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
+    void reset() { if (p) (void)hipFree(p); p = nullptr; }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)); }
     template <class T> T* as() { return (T*)p; }
 };
@@ -235,7 +236,7 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
                            d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
         if (nruns) {
             const unsigned wblocks = (nruns + 255) / 256;
-            if (N * 4 <= 64 * 1024)
+            if (N * 4 + 256 <= 64 * 1024)
                 hipLaunchKernelGGL(n2a_walk_kernel<true>, dim3(wblocks), dim3(256), N * 4, st, d_uniq.as<unsigned long long>(),
                                    d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent,
                                    e.sub_end, e.bits, (uint32_t)N, d_sim.as<uint32_t>());
@@ -255,11 +256,26 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
     return 0;
 }
 
+static int new2all_once(kmdb_db* dbh, const uint64_t* const* kmers, const size_t* counts, size_t nq, uint32_t* out_dense, const kmdb_opts* opts);
+
 extern "C" int kmdb_new2all_batch(kmdb_db* dbh, const uint64_t* const* kmers, const size_t* counts, size_t nq,
                                   uint32_t* out_dense, const kmdb_opts* opts) {
     if (!dbh || (nq && (!kmers || !counts || !out_dense))) return kmdb_set_error("kmdb_new2all_batch: null argument");
     kmdb_engine_view e;
-    kmdb_engine_get(dbh, &e);
+    if (kmdb_engine_get(dbh, &e)) return 1;
+    for (size_t q0 = 0; q0 < nq;) {
+        size_t q1 = q0;
+        uint64_t total = 0;
+        do { total += counts[q1]; ++q1; } while (q1 < nq && total + counts[q1] <= (1ull << 30));      // k-mers per piece
+        if (new2all_once(dbh, kmers + q0, counts + q0, q1 - q0, out_dense + q0 * e.N, opts)) return 1;
+        q0 = q1;
+    }
+    return 0;
+}
+
+static int new2all_once(kmdb_db* dbh, const uint64_t* const* kmers, const size_t* counts, size_t nq, uint32_t* out_dense, const kmdb_opts* opts) {
+    kmdb_engine_view e;
+    if (kmdb_engine_get(dbh, &e)) return 1;
     if (!e.n_buckets || !e.slots) return kmdb_set_error("kmdb_new2all_batch: database was uploaded without hashtables");
     if (nq >= (1ull << 31)) return kmdb_set_error("kmdb_new2all_batch: too many queries in one batch");
     N2_TRY(hipSetDevice(e.device));
@@ -267,7 +283,7 @@ extern "C" int kmdb_new2all_batch(kmdb_db* dbh, const uint64_t* const* kmers, co
     std::vector<uint64_t> qoff(nq + 1, 0);
     for (size_t q = 0; q < nq; ++q) qoff[q + 1] = qoff[q] + counts[q];
     const size_t total = qoff[nq];
-    if (total >= (1ull << 32) - 2) return kmdb_set_error("kmdb_new2all_batch: more than 2^32 k-mers in one batch; split it");
+    if (total >= (1ull << 32) - 2) return kmdb_set_error("kmdb_new2all_batch: a single query of 2^32 k-mers or more is not supported");
     if (!nq) return 0;
     DevBuf d_k, d_qoff;
     N2_TRY(d_k.alloc(total * 8));
@@ -380,12 +396,40 @@ __global__ void n2a_query_offsets_kernel(const uint32_t* __restrict__ qid, const
 
 }  // namespace
 
+// device scratch of the sequence path is ~40 bytes per base and positions are 32-bit: larger batches are run in pieces
+static uint64_t n2_seq_budget() {                        // bases per piece (one longer query still goes alone)
+    if (const char* e = getenv("KMDB_N2A_BASES_PER_PIECE")) return std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    return 256ull << 20;
+}
+
+static int new2all_seq_once(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
+                            double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                            const kmdb_opts* opts);
+
 extern "C" int kmdb_new2all_batch_seq(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
                                       double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
                                       const kmdb_opts* opts) {
     if (!dbh || (nq && (!seqs || !seq_lens || !out_dense || !out_kmer_counts))) return kmdb_set_error("kmdb_new2all_batch_seq: null argument");
     kmdb_engine_view e;
-    kmdb_engine_get(dbh, &e);
+    if (kmdb_engine_get(dbh, &e)) return 1;
+    // rows of different queries are independent: cut the batch where the accumulated bases pass the budget
+    const uint64_t budget = n2_seq_budget();
+    for (size_t q0 = 0; q0 < nq;) {
+        size_t q1 = q0;
+        uint64_t bases = 0;
+        do { bases += seq_lens[q1]; ++q1; } while (q1 < nq && bases + seq_lens[q1] <= budget);
+        if (new2all_seq_once(dbh, seqs + q0, seq_lens + q0, q1 - q0, fraction, start_fraction, preserve_strand, out_dense + q0 * e.N,
+                             out_kmer_counts + q0, opts)) return 1;
+        q0 = q1;
+    }
+    return 0;
+}
+
+static int new2all_seq_once(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
+                            double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                            const kmdb_opts* opts) {
+    kmdb_engine_view e;
+    if (kmdb_engine_get(dbh, &e)) return 1;
     if (!e.n_buckets || !e.slots) return kmdb_set_error("kmdb_new2all_batch_seq: database was uploaded without hashtables");
     const uint32_t k = e.kmer_length;
     if (k == 0 || k > 31) return kmdb_set_error("kmdb_new2all_batch_seq: k-mer length must be 1..31");
@@ -395,7 +439,7 @@ extern "C" int kmdb_new2all_batch_seq(kmdb_db* dbh, const char* const* seqs, con
     std::vector<uint64_t> soff(nq + 1, 0);
     for (size_t q = 0; q < nq; ++q) soff[q + 1] = soff[q] + seq_lens[q];
     const uint64_t L = soff[nq];
-    if (L >= (1ull << 31) - 2) return kmdb_set_error("kmdb_new2all_batch_seq: more than 2^31 bases in one batch; split it");
+    if (L >= (1ull << 31) - 2) return kmdb_set_error("kmdb_new2all_batch_seq: a single query of 2^31 bases or more; extract its k-mers on the host (kmdbh_extract_kmers) and use kmdb_new2all_batch");
     if (nq >= (1ull << 31)) return kmdb_set_error("kmdb_new2all_batch_seq: too many queries in one batch");
     DevBuf d_seq, d_soff, d_kmer, d_kmer2, d_qid, d_qid2, d_head, d_hscan, d_k, d_qoff, d_tmp;
     N2_TRY(d_seq.alloc(L + 32));
@@ -462,8 +506,7 @@ extern "C" int kmdb_new2all_batch_seq(kmdb_db* dbh, const char* const* seqs, con
     }
     for (size_t q = 0; q < nq; ++q) out_kmer_counts[q] = qoff[q + 1] - qoff[q];
     // the sort buffers are not needed any more: release them before the probe pipeline allocates its own
-    d_kmer.~DevBuf(); d_kmer.p = nullptr; d_kmer2.~DevBuf(); d_kmer2.p = nullptr; d_qid2.~DevBuf(); d_qid2.p = nullptr;
-    d_head.~DevBuf(); d_head.p = nullptr; d_hscan.~DevBuf(); d_hscan.p = nullptr; d_qid.~DevBuf(); d_qid.p = nullptr;
+    d_kmer.reset(); d_kmer2.reset(); d_qid2.reset(); d_head.reset(); d_hscan.reset(); d_qid.reset();
     return n2a_run(dbh, e, st, d_k.as<uint64_t>(), d_qoff.as<uint64_t>(), total, nq, out_dense);
 }
 
@@ -473,7 +516,7 @@ extern "C" int kmdb_new2all_batch_sparse(kmdb_db* dbh, const uint64_t* const* km
     std::memset(out, 0, sizeof *out);
     kmdb_engine_view e;
     if (!dbh) return kmdb_set_error("kmdb_new2all_batch_sparse: null argument");
-    kmdb_engine_get(dbh, &e);
+    if (kmdb_engine_get(dbh, &e)) return 1;
     const uint64_t N = e.N;
     std::vector<uint32_t> dense(std::max<uint64_t>(nq * N, 1));
     if (kmdb_new2all_batch(dbh, kmers, counts, nq, dense.data(), opts)) return 1;

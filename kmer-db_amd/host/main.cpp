@@ -26,6 +26,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -279,19 +280,28 @@ int run_all2all_parts(std::vector<std::string>& args, Common& c) {
     std::vector<uint32_t> cols, vals;
     size_t saved = 0;
     uint64_t row_shift = 0;
-    auto load = [&](size_t i, Db& d) {
-        check(kmdbh_db_load(files[i].c_str(), 0, &d.h));
-        check(kmdb_db_upload(kmdbh_db_view(d.h), &o, 1, &d.d));
+    // every part serves as the row database once and as a column database for all later rows: uploaded parts stay resident
+    // while HBM lasts (an upload that fails evicts the others and is tried again)
+    std::vector<std::unique_ptr<Db>> resident(files.size());
+    auto get = [&](size_t i, size_t keep) -> Db& {
+        if (resident[i]) return *resident[i];
+        auto d = std::make_unique<Db>();
+        check(kmdbh_db_load(files[i].c_str(), 0, &d->h));
+        if (kmdb_db_upload(kmdbh_db_view(d->h), &o, 1, &d->d)) {
+            for (size_t j = 0; j < resident.size(); ++j) if (j != keep) resident[j].reset();
+            check(kmdb_db_upload(kmdbh_db_view(d->h), &o, 1, &d->d));
+        }
+        kmdbh_db_free(d->h); d->h = nullptr;                   // the host copy is not needed once the part is in HBM
+        resident[i] = std::move(d);
+        return *resident[i];
     };
     for (size_t i = 0; i < files.size(); ++i) {
-        Db drow;
-        load(i, drow);
+        Db& drow = get(i, i);
         const uint64_t nr = part_n[i];
         std::vector<std::vector<uint32_t>> cross(i);              // cross[j]: nr x part_n[j]
         for (size_t j = 0; j < i; ++j) {
             std::cerr << "Processing cell (" << i + 1 << "," << j + 1 << ")" << std::endl;
-            Db dcol;
-            load(j, dcol);
+            Db& dcol = get(j, i);
             cross[j].resize(nr * part_n[j] + 1);
             check(kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &o));
         }
@@ -371,7 +381,14 @@ void split_fasta(const std::string& data, std::vector<Record>& recs) {
     }
 }
 
-struct Query { std::string name; std::vector<uint64_t> kmers; std::string text; };   // text: records joined by '\n' (device-side extraction)
+struct Query {
+    std::string name;
+    std::vector<uint64_t> kmers;             // from_kmers: sorted unique k-mers from the host loader
+    std::string text;                        // else: records joined by '\n' (device-side extraction)
+    bool from_kmers = false;
+};
+// the device loader indexes positions with 32 bits: longer genomes go through the host loader
+constexpr size_t LONG_QUERY_BASES = 1800u << 20;
 
 std::string basename_of(const std::string& p) {
     size_t s = p.find_last_of('/');
@@ -418,22 +435,38 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
     // queries are produced in input order; similarities are computed in batches on the GPU and rows
     // written in the same order (the reference re-orders through a priority queue, :60,114-117)
     std::vector<Query> batch;
+    size_t batch_bases = 0;                    // flushed by size as well as by count: the engine's scratch grows with the bases
     auto flush = [&]() {
         if (batch.empty()) return;
+        batch_bases = 0;
         std::vector<size_t> cnts(batch.size());
         std::vector<uint32_t> out(batch.size() * n + 1);
-        if (host_extract) {
-            std::vector<const uint64_t*> ptrs(batch.size());
-            for (size_t q = 0; q < batch.size(); ++q) { ptrs[q] = batch[q].kmers.data(); cnts[q] = batch[q].kmers.size(); }
-            check(kmdb_new2all_batch(db.d, ptrs.data(), cnts.data(), batch.size(), out.data(), &o));
-        } else {
-            // loader + KmerHelper::unique + one2all on the device (kmdb_new2all_batch_seq)
-            std::vector<const char*> ptrs(batch.size());
-            std::vector<size_t> lens(batch.size());
-            std::vector<uint64_t> uniq(batch.size());
-            for (size_t q = 0; q < batch.size(); ++q) { ptrs[q] = batch[q].text.data(); lens[q] = batch[q].text.size(); }
-            check(kmdb_new2all_batch_seq(db.d, ptrs.data(), lens.data(), batch.size(), fraction, fstart, preserve, out.data(), uniq.data(), &o));
-            for (size_t q = 0; q < batch.size(); ++q) cnts[q] = (size_t)uniq[q];
+        // a query is either sequence text (loader + KmerHelper::unique + one2all on the device, kmdb_new2all_batch_seq) or,
+        // with -host-extract and for genomes beyond the device loader's 2^31 positions, a k-mer list (kmdb_new2all_batch)
+        std::vector<size_t> by_text, by_kmers;
+        for (size_t q = 0; q < batch.size(); ++q) (batch[q].from_kmers ? by_kmers : by_text).push_back(q);
+        if (!by_kmers.empty()) {
+            std::vector<const uint64_t*> ptrs(by_kmers.size());
+            std::vector<size_t> kc(by_kmers.size());
+            std::vector<uint32_t> part(by_kmers.size() * n + 1);
+            for (size_t t = 0; t < by_kmers.size(); ++t) { ptrs[t] = batch[by_kmers[t]].kmers.data(); kc[t] = batch[by_kmers[t]].kmers.size(); }
+            check(kmdb_new2all_batch(db.d, ptrs.data(), kc.data(), by_kmers.size(), part.data(), &o));
+            for (size_t t = 0; t < by_kmers.size(); ++t) {
+                cnts[by_kmers[t]] = kc[t];
+                std::copy(part.begin() + t * n, part.begin() + (t + 1) * n, out.begin() + by_kmers[t] * n);
+            }
+        }
+        if (!by_text.empty()) {
+            std::vector<const char*> ptrs(by_text.size());
+            std::vector<size_t> lens(by_text.size());
+            std::vector<uint64_t> uniq(by_text.size());
+            std::vector<uint32_t> part(by_text.size() * n + 1);
+            for (size_t t = 0; t < by_text.size(); ++t) { ptrs[t] = batch[by_text[t]].text.data(); lens[t] = batch[by_text[t]].text.size(); }
+            check(kmdb_new2all_batch_seq(db.d, ptrs.data(), lens.data(), by_text.size(), fraction, fstart, preserve, part.data(), uniq.data(), &o));
+            for (size_t t = 0; t < by_text.size(); ++t) {
+                cnts[by_text[t]] = (size_t)uniq[t];
+                std::copy(part.begin() + t * n, part.begin() + (t + 1) * n, out.begin() + by_text[t] * n);
+            }
         }
         std::vector<uint32_t> cols, vals;
         for (size_t q = 0; q < batch.size(); ++q) {
@@ -458,9 +491,10 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
     auto make_query = [&](const std::string& name, const std::vector<const std::string*>& seqs) {
         Query q;
         q.name = name;
-        if (!host_extract) {
-            size_t bytes = 0;
-            for (auto* s : seqs) bytes += s->size() + 1;
+        size_t bytes = 0;
+        for (auto* s : seqs) bytes += s->size() + 1;
+        q.from_kmers = host_extract || bytes >= LONG_QUERY_BASES;
+        if (!q.from_kmers) {
             q.text.reserve(bytes);
             for (auto* s : seqs) { q.text += *s; q.text += '\n'; }
             return q;
@@ -475,7 +509,12 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
         return q;
     };
 
-    const size_t BATCH = 64;
+    const size_t BATCH = 64, BATCH_BASES = 512u << 20;
+    auto add = [&](Query&& q) {
+        batch_bases += q.text.size() + q.kmers.size();
+        batch.push_back(std::move(q));
+        if (batch.size() == BATCH || batch_bases >= BATCH_BASES) flush();
+    };
     if (multi) {
         for (auto& e : entries) {
             std::string data;
@@ -483,8 +522,7 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
             std::vector<Record> recs;
             split_fasta(data, recs);
             for (auto& r : recs) {
-                batch.push_back(make_query(r.header, {&r.seq}));
-                if (batch.size() == BATCH) flush();
+                add(make_query(r.header, {&r.seq}));
             }
         }
     } else {
@@ -510,9 +548,8 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
             for (auto& t : pool) t.join();
             for (size_t i = 0; i < cntq; ++i) {
                 if (!okv[i]) { std::cerr << "failed:" << entries[base + i] << std::endl; continue; }
-                batch.push_back(std::move(qs[i]));
+                add(std::move(qs[i]));
             }
-            flush();
         }
     }
     flush();
@@ -543,15 +580,30 @@ int run_one2all(std::vector<std::string>& args, Common& c) {
     if (!slurp(args[1], data)) throw std::runtime_error("Cannot open sample file: " + args[1]);
     std::vector<Record> recs;
     split_fasta(data, recs);
-    // loader (kmer_extract.h, filter.h), KmerHelper::sortAndUnique (console_one2all.cpp:64-66) and one2all on the device
-    std::string text;
-    for (auto& r : recs) { text += r.seq; text += '\n'; }
-    const char* tp = text.data();
-    size_t tl = text.size();
+    // loader (kmer_extract.h, filter.h), KmerHelper::sortAndUnique (console_one2all.cpp:64-66) and one2all on the device;
+    // genomes beyond the device loader's 32-bit positions take the host loader
+    size_t bases = 0;
+    for (auto& r : recs) bases += r.seq.size() + 1;
     uint64_t cnt = 0;
     std::vector<uint32_t> sims(n + 1);
     std::cerr << "Calculating similarity vector..." << std::endl;
-    check(kmdb_new2all_batch_seq(db.d, &tp, &tl, 1, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, sims.data(), &cnt, &o));
+    if (bases < LONG_QUERY_BASES) {
+        std::string text;
+        text.reserve(bases);
+        for (auto& r : recs) { text += r.seq; text += '\n'; }
+        const char* tp = text.data();
+        size_t tl = text.size();
+        check(kmdb_new2all_batch_seq(db.d, &tp, &tl, 1, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, sims.data(), &cnt, &o));
+    } else {
+        std::vector<uint64_t> kmers(bases + 1);
+        size_t kc = 0;
+        for (auto& r : recs)
+            kc += kmdbh_extract_kmers(r.seq.data(), r.seq.size(), k, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, kmers.data() + kc);
+        kc = kmdbh_sort_unique(kmers.data(), kc);
+        const uint64_t* kp = kmers.data();
+        check(kmdb_new2all_batch(db.d, &kp, &kc, 1, sims.data(), &o));
+        cnt = kc;
+    }
     std::cerr << "Number of k-mers: " << cnt << std::endl;
     std::ofstream ofs(args[2]);
     write_header(db, ofs);

@@ -411,6 +411,69 @@ def write_db(path, k, fraction, names, sample_counts, arrays, n_buckets=None, km
             start = end
 
 
+def write_db_fast(path, k, fraction, names, sample_counts, arrays, kmers_count=0, device="cpu", n_buckets=None):
+    """write_db for databases of 10^8 patterns: the pattern section (prefix_kmer_db.cpp:438-574, pattern.cpp:15-46) is
+    assembled as one uint64 image with vectorised torch ops on `device` and written block by block; the raw
+    hashtables are EMPTY (all2all / all2all-sp skip them, console_all2all.cpp:26)."""
+    dev = torch.device(device)
+    if n_buckets is None:
+        n_buckets = 1 << max(8, 2 * k - 32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    P = arrays["num_kmers"].size
+    nb = t(arrays["num_bits"].astype(np.int64))
+    words = ((nb + 127) // 128) * 2
+    sizes = 5 + words                                                    # uint64 words per pattern
+    off = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(sizes, 0)
+    total = int(off[-1])
+    img = torch.zeros(total, dtype=torch.int64, device=dev)
+    o = off[:-1]
+    img[o] = t(arrays["num_kmers"].astype(np.int64))
+    img[o + 1] = t(arrays["parent_id"].astype(np.int64))
+    img[o + 2] = t(arrays["num_samples"].astype(np.int64)) | (t(arrays["num_local"].astype(np.int64)) << 32)
+    img[o + 3] = t(arrays["last_sample_id"].astype(np.int64)) | (nb << 32)
+    data = t(arrays["data"].view(np.int64))
+    doff = t(arrays["data_offset"].astype(np.int64))
+    for j in range(int(words.max()) if P else 0):
+        m = words > j
+        img[o[m] + 5 + j] = data[doff[m] + j]
+    del data, doff
+    cum = (off[1:] * 8).cpu().numpy()                                    # bytes up to and including pattern p
+    with open(path, "wb") as f:
+        f.write(struct.pack("<QIddiBQ", 1, k, fraction, 0.0, 0, 1, kmers_count))
+        f.write(struct.pack("<Q", len(names)))
+        for nm, c in zip(names, sample_counts):
+            b = nm.encode()
+            f.write(struct.pack("<QQ", int(c), len(b)))
+            f.write(b)
+        f.write(struct.pack("<Q", n_buckets))
+        empty = struct.pack("<dQQQQQQQ", 0.8, 0, 16, 12, 15, 128, 0, 0) + struct.pack("<Q", 0)
+        f.write(empty * n_buckets)
+        f.write(struct.pack("<Q", P))
+        limit = 64 << 20
+        start, done_bytes = 0, 0
+        while start < P:
+            end = int(np.searchsorted(cum, done_bytes + limit, side="right"))        # greedily fill a 64 MB block (:544-551)
+            end = min(P, max(end, start + 1))
+            a, b = done_bytes // 8, int(cum[end - 1]) // 8
+            f.write(struct.pack("<Q", (b - a) * 8))
+            f.write(img[a:b].cpu().numpy().tobytes())
+            start, done_bytes = end, int(cum[end - 1])
+
+
+def shard_item_lists(dictionary, kmer_pid, k):
+    """(bucket_offset, items) of the k-mer -> pattern map grouped by prefix bucket (kmer >> 32): items = key | pid << 32
+    like hashmap_lp's item_t (src/hashmap_lp.h:71-74), but WITHOUT empty slots and in sorted order — enough for
+    kmdb_db_upload_shard, which only counts the items of a shard's buckets per pattern; not a probe-able table."""
+    nb = 1 << max(8, 2 * k - 32)
+    bucket = _lsr(dictionary, 32)
+    counts = torch.bincount(bucket, minlength=nb)
+    boff = torch.zeros(nb + 1, dtype=torch.int64, device=dictionary.device)
+    boff[1:] = torch.cumsum(counts, 0)
+    items = (dictionary & 0xFFFFFFFF) | (kmer_pid.to(torch.int64) << 32)       # the dictionary is sorted: buckets are contiguous
+    return boff.cpu().numpy().astype(np.uint64), items.cpu().numpy().view(np.uint64)
+
+
 def synth_database(n_samples, clade_size, length, k=18, fraction=1.0, seed=20260928, r1=0.10, r2=0.01,
                    device="cpu", progress=None):
     """Genomes -> k-mers -> patterns.  Returns (genomes, pat) with pat as in build_patterns()."""

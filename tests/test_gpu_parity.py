@@ -37,19 +37,21 @@ def test_all2all_dense_bit_exact(K, O, golden_dir, dev, stem):
     assert st["algorithmic_bytes"] == h.pattern_section_bytes + 4 * d.tri_size()
     # idempotent: the resident db is not mutated (the reference accumulates num_kmers in place, :64-72)
     assert np.array_equal(d.all2all_dense(), ref)
-    # the default path for these sizes is the block-record pipeline
-    assert d.stats()["n_records"] > 0 or d.P <= 1
-    # the other kernels: generic (global stack + HBM atomics), LDS stack + HBM atomics, wave-private LDS tile
-    if stem != "synth_k21":
-        assert d.stats()["k0_ms"] > 0                    # root paths <= 192 nodes: the batch-parallel front half ran
-    dseq = K.DeviceDB(h, device=dev, flags=K.capi.FLAG_FORCE_SEQ_EMIT)      # laid out for the sequential emit kernel
-    assert np.array_equal(dseq.all2all_dense(), ref)
-    assert dseq.stats()["n_records"] > 0 or d.P <= 1
-    assert dseq.stats()["k0_ms"] == 0                     # no separate decode kernel in this layout
-    dseq.close()
+    # the default path is the block-record pipeline; the second call reuses the grid sizes the first one measured
+    st = d.stats()
+    assert st["path"] == K.capi.PATH_RECORDS and st["sized_call"] == 0 and (st["n_records"] > 0 or d.P <= 1)
+    # a database laid out again (nothing cached) and forced to fail instead of falling back
+    d2 = K.DeviceDB(h, device=dev)
+    assert np.array_equal(d2.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), ref)
+    assert d2.stats()["sized_call"] == 1
+    d2.close()
+    # the A/B kernels: generic (global stack + HBM atomics), LDS stack + HBM atomics, wave-private LDS tile
     for fl in (K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT, K.capi.FLAG_FORCE_TILE):
         assert np.array_equal(d.all2all_dense(flags=fl), ref), fl
-    assert d.stats()["n_records"] == 0
+    assert d.stats()["n_records"] == 0 and d.stats()["path"] in (K.capi.PATH_TILE, K.capi.PATH_GLOBAL)
+    # unknown flag bits are rejected (they used to select timing experiments)
+    with pytest.raises(K.KmdbError, match="unknown bits"):
+        d.all2all_dense(flags=1 << 9)
 
 
 @pytest.mark.parametrize("stem", ["virus_k18", "clade64", "clade64_k25_f01"])
@@ -60,6 +62,7 @@ def test_shards_sum_to_full_matrix(K, golden_dir, dev, stem, shards):
     acc = np.zeros(d.tri_size(), dtype=np.uint32)
     for s in range(shards):
         acc += d.all2all_dense(shard=(s, shards))
+        assert d.stats()["path"] == K.capi.PATH_RECORDS          # slices of the pattern stream stay on the fast path
     assert np.array_equal(acc, _ref_dense(golden_dir, stem))
 
 
@@ -272,21 +275,18 @@ def test_synthetic_databases_bit_exact(K, O, dev, tmp_path, N, cs, L, k):
     got = d.all2all_dense()
     assert np.array_equal(got, exp)
     st = d.stats()
-    assert st["n_records"] > 0 and st["sum_pairs"] == int(exp.astype(np.uint64).sum())
+    assert st["n_records"] > 0 and st["path"] == K.capi.PATH_RECORDS and st["sum_pairs"] == int(exp.astype(np.uint64).sum())
     for fl in (K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS):
         assert np.array_equal(d.all2all_dense(flags=fl), exp), fl
-    dseq = K.DeviceDB(view, device=dev, flags=K.capi.FLAG_FORCE_SEQ_EMIT)
-    assert np.array_equal(dseq.all2all_dense(), exp)
-    dseq.close()
     # the same database read back through the front-end's .db reader
     d2 = K.DeviceDB(K.HostDB(path, skip_hashtables=True), device=dev)
     assert np.array_equal(d2.all2all_dense(), exp)
 
 
 @pytest.mark.parametrize("N,cs,L", [(3000, 100, 1500), (5000, 50, 600)])
-def test_many_samples_fall_back_to_v1_kernels(K, O, dev, tmp_path, N, cs, L):
-    """N > 2048 is outside the block-record pipeline: the LDS-tile kernel (N <= 4096) and the generic
-    HBM-atomics kernel (any N <= 65535) take over, same bit-exact result."""
+def test_many_samples_on_the_block_record_pipeline(K, O, dev, tmp_path, N, cs, L):
+    """The block-record pipeline has no sample-count limit (the reference has none either,
+    similarity_calculator.cpp:42-438, array.h:136-140): thousands of samples = hundreds of blocks."""
     import importlib
     import torch
     S = importlib.import_module("kmerdb_amd.synth")
@@ -298,8 +298,9 @@ def test_many_samples_fall_back_to_v1_kernels(K, O, dev, tmp_path, N, cs, L):
     view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
                        arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
     d = K.DeviceDB(view, device=dev)
-    assert np.array_equal(d.all2all_dense(), exp)
-    assert d.stats()["n_records"] == 0
+    assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp)
+    st = d.stats()
+    assert st["path"] == K.capi.PATH_RECORDS and st["n_records"] > 0
     assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_FORCE_GLOBAL_ATOMICS), exp)
     sp = d.all2all_sparse()
     for i in (1, N // 2, N - 1):
@@ -393,9 +394,6 @@ def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local):
     assert np.array_equal(d.all2all_dense(), exp)
     for fl in (K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT):
         assert np.array_equal(d.all2all_dense(flags=fl), exp), fl
-    dseq = K.DeviceDB(view, device=dev, flags=K.capi.FLAG_FORCE_SEQ_EMIT)
-    assert np.array_equal(dseq.all2all_dense(), exp)
-    dseq.close()
     acc = np.zeros_like(exp)
     for sh in range(3):
         acc += d.all2all_dense(shard=(sh, 3))
@@ -511,9 +509,9 @@ def test_new2all_synthetic_scale(K, O, dev, tmp_path):
 
 @pytest.mark.gpu
 def test_randomised_stress_of_the_block_record_pipeline(dev):
-    """profiles/r01_fuzz_stress.py: random forests x random block widths (odd ones too, which the width search never
+    """profiles/r02_fuzz_stress.py: random forests x random block widths (odd ones too, which the width search never
     picks) x both front halves, against the v1 kernels that the tests above pin to the oracle."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "r01_fuzz_stress.py"), "60", "2026"], capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "r02_fuzz_stress.py"), "60", "2026"], capture_output=True,
                        text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60 cases, 0 mismatches" in r.stdout
