@@ -23,10 +23,12 @@
 //   K2  k2_apply_kernel    one workgroup per record chunk: 64 records per wave step as bit matrices, int8 MFMA
 //                          accumulate into a 64 x 64 LDS tile (popcount passes per bit plane for weights >= 128),
 //                          one HBM atomic per non-zero cell.
-// Records are grouped by (block pair, weight class) WITHOUT a counting pass: every stream owns a current chunk of the
-// record pool; a wave reserves slots for a whole group of lanes with one 64-bit atomic on the stream's state
-// (chunk << 32 | used), and the reservation that crosses the end of a chunk takes a fresh chunk from the pool and
-// publishes it.  K2's work items are the chunks.
+// Records are grouped by (block pair, weight class) = "stream" WITHOUT a counting pass and WITHOUT global atomics
+// (same-address device atomics run at a few million per second on this part: measured, profiles/README.md): every
+// emitting wave owns an arena of 64-record chunks (chunk ids w, w + W, w + 2W, ...) and keeps up to 64 open chunks, one
+// per stream, in registers (lane e holds entry e: stream, next slot, end of chunk); a group of lanes reserves its slots
+// with a ballot look-up.  After the emit kernels the chunk table (stream of every chunk) is radix-sorted, and K2 walks
+// windows of 128 sorted chunks: all records of a stream meet in one 64 x 64 LDS tile per window.
 #include "device_common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -58,63 +60,140 @@ __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, in
 // ------------------------------------------------------------------------------------------
 // record pool
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t CH_SHIFT = 6, CH_REC = 1u << CH_SHIFT;      // records per chunk = one wave step of K2
 struct PoolView {
-    unsigned long long* state;     // [n_states] chunk << 32 | used
     uint32_t* counters;            // KCTR_*
-    uint32_t* chunk_key;           // [pool_cap]
+    uint32_t* chunk_key;           // [pool_cap] stream of the chunk (n_states: never opened)
+    uint32_t* chunk_fill;          // [pool_cap] records in the chunk
     unsigned char* rec;            // record slots, 16 bytes each
     uint32_t* recw;
-    uint32_t c_shift;              // records per chunk = 1 << c_shift
+    uint32_t* sub_cursor;          // [KMDB_SUBPOOLS * 16] chunks taken from every sub-pool
+    uint32_t sub_cap;              // chunks per sub-pool
     uint32_t pool_cap;             // chunks
+    uint32_t* rkey;                // dense mode: stream of every record slot
+    uint32_t raw_key;              // dense mode: chunk_key of a chunk with records of mixed streams (n_states + 1)
+    uint32_t dense;                // 1: this kernel writes its records in arrival order and tags every slot with its stream
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
-
-// cnt (<= 64) slots of stream s, for ONE lane to call.  Slots of a reservation are consecutive inside a chunk; the
-// reservation that crosses the end of the current chunk (or finds the stream without one) takes the next chunk of the
-// pool and publishes it; reservations that arrive between its atomic and the publication try again.
-__device__ __forceinline__ Resv pool_reserve(const PoolView& pv, uint32_t s, uint32_t cnt) {
-    const uint32_t C = 1u << pv.c_shift;
-    for (;;) {
-        const unsigned long long old = atomicAdd(&pv.state[s], (unsigned long long)cnt);
-        const uint32_t u = (uint32_t)old, ch = (uint32_t)(old >> 32);
-        if (u + cnt <= C) return Resv{(ch << pv.c_shift) + u, cnt, 0u};
-        if (u <= C) {
-            uint32_t nc = atomicAdd(&pv.counters[KCTR_CHUNKS], 1u);
-            if (nc >= pv.pool_cap) { atomicOr(&pv.counters[KCTR_POOL_OVERFLOW], 1u); nc = pv.pool_cap - 1u; }   // in range; the call is repeated
-            pv.chunk_key[nc] = s;
-            const uint32_t n1 = C - u;
-            atomicExch(&pv.state[s], ((unsigned long long)nc << 32) | (unsigned long long)(cnt - n1));
-            return Resv{(ch << pv.c_shift) + u, n1, nc << pv.c_shift};
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
 
+// A wave's private allocator.  Chunk ids come from one of KMDB_SUBPOOLS sub-pools (sub-pool p owns the ids p, p + SUBPOOLS,
+// p + 2 SUBPOOLS, ...), ARENA_GRAB at a time: one device atomic per 1024 records and wave, spread over 256 cursors (a single
+// cursor would serialise: same-address atomics run at a few million per second).  The open chunks live in an LDS table,
+// direct-mapped by stream (entry = stream mod table size; with at most that many streams an open chunk is only ever
+// closed full, otherwise a colliding stream evicts it).  An entry = {stream, chunk id << 6 | records used}; a chunk that
+// fills up is closed at once, so `used` of an open entry is below 64.
+constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+constexpr uint32_t ST_MAX_BITS = 10;            // at most 1024 open chunks per wave
+struct WaveArena {
+    uint32_t* t_key;               // LDS [1 << tbits]
+    uint32_t* t_slot;              // LDS [1 << tbits]
+    uint32_t tmask;
+    uint32_t sub;                  // this wave's sub-pool
+    uint32_t stock, next;          // wave-uniform: chunks left of the last grab, the next of them (index inside the sub-pool)
+    uint32_t dslot;                // dense mode: next slot of the wave's one open chunk (0 with dopen == 0: none)
+    uint32_t dopen;
+};
+constexpr uint32_t ARENA_GRAB = 16;
+__host__ __device__ inline uint32_t arena_table_bits(uint32_t n_states) {
+    uint32_t b = 4;
+    while (b < ST_MAX_BITS && (1u << b) < n_states) ++b;
+    return b;
+}
+__device__ __forceinline__ void arena_init(WaveArena& A, uint32_t* lds, uint32_t tbits, uint32_t wave_id, uint32_t lane) {
+    A.t_key = lds; A.t_slot = lds + (1u << tbits); A.tmask = (1u << tbits) - 1u;
+    A.sub = wave_id % KMDB_SUBPOOLS; A.stock = 0; A.next = 0; A.dslot = 0; A.dopen = 0;
+    if (tbits == 0) return;                                   // dense mode: no table
+    for (uint32_t e = lane; e <= A.tmask; e += WAVE) A.t_key[e] = KEY_NONE;
+    lds_sync();
+}
+__device__ __forceinline__ uint32_t arena_take(WaveArena& A, const PoolView& pv, uint32_t s, uint32_t lane) {
+    if (A.stock == 0) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&pv.sub_cursor[A.sub * 16u], ARENA_GRAB);
+        base = bcast(base, 0);
+        if (base + ARENA_GRAB > pv.sub_cap) {                     // stays in range; the call is repeated with a larger pool
+            if (lane == 0) atomicOr(&pv.counters[KCTR_POOL_OVERFLOW], 1u);
+            base = pv.sub_cap - ARENA_GRAB;
+        }
+        A.next = base; A.stock = ARENA_GRAB;
+    }
+    const uint32_t id = A.next * KMDB_SUBPOOLS + A.sub;
+    ++A.next; --A.stock;
+    if (lane == 0) pv.chunk_key[id] = s;
+    return id;
+}
+// cnt (1..64) slots of stream s; s and cnt wave-uniform, every lane of the wave calls
+__device__ __forceinline__ Resv arena_reserve(WaveArena& A, const PoolView& pv, uint32_t s, uint32_t cnt, uint32_t lane) {
+    if (pv.dense) {
+        // records of all streams share the wave's one open chunk; they are grouped by a device-wide sort afterwards
+        if (!A.dopen) { A.dslot = arena_take(A, pv, pv.raw_key, lane) << CH_SHIFT; A.dopen = 1; }
+        const uint32_t v = A.dslot, rem = CH_REC - (v & (CH_REC - 1u));
+        if (cnt < rem) { A.dslot = v + cnt; return Resv{v, cnt, 0u}; }
+        if (lane == 0) pv.chunk_fill[v >> CH_SHIFT] = CH_REC;
+        if (cnt == rem) { A.dopen = 0; return Resv{v, cnt, 0u}; }
+        const uint32_t nv = arena_take(A, pv, pv.raw_key, lane) << CH_SHIFT;
+        A.dslot = nv + (cnt - rem);
+        return Resv{v, rem, nv};
+    }
+    const uint32_t e = s & A.tmask;
+    const uint32_t key = A.t_key[e];
+    uint32_t v = A.t_slot[e];
+    if (key != s) {
+        if (key != KEY_NONE && lane == 0) pv.chunk_fill[v >> CH_SHIFT] = v & (CH_REC - 1u);        // evicted partly filled
+        v = arena_take(A, pv, s, lane) << CH_SHIFT;
+    }
+    const uint32_t rem = CH_REC - (v & (CH_REC - 1u));
+    Resv r{v, cnt, 0u};
+    uint32_t nkey = s, nv = v + cnt;
+    if (cnt >= rem) {
+        if (lane == 0) pv.chunk_fill[v >> CH_SHIFT] = CH_REC;                                      // full
+        if (cnt == rem) nkey = KEY_NONE;
+        else {
+            nv = arena_take(A, pv, s, lane) << CH_SHIFT;
+            r = Resv{v, rem, nv};
+            nv += cnt - rem;
+        }
+    }
+    if (lane == 0) { A.t_key[e] = nkey; A.t_slot[e] = nv; }
+    lds_sync();
+    return r;
+}
+__device__ __forceinline__ void arena_finish(const WaveArena& A, const PoolView& pv, uint32_t lane) {
+    if (pv.dense) {
+        if (A.dopen && lane == 0) pv.chunk_fill[A.dslot >> CH_SHIFT] = A.dslot & (CH_REC - 1u);
+        return;
+    }
+    for (uint32_t e = lane; e <= A.tmask; e += WAVE)
+        if (A.t_key[e] != KEY_NONE) { const uint32_t v = A.t_slot[e]; pv.chunk_fill[v >> CH_SHIFT] = v & (CH_REC - 1u); }
+}
+
 // diagonal streams (X == Y, cols == rows) pack 8-byte rows into the first half of their chunks
-__device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t cls, uint32_t w) {
-    const uint32_t ch = slot >> pv.c_shift, r = slot & ((1u << pv.c_shift) - 1u);
-    ((unsigned long long*)(pv.rec + ((size_t)ch << (pv.c_shift + 4))))[r] = rows;
+__device__ __forceinline__ void rec_store_dense(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t w, uint32_t stream) {
+    ((ulonglong2*)pv.rec)[slot] = make_ulonglong2(rows, cols);
+    pv.recw[slot] = w;
+    pv.rkey[slot] = stream;
+}
+__device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t cls, uint32_t w, uint32_t stream) {
+    if (pv.dense) { rec_store_dense(pv, slot, rows, rows, w, stream); return; }
+    const uint32_t ch = slot >> CH_SHIFT, r = slot & (CH_REC - 1u);
+    ((unsigned long long*)(pv.rec + ((size_t)ch << (CH_SHIFT + 4))))[r] = rows;
     if (cls) pv.recw[slot] = w;
 }
-__device__ __forceinline__ void rec_store_off(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t cls, uint32_t w) {
+__device__ __forceinline__ void rec_store_off(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t cls, uint32_t w,
+                                              uint32_t stream) {
+    if (pv.dense) { rec_store_dense(pv, slot, rows, cols, w, stream); return; }
     ((ulonglong2*)pv.rec)[slot] = make_ulonglong2(rows, cols);
     if (cls) pv.recw[slot] = w;
 }
 
-__global__ void pool_init_kernel(unsigned long long* __restrict__ state, uint32_t n_states, uint32_t c_shift) {
+__global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t n, uint32_t v) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_states) state[i] = (0xFFFFFFFFull << 32) | (unsigned long long)(1u << c_shift);     // no chunk yet: the first reservation takes one
+    if (i < n) p[i] = v;
 }
-
-// the last chunk of every stream is partly filled
-__global__ void pool_finalize_kernel(const unsigned long long* __restrict__ state, uint32_t n_states, uint32_t c_shift, uint32_t pool_cap,
-                                     uint32_t* __restrict__ chunk_fill) {
+__global__ void iota_u32_kernel(uint32_t* __restrict__ p, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_states) return;
-    const unsigned long long st = state[i];
-    const uint32_t ch = (uint32_t)(st >> 32), used = (uint32_t)st, C = 1u << c_shift;
-    if (ch < pool_cap && used < C) chunk_fill[ch] = used;
+    if (i < n) p[i] = i;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -134,7 +213,7 @@ struct K0Params {
     uint16_t* pair_blk;
     unsigned long long* pair_mask;
     uint32_t* pair_cursor;         // [KMDB_PAIR_REGIONS * 16]
-    uint32_t region_cap;
+    uint32_t n_regions, region_cap;
     uint32_t* counters;
 };
 
@@ -229,6 +308,7 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
             // wide list: second pass with absolute ids; the blocks it can touch bound the reservation
             second_pass = true;
             need = bm.blk(last) - blk0;
+            need = need < l - 1u ? need : l - 1u;                 // l ids touch at most l blocks
         }
     }
     // extra pairs: one reservation per wave in the wave's region of the pair pool
@@ -237,7 +317,7 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
         const uint32_t incl = wave_incl_scan(need, lane);
         const uint32_t total = bcast(incl, WAVE - 1);
         if (total) {
-            const uint32_t region = (blockIdx.x * 4u + (threadIdx.x >> 6)) % KMDB_PAIR_REGIONS;
+            const uint32_t region = (blockIdx.x * 4u + (threadIdx.x >> 6)) % q.n_regions;
             uint32_t base = 0;
             if (lane == WAVE - 1) base = atomicAdd(&q.pair_cursor[region * 16u], total);
             base = bcast(base, WAVE - 1);
@@ -335,10 +415,11 @@ struct NParams {
     unsigned long long* widebits;
     uint32_t P, nseg_nodes, n_segs, chain_cap;
     uint32_t emit_lo, emit_hi;
+    uint32_t tbits;                // log2 of the open-chunk table
     PoolView pool;
 };
 constexpr int K1N_WAVES = 4;
-__host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap) { return ((size_t)chain_cap * 20 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tbits) { return (((size_t)chain_cap * 20 + 15) & ~(size_t)15) + ((size_t)8 << tbits); }
 
 __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -346,7 +427,9 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg = blockIdx.x * K1N_WAVES + wave;
     if (seg >= q.n_segs) return;
-    ulonglong2* chain_m = (ulonglong2*)(lds_raw + k1n_wave_bytes(q.chain_cap) * wave);       // [chain_cap] one slot per depth:
+    unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits) * wave;
+    uint32_t* table = (uint32_t*)wbase;                                                      // open chunks: [2 << tbits]
+    ulonglong2* chain_m = (ulonglong2*)(wbase + ((size_t)8 << q.tbits));                    // [chain_cap] one slot per depth:
     uint32_t* chain_b = (uint32_t*)(chain_m + q.chain_cap);                                  // the latest node of that depth on the current root path
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t first = seg * q.nseg_nodes;
@@ -403,7 +486,8 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         if ((nx_info >> 16) > 1u) { const uint32_t po = q.pair_ofs[ii]; nx_e1b = q.pair_blk[po]; nx_e1m = q.pair_mask[po]; }
     };
     fetch(first);
-    unsigned long long n_rec = 0;
+    WaveArena A;
+    arena_init(A, table, q.tbits, seg, lane);
     for (uint32_t base = first; base < end; base += WAVE) {
         const uint32_t idx = base + lane;
         const bool valid = idx < end;
@@ -446,20 +530,16 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         while (pend) {
             const uint32_t X0 = bcast(w0, (uint32_t)__builtin_ctzll(pend));
             const bool mine = act && __popcll(F0) >= 2 && w0 == X0;
-            const unsigned long long b0 = __ballot(mine && cls == 0u), b1 = __ballot(mine && cls == 1u), b2 = __ballot(mine && cls == 2u);
-            Resv r{0u, 0u, 0u};
-            if (lane < NCLS) {
-                const uint32_t cnt = (uint32_t)__popcll(lane == 0 ? b0 : lane == 1 ? b1 : b2);
-                if (cnt) r = pool_reserve(q.pool, (tri32(X0) + X0) * NCLS + lane, cnt);
+            const uint32_t sb = (tri32(X0) + X0) * NCLS;
+#pragma unroll
+            for (uint32_t c3 = 0; c3 < NCLS; ++c3) {
+                const unsigned long long bc = __ballot(mine && cls == c3);
+                if (bc) {
+                    const Resv r = arena_reserve(A, q.pool, sb + c3, (uint32_t)__popcll(bc), lane);
+                    if (mine && cls == c3) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, cls, w, sb + c3);
+                }
             }
-            const uint32_t src = cls;                            // lane that holds this class's reservation
-            const Resv mr{(uint32_t)__shfl((int)r.base1, (int)src, WAVE), (uint32_t)__shfl((int)r.n1, (int)src, WAVE), (uint32_t)__shfl((int)r.base2, (int)src, WAVE)};
-            if (mine) {
-                const unsigned long long mb = cls == 0u ? b0 : cls == 1u ? b1 : b2;
-                rec_store_diag(q.pool, resv_slot(mr, (uint32_t)__popcll(mb & lt_mask)), F0, cls, w);
-            }
-            n_rec += (unsigned long long)__popcll(b0 | b1 | b2);
-            pend &= ~(b0 | b1 | b2);
+            pend &= ~__ballot(mine);
         }
         // second blocks: one round per distinct (w0, w1) of the batch
         const bool act2 = act && F1 != 0;
@@ -469,33 +549,20 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
             const uint32_t Y0 = key & 0x7FFFu, X1 = key >> 15;
             const bool mine = act2 && (S.bw & 0x3FFFFFFFu) == key;
             const bool dg = mine && __popcll(F1) >= 2;
-            const unsigned long long a0 = __ballot(mine && cls == 0u), a1 = __ballot(mine && cls == 1u), a2 = __ballot(mine && cls == 2u);
-            const unsigned long long d0 = __ballot(dg && cls == 0u), d1 = __ballot(dg && cls == 1u), d2 = __ballot(dg && cls == 2u);
-            Resv r{0u, 0u, 0u};
-            if (lane < 2 * NCLS) {
-                const uint32_t c3 = lane % NCLS;
-                const bool isd = lane >= NCLS;
-                const unsigned long long bl = isd ? (c3 == 0 ? d0 : c3 == 1 ? d1 : d2) : (c3 == 0 ? a0 : c3 == 1 ? a1 : a2);
-                const uint32_t cnt = (uint32_t)__popcll(bl);
-                if (cnt) r = pool_reserve(q.pool, (tri32(X1) + (isd ? X1 : Y0)) * NCLS + c3, cnt);
-            }
-            {
-                const Resv mr{(uint32_t)__shfl((int)r.base1, (int)cls, WAVE), (uint32_t)__shfl((int)r.n1, (int)cls, WAVE), (uint32_t)__shfl((int)r.base2, (int)cls, WAVE)};
-                if (mine) {
-                    const unsigned long long mb = cls == 0u ? a0 : cls == 1u ? a1 : a2;
-                    rec_store_off(q.pool, resv_slot(mr, (uint32_t)__popcll(mb & lt_mask)), F1, F0, cls, w);
+#pragma unroll
+            for (uint32_t c3 = 0; c3 < NCLS; ++c3) {
+                const unsigned long long bc = __ballot(mine && cls == c3);
+                if (bc) {
+                    const Resv r = arena_reserve(A, q.pool, (tri32(X1) + Y0) * NCLS + c3, (uint32_t)__popcll(bc), lane);
+                    if (mine && cls == c3) rec_store_off(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F1, F0, cls, w, (tri32(X1) + Y0) * NCLS + c3);
+                }
+                const unsigned long long dc = __ballot(dg && cls == c3);
+                if (dc) {
+                    const Resv r = arena_reserve(A, q.pool, (tri32(X1) + X1) * NCLS + c3, (uint32_t)__popcll(dc), lane);
+                    if (dg && cls == c3) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(dc & lt_mask)), F1, cls, w, (tri32(X1) + X1) * NCLS + c3);
                 }
             }
-            {
-                const int src = (int)(cls + NCLS);
-                const Resv mr{(uint32_t)__shfl((int)r.base1, src, WAVE), (uint32_t)__shfl((int)r.n1, src, WAVE), (uint32_t)__shfl((int)r.base2, src, WAVE)};
-                if (dg) {
-                    const unsigned long long mb = cls == 0u ? d0 : cls == 1u ? d1 : d2;
-                    rec_store_diag(q.pool, resv_slot(mr, (uint32_t)__popcll(mb & lt_mask)), F1, cls, w);
-                }
-            }
-            n_rec += (unsigned long long)(__popcll(a0 | a1 | a2) + __popcll(d0 | d1 | d2));
-            pend2 &= ~(a0 | a1 | a2);
+            pend2 &= ~__ballot(mine);
         }
         // ---- chain slots for the next batch: the nodes on the root path of this batch's last node, i.e. the
         // lanes whose depth is smaller than the depth of every later lane
@@ -512,7 +579,7 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
             lds_sync();
         }
     }
-    if (lane == 0 && n_rec) atomicAdd((unsigned long long*)&q.pool.counters[KCTR_RECORDS], n_rec);
+    arena_finish(A, q.pool, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,7 +614,9 @@ struct GParams {
     const uint32_t* nl;
     const int32_t* parent;
     const uint32_t* w;
+    const uint16_t* dflag;
     const unsigned long long* widebits;
+    const uint32_t* wide_base;     // wide nodes before every 64-node word of the DFS stream
     const unsigned long long* p0_mask;
     const uint32_t* p0_info;
     const uint32_t* pair_ofs;
@@ -556,91 +625,60 @@ struct GParams {
     const ulonglong2* fn_mask;
     const uint32_t* fn_blk;
     uint32_t emit_lo, emit_hi;
+    uint32_t n_waves;              // waves of the launch, each with a run of consecutive batches of 64 wide nodes
+    uint32_t tbits;
     PoolView pool;
 };
 constexpr int K1G_WAVES = 4;
-constexpr uint32_t K1G_ENT = 768;          // entries of the per-wave pool
+constexpr uint32_t K1G_ROW = 12;           // entries of a lane's row (lists with more blocks take the climbing path)
+constexpr uint32_t K1G_ENT = 64 * K1G_ROW; // the rows double as the entry pool of the climbing path
+constexpr uint32_t K1G_CH = 32;            // chain slots (by depth mod 32)
 constexpr uint32_t K1G_QCAP = 256;         // record descriptors queued per round
 struct K1GWave {
     unsigned long long ent_mask[K1G_ENT];
+    unsigned long long ch_mask[K1G_CH * K1G_ROW];
     uint32_t queue[K1G_QCAP];               // owner lane | a << 6 | b << 19
     uint32_t st_w[64];
+    uint32_t ch_node[K1G_CH];
     uint16_t ent_blk[K1G_ENT];
+    uint16_t ch_blk[K1G_CH * K1G_ROW];
     uint16_t st_start[64];
+    uint16_t ch_len[K1G_CH];
 };
 
+// One lane per wide node, batches of 64 consecutive nodes of the (DFS-ordered) wide list, a run of batches per wave.
+// A wide node's parent is wide as well or has at most two blocks.  Its list = the parent's list + its own pairs:
+//   parent with <= 2 blocks: the (blocks, masks) the narrow kernel left in HBM;
+//   wide parent inside the batch: that lane's row in LDS (lanes resolve in rounds, parents first);
+//   wide parent before the batch: the wave's chain table (the latest wide node of every depth, by depth mod 32);
+//   anything else (the parent belongs to another wave's run, a list longer than a row): the lane climbs the parent links
+//   up to the nearest ancestor with <= 2 blocks and gathers the pairs on the way (the slow path, a few lanes per wave).
 __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) {
     __shared__ K1GWave lds[K1G_WAVES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];       // open-chunk tables: [K1G_WAVES][2 << tbits]
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     K1GWave& L = lds[wave];
-    const uint32_t batch = blockIdx.x * K1G_WAVES + wave;
-    const uint32_t k = batch * WAVE + lane;
-    const bool valid = k < q.n_wide;
-    if (batch * WAVE >= q.n_wide) return;
-    const uint32_t node = valid ? q.widx[k] : 0u;
+    const uint32_t wid = blockIdx.x * K1G_WAVES + wave;          // every wave takes a run of consecutive batches
+    if (wid >= q.n_waves) return;
+    const uint32_t n_batches = (q.n_wide + WAVE - 1) / WAVE;
+    const uint32_t b_lo = (uint32_t)((uint64_t)n_batches * wid / q.n_waves), b_hi = (uint32_t)((uint64_t)n_batches * (wid + 1) / q.n_waves);
     auto iswide = [&](uint32_t y) -> bool { return (q.widebits[y >> 6] >> (y & 63u)) & 1ull; };
-    // pass 1: how many (block, mask) pairs lie between the node and its nearest ancestor with at most two blocks
-    uint32_t cnt = 0;
-    if (valid) {
-        cnt = q.p0_info[node] >> 16;
-        int32_t y = q.parent[node];
-        while (y >= 0 && iswide((uint32_t)y)) { cnt += q.p0_info[y] >> 16; y = q.parent[y]; }
-        if (y >= 0) cnt += 2;
-        if (cnt > K1G_ENT) { atomicOr(&q.pool.counters[KCTR_LIST_OVERFLOW], 1u); cnt = 0; }      // the engine falls back
-    }
-    const uint32_t nlv = valid ? q.nl[node] : 0u;
-    const uint32_t wv = valid ? q.w[node] : 0u;
-    const bool act = valid && cnt != 0 && wv != 0 && (nlv & 0xFFFFu) >= 2u && node >= q.emit_lo && node < q.emit_hi;
-    const uint32_t cls = weight_class(wv);
-    unsigned long long n_rec = 0;
-    uint32_t done = 0;                                         // lanes below `done` are finished
-    while (done < (uint32_t)WAVE) {
-        // the lanes [done, hi) whose pairs fit the entry pool together
-        const uint32_t c = lane >= done ? cnt : 0u;
-        const uint32_t incl = wave_incl_scan(c, lane);
-        const unsigned long long over = __ballot(incl > K1G_ENT);
-        const uint32_t hi = over ? (uint32_t)__builtin_ctzll(over) : (uint32_t)WAVE;      // > done: a single list fits
-        const bool on = lane >= done && lane < hi && cnt != 0;
-        const uint32_t off = incl - c;
-        // pass 2: fill the lane's region right to left (the climb meets the blocks in descending order)
-        uint32_t m = 0, start = 0;
-        if (on) {
-            uint32_t pos = off + cnt, cur = 0xFFFFFFFFu;
-            auto push = [&](uint32_t blk, unsigned long long mask) {
-                if (blk == cur) L.ent_mask[pos] |= mask;
-                else { --pos; L.ent_blk[pos] = (uint16_t)blk; L.ent_mask[pos] = mask; cur = blk; }
-            };
-            int32_t y = (int32_t)node;
-            for (;;) {
-                const uint32_t info = q.p0_info[y];
-                const uint32_t np = info >> 16;
-                if (np > 1) {
-                    const uint32_t po = q.pair_ofs[y];
-                    for (uint32_t t = np - 1; t-- > 0;) push(q.pair_blk[po + t], q.pair_mask[po + t]);
-                }
-                if (np) push(info & 0xFFFFu, q.p0_mask[y]);
-                y = q.parent[y];
-                if (y < 0) break;
-                if (!iswide((uint32_t)y)) {
-                    const uint32_t fb = q.fn_blk[y];
-                    const ulonglong2 fm = q.fn_mask[y];
-                    if ((fb >> 16) != 0xFFFFu) push(fb >> 16, fm.y);
-                    if ((fb & 0xFFFFu) != 0xFFFFu) push(fb & 0xFFFFu, fm.x);
-                    break;
-                }
-            }
-            m = off + cnt - pos; start = pos;
-        }
-        L.st_start[lane] = (uint16_t)start;
-        L.st_w[lane] = wv;
-        // record-parallel emission: a node with m blocks owns m (m + 1) / 2 records (block pairs a >= b); the records of
-        // the round are numbered by a prefix sum, every owner pushes one descriptor per record into a queue, then
-        // the wave takes 64 descriptors at a time, one record per lane
-        const uint32_t myrec = (on && act) ? m * (m + 1u) / 2u : 0u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    WaveArena A;
+    arena_init(A, (uint32_t*)(lds_raw + ((size_t)8 << q.tbits) * wave), q.tbits, wid + 64u, lane);
+    if (lane < K1G_CH) L.ch_node[lane] = 0xFFFFFFFFu;
+    lds_sync();
+
+    // record-parallel emission of the lanes in `on` (list of lane j: m entries from st_start[j]): a node with m blocks owns
+    // m (m + 1) / 2 records (block pairs a >= b); the records are numbered by a prefix sum, every owner pushes one descriptor per
+    // record into a queue, then the wave takes 64 descriptors at a time, one record per lane
+    auto emit = [&](bool on, uint32_t m, uint32_t wv) {
+        const uint32_t myrec = on ? m * (m + 1u) / 2u : 0u;
         const uint32_t rincl = wave_incl_scan(myrec, lane);
         const uint32_t T = bcast(rincl, WAVE - 1);
         const uint32_t rexcl = rincl - myrec;
+        L.st_w[lane] = wv;
         lds_sync();
         for (uint32_t q0 = 0; q0 < T; q0 += K1G_QCAP) {
             if (myrec) {
@@ -662,30 +700,188 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
             const uint32_t tend = T < q0 + K1G_QCAP ? T : q0 + K1G_QCAP;
             for (uint32_t t0 = q0; t0 < tend; t0 += WAVE) {
                 const uint32_t t = t0 + lane;
+                bool rec_on = false, diag = false;
+                uint32_t stream = 0, ww = 0, cl = 0;
+                unsigned long long FX = 0, FY = 0;
                 if (t < tend) {
                     const uint32_t d = L.queue[t - q0];
                     const uint32_t own = d & 63u, a = (d >> 6) & 0x1FFFu, b = d >> 19;
                     const uint32_t st = L.st_start[own];
-                    const unsigned long long FX = L.ent_mask[st + a], FY = L.ent_mask[st + b];
+                    FX = L.ent_mask[st + a]; FY = L.ent_mask[st + b];
                     const uint32_t X = L.ent_blk[st + a], Y = L.ent_blk[st + b];
-                    const uint32_t ww = L.st_w[own];
-                    const uint32_t cl = weight_class(ww);
-                    if (a != b || __popcll(FX) >= 2) {
-                        const Resv r = pool_reserve(q.pool, (tri32(X) + Y) * NCLS + cl, 1u);
-                        if (a != b) rec_store_off(q.pool, r.n1 ? r.base1 : r.base2, FX, FY, cl, ww);
-                        else rec_store_diag(q.pool, r.n1 ? r.base1 : r.base2, FX, cl, ww);
-                        ++n_rec;
+                    ww = L.st_w[own];
+                    cl = weight_class(ww);
+                    diag = a == b;
+                    rec_on = !diag || __popcll(FX) >= 2;           // a diagonal record needs two ids to have a pair
+                    stream = (tri32(X) + Y) * NCLS + cl;
+                }
+                // one reservation per distinct stream of the step (the records of neighbouring nodes share their streams)
+                unsigned long long pend = __ballot(rec_on);
+                while (pend) {
+                    const uint32_t s0 = bcast(stream, (uint32_t)__builtin_ctzll(pend));
+                    const unsigned long long grp = q.pool.dense ? pend : __ballot(rec_on && stream == s0);     // dense: the whole step at once
+                    const Resv r = arena_reserve(A, q.pool, s0, (uint32_t)__popcll(grp), lane);
+                    if ((grp >> lane) & 1ull) {
+                        const uint32_t slot = resv_slot(r, (uint32_t)__popcll(grp & lt_mask));
+                        if (diag) rec_store_diag(q.pool, slot, FX, cl, ww, stream); else rec_store_off(q.pool, slot, FX, FY, cl, ww, stream);
                     }
+                    pend &= ~grp;
                 }
             }
             lds_sync();
         }
-        done = hi;
-    }
-    (void)cls;
+    };
+
+    for (uint32_t batch = b_lo; batch < b_hi; ++batch) {
+        const uint32_t k = batch * WAVE + lane;
+        const bool valid = k < q.n_wide;
+        const uint32_t node = valid ? q.widx[k] : 0u;
+        const uint32_t nlv = valid ? q.nl[node] : 0u;
+        const uint32_t wv = valid ? q.w[node] : 0u;
+        const bool act = valid && wv != 0 && (nlv & 0xFFFFu) >= 2u && node >= q.emit_lo && node < q.emit_hi;
+        const int32_t par = valid ? q.parent[node] : -1;
+        const uint32_t dep = valid ? (uint32_t)(q.dflag[node] & 0x7FFFu) : 0x7FFFu;
+        const uint32_t info = valid ? q.p0_info[node] : 0u;
+        const uint32_t np = info >> 16;
+        const unsigned long long m0 = valid ? q.p0_mask[node] : 0ull;
+        const uint32_t po = np > 1 ? q.pair_ofs[node] : 0u;
+        // ---- where the parent's list comes from
+        enum : uint32_t { SRC_NOW = 0, SRC_LANE = 1, SRC_CHAIN = 2, SRC_SLOW = 3 };
+        uint32_t src = SRC_NOW, plane = 0;
+        bool par_narrow = false;
+        if (valid && par >= 0) {
+            if (!iswide((uint32_t)par)) par_narrow = true;
+            else {
+                const uint32_t pw = (uint32_t)par >> 6;
+                const uint32_t prank = q.wide_base[pw] + (uint32_t)__popcll(q.widebits[pw] & ((1ull << ((uint32_t)par & 63u)) - 1ull));
+                if (prank >= batch * WAVE) { src = SRC_LANE; plane = prank - batch * WAVE; }
+                else {
+                    const uint32_t cs = (dep - 1u) & (K1G_CH - 1u);
+                    src = (L.ch_node[cs] == (uint32_t)par && L.ch_len[cs] != 0xFFFFu) ? SRC_CHAIN : SRC_SLOW;
+                }
+            }
+        }
+        // ---- rows: the parent's entries, then the node's own pairs (ascending; an equal block at the seam merges)
+        const uint32_t row = lane * K1G_ROW;
+        uint32_t len = 0;
+        bool slow = valid && src == SRC_SLOW, done = !valid || src == SRC_NOW || src == SRC_CHAIN || src == SRC_SLOW;
+        auto push = [&](uint32_t blk, unsigned long long mask) {
+            if (len && L.ent_blk[row + len - 1u] == blk) L.ent_mask[row + len - 1u] |= mask;
+            else if (len < K1G_ROW) { L.ent_blk[row + len] = (uint16_t)blk; L.ent_mask[row + len] = mask; ++len; }
+            else slow = true;                                   // longer than a row
+        };
+        auto push_own = [&]() {
+            if (np) push(info & 0xFFFFu, m0);
+            for (uint32_t t = 0; t + 1 < np && !slow; ++t) push(q.pair_blk[po + t], q.pair_mask[po + t]);
+        };
+        if (valid && !slow) {
+            if (src == SRC_NOW) {
+                if (par_narrow) {
+                    const uint32_t fb = q.fn_blk[par];
+                    const ulonglong2 fm = q.fn_mask[par];
+                    if ((fb & 0xFFFFu) != 0xFFFFu) push(fb & 0xFFFFu, fm.x);
+                    if ((fb >> 16) != 0xFFFFu) push(fb >> 16, fm.y);
+                }
+                push_own();
+            } else if (src == SRC_CHAIN) {
+                const uint32_t cs = (dep - 1u) & (K1G_CH - 1u);
+                const uint32_t cl = L.ch_len[cs];
+                for (uint32_t e = 0; e < cl; ++e) { L.ent_blk[row + e] = L.ch_blk[cs * K1G_ROW + e]; L.ent_mask[row + e] = L.ch_mask[cs * K1G_ROW + e]; }
+                len = cl;
+                push_own();
+            }
+        }
+        // in-batch parents, parents first
+        while (__ballot(!done)) {
+            const uint32_t pstate = (uint32_t)__shfl((int)((done ? 1u : 0u) | (slow ? 2u : 0u) | (len << 2)), (int)plane, WAVE);
+            if (!done && (pstate & 1u)) {
+                if (pstate & 2u) slow = true;
+                else {
+                    const uint32_t pl = pstate >> 2, prow = plane * K1G_ROW;
+                    for (uint32_t e = 0; e < pl; ++e) { L.ent_blk[row + e] = L.ent_blk[prow + e]; L.ent_mask[row + e] = L.ent_mask[prow + e]; }
+                    len = pl;
+                    push_own();
+                }
+                done = true;
+            }
+            lds_sync();
+        }
+        // ---- chain slots for the next batches: the lanes on the root path of the batch's last node
+        {
+            uint32_t mdep = dep;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n_rec += shfl64(n_rec, (int)(lane ^ (uint32_t)d));
-    if (lane == 0 && n_rec) atomicAdd((unsigned long long*)&q.pool.counters[KCTR_RECORDS], n_rec);
+            for (int sft = 1; sft < WAVE; sft <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_down((int)mdep, sft, WAVE);
+                if (lane + (uint32_t)sft < (uint32_t)WAVE) mdep = o < mdep ? o : mdep;
+            }
+            uint32_t later = (uint32_t)__shfl_down((int)mdep, 1, WAVE);
+            if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
+            if (valid && dep < later) {
+                const uint32_t cs = dep & (K1G_CH - 1u);
+                L.ch_node[cs] = node;
+                L.ch_len[cs] = slow ? (uint16_t)0xFFFFu : (uint16_t)len;
+                if (!slow) for (uint32_t e = 0; e < len; ++e) { L.ch_blk[cs * K1G_ROW + e] = L.ent_blk[row + e]; L.ch_mask[cs * K1G_ROW + e] = L.ent_mask[row + e]; }
+            }
+        }
+        L.st_start[lane] = (uint16_t)row;
+        lds_sync();
+        emit(act && !slow, len, wv);
+        // ---- the slow path: climb to the nearest ancestor with at most two blocks, twice (count, then fill)
+        if (__ballot(slow)) {
+            uint32_t cnt = 0;
+            if (slow) {
+                cnt = np;
+                int32_t y = par;
+                while (y >= 0 && iswide((uint32_t)y)) { cnt += q.p0_info[y] >> 16; y = q.parent[y]; }
+                if (y >= 0) cnt += 2;
+                if (cnt > K1G_ENT) { atomicOr(&q.pool.counters[KCTR_LIST_OVERFLOW], 1u); cnt = 0; }      // the engine falls back
+            }
+            uint32_t fin = 0;                                      // lanes below `fin` are finished
+            while (fin < (uint32_t)WAVE) {
+                // the lanes [fin, hi) whose pairs fit the entry pool together
+                const uint32_t c = lane >= fin ? cnt : 0u;
+                const uint32_t incl = wave_incl_scan(c, lane);
+                const unsigned long long over = __ballot(incl > K1G_ENT);
+                const uint32_t hi = over ? (uint32_t)__builtin_ctzll(over) : (uint32_t)WAVE;      // > fin: a single list fits
+                const bool on = lane >= fin && lane < hi && cnt != 0;
+                const uint32_t off = incl - c;
+                uint32_t m = 0, start = 0;
+                if (on) {
+                    // fill the lane's region right to left (the climb meets the blocks in descending order)
+                    uint32_t pos = off + cnt, cur = 0xFFFFFFFFu;
+                    auto rpush = [&](uint32_t blk, unsigned long long mask) {
+                        if (blk == cur) L.ent_mask[pos] |= mask;
+                        else { --pos; L.ent_blk[pos] = (uint16_t)blk; L.ent_mask[pos] = mask; cur = blk; }
+                    };
+                    int32_t y = (int32_t)node;
+                    for (;;) {
+                        const uint32_t yi = q.p0_info[y];
+                        const uint32_t ynp = yi >> 16;
+                        if (ynp > 1) {
+                            const uint32_t ypo = q.pair_ofs[y];
+                            for (uint32_t t = ynp - 1; t-- > 0;) rpush(q.pair_blk[ypo + t], q.pair_mask[ypo + t]);
+                        }
+                        if (ynp) rpush(yi & 0xFFFFu, q.p0_mask[y]);
+                        y = q.parent[y];
+                        if (y < 0) break;
+                        if (!iswide((uint32_t)y)) {
+                            const uint32_t fb = q.fn_blk[y];
+                            const ulonglong2 fm = q.fn_mask[y];
+                            if ((fb >> 16) != 0xFFFFu) rpush(fb >> 16, fm.y);
+                            if ((fb & 0xFFFFu) != 0xFFFFu) rpush(fb & 0xFFFFu, fm.x);
+                            break;
+                        }
+                    }
+                    m = off + cnt - pos; start = pos;
+                }
+                L.st_start[lane] = (uint16_t)start;
+                lds_sync();
+                emit(on && act, m, wv);
+                fin = hi;
+            }
+        }
+    }
+    arena_finish(A, q.pool, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -736,16 +932,33 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
 }
 
 struct K2Item {
-    uint32_t X, Y, cls, n;                 // block pair, weight class, records in the chunk
-    const unsigned char* rec;              // the chunk's record slots
-    const uint32_t* w;                     // the chunk's weights
+    uint32_t X, Y, cls, count;             // block pair, weight class, wave steps (64 records each) of this stream in the window
+    const uint32_t* ids;                   // chunk mode: [count] chunk ids (LDS)
+    const uint32_t* fills;                 //             [count] records in every chunk (LDS)
+    const uint32_t* sslot;                 // gather mode (records sorted by stream): slots of the run, n_rec of them
+    uint32_t n_rec;
+    const unsigned char* rec;              // record pool
+    const uint32_t* recw;
 };
-__device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t j, bool weighted, unsigned long long& R, unsigned long long& Cc, uint32_t& W) {
+// the 64 records of step ci, one per lane (lanes beyond the fill get an empty record)
+__device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t ci, uint32_t lane, bool weighted, unsigned long long& R,
+                                         unsigned long long& Cc, uint32_t& W) {
     R = 0; Cc = 0; W = 0;
-    if (j < it.n) {
-        if (diag) { R = ((const unsigned long long*)it.rec)[j]; Cc = R; }
-        else { const ulonglong2 rc = ((const ulonglong2*)it.rec)[j]; R = rc.x; Cc = rc.y; }
-        W = weighted ? it.w[j] : 1u;
+    if (ci >= it.count) return;
+    if (it.sslot) {
+        const uint32_t p = ci * 64u + lane;
+        if (p < it.n_rec) {
+            const uint32_t slot = it.sslot[p];
+            const ulonglong2 rc = ((const ulonglong2*)it.rec)[slot];
+            R = rc.x; Cc = rc.y;
+            W = weighted ? it.recw[slot] : 1u;
+        }
+    } else if (lane < it.fills[ci]) {
+        const uint32_t id = it.ids[ci];
+        const unsigned char* base = it.rec + ((size_t)id << (CH_SHIFT + 4));
+        if (diag) { R = ((const unsigned long long*)base)[lane]; Cc = R; }
+        else { const ulonglong2 rc = ((const ulonglong2*)base)[lane]; R = rc.x; Cc = rc.y; }
+        W = weighted ? it.recw[((size_t)id << CH_SHIFT) + lane] : 1u;
     }
 }
 
@@ -770,11 +983,11 @@ __device__ __forceinline__ void k2_apply_popc(const K2Item& it, uint32_t* __rest
 #define ROWMASK(j) (DIAG ? rt[((uint32_t)(j) + 1u < wrapd ? lane + (uint32_t)(j) + 1u : lane + (uint32_t)(j) + 1u - bwidth) & 63u] : rt[(j)])
     unsigned long long nR = 0, nC = 0;
     uint32_t nW = 0;
-    k2_fetch(it, DIAG, wave * 64 + lane, true, nR, nC, nW);
-    for (uint32_t g0 = wave * 64; g0 < it.n; g0 += 256) {
+    k2_fetch(it, DIAG, wave, lane, true, nR, nC, nW);
+    for (uint32_t ci = wave; ci < it.count; ci += 4) {
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
-        if (g0 + 256 < it.n) k2_fetch(it, DIAG, g0 + 256 + lane, true, nR, nC, nW);
+        k2_fetch(it, DIAG, ci + 4, lane, true, nR, nC, nW);
         const unsigned long long Ct = transpose64(C, lane);
         rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
         lds_sync();
@@ -841,11 +1054,11 @@ __device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, u
     };
     unsigned long long nR = 0, nC = 0;
     uint32_t nW = 0;
-    k2_fetch(it, DIAG, wave * 64 + lane, WEIGHTED, nR, nC, nW);
-    for (uint32_t g0 = wave * 64; g0 < it.n; g0 += 256) {
+    k2_fetch(it, DIAG, wave, lane, WEIGHTED, nR, nC, nW);
+    for (uint32_t ci = wave; ci < it.count; ci += 4) {
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
-        if (g0 + 256 < it.n) k2_fetch(it, DIAG, g0 + 256 + lane, WEIGHTED, nR, nC, nW);
+        k2_fetch(it, DIAG, ci + 4, lane, WEIGHTED, nR, nC, nW);
         const unsigned long long Ct = transpose64(C, lane);
         rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);
         if (!DIAG) ctbuf[wave][lane] = Ct;
@@ -882,32 +1095,24 @@ __device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, u
     }
 }
 
+constexpr uint32_t K2_WIN = 128;           // sorted chunks per workgroup (8192 records)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
-                                                       const uint32_t* __restrict__ chunk_key, const uint32_t* __restrict__ chunk_fill,
-                                                       const uint32_t* __restrict__ counters, uint32_t c_shift,
+                                                       const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
+                                                       const uint32_t* __restrict__ chunk_fill, uint32_t n_states, uint32_t pool_cap,
                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= counters[KCTR_CHUNKS]) return;
-    K2Item it;
-    {
-        const uint32_t key = chunk_key[chunk];
-        const uint32_t bucket = key / NCLS;
-        it.cls = key - bucket * NCLS;
-        uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)bucket + 1.0f) - 1.0f) * 0.5f);
-        while (tri32(X) > bucket) --X;
-        while (tri32(X + 1u) <= bucket) ++X;
-        it.X = X; it.Y = bucket - tri32(X);
-        const uint32_t f = chunk_fill[chunk];
-        it.n = f ? f : (1u << c_shift);
-        it.rec = rec + ((size_t)chunk << (c_shift + 4));
-        it.w = recw + ((size_t)chunk << c_shift);
+    __shared__ uint32_t s_key[K2_WIN], s_id[K2_WIN], s_fill[K2_WIN];
+    // the window: K2_WIN chunks of the stream-sorted chunk table (never-opened chunks sort last)
+    if (threadIdx.x < K2_WIN) {
+        const uint32_t j = blockIdx.x * K2_WIN + threadIdx.x;
+        const uint32_t key = j < pool_cap ? sorted_key[j] : n_states;
+        const uint32_t id = key < n_states ? sorted_id[j] : 0u;
+        s_key[threadIdx.x] = key; s_id[threadIdx.x] = id; s_fill[threadIdx.x] = key < n_states ? chunk_fill[id] : 0u;
     }
-    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     {
         unsigned long long v = 0;
 #pragma unroll
@@ -916,22 +1121,152 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         lut_01[threadIdx.x] = v & 0x0101010101010101ull;
     }
     __syncthreads();
-    if (it.X == it.Y) {
-        if (it.cls == 0) k2_apply_mfma<false, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-        else if (it.cls == 1) k2_apply_mfma<true, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-        else k2_apply_popc<true>(it, M, bwidth, acc, rtbuf);
-    } else {
-        if (it.cls == 0) k2_apply_mfma<false, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-        else if (it.cls == 1) k2_apply_mfma<true, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-        else k2_apply_popc<false>(it, M, bwidth, acc, rtbuf);
+    uint32_t a = 0;
+    while (a < K2_WIN && s_key[a] < n_states) {
+        // one run of the window = the chunks of one stream
+        const uint32_t key = s_key[a];
+        uint32_t b = a + 1;
+        while (b < K2_WIN && s_key[b] == key) ++b;
+        K2Item it;
+        {
+            const uint32_t bucket = key / NCLS;
+            it.cls = key - bucket * NCLS;
+            uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)bucket + 1.0f) - 1.0f) * 0.5f);
+            while (tri32(X) > bucket) --X;
+            while (tri32(X + 1u) <= bucket) ++X;
+            it.X = X; it.Y = bucket - tri32(X);
+            it.count = b - a; it.ids = s_id + a; it.fills = s_fill + a; it.sslot = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw;
+        }
+        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
+        __syncthreads();
+        if (it.X == it.Y) {
+            if (it.cls == 0) k2_apply_mfma<false, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else if (it.cls == 1) k2_apply_mfma<true, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else k2_apply_popc<true>(it, M, bwidth, acc, rtbuf);
+        } else {
+            if (it.cls == 0) k2_apply_mfma<false, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else if (it.cls == 1) k2_apply_mfma<true, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else k2_apply_popc<false>(it, M, bwidth, acc, rtbuf);
+        }
+        // one HBM atomic per non-zero cell of the block
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
+            const uint32_t v = acc[k];
+            if (!v) continue;
+            const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
+            if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
+        }
+        __syncthreads();
+        a = b;
     }
-    // one HBM atomic per non-zero cell of the block
+}
+
+// positions of the sorted chunk table: [0, lo) chunks of one stream each, [lo, raw_lo) never opened, [raw_lo, pool_cap) mixed
+__global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uint32_t pool_cap, uint32_t n_states, uint32_t* __restrict__ counters) {
+    uint32_t lo = 0, hi = pool_cap;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_key[mid] < n_states) lo = mid + 1; else hi = mid; }
+    counters[KCTR_CHUNKS] = lo;
+    hi = pool_cap;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_key[mid] <= n_states) lo = mid + 1; else hi = mid; }
+    counters[KCTR_RAW] = pool_cap - lo;
+}
+
+// dense mode: (stream, slot) of every record of the mixed chunks, never-written slots tagged n_states (they sort last)
+__global__ __launch_bounds__(64) void raw_expand_kernel(const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ chunk_fill,
+                                                        const uint32_t* __restrict__ rkey, const uint32_t* __restrict__ counters, uint32_t pool_cap,
+                                                        uint32_t n_states, uint32_t* __restrict__ wkey, uint32_t* __restrict__ wslot) {
+    const uint32_t n_raw = counters[KCTR_RAW];
+    if (blockIdx.x >= n_raw) return;
+    const uint32_t id = sorted_id[pool_cap - n_raw + blockIdx.x];
+    const uint32_t slot = (id << CH_SHIFT) + threadIdx.x;
+    const size_t o = (size_t)blockIdx.x * CH_REC + threadIdx.x;
+    wkey[o] = threadIdx.x < chunk_fill[id] ? rkey[slot] : n_states;
+    wslot[o] = slot;
+}
+
+// K2 over records sorted by stream (dense mode): a window of K2S_WIN sorted positions, one 64 x 64 tile per run of equal streams
+constexpr uint32_t K2S_WIN = 8192;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
+                                                        const uint32_t* __restrict__ swkey, const uint32_t* __restrict__ swslot,
+                                                        const uint32_t* __restrict__ counters, uint32_t n_states,
+                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+    __shared__ uint32_t acc[64 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
+    __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
+    __shared__ unsigned long long lut_ff[256], lut_01[256];
+    __shared__ uint16_t bnd[K2S_WIN + 2];          // run starts inside the window, then the end
+    __shared__ uint32_t tcount[256];
+    const uint32_t total = counters[KCTR_RAW] * CH_REC;
+    const uint32_t p0 = blockIdx.x * K2S_WIN;
+    if (p0 >= total || swkey[p0] >= n_states) return;
+    const uint32_t wend = total - p0 < K2S_WIN ? total - p0 : K2S_WIN;
+    {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= ((threadIdx.x >> i) & 1u) ? 0xFFull << (8 * i) : 0ull;
+        lut_ff[threadIdx.x] = v;
+        lut_01[threadIdx.x] = v & 0x0101010101010101ull;
+    }
+    // run starts: every thread scans 32 consecutive positions; a block scan puts them in order
+    constexpr uint32_t PER = K2S_WIN / 256;
+    const uint32_t t0 = threadIdx.x * PER;
+    uint32_t prev = (t0 == 0 || t0 >= wend) ? 0xFFFFFFFFu : swkey[p0 + t0 - 1];
+    uint32_t mine = 0, flags = 0;
+    for (uint32_t i = 0; i < PER && t0 + i < wend; ++i) {
+        const uint32_t k = swkey[p0 + t0 + i];
+        if (k != prev) { flags |= 1u << i; ++mine; }               // the first never-written slot starts a last "run" that ends the loop below
+        prev = k;
+    }
+    tcount[threadIdx.x] = mine;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
-        const uint32_t v = acc[k];
-        if (!v) continue;
-        const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
-        if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? tcount[threadIdx.x - d] : 0u;
+        __syncthreads();
+        tcount[threadIdx.x] += v;
+        __syncthreads();
+    }
+    {
+        uint32_t o = tcount[threadIdx.x] - mine;
+        for (uint32_t i = 0; i < PER; ++i) if ((flags >> i) & 1u) bnd[o++] = (uint16_t)(t0 + i);
+    }
+    const uint32_t nb = tcount[255];
+    if (threadIdx.x == 0) bnd[nb] = (uint16_t)wend;
+    __syncthreads();
+    for (uint32_t r = 0; r < nb; ++r) {
+        const uint32_t a = bnd[r], b = bnd[r + 1];
+        const uint32_t key = swkey[p0 + a];
+        if (key >= n_states) break;
+        K2Item it;
+        {
+            const uint32_t bucket = key / NCLS;
+            it.cls = key - bucket * NCLS;
+            uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)bucket + 1.0f) - 1.0f) * 0.5f);
+            while (tri32(X) > bucket) --X;
+            while (tri32(X + 1u) <= bucket) ++X;
+            it.X = X; it.Y = bucket - tri32(X);
+            it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.sslot = swslot + p0 + a; it.rec = rec; it.recw = recw;
+        }
+        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
+        __syncthreads();
+        // dense records always carry both masks: the off-diagonal code path reads them; the diagonal tile keeps c < r
+        if (it.X == it.Y) {
+            if (it.cls == 0) k2_apply_mfma<false, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else if (it.cls == 1) k2_apply_mfma<true, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else k2_apply_popc<true>(it, M, bwidth, acc, rtbuf);
+        } else {
+            if (it.cls == 0) k2_apply_mfma<false, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else if (it.cls == 1) k2_apply_mfma<true, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+            else k2_apply_popc<false>(it, M, bwidth, acc, rtbuf);
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
+            const uint32_t v = acc[k];
+            if (!v) continue;
+            const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
+            if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
+        }
+        __syncthreads();
     }
 }
 
@@ -950,20 +1285,19 @@ struct EstParams {
     uint32_t P, stride;
     uint32_t widths[EST_NW];
     uint32_t magics[EST_NW];
-    unsigned long long* out;       // [EST_NW] records of the sampled nodes, + [EST_NW] nodes sampled
+    unsigned long long* out;       // [EST_NW] records of the sampled nodes with <= 2 blocks, [EST_NW] of the others, [1] nodes sampled
 };
 // One thread per sampled node: climbs the root path, decodes every node's local ids (the only decoder run outside the
 // call: it looks at one node in `stride`) and counts the blocks of the full list for every candidate width.
 __global__ void width_estimate_kernel(const EstParams q) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t i0 = (uint64_t)t * q.stride + (t * 2654435761u) % q.stride;
-    if (i0 >= q.P) return;
     const uint32_t node = (uint32_t)i0;
-    if (q.w[node] == 0 || (q.nl[node] & 0xFFFFu) < 2u) return;
+    const bool on = i0 < q.P && q.w[node] != 0 && (q.nl[node] & 0xFFFFu) >= 2u;
     uint32_t nblk[EST_NW], lower_first[EST_NW];
 #pragma unroll
     for (int c = 0; c < EST_NW; ++c) { nblk[c] = 0; lower_first[c] = 0xFFFFFFFFu; }
-    int32_t y = (int32_t)node;
+    int32_t y = on ? (int32_t)node : -1;
     while (y >= 0) {
         const uint2 km = q.k0in[y];
         const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16;
@@ -988,9 +1322,18 @@ __global__ void width_estimate_kernel(const EstParams q) {
         }
         y = q.parent[y];
     }
+    // one atomic per wave and counter
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (int c = 0; c < EST_NW; ++c) atomicAdd(&q.out[c], (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u);
-    atomicAdd(&q.out[EST_NW], 1ull);
+    for (int c = 0; c < EST_NW; ++c) {
+        unsigned long long rn = on && nblk[c] <= 2u ? (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u : 0ull;
+        unsigned long long rg = on && nblk[c] > 2u ? (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { rn += shfl64(rn, (int)(lane ^ (uint32_t)d)); rg += shfl64(rg, (int)(lane ^ (uint32_t)d)); }
+        if (lane == 0) { if (rn) atomicAdd(&q.out[c], rn); if (rg) atomicAdd(&q.out[EST_NW + c], rg); }
+    }
+    const unsigned long long nb = __ballot(on);
+    if (lane == 0 && nb) atomicAdd(&q.out[2 * EST_NW], (unsigned long long)__popcll(nb));
 }
 
 // v1 / new2all node arrays from the compact layout
@@ -1004,22 +1347,56 @@ __global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t*
     bitpos[i] = blkbase[i >> 8] + bitrel[i];
 }
 
-PoolView pool_view(const kmdb_db* db) {
-    return PoolView{db->state, db->counters, db->chunk_key, db->rec, db->recw, db->c_shift, (uint32_t)db->pool_cap};
+PoolView pool_view(const kmdb_db* db, bool dense) {
+    return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
+                    (uint32_t)db->pool_cap, db->rkey, db->n_states + 1u, dense ? 1u : 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 #define FREE_NULL(x) free_and_null((void**)&(x))
 
+constexpr uint32_t K1G_MAX_WAVES = 4096;
+struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
+
 int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
-    FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->rec); FREE_NULL(db->recw);
+    FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota);
+    FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->sort_tmp);
+    FREE_NULL(db->rkey); FREE_NULL(db->wkey); FREE_NULL(db->wslot); FREE_NULL(db->swkey); FREE_NULL(db->swslot); FREE_NULL(db->sort2_tmp);
     db->pool_cap = 0;
-    if (chunks >= (1ull << 32) >> db->c_shift) return kmdb_set_error("kmdb: record pool would exceed 2^32 record slots");
+    chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB);
+    if (chunks >= (1ull << 31) >> CH_SHIFT) return kmdb_set_error("kmdb: record pool would exceed 2^31 record slots");
     HIP_TRY(hipMalloc((void**)&db->chunk_key, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->chunk_fill, chunks * 4));
-    HIP_TRY(hipMalloc((void**)&db->rec, (chunks << db->c_shift) * 16));
-    HIP_TRY(hipMalloc((void**)&db->recw, (chunks << db->c_shift) * 4));
+    HIP_TRY(hipMalloc((void**)&db->sorted_key, chunks * 4));
+    HIP_TRY(hipMalloc((void**)&db->sorted_id, chunks * 4));
+    HIP_TRY(hipMalloc((void**)&db->chunk_iota, chunks * 4));
+    HIP_TRY(hipMalloc((void**)&db->rec, (chunks << CH_SHIFT) * 16));
+    HIP_TRY(hipMalloc((void**)&db->recw, (chunks << CH_SHIFT) * 4));
+    hipLaunchKernelGGL(iota_u32_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, db->stream, db->chunk_iota, (uint32_t)chunks);
+    int key_bits = 1;
+    while ((1ull << key_bits) <= (uint64_t)db->n_states + 1) ++key_bits;          // streams, n_states = never opened, n_states + 1 = mixed
+    db->key_bits = key_bits;
+    size_t tb = 0, tb2 = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id, (int)chunks, 0, key_bits, db->stream));
+    {
+        hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
+        HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, tb2, it, (unsigned long long*)nullptr, (int)chunks, db->stream));
+    }
+    db->sort_tmp_bytes = std::max(tb, tb2);
+    HIP_TRY(hipMalloc(&db->sort_tmp, std::max<size_t>(db->sort_tmp_bytes, 16)));
     db->pool_cap = chunks;
+    if (db->dense_wide || db->dense_narrow) {
+        // dense mode: every record slot carries its stream; the records of the mixed chunks are sorted by it
+        const uint64_t slots = chunks << CH_SHIFT;
+        HIP_TRY(hipMalloc((void**)&db->rkey, slots * 4));
+        HIP_TRY(hipMalloc((void**)&db->wkey, slots * 4));
+        HIP_TRY(hipMalloc((void**)&db->wslot, slots * 4));
+        HIP_TRY(hipMalloc((void**)&db->swkey, slots * 4));
+        HIP_TRY(hipMalloc((void**)&db->swslot, slots * 4));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, db->sort2_tmp_bytes, db->wkey, db->swkey, db->wslot, db->swslot, (int)std::min<uint64_t>(slots, 0x7FFFFFFF),
+                                                   0, key_bits, db->stream));
+        HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
+    }
     return 0;
 }
 int alloc_pair_pool(kmdb_db* db, uint64_t entries) {
@@ -1049,7 +1426,8 @@ int kmdb_ensure_v1_arrays(kmdb_db* db) {
                               (uint32_t)P, db->meta, db->bitpos);
     HIP_TRY(hipGetLastError());
     std::vector<Segment> segs;
-    for (uint64_t f = 0; f < P; f += db->nseg_nodes) segs.push_back(Segment{(uint32_t)f, (uint32_t)std::min<uint64_t>(P, f + db->nseg_nodes)});
+    const uint64_t step = 2048;
+    for (uint64_t f = 0; f < P; f += step) segs.push_back(Segment{(uint32_t)f, (uint32_t)std::min<uint64_t>(P, f + step)});
     while (segs.size() % WAVES_PER_BLOCK) segs.push_back(Segment{(uint32_t)P, (uint32_t)P});
     HIP_TRY(hipMalloc((void**)&db->segs, std::max<size_t>(segs.size(), 1) * sizeof(Segment)));
     if (!segs.empty()) HIP_TRY(hipMemcpy(db->segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
@@ -1077,46 +1455,40 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     uint32_t forced = 0;
     if (const char* e = getenv("KMDB_BLOCK_WIDTH")) forced = (uint32_t)strtoul(e, nullptr, 10);
     const uint32_t stride = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, P / 65536));
+    uint64_t est_n = 0, est_g = 0;
     {
         EstParams q{};
         q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.parent = db->parent; q.nl = db->nl; q.w = db->w;
         q.P = (uint32_t)P; q.stride = stride;
         for (int c = 0; c < EST_NW; ++c) { q.widths[c] = cands[c]; q.magics[c] = (uint32_t)((1ull << 32) / cands[c]) + 1u; }
-        HIP_TRY(hipMalloc((void**)&q.out, (EST_NW + 1) * 8));
-        HIP_TRY(hipMemsetAsync(q.out, 0, (EST_NW + 1) * 8, db->stream));
+        HIP_TRY(hipMalloc((void**)&q.out, (2 * EST_NW + 1) * 8));
+        HIP_TRY(hipMemsetAsync(q.out, 0, (2 * EST_NW + 1) * 8, db->stream));
         const uint64_t nthreads = (P + stride - 1) / stride;
         hipLaunchKernelGGL(width_estimate_kernel, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, db->stream, q);
         HIP_TRY(hipGetLastError());
-        unsigned long long h[EST_NW + 1];
+        unsigned long long h[2 * EST_NW + 1];
         HIP_TRY(hipMemcpyAsync(h, q.out, sizeof h, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
         (void)hipFree(q.out);
         int best = 0;
-        for (int c = 1; c < EST_NW; ++c) if (h[c] < h[best]) best = c;
+        for (int c = 1; c < EST_NW; ++c) if (h[c] + h[EST_NW + c] < h[best] + h[EST_NW + best]) best = c;
         if (forced >= 32 && forced <= 64) {
             db->width = forced;
             best = 0;
             for (int c = 0; c < EST_NW; ++c) if (cands[c] >= forced) best = c;
         } else db->width = cands[best];
-        db->est_records = h[best] * stride;
+        est_n = h[best] * stride; est_g = h[EST_NW + best] * stride;
+        db->est_records = est_n + est_g;
         if (verbose) {
-            fprintf(stderr, "[kmdb] width estimate (1 node in %u, %llu sampled):", stride, h[EST_NW]);
-            for (int c = 0; c < EST_NW; ++c) fprintf(stderr, " %u:%llu", cands[c], h[c] * stride);
+            fprintf(stderr, "[kmdb] width estimate (1 node in %u, %llu sampled):", stride, h[2 * EST_NW]);
+            for (int c = 0; c < EST_NW; ++c) fprintf(stderr, " %u:%llu", cands[c], (h[c] + h[EST_NW + c]) * stride);
             fprintf(stderr, " -> width %u\n", db->width);
         }
     }
     db->NB = (uint32_t)((N + db->width - 1) / db->width);
     const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2 * NCLS;
-    if (n_states >= (1ull << 31)) { db->fallback_reason = "too many block pairs"; return 0; }
+    if (n_states >= (1ull << 30)) { db->fallback_reason = "too many block pairs"; return 0; }
     db->n_states = (uint32_t)n_states;
-    // chunk size: every stream ends in a partly filled chunk, so many streams want small chunks
-    {
-        uint64_t budget = 2ull << 30;                              // bytes of partly filled chunks at most
-        uint32_t sh = 13;
-        while (sh > 6 && (n_states << sh) * 20 > budget) --sh;
-        db->c_shift = sh;
-        if (const char* e = getenv("KMDB_CHUNK_SHIFT")) db->c_shift = std::min(16u, std::max(6u, (uint32_t)strtoul(e, nullptr, 10)));
-    }
     // ---- working set
     HIP_TRY(hipMalloc((void**)&db->p0_mask, P * 8));
     HIP_TRY(hipMalloc((void**)&db->p0_info, P * 4));
@@ -1130,29 +1502,36 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->wide_base, (n_words + 1) * 4));
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1)));
     HIP_TRY(hipMalloc(&db->scan_tmp, std::max<size_t>(db->scan_tmp_bytes, 16)));
-    HIP_TRY(hipMalloc((void**)&db->state, n_states * 8));
     HIP_TRY(hipMalloc((void**)&db->counters, KCTR_COUNT * 4));
     HIP_TRY(hipHostMalloc((void**)&db->h_counters, KCTR_COUNT * 4));
-    if (alloc_pair_pool(db, std::max<uint64_t>(P / 3, 1u << 16))) return 1;
-    const uint64_t C = 1ull << db->c_shift;
-    uint64_t chunks = (db->est_records + db->est_records / 4) / C + std::min<uint64_t>(n_states, db->est_records / 8 + 1024) + 64;
-    if (alloc_record_pool(db, chunks)) return 1;
+    if (alloc_pair_pool(db, std::max<uint64_t>(P + P / 2, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
+    HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
+    // more streams than a wave's open-chunk table holds: the nodes with many blocks scatter their records over all of them,
+    // so the wide kernel writes them in arrival order and a device-wide sort groups them (the narrow kernel keeps its table:
+    // its records follow the clustering of the DFS stream; it switches too if its chunks turn out nearly empty)
+    db->dense_wide = db->n_states > (1u << ST_MAX_BITS);
+    db->dense_narrow = false;
+    if (const char* e = getenv("KMDB_DENSE")) { db->dense_wide = atoi(e) >= 1; db->dense_narrow = atoi(e) >= 2; }
+    // chunks: the estimate at two thirds average fill, plus what the waves hold when they end (an unfinished grab, open chunks)
+    (void)est_n; (void)est_g;
+    if (alloc_record_pool(db, db->est_records * 3 / 2 / CH_REC + (uint64_t)(db->n_nsegs + K1G_MAX_WAVES) * (ARENA_GRAB + 8) + 4096)) return 1;
     return 0;
 }
 
 void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->p0_mask); FREE_NULL(db->p0_info); FREE_NULL(db->pair_ofs); FREE_NULL(db->pair_blk); FREE_NULL(db->pair_mask);
     FREE_NULL(db->pair_cursor); FREE_NULL(db->fn_mask); FREE_NULL(db->fn_blk); FREE_NULL(db->widebits); FREE_NULL(db->wide_cnt);
-    FREE_NULL(db->wide_base); FREE_NULL(db->widx); FREE_NULL(db->state); FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill);
-    FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp);
+    FREE_NULL(db->wide_base); FREE_NULL(db->widx); FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key);
+    FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota); FREE_NULL(db->sort_tmp);
+    FREE_NULL(db->rkey); FREE_NULL(db->wkey); FREE_NULL(db->wslot); FREE_NULL(db->swkey); FREE_NULL(db->swslot); FREE_NULL(db->sort2_tmp);
+    FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
     db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
 }
 
 uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
-    if (!db->state) return 0;
-    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << db->c_shift) * 20) + db->pool_cap * 8 + (uint64_t)db->n_states * 8 +
-           db->wide_cap * 4 + (db->P / 64) * 16;
+    if (!db->counters) return 0;
+    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 20 + db->wide_cap * 4 + (db->P / 64) * 16;
 }
 
 namespace {
@@ -1171,17 +1550,22 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     const uint32_t P = (uint32_t)db->P;
     const BlockMap bm{db->width, (uint32_t)((1ull << 32) / db->width) + 1u};
     const uint32_t n_words = (P + 63) / 64;
+    const uint32_t pool_cap = (uint32_t)db->pool_cap;
     HIP_TRY(hipMemsetAsync(db->counters, 0, KCTR_COUNT * 4, st));
     HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, KMDB_PAIR_REGIONS * 16 * 4, st));
-    HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, db->pool_cap * 4, st));
-    hipLaunchKernelGGL(pool_init_kernel, dim3((db->n_states + 255) / 256), dim3(256), 0, st, db->state, db->n_states, db->c_shift);
+    HIP_TRY(hipMemsetAsync(db->sub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
+    HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, st));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, st, db->chunk_key, pool_cap, db->n_states);
     if (stage("init")) return 1;
     // ---- K0
     {
         K0Params q{};
         q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.perm = nullptr; q.P = P; q.bm = bm;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
-        q.pair_cursor = db->pair_cursor; q.region_cap = (uint32_t)(db->pair_cap / KMDB_PAIR_REGIONS); q.counters = db->counters;
+        // sub-pools of the pair pool: enough of them that their cursors are not hot, few enough that one wave's need fits a share
+        uint32_t nreg = 1;
+        while (nreg < KMDB_PAIR_REGIONS && (uint64_t)nreg * 16384 < P) nreg <<= 1;
+        q.pair_cursor = db->pair_cursor; q.n_regions = nreg; q.region_cap = (uint32_t)(db->pair_cap / nreg); q.counters = db->counters;
         hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
         if (db->n_long) {
             q.perm = db->long_nodes; q.P = db->n_long;
@@ -1198,8 +1582,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.widebits = db->widebits;
         q.P = P; q.nseg_nodes = db->nseg_nodes; q.n_segs = db->n_nsegs; q.chain_cap = db->chain_cap;
-        q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db);
-        const size_t lds = k1n_wave_bytes(q.chain_cap) * K1N_WAVES;
+        q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.tbits = db->dense_narrow ? 0u : arena_table_bits(db->n_states); q.pool = pool_view(db, db->dense_narrow);
+        const size_t lds = k1n_wave_bytes(q.chain_cap, q.tbits) * K1N_WAVES;
         HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + K1N_WAVES - 1) / K1N_WAVES), dim3(WAVE * K1N_WAVES), lds, st, q);
         HIP_TRY(hipGetLastError());
@@ -1228,29 +1612,57 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     if (n_wide) {
         GParams q{};
         q.widx = db->widx; q.n_wide = n_wide; q.nl = db->nl; q.parent = db->parent; q.w = db->w; q.widebits = db->widebits;
+        q.dflag = db->dflag; q.wide_base = db->wide_base;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
-        q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db);
+        q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
         const uint32_t batches = (n_wide + WAVE - 1) / WAVE;
-        hipLaunchKernelGGL(k1g_kernel, dim3((batches + K1G_WAVES - 1) / K1G_WAVES), dim3(WAVE * K1G_WAVES), 0, st, q);
+        q.n_waves = std::min<uint32_t>(K1G_MAX_WAVES, batches);
+        q.tbits = db->dense_wide ? 0u : arena_table_bits(db->n_states);
+        const size_t lds = ((size_t)8 << q.tbits) * K1G_WAVES;
+        HIP_TRY(hipFuncSetAttribute((const void*)k1g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(K1GWave) * K1G_WAVES)));
+        hipLaunchKernelGGL(k1g_kernel, dim3((q.n_waves + K1G_WAVES - 1) / K1G_WAVES), dim3(WAVE * K1G_WAVES), lds, st, q);
     }
     HIP_TRY(hipGetLastError());
     if (stage("wide emit")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[2], st));
-    // ---- K2 over the chunks
-    hipLaunchKernelGGL(pool_finalize_kernel, dim3((db->n_states + 255) / 256), dim3(256), 0, st, db->state, db->n_states, db->c_shift,
-                       (uint32_t)db->pool_cap, db->chunk_fill);
-    uint32_t grid;
-    if (db->have_counts) grid = db->last_n_chunks;
-    else {
-        HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        grid = std::min<uint32_t>(db->h_counters[KCTR_CHUNKS], (uint32_t)db->pool_cap);
+    // ---- chunk table sorted by stream, K2 over windows of it
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort_tmp, db->sort_tmp_bytes, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id,
+                                               (int)pool_cap, 0, db->key_bits, st));
+    hipLaunchKernelGGL(count_chunks_kernel, dim3(1), dim3(1), 0, st, db->sorted_key, pool_cap, db->n_states, db->counters);
+    {
+        hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
+        HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, st));
     }
+    if (stage("chunk sort")) return 1;
+    uint32_t grid = (pool_cap + K2_WIN - 1) / K2_WIN;
+    if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + K2_WIN - 1) / K2_WIN);
     if (grid)
-        hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, st, db->rec, db->recw, db->chunk_key, db->chunk_fill, db->counters, db->c_shift,
-                           M, (uint32_t)db->N, db->width);
+        hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, st, db->rec, db->recw, db->sorted_key, db->sorted_id, db->chunk_fill, db->n_states,
+                           pool_cap, M, (uint32_t)db->N, db->width);
     HIP_TRY(hipGetLastError());
     if (stage("apply")) return 1;
+    if (db->dense_wide || db->dense_narrow) {
+        // the mixed chunks: (stream, slot) of their records, sorted by stream, one tile per run
+        uint32_t n_raw;
+        if (db->have_counts) n_raw = db->last_n_raw;
+        else {
+            HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            n_raw = db->h_counters[KCTR_RAW];
+        }
+        if (n_raw) {
+            hipLaunchKernelGGL(raw_expand_kernel, dim3(n_raw), dim3(64), 0, st, db->sorted_id, db->chunk_fill, db->rkey, db->counters, pool_cap, db->n_states,
+                               db->wkey, db->wslot);
+            size_t tb = db->sort2_tmp_bytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, db->wslot, db->swslot, (int)((uint64_t)n_raw << CH_SHIFT), 0,
+                                                       db->key_bits, st));
+            const uint32_t g2 = (uint32_t)((((uint64_t)n_raw << CH_SHIFT) + K2S_WIN - 1) / K2S_WIN);
+            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->rec, db->recw, db->swkey, db->swslot, db->counters, db->n_states, M,
+                               (uint32_t)db->N, db->width);
+            HIP_TRY(hipGetLastError());
+        }
+        if (stage("sorted apply")) return 1;
+    }
     HIP_TRY(hipEventRecord(db->ev_k[3], st));
     // ---- what the call found
     HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
@@ -1260,22 +1672,36 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         db->fallback_reason = "a chain of more-than-two-block nodes does not fit the entry pool of the wide-node kernel";
         return 0;
     }
-    if (c[KCTR_PAIR_OVERFLOW]) {
-        if (alloc_pair_pool(db, db->pair_cap * 2)) return 1;
+    if (c[KCTR_PAIR_OVERFLOW] || c[KCTR_POOL_OVERFLOW]) {
+        const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
+        if (c[KCTR_PAIR_OVERFLOW]) {
+            if (verbose) fprintf(stderr, "[kmdb] pair pool too small (%llu entries): doubling\n", (unsigned long long)db->pair_cap);
+            if (alloc_pair_pool(db, db->pair_cap * 2)) return 1;
+        }
+        if (c[KCTR_POOL_OVERFLOW]) {
+            uint64_t want = db->pool_cap * 2;
+            if (!db->dense_narrow && db->n_states > (1u << ST_MAX_BITS) && db->pool_cap > 2 * (db->est_records / CH_REC + 65536)) {
+                // the estimate is long covered: the narrow kernel's chunks are being evicted nearly empty.  Dense mode for it as well.
+                db->dense_narrow = true;
+                want = db->est_records * 3 / 2 / CH_REC + (uint64_t)(db->n_nsegs + K1G_MAX_WAVES) * (ARENA_GRAB + 8) + 4096;
+                if (verbose) fprintf(stderr, "[kmdb] record chunks of the narrow kernel are evicted nearly empty: dense mode for it too\n");
+            } else if (want >= ((1ull << 31) >> CH_SHIFT) || (want << CH_SHIFT) * 48 > (160ull << 30)) {
+                db->fallback_reason = "the record pool does not converge (" + std::to_string(db->n_states) + " streams, " +
+                                      std::to_string(db->pool_cap) + " chunks were not enough)";
+                return 0;
+            }
+            if (verbose) fprintf(stderr, "[kmdb] record pool too small (%llu chunks): %llu\n", (unsigned long long)db->pool_cap, (unsigned long long)want);
+            if (alloc_record_pool(db, want)) return 1;
+        }
         db->have_counts = false; *retry = true;
         return 0;
     }
-    if (c[KCTR_POOL_OVERFLOW]) {
-        if (alloc_record_pool(db, std::max<uint64_t>(db->pool_cap * 2, (uint64_t)c[KCTR_CHUNKS] + 64))) return 1;
-        db->have_counts = false; *retry = true;
-        return 0;
-    }
-    if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks)) {
+    if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks || c[KCTR_RAW] != db->last_n_raw)) {
         // cannot happen for an unchanged database and emit range; redo the call with measured sizes
         db->have_counts = false; *retry = true;
         return 0;
     }
-    db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS];
+    db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW];
     db->last_records = (uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32);
     return 0;
 }
@@ -1286,14 +1712,12 @@ int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi
     if (db->last_emit_lo != emit_lo || db->last_emit_hi != emit_hi) db->have_counts = false;   // grid sizes belong to one emit range
     db->last_emit_lo = emit_lo; db->last_emit_hi = emit_hi;
     const uint64_t cells = db->N * (db->N - 1) / 2;
-    for (int attempt = 0; attempt < 8; ++attempt) {
+    for (int attempt = 0; attempt < 24; ++attempt) {
         bool retry = false;
         if (attempt) HIP_TRY(hipMemsetAsync(M, 0, cells * 4, st));
         if (blocks_attempt(db, M, emit_lo, emit_hi, st, &retry)) return 1;
         if (!db->fallback_reason.empty()) return 0;
         if (!retry) { db->have_counts = true; return 0; }
-        if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] pools enlarged (pairs %llu, chunks %llu), repeating the call\n",
-                                            (unsigned long long)db->pair_cap, (unsigned long long)db->pool_cap);
     }
     return kmdb_set_error("kmdb_blocks_run: the record pools did not converge");
 }

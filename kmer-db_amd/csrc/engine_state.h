@@ -21,16 +21,18 @@ struct Segment { uint32_t first, end; };
 
 // counters of the block-record pipeline, zeroed at the start of every call and read back at its end
 enum : uint32_t {
-    KCTR_CHUNKS = 0,        // record chunks handed out
+    KCTR_CHUNKS = 0,        // record chunks opened
     KCTR_POOL_OVERFLOW,     // != 0: the chunk pool was too small (results invalid; the call is repeated with a larger pool)
     KCTR_PAIR_OVERFLOW,     // != 0: the pool of extra (block, mask) pairs was too small
     KCTR_NWIDE,             // nodes whose full list touches more than two blocks
     KCTR_LIST_OVERFLOW,     // != 0: a wide node's path did not fit the per-wave entry pool
+    KCTR_RAW = 5,           // dense mode: chunks with records of mixed streams
     KCTR_RECORDS = 6,       // low word of the number of block records written (64-bit atomic: even index)
     KCTR_RECORDS_HI = 7,
     KCTR_COUNT = 16
 };
-constexpr uint32_t KMDB_PAIR_REGIONS = 256;   // sub-pools of the extra-pair pool (one allocation cursor each)
+constexpr uint32_t KMDB_PAIR_REGIONS = 4096;
+constexpr uint32_t KMDB_SUBPOOLS = 256;      // sub-pools of the record chunk pool (one allocation cursor each)   // sub-pools of the extra-pair pool (one allocation cursor each)
 
 struct kmdb_db {
     int device = 0;
@@ -60,7 +62,6 @@ struct kmdb_db {
     // ---- per-call working set of the block-record pipeline (contents rebuilt by every call)
     uint32_t width = 64;            // sample ids per block, picked at upload from a sampled estimate
     uint32_t NB = 0, n_states = 0;  // blocks, (bucket, weight class) streams
-    uint32_t c_shift = 13;          // records per chunk = 1 << c_shift
     unsigned long long* p0_mask = nullptr;   // [P] first (block, mask) pair of every node's local list
     uint32_t* p0_info = nullptr;    // [P] block | npairs << 16
     uint32_t* pair_ofs = nullptr;   // [P] first extra pair (valid when npairs > 1)
@@ -75,18 +76,30 @@ struct kmdb_db {
     uint32_t* wide_base = nullptr;
     uint32_t* widx = nullptr;       // [wide_cap] the wide nodes, DFS order
     uint64_t wide_cap = 0;
-    unsigned long long* state = nullptr;     // [n_states] current chunk << 32 | records used
-    uint32_t* chunk_key = nullptr;  // [pool_cap] stream (state index) of every chunk
-    uint32_t* chunk_fill = nullptr; // [pool_cap] records in the chunk, 0 = full
-    unsigned char* rec = nullptr;   // [pool_cap << c_shift] 16-byte record slots ({rows, cols}; diagonal streams pack 8-byte rows)
-    uint32_t* recw = nullptr;       // [pool_cap << c_shift] weights of the classes with w > 1
-    uint64_t pool_cap = 0;          // chunks
+    uint32_t* chunk_key = nullptr;  // [pool_cap] stream of every chunk (n_states: never opened)
+    uint32_t* chunk_fill = nullptr; // [pool_cap] records in the chunk
+    uint32_t* sorted_key = nullptr; // the chunk table sorted by stream
+    uint32_t* sorted_id = nullptr;
+    uint32_t* chunk_iota = nullptr; // 0, 1, 2, ...
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int key_bits = 1;
+    unsigned char* rec = nullptr;   // [pool_cap * 64] 16-byte record slots ({rows, cols}; diagonal streams pack 8-byte rows)
+    uint32_t* recw = nullptr;       // [pool_cap * 64] weights of the classes with w > 1
+    uint64_t pool_cap = 0;          // chunks of 64 records, KMDB_SUBPOOLS interleaved sub-pools
+    uint32_t* sub_cursor = nullptr; // [KMDB_SUBPOOLS * 16]
+    // dense mode (more streams than a wave's open-chunk table): records in arrival order + a device-wide sort by stream
+    bool dense_wide = false, dense_narrow = false;
+    uint32_t* rkey = nullptr;       // [slots] stream of every record
+    uint32_t *wkey = nullptr, *wslot = nullptr, *swkey = nullptr, *swslot = nullptr;   // (stream, slot) of the mixed chunks' records, unsorted / sorted
+    void* sort2_tmp = nullptr;
+    size_t sort2_tmp_bytes = 0;
     uint32_t* counters = nullptr;   // [KCTR_COUNT]
     uint32_t* h_counters = nullptr; // pinned host copy
     uint64_t est_records = 0;       // sampled estimate for the chosen width
     // what the previous call found (the pipeline is deterministic per database: grid sizes of the next call)
     bool have_counts = false;
-    uint32_t last_n_wide = 0, last_n_chunks = 0;
+    uint32_t last_n_wide = 0, last_n_chunks = 0, last_n_raw = 0;
     uint64_t last_records = 0;
     uint32_t last_emit_lo = 0, last_emit_hi = 0;
     void* scan_tmp = nullptr;

@@ -25,27 +25,28 @@ namespace {
 
 struct U32toU64 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
 
-__global__ void lay_child_count_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* __restrict__ cnt /*[P+1], index = parent + 1*/) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) atomicAdd(&cnt[parent[i] + 1], 1u);
+// children of every node = one run of the parent-sorted child list: first position and length per parent key
+// (key = parent + 1, key 0 = the roots); no atomics (a hot parent has 10^5 children, and same-address atomics crawl)
+__global__ void lay_child_runs_kernel(const uint32_t* __restrict__ skeys, uint32_t P, uint32_t* __restrict__ start, uint32_t* __restrict__ cnt) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const uint32_t k = skeys[j];
+    if (j == 0 || skeys[j - 1] != k) start[k] = j;
+    if (j + 1 == P || skeys[j + 1] != k) cnt[k] = j + 1;          // run end for now; turned into a length below
 }
-
-// subtree sizes: every leaf climbs; a node continues upwards only as the LAST of its siblings to arrive
-__global__ void lay_sizes_kernel(const int32_t* __restrict__ parent, const uint32_t* __restrict__ cnt, uint32_t P, uint32_t* __restrict__ size,
-                                 uint32_t* __restrict__ pending) {
+__global__ void lay_child_len_kernel(const uint32_t* __restrict__ start, uint32_t n_keys, uint32_t* __restrict__ cnt) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_keys && cnt[k]) cnt[k] -= start[k];
+}
+// subtree sizes, one tree level per launch, deepest first: size = 1 + sizes of the children (already final)
+__global__ void lay_sizes_level_kernel(const uint32_t* __restrict__ dep, uint32_t level, const uint32_t* __restrict__ start, const uint32_t* __restrict__ cnt,
+                                       const uint32_t* __restrict__ schild, uint32_t P, uint32_t* __restrict__ size) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P || cnt[i + 1] != 0) return;
-    uint32_t v = i, sz = 1;
-    for (;;) {
-        const int32_t p = parent[v];
-        if (p < 0) break;
-        atomicAdd(&size[p], sz);
-        __threadfence();
-        if (atomicSub(&pending[p], 1u) != 1u) break;
-        __threadfence();
-        sz = atomicAdd(&size[p], 0u);
-        v = (uint32_t)p;
-    }
+    if (i >= P || dep[i] != level) return;
+    const uint32_t c = cnt[i + 1], s0 = start[i + 1];
+    uint32_t sz = 1;
+    for (uint32_t j = 0; j < c; ++j) sz += size[schild[s0 + j]];
+    size[i] = sz;
 }
 
 __global__ void lay_keys_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -66,28 +67,24 @@ __global__ void lay_gather_u32_kernel(const uint32_t* __restrict__ src, const ui
 }
 // offset of a child inside its parent's subtree: 1 + sizes of the earlier siblings
 __global__ void lay_rel_kernel(const uint32_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_child, const uint32_t* __restrict__ S,
-                               const uint32_t* __restrict__ child_begin, uint32_t P, uint32_t* __restrict__ acc, uint32_t* __restrict__ dep,
-                               int32_t* __restrict__ anc, const int32_t* __restrict__ parent) {
+                               const uint32_t* __restrict__ child_begin, uint32_t P, uint32_t* __restrict__ acc) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P) return;
-    const uint32_t c = sorted_child[j];
-    acc[c] = 1u + S[j] - S[child_begin[sorted_keys[j]]];
-    dep[c] = 1u;
-    anc[c] = parent[c];
+    acc[sorted_child[j]] = 1u + S[j] - S[child_begin[sorted_keys[j]]];
 }
-// one round of pointer doubling: (sum of offsets, number of nodes) along the path to the current ancestor pointer
-__global__ void lay_jump_kernel(const uint32_t* __restrict__ acc_in, const uint32_t* __restrict__ dep_in, const int32_t* __restrict__ anc_in, uint32_t P,
-                                uint32_t* __restrict__ acc_out, uint32_t* __restrict__ dep_out, int32_t* __restrict__ anc_out, uint32_t* __restrict__ active) {
+// one round of pointer doubling: the sum of `val` along the path to the current ancestor pointer
+__global__ void lay_jump_kernel(const uint32_t* __restrict__ val_in, const int32_t* __restrict__ anc_in, uint32_t P,
+                                uint32_t* __restrict__ val_out, int32_t* __restrict__ anc_out, uint32_t* __restrict__ active) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const int32_t a = anc_in[i];
-    uint32_t ac = acc_in[i], dp = dep_in[i];
+    uint32_t v = val_in[i];
     int32_t na = -1;
     if (a >= 0) {
-        ac += acc_in[a]; dp += dep_in[a]; na = anc_in[a];
+        v += val_in[a]; na = anc_in[a];
         if (na >= 0) *active = 1u;
     }
-    acc_out[i] = ac; dep_out[i] = dp; anc_out[i] = na;
+    val_out[i] = v; anc_out[i] = na;
 }
 __global__ void lay_order_kernel(const uint32_t* __restrict__ acc, uint32_t P, uint32_t* __restrict__ order, uint32_t* __restrict__ bad) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,10 +100,11 @@ __global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint
                                   const uint32_t* __restrict__ h_w, const unsigned long long* __restrict__ h_wfull, uint32_t P,
                                   uint2* __restrict__ k0in, uint32_t* __restrict__ nl, int32_t* __restrict__ dparent, uint32_t* __restrict__ w,
                                   uint16_t* __restrict__ dflag, uint32_t* __restrict__ sub_end, LayStats* __restrict__ st) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long alg = 0, upd = 0, pairs = 0;
     uint32_t mn = 0, md = 0, nlong = 0;
-    if (i < P) {
+    // grid-stride: the statistics end in one atomic per block and counter, so the grid stays small
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= P; i += gridDim.x * blockDim.x) {
+        if (i == P) { w[P] = 0; break; }
         const uint32_t pid = order[i];
         const uint32_t ll = h_ll[pid], n = h_n[pid], nb = h_nbits[pid], l = ll & 0xFFFFu;
         k0in[i] = make_uint2(ll, nb);
@@ -117,11 +115,11 @@ __global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint
         const uint32_t d = dep[pid];
         dflag[i] = (uint16_t)((d > 0x7FFFu ? 0x7FFFu : d) | (cnt[pid + 1] ? 0x8000u : 0u));
         sub_end[i] = i + size[pid];
-        alg = 40ull + (unsigned long long)((nb + 127u) / 128u) * 16ull;
-        upd = (unsigned long long)(n - l) * l + (unsigned long long)l * (l ? l - 1 : 0) / 2;
-        pairs = (h_wfull ? h_wfull[pid] : (unsigned long long)h_w[pid]) * ((unsigned long long)n * (n ? n - 1 : 0) / 2);
-        mn = n; md = d; nlong = kmdb_long_node(l, nb) ? 1u : 0u;
-    } else if (i == P) w[P] = 0;
+        alg += 40ull + (unsigned long long)((nb + 127u) / 128u) * 16ull;
+        upd += (unsigned long long)(n - l) * l + (unsigned long long)l * (l ? l - 1 : 0) / 2;
+        pairs += (h_wfull ? h_wfull[pid] : (unsigned long long)h_w[pid]) * ((unsigned long long)n * (n ? n - 1 : 0) / 2);
+        mn = max(mn, n); md = max(md, d); nlong += kmdb_long_node(l, nb) ? 1u : 0u;
+    }
     // block reduction of the statistics
     __shared__ unsigned long long s_alg[256], s_upd[256], s_pairs[256];
     __shared__ uint32_t s_mn[256], s_md[256], s_nl[256];
@@ -172,27 +170,17 @@ __global__ void lay_copy_bits_kernel(const uint32_t* __restrict__ order, const u
         sp += take; dp += take;
     }
 }
-// long nodes: (work key, DFS index), compacted with a block-aggregated cursor
-__global__ void lay_long_kernel(const uint2* __restrict__ k0in, uint32_t P, uint32_t* __restrict__ cursor, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool is = false;
-    uint32_t work = 0;
-    if (i < P) {
-        const uint2 km = k0in[i];
-        const uint32_t l = km.x & 0xFFFFu;
-        is = kmdb_long_node(l, km.y);
-        work = km.y - (l ? l - 1u : 0u);
-    }
-    const unsigned long long bal = __ballot(is);
-    if (!bal) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(cursor, (uint32_t)__popcll(bal));
-    base = (uint32_t)__shfl((int)base, 0, WAVE);
-    if (is) {
-        const uint32_t o = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        keys[o] = work; vals[o] = i;
-    }
+// long nodes: selected in DFS order (stable partition), then ordered by work
+struct LongNodePred {
+    const uint2* k0in;
+    __host__ __device__ bool operator()(uint32_t i) const { const uint2 km = k0in[i]; return kmdb_long_node(km.x & 0xFFFFu, km.y); }
+};
+__global__ void lay_long_keys_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ keys) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint2 km = k0in[idx[t]];
+    const uint32_t l = km.x & 0xFFFFu;
+    keys[t] = km.y - (l ? l - 1u : 0u);                     // work of a node ~ stream bits beyond one per delta
 }
 // root path of the first node of every slice, root first
 __global__ void lay_seg_anc_kernel(const int32_t* __restrict__ parent, const uint16_t* __restrict__ dflag, uint32_t P, uint32_t nseg_nodes, uint32_t n_segs,
@@ -355,18 +343,12 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     h_parent.reset(); h_ll.reset(); h_n.reset(); h_nbits.reset(); h_w.reset(); h_bits.reset();
 
     // ---- device: DFS pre-order
-    DevTmp<uint32_t> cnt, size, pending, keys, vals, skeys, schild, ssz, S, child_begin, acc[2], dep[2], order, flags;
+    DevTmp<uint32_t> cnt, cstart, size, keys, vals, skeys, schild, ssz, S, acc[2], dep[2], order, flags;
     DevTmp<int32_t> anc[2];
-    if (cnt.alloc(P + 2) || size.alloc(P) || pending.alloc(P) || flags.alloc(4)) return 1;
+    if (cnt.alloc(P + 2) || cstart.alloc(P + 2) || size.alloc(P) || flags.alloc(4)) return 1;
     HIP_TRY(hipMemsetAsync(cnt.p, 0, (P + 2) * 4, st));
+    HIP_TRY(hipMemsetAsync(cstart.p, 0, (P + 2) * 4, st));
     HIP_TRY(hipMemsetAsync(flags.p, 0, 16, st));
-    hipLaunchKernelGGL(lay_child_count_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, cnt.p);
-    // size = 1, pending = children
-    HIP_TRY(hipMemcpyAsync(pending.p, cnt.p + 1, P * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(lay_fill_kernel, dim3(G), dim3(B), 0, st, size.p, (uint32_t)P, 1u);
-    hipLaunchKernelGGL(lay_sizes_kernel, dim3(G), dim3(B), 0, st, d_parent.p, cnt.p, (uint32_t)P, size.p, pending.p);
-    HIP_TRY(hipGetLastError());
-    pending.reset();
     // children grouped by parent, pid order inside a family
     if (keys.alloc(P) || vals.alloc(P) || skeys.alloc(P) || schild.alloc(P)) return 1;
     hipLaunchKernelGGL(lay_keys_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, keys.p, vals.p);
@@ -381,35 +363,65 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         HIP_TRY(hipStreamSynchronize(st));
     }
     keys.reset(); vals.reset();
-    if (ssz.alloc(P) || S.alloc(P + 1) || child_begin.alloc(P + 2)) return 1;
+    hipLaunchKernelGGL(lay_child_runs_kernel, dim3(G), dim3(B), 0, st, skeys.p, (uint32_t)P, cstart.p, cnt.p);
+    hipLaunchKernelGGL(lay_child_len_kernel, dim3(G1), dim3(B), 0, st, cstart.p, (uint32_t)(P + 1), cnt.p);
+    phase("  sort by parent");
+    // depth of every node: pointer doubling along the parent links (ping-pong buffers)
+    for (int k = 0; k < 2; ++k) if (acc[k].alloc(P) || dep[k].alloc(P) || anc[k].alloc(P)) return 1;
+    auto jump_all = [&](DevTmp<uint32_t>* val, int* cur_out) -> int {
+        int cur = 0;
+        HIP_TRY(hipMemcpyAsync(anc[0].p, d_parent.p, P * 4, hipMemcpyDeviceToDevice, st));
+        for (int round = 0; round < 40; ++round) {
+            HIP_TRY(hipMemsetAsync(flags.p, 0, 4, st));
+            hipLaunchKernelGGL(lay_jump_kernel, dim3(G), dim3(B), 0, st, val[cur].p, anc[cur].p, (uint32_t)P, val[cur ^ 1].p, anc[cur ^ 1].p, flags.p);
+            uint32_t active = 0;
+            HIP_TRY(hipMemcpyAsync(&active, flags.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            cur ^= 1;
+            if (!active) break;
+        }
+        *cur_out = cur;
+        return 0;
+    };
+    int dcur = 0;
+    hipLaunchKernelGGL(lay_fill_kernel, dim3(G), dim3(B), 0, st, dep[0].p, (uint32_t)P, 1u);
+    if (jump_all(dep, &dcur)) return 1;
+    dep[dcur ^ 1].reset();
+    uint32_t max_depth = 0;
+    {
+        DevTmp<uint32_t> dmax;
+        if (dmax.alloc(1)) return 1;
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, dep[dcur].p, dmax.p, (int)P, st));
+        DevTmp<unsigned char> tmp;
+        if (tmp.alloc(tb)) return 1;
+        HIP_TRY(hipcub::DeviceReduce::Max(tmp.p, tb, dep[dcur].p, dmax.p, (int)P, st));
+        HIP_TRY(hipMemcpyAsync(&max_depth, dmax.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    phase("  depth");
+    for (uint32_t level = max_depth; level >= 1; --level)
+        hipLaunchKernelGGL(lay_sizes_level_kernel, dim3(G), dim3(B), 0, st, dep[dcur].p, level, cstart.p, cnt.p, schild.p, (uint32_t)P, size.p);
+    HIP_TRY(hipGetLastError());
+    phase("  subtree sizes");
+    // pre-order offsets among siblings, then their sums along the root paths
+    if (ssz.alloc(P) || S.alloc(P + 1)) return 1;
     hipLaunchKernelGGL(lay_gather_u32_kernel, dim3(G), dim3(B), 0, st, size.p, schild.p, (uint32_t)P, ssz.p);
     {
-        size_t tb1 = 0, tb2 = 0;
+        size_t tb1 = 0;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, ssz.p, S.p, (int)P, st));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, cnt.p, child_begin.p, (int)(P + 1), st));
         DevTmp<unsigned char> tmp;
-        if (tmp.alloc(std::max(tb1, tb2))) return 1;
+        if (tmp.alloc(tb1)) return 1;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb1, ssz.p, S.p, (int)P, st));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, cnt.p, child_begin.p, (int)(P + 1), st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     ssz.reset();
-    for (int k = 0; k < 2; ++k) if (acc[k].alloc(P) || dep[k].alloc(P) || anc[k].alloc(P)) return 1;
-    hipLaunchKernelGGL(lay_rel_kernel, dim3(G), dim3(B), 0, st, skeys.p, schild.p, S.p, child_begin.p, (uint32_t)P, acc[0].p, dep[0].p, anc[0].p, d_parent.p);
+    hipLaunchKernelGGL(lay_rel_kernel, dim3(G), dim3(B), 0, st, skeys.p, schild.p, S.p, cstart.p, (uint32_t)P, acc[0].p);
     HIP_TRY(hipGetLastError());
-    skeys.reset(); schild.reset(); S.reset(); child_begin.reset();
     int cur = 0;
-    for (int round = 0; round < 40; ++round) {
-        HIP_TRY(hipMemsetAsync(flags.p, 0, 4, st));
-        hipLaunchKernelGGL(lay_jump_kernel, dim3(G), dim3(B), 0, st, acc[cur].p, dep[cur].p, anc[cur].p, (uint32_t)P, acc[cur ^ 1].p, dep[cur ^ 1].p,
-                           anc[cur ^ 1].p, flags.p);
-        uint32_t active = 0;
-        HIP_TRY(hipMemcpyAsync(&active, flags.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        cur ^= 1;
-        if (!active) break;
-    }
-    anc[0].reset(); anc[1].reset(); acc[cur ^ 1].reset(); dep[cur ^ 1].reset();
+    if (jump_all(acc, &cur)) return 1;
+    skeys.reset(); schild.reset(); S.reset(); cstart.reset();
+    anc[0].reset(); anc[1].reset(); acc[cur ^ 1].reset();
     if (order.alloc(P)) return 1;
     HIP_TRY(hipMemsetAsync(order.p, 0xFF, P * 4, st));
     hipLaunchKernelGGL(lay_order_kernel, dim3(G), dim3(B), 0, st, acc[cur].p, (uint32_t)P, order.p, flags.p + 1);
@@ -430,7 +442,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         if (d_wfull.alloc(P)) return 1;
         HIP_TRY(hipMemcpyAsync(d_wfull.p, v->num_kmers, P * 8, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(lay_gather_kernel, dim3(G1), dim3(B), 0, st, order.p, acc[cur].p, dep[cur].p, cnt.p, size.p, d_parent.p, d_ll.p, d_n.p, d_nbits.p, d_w.p,
+    hipLaunchKernelGGL(lay_gather_kernel, dim3(std::min<unsigned>(G1, 2048u)), dim3(B), 0, st, order.p, acc[cur].p, dep[dcur].p, cnt.p, size.p, d_parent.p, d_ll.p, d_n.p, d_nbits.p, d_w.p,
                        d_wfull.p, (uint32_t)P, db->k0in, db->nl, db->parent, db->w, db->dflag, db->sub_end, d_stats.p);
     HIP_TRY(hipGetLastError());
     LayStats hs{};
@@ -445,7 +457,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         hipLaunchKernelGGL(lay_pid2dfs_kernel, dim3(G), dim3(B), 0, st, acc[cur].p, (uint32_t)P, db->pid2dfs);
         HIP_TRY(hipStreamSynchronize(st));
     }
-    d_wfull.reset(); d_ll.reset(); d_n.reset(); d_w.reset(); size.reset(); cnt.reset(); dep[cur].reset(); d_parent.reset();
+    d_wfull.reset(); d_ll.reset(); d_n.reset(); d_w.reset(); size.reset(); cnt.reset(); dep[dcur].reset(); d_parent.reset();
     phase("device: node arrays");
 
     // ---- streams re-packed in DFS order
@@ -479,6 +491,9 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     db->max_n = hs.max_n; db->max_depth = hs.max_depth;
     db->chain_ok = hs.max_depth <= (uint32_t)KMDB_CHAIN_MAX;
     db->chain_cap = std::min<uint32_t>(KMDB_CHAIN_MAX, std::max<uint32_t>(8, (hs.max_depth + 7) / 8 * 8));
+    // one wave per slice, and every wave keeps its own open record chunks: about 8192 slices (two waves per SIMD
+    // on the whole chip), never shorter than 2048 nodes
+    db->nseg_nodes = (uint32_t)std::max<uint64_t>(2048, ((P + 8191) / 8192 + 63) / 64 * 64);
     if (const char* e = getenv("KMDB_NSEG")) db->nseg_nodes = (uint32_t)std::max<uint64_t>(64, strtoull(e, nullptr, 10) / 64 * 64);
     db->n_nsegs = (uint32_t)((P + db->nseg_nodes - 1) / db->nseg_nodes);
     HIP_TRY(hipMalloc((void**)&db->nseg_anc, std::max<size_t>((size_t)db->n_nsegs * db->chain_cap, 1) * 4));
@@ -488,24 +503,22 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
                            db->chain_cap, db->nseg_anc, db->nseg_anc_n);
     db->n_long = hs.n_long;
     if (hs.n_long) {
-        DevTmp<uint32_t> lk, lv, lk2, cursor;
-        if (lk.alloc(hs.n_long) || lv.alloc(hs.n_long) || lk2.alloc(hs.n_long) || cursor.alloc(1)) return 1;
+        DevTmp<uint32_t> sel, lk, lk2, nsel;
+        if (sel.alloc(hs.n_long + 1) || lk.alloc(hs.n_long) || lk2.alloc(hs.n_long) || nsel.alloc(1)) return 1;
         HIP_TRY(hipMalloc((void**)&db->long_nodes, (size_t)hs.n_long * 4));
-        HIP_TRY(hipMemsetAsync(cursor.p, 0, 4, st));
-        hipLaunchKernelGGL(lay_long_kernel, dim3(G), dim3(B), 0, st, db->k0in, (uint32_t)P, cursor.p, lk.p, lv.p);
-        // most work first; equal work in ascending DFS order needs a stable sort on (work desc) of DFS-ordered input:
-        // the compaction above is not ordered across waves, so sort by DFS index first
+        hipcub::CountingInputIterator<uint32_t> first(0u);
         size_t tb = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lv.p, db->long_nodes, lk.p, lk2.p, (int)hs.n_long, 0, 32, st));
+        HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, lv.p, db->long_nodes, lk.p, lk2.p, (int)hs.n_long, 0, 32, st));
+        HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
+        hipLaunchKernelGGL(lay_long_keys_kernel, dim3((hs.n_long + 255) / 256), dim3(256), 0, st, db->k0in, sel.p, hs.n_long, lk.p);
+        // most work first; the sort is stable, so equal work keeps ascending DFS order
         size_t tb2 = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb2, lk2.p, lk.p, db->long_nodes, lv.p, (int)hs.n_long, 0, 32, st));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb2, lk.p, lk2.p, sel.p, db->long_nodes, (int)hs.n_long, 0, 32, st));
         DevTmp<unsigned char> tmp2;
         if (tmp2.alloc(tb2)) return 1;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2.p, tb2, lk2.p, lk.p, db->long_nodes, lv.p, (int)hs.n_long, 0, 32, st));
-        HIP_TRY(hipMemcpyAsync(db->long_nodes, lv.p, (size_t)hs.n_long * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2.p, tb2, lk.p, lk2.p, sel.p, db->long_nodes, (int)hs.n_long, 0, 32, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     HIP_TRY(hipStreamSynchronize(st));

@@ -310,6 +310,73 @@ def test_many_samples_on_the_block_record_pipeline(K, O, dev, tmp_path, N, cs, L
         assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
 
 
+@pytest.mark.parametrize("stem,shards", [("virus_k18", 2), ("virus_k18", 8), ("clade64", 3), ("virus_k24", 5)])
+def test_upload_shards_of_a_real_db_sum_to_full_matrix(K, golden_dir, dev, stem, shards):
+    """kmdb_db_upload_shard on a .db built by the real reference: shard s keeps the k-mers of the prefix buckets b with
+    b % shards == s (w_s[p] from the hashtable items, reference src/hashmap_lp.h:71-78, bucket = kmer >> 32 types.h:25-27);
+    every shard runs the block-record pipeline and the partial matrices sum to the reference's matrix."""
+    h = K.HostDB(os.path.join(golden_dir, stem + ".db"))
+    ref = np.fromfile(os.path.join(golden_dir, stem + ".a2a.ref.u32"), dtype=np.uint32) if stem != "virus_k24" else \
+        K.DeviceDB(h, device=dev).all2all_dense()
+    acc = np.zeros_like(ref)
+    total_pairs = 0
+    for s in range(shards):
+        d = K.DeviceDB(h, device=dev, prefix_shard=(s, shards))
+        part = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+        st = d.stats()
+        assert st["path"] == K.capi.PATH_RECORDS and (st["n_records"] > 0 or st["sum_pairs"] == 0)
+        assert st["sum_pairs"] == int(part.astype(np.uint64).sum())          # the shard's own checksum identity
+        total_pairs += st["sum_pairs"]
+        acc += part
+        d.close()
+    assert np.array_equal(acc, ref) and total_pairs == int(ref.astype(np.uint64).sum())
+    with pytest.raises(K.KmdbError, match="no hashtables"):
+        K.DeviceDB(K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True), device=dev, prefix_shard=(0, 2))
+
+
+@pytest.mark.parametrize("N,cs,L,k,f,check", [(10000, 50, 400, 18, 1.0, "oracle"), (20000, 50, 1500, 25, 0.1, "oracle"),
+                                               (50000, 50, 2000, 25, 0.1, "checksum")])
+def test_baseline_sample_counts_on_the_block_record_pipeline(K, O, dev, tmp_path, N, cs, L, k, f, check):
+    """BASELINE.json configs [2]-[4] have 10 000 and 50 000 samples (k=18 f=1 / k=25 f=0.1): the same sample counts at
+    genome lengths the oracle can afford, bit-exact; at 50 000 samples (5 GB matrix) through the checksum identity and
+    the sparse entry point's structure."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    device = torch.device("cuda", dev)
+    g, pat = S.synth_database(N, cs, L, k=k, fraction=f, seed=11, device=device)
+    arr = S.to_view_arrays(pat)
+    view = K.make_view(k, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    if check == "oracle":
+        path = str(tmp_path / "s.db")
+        S.write_db_fast(path, k, f, [g.name(i) for i in range(N)], pat["sample_counts"], arr, device=device)
+        exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+        got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+        assert np.array_equal(got, exp)
+        st = d.stats()
+        assert st["path"] == K.capi.PATH_RECORDS and st["n_records"] > 0 and st["sum_pairs"] == int(exp.astype(np.uint64).sum())
+        # and the same file read back by the front-end's reader
+        assert np.array_equal(K.DeviceDB(K.HostDB(path, skip_hashtables=True), device=dev).all2all_dense(), exp)
+    else:
+        M = torch.zeros(d.tri_size(), dtype=torch.int32, device=device)
+        d.all2all_dense_device(M.data_ptr(), flags=K.capi.FLAG_NO_FALLBACK)
+        st = d.stats()
+        assert st["path"] == K.capi.PATH_RECORDS and st["n_records"] > 0
+        assert int(M.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == st["sum_pairs"]
+        # row sums against an independent torch computation on the incidence structure is too large here; spot rows of the
+        # sparse entry point must agree with the dense cells
+        sp = d.all2all_sparse()
+        assert sp.n_rows == N and int(sp.val.astype(np.uint64).sum()) == st["sum_pairs"]
+        Mh = M.cpu().numpy().view(np.uint32)
+        for i in (1, 49, 50, N // 2, N - 1):
+            c, v = sp.row(i)
+            row = O.tri_row(Mh, i)
+            nz = np.nonzero(row)[0]
+            assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
+
+
 def test_prefix_sharded_ranks_on_one_gpu(K, O, dev, tmp_path):
     """bench.py's multi-GPU scheme with the ranks run one after another on a single GPU:
     the partial matrices of the prefix-bucket shards add up to the unsharded matrix."""
@@ -456,16 +523,24 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "u32" and "workload" in d["config"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                         "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-                         "--length", "30000", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
-    assert r2.returncode == 0, r2.stderr[-3000:]
-    lines = [ln for ln in r2.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1
-    d2 = json.loads(lines[0])
-    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["config"]["genome_length_bp"] == 60000
-    # both runs cover a 60 kbp genome set of the same model: two prefix shards do the same total work
-    assert abs(d2["value"] * d2["ms_per_step"] - d["value"] * d["ms_per_step"]) / (d["value"] * d["ms_per_step"]) < 1e-9
+    # wall-clock half of the metric: upload, first call, both together; and the fast path ran
+    assert set(("upload_s", "cold_call_ms", "cold_total_s", "warm_ms")) <= set(d["wall"])
+    assert d["config"]["path"] == "block-record pipeline" and d["roofline"]["block_records_per_launch"] > 0
+    if d["cpu_baseline"]["kind"] == "reference":
+        assert "full" in d["cpu_baseline"]["sample"]           # the reference timed on the whole database of the timed workload
+    # `--gpus 2` with NO launcher: bench.py starts its own two ranks (weak scaling: per-rank databases)
+    for scaling in ("weak", "strong"):
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling,
+                             "--length", "30000" if scaling == "weak" else "60000", "--steps", "2", "--warmup", "1"],
+                            capture_output=True, text=True, env=env, timeout=900)
+        assert r2.returncode == 0, r2.stderr[-3000:]
+        lines = [ln for ln in r2.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1
+        d2 = json.loads(lines[0])
+        assert d2["n_gpus"] == 2 and d2["scaling"] == scaling and d2["config"]["genome_length_bp"] == 60000
+        assert d2["config"]["path"] == "block-record pipeline"
+        # all runs cover a 60 kbp genome set of the same model: two prefix shards do the same total work
+        assert abs(d2["value"] * d2["ms_per_step"] - d["value"] * d["ms_per_step"]) / (d["value"] * d["ms_per_step"]) < 1e-9
 
 
 def test_new2all_synthetic_scale(K, O, dev, tmp_path):
@@ -505,6 +580,59 @@ def test_new2all_synthetic_scale(K, O, dev, tmp_path):
         assert np.array_equal(rows.reshape(len(qs), N), exp)
     # all2all of the same upload still works (hashtables do not disturb it)
     assert np.array_equal(d.all2all_dense(), o.all2all_dense())
+
+
+@pytest.mark.gpu
+def test_new2all_thousand_queries_vs_ten_thousand_samples(K, O, dev, tmp_path, monkeypatch):
+    """BASELINE.json configs[4] in shape: 1000 queries (fresh strains of known clades) against a 10 000-sample k=18 database,
+    streamed in batches; genome length scaled down so that the oracle checks every row.  Also the sequence-text entry point
+    with a batch far over its per-piece base budget (the engine cuts it, rows are independent)."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    N, cs, L, k, NQ = 10000, 50, 600, 18, 1000
+    device = torch.device("cuda", dev)
+    g, pat = S.synth_database(N, cs, L, k=k, seed=41, device=device)
+    arr = S.to_view_arrays(pat)
+    tables = S.build_hashtables(pat["dictionary"], pat["kmer_pid"], k)
+    view = K.make_view(k, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"], bucket_offset=tables[0], slots=tables[1])
+    d = K.DeviceDB(view, device=dev, with_hashtables=True)
+    g_more = S.CladeGenomes(N + NQ, cs, L, seed=41, device=device)          # strains N.. are new members of clades 200..219
+    codes = [g_more.sample(N + i) for i in range(NQ)]
+    qs = [S.kmers_of(c, k).cpu().numpy().view(np.uint64) for c in codes]
+    got = np.concatenate([d.new2all(qs[b: b + 256]) for b in range(0, NQ, 256)])
+    path = str(tmp_path / "s.db")
+    S.write_db(path, k, 1.0, [g.name(i) for i in range(N)], pat["sample_counts"], arr, kmers_count=int(pat["dictionary"].numel()), tables=tables)
+    o = O.OracleDB(path)
+    exp = np.stack([o.one2all(q) for q in qs])
+    assert np.array_equal(got, exp) and int(exp.sum()) > 0
+    # sequence text, 1000 queries of 600 bases with a 5000-base budget per piece
+    monkeypatch.setenv("KMDB_N2A_BASES_PER_PIECE", "5000")
+    texts = ["".join("ACGT"[int(x)] for x in c.cpu().numpy()) for c in codes]
+    rows, cnt = d.new2all_seq(texts)
+    assert np.array_equal(rows, exp) and np.array_equal(cnt, np.array([q.size for q in qs], dtype=np.uint64))
+
+
+@pytest.mark.gpu
+def test_integration_glue_inside_the_reference(golden_dir, tmp_path):
+    """integration/kmdb_bridge.h compiled against the unmodified reference headers and translation units
+    (oracle/Makefile -> oracle/_ref/bridge_driver): the database is loaded by the reference's own deserialize, flattened by
+    the bridge, run by libkmdb_amd.so, and the outputs equal the reference's golden outputs / its own one2all."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "bridge_driver")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/bridge_driver is built only where /root/reference exists")
+    for stem in ("virus_k18", "clade64_k25_f01"):
+        out = str(tmp_path / (stem + ".u32"))
+        r = subprocess.run([exe, "all2all", os.path.join(golden_dir, stem + ".db"), out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert np.array_equal(np.fromfile(out, dtype=np.uint32), _ref_dense(golden_dir, stem))
+    out = str(tmp_path / "sp.txt")
+    r = subprocess.run([exe, "all2all_sp", os.path.join(golden_dir, "clade64.db"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out, "rb").read() == open(os.path.join(golden_dir, "clade64.a2a_sp.ref.txt"), "rb").read()
+    r = subprocess.run([exe, "new2all", os.path.join(golden_dir, "clade64.db"), str(tmp_path / "row.u32")], capture_output=True, text=True)
+    assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -142,6 +142,43 @@ def test_gpu_entry_points_fail_loudly_without_a_device(K, golden_dir):
     assert r.returncode != 0 and "ERROR:" in r.stderr
 
 
+def test_unknown_flag_bits_are_rejected(K, golden_dir):
+    """kmdb_opts.flags: only the documented bits are accepted (the library used to read timing experiments from the high
+    bits); the check comes before any device work, so it holds on a box without a GPU too."""
+    h = K.HostDB(os.path.join(golden_dir, "synth_k21.db"))
+    for bad in (1 << 8, 1 << 9, 1 << 13, 16, 0x80000000):
+        with pytest.raises(K.KmdbError, match="unknown bits"):
+            K.DeviceDB(h, flags=bad)
+    # the shard arguments of the prefix-shard upload are checked up front as well
+    with pytest.raises(K.KmdbError, match="shard_index"):
+        K.DeviceDB(h, prefix_shard=(2, 2))
+
+
+def test_hashtable_headers_are_validated(K, golden_dir, tmp_path):
+    """a capacity that is not a power of two, or a table without an empty slot, would hang or misdirect the device probes
+    (reference src/hashmap_lp.h:150,308-333,427-437): the reader refuses such files"""
+    import struct
+    raw = bytearray(open(os.path.join(golden_dir, "synth_k21.db"), "rb").read())
+    # header: formatWord u64, k u32, fraction f64, startFraction f64, alphabet i32, isInit u8, kmersCount u64 | N u64, samples | buckets
+    off = 8 + 4 + 8 + 8 + 4 + 1 + 8
+    n = struct.unpack_from("<Q", raw, off)[0]
+    off += 8
+    for _ in range(n):
+        off += 8
+        ln = struct.unpack_from("<Q", raw, off)[0]
+        off += 8 + ln
+    off += 8                                             # bucket count; first table: f64 maxFill, u64 filled, u64 allocated
+    filled, allocated = struct.unpack_from("<QQ", raw, off + 8)
+    assert allocated and allocated & (allocated - 1) == 0 and filled < allocated
+    for bad_alloc in (allocated - 1, 0):
+        b = bytearray(raw)
+        struct.pack_into("<Q", b, off + 16, bad_alloc)
+        p = str(tmp_path / "bad.db")
+        open(p, "wb").write(b)
+        with pytest.raises(K.KmdbError, match="hashtable"):
+            K.HostDB(p)
+
+
 def test_cli_usage_and_open_errors(golden_dir):
     exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
     r = subprocess.run([exe, "all2all", "/nonexistent.db", os.path.join(golden_dir, "o2.csv")], capture_output=True, text=True)
