@@ -310,7 +310,8 @@ def main():
                 "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3]),
                                   "whole_call": kern_ms},
                 "cold_call_frac": alg / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "block_records_per_launch": stl["n_records"], "wide_nodes": stl["n_wide"], "record_chunks": stl["n_chunks"],
+                "block_records_per_launch": stl["n_records"], "wide_nodes": stl["n_wide"], "wide_nodes_climbing": stl["n_slow_wide"],
+                "record_chunks": stl["n_chunks"],
             },
         }
         if world == 1 and not args.no_cpu_baseline:

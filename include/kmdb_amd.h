@@ -117,7 +117,7 @@ typedef struct kmdb_stats {        /* measurements of the LAST call on this db h
     uint32_t path;                 /* KMDB_PATH_* of the last all2all call */
     uint32_t width;                /* sample ids per block */
     uint32_t sized_call;           /* 1: the last call measured its own grid sizes (first call on a handle, two host syncs more) */
-    uint32_t reserved;
+    uint32_t n_slow_wide;          /* wide nodes that took the climbing path of the wide kernel */
 } kmdb_stats;
 
 const char* kmdb_last_error(void);

@@ -60,7 +60,9 @@ __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, in
 // ------------------------------------------------------------------------------------------
 // record pool
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t CH_SHIFT = 6, CH_REC = 1u << CH_SHIFT;      // records per chunk = one wave step of K2
+constexpr uint32_t CH_SHIFT = 8, CH_REC = 1u << CH_SHIFT;      // records per stream chunk: four wave steps of K2, 4 KB contiguous
+constexpr uint32_t WCH_SHIFT = 6, WCH_REC = 1u << WCH_SHIFT;   // records per chunk of the wide pool (grouped by a sort, not by chunk)
+struct WideRec { unsigned long long rows, cols; uint32_t w, pad; };      // record of the wide pool: moved by the sort next to its stream key
 struct PoolView {
     uint32_t* counters;            // KCTR_*
     uint32_t* chunk_key;           // [pool_cap] stream of the chunk (n_states: never opened)
@@ -70,9 +72,12 @@ struct PoolView {
     uint32_t* sub_cursor;          // [KMDB_SUBPOOLS * 16] chunks taken from every sub-pool
     uint32_t sub_cap;              // chunks per sub-pool
     uint32_t pool_cap;             // chunks
-    uint32_t* rkey;                // dense mode: stream of every record slot
-    uint32_t raw_key;              // dense mode: chunk_key of a chunk with records of mixed streams (n_states + 1)
-    uint32_t dense;                // 1: this kernel writes its records in arrival order and tags every slot with its stream
+    // wide pool (dense mode): records in arrival order with their stream keys; a device-wide sort groups them afterwards
+    uint32_t* wkey;                // [wide slots] stream of the record, 0xFFFFFFFF = never written
+    WideRec* wrec;                 // [wide slots]
+    uint32_t* wsub_cursor;         // [KMDB_SUBPOOLS * 16]
+    uint32_t wsub_cap;             // chunks per sub-pool of the wide pool
+    uint32_t dense;                // 1: this kernel writes into the wide pool
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
@@ -86,25 +91,32 @@ __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { re
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ST_MAX_BITS = 10;            // at most 1024 open chunks per wave
 struct WaveArena {
-    uint32_t* t_key;               // LDS [1 << tbits]
-    uint32_t* t_slot;              // LDS [1 << tbits]
+    uint32_t* t_key;               // LDS [1 << tbits]; not there (direct) when every stream has its own entry
+    uint32_t* t_slot;              // LDS [1 << tbits], KEY_NONE = no open chunk
     uint32_t tmask;
+    uint32_t direct;
     uint32_t sub;                  // this wave's sub-pool
     uint32_t stock, next;          // wave-uniform: chunks left of the last grab, the next of them (index inside the sub-pool)
     uint32_t dslot;                // dense mode: next slot of the wave's one open chunk (0 with dopen == 0: none)
     uint32_t dopen;
 };
-constexpr uint32_t ARENA_GRAB = 16;
+constexpr uint32_t ARENA_GRAB = 4;         // stream chunks (256 records) per grab
+constexpr uint32_t WIDE_GRAB = 16;         // wide-pool chunks (64 records) per grab
 __host__ __device__ inline uint32_t arena_table_bits(uint32_t n_states) {
     uint32_t b = 4;
     while (b < ST_MAX_BITS && (1u << b) < n_states) ++b;
     return b;
 }
-__device__ __forceinline__ void arena_init(WaveArena& A, uint32_t* lds, uint32_t tbits, uint32_t wave_id, uint32_t lane) {
-    A.t_key = lds; A.t_slot = lds + (1u << tbits); A.tmask = (1u << tbits) - 1u;
+__host__ __device__ inline size_t arena_table_bytes(uint32_t tbits, uint32_t n_states) {
+    if (tbits == 0) return 16;
+    return ((size_t)4 << tbits) * (n_states <= (1u << tbits) ? 1 : 2);
+}
+__device__ __forceinline__ void arena_init(WaveArena& A, uint32_t* lds, uint32_t tbits, uint32_t n_states, uint32_t wave_id, uint32_t lane) {
+    A.direct = n_states <= (1u << tbits) ? 1u : 0u;
+    A.t_slot = lds; A.t_key = lds + (1u << tbits); A.tmask = (1u << tbits) - 1u;
     A.sub = wave_id % KMDB_SUBPOOLS; A.stock = 0; A.next = 0; A.dslot = 0; A.dopen = 0;
     if (tbits == 0) return;                                   // dense mode: no table
-    for (uint32_t e = lane; e <= A.tmask; e += WAVE) A.t_key[e] = KEY_NONE;
+    for (uint32_t e = lane; e <= A.tmask; e += WAVE) { A.t_slot[e] = KEY_NONE; if (!A.direct) A.t_key[e] = KEY_NONE; }
     lds_sync();
 }
 __device__ __forceinline__ uint32_t arena_take(WaveArena& A, const PoolView& pv, uint32_t s, uint32_t lane) {
@@ -123,56 +135,73 @@ __device__ __forceinline__ uint32_t arena_take(WaveArena& A, const PoolView& pv,
     if (lane == 0) pv.chunk_key[id] = s;
     return id;
 }
+// next chunk of the wide pool
+__device__ __forceinline__ uint32_t arena_take_wide(WaveArena& A, const PoolView& pv, uint32_t lane) {
+    if (A.stock == 0) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&pv.wsub_cursor[A.sub * 16u], WIDE_GRAB);
+        base = bcast(base, 0);
+        if (base + WIDE_GRAB > pv.wsub_cap) {                     // stays in range; the call is repeated with a larger pool
+            if (lane == 0) atomicOr(&pv.counters[KCTR_WIDE_OVERFLOW], 1u);
+            base = pv.wsub_cap - WIDE_GRAB;
+        }
+        A.next = base; A.stock = WIDE_GRAB;
+    }
+    const uint32_t id = A.next * KMDB_SUBPOOLS + A.sub;
+    ++A.next; --A.stock;
+    return id;
+}
 // cnt (1..64) slots of stream s; s and cnt wave-uniform, every lane of the wave calls
 __device__ __forceinline__ Resv arena_reserve(WaveArena& A, const PoolView& pv, uint32_t s, uint32_t cnt, uint32_t lane) {
     if (pv.dense) {
         // records of all streams share the wave's one open chunk; they are grouped by a device-wide sort afterwards
-        if (!A.dopen) { A.dslot = arena_take(A, pv, pv.raw_key, lane) << CH_SHIFT; A.dopen = 1; }
-        const uint32_t v = A.dslot, rem = CH_REC - (v & (CH_REC - 1u));
+        if (!A.dopen) { A.dslot = arena_take_wide(A, pv, lane) << WCH_SHIFT; A.dopen = 1; }
+        const uint32_t v = A.dslot, rem = WCH_REC - (v & (WCH_REC - 1u));
         if (cnt < rem) { A.dslot = v + cnt; return Resv{v, cnt, 0u}; }
-        if (lane == 0) pv.chunk_fill[v >> CH_SHIFT] = CH_REC;
         if (cnt == rem) { A.dopen = 0; return Resv{v, cnt, 0u}; }
-        const uint32_t nv = arena_take(A, pv, pv.raw_key, lane) << CH_SHIFT;
+        const uint32_t nv = arena_take_wide(A, pv, lane) << WCH_SHIFT;
         A.dslot = nv + (cnt - rem);
         return Resv{v, rem, nv};
     }
     const uint32_t e = s & A.tmask;
-    const uint32_t key = A.t_key[e];
     uint32_t v = A.t_slot[e];
-    if (key != s) {
-        if (key != KEY_NONE && lane == 0) pv.chunk_fill[v >> CH_SHIFT] = v & (CH_REC - 1u);        // evicted partly filled
-        v = arena_take(A, pv, s, lane) << CH_SHIFT;
+    if (A.direct) {
+        if (v == KEY_NONE) v = arena_take(A, pv, s, lane) << CH_SHIFT;
+    } else {
+        const uint32_t key = A.t_key[e];
+        if (key != s) {
+            if (key != KEY_NONE && lane == 0) pv.chunk_fill[v >> CH_SHIFT] = v & (CH_REC - 1u);        // evicted partly filled
+            v = arena_take(A, pv, s, lane) << CH_SHIFT;
+        }
     }
     const uint32_t rem = CH_REC - (v & (CH_REC - 1u));
     Resv r{v, cnt, 0u};
     uint32_t nkey = s, nv = v + cnt;
     if (cnt >= rem) {
         if (lane == 0) pv.chunk_fill[v >> CH_SHIFT] = CH_REC;                                      // full
-        if (cnt == rem) nkey = KEY_NONE;
+        if (cnt == rem) { nkey = KEY_NONE; nv = KEY_NONE; }
         else {
             nv = arena_take(A, pv, s, lane) << CH_SHIFT;
             r = Resv{v, rem, nv};
             nv += cnt - rem;
         }
     }
-    if (lane == 0) { A.t_key[e] = nkey; A.t_slot[e] = nv; }
+    if (lane == 0) { A.t_slot[e] = nv; if (!A.direct) A.t_key[e] = nkey; }
     lds_sync();
     return r;
 }
 __device__ __forceinline__ void arena_finish(const WaveArena& A, const PoolView& pv, uint32_t lane) {
-    if (pv.dense) {
-        if (A.dopen && lane == 0) pv.chunk_fill[A.dslot >> CH_SHIFT] = A.dslot & (CH_REC - 1u);
-        return;
+    if (pv.dense) return;                                       // never-written slots of the wide pool keep their 0xFFFFFFFF key
+    for (uint32_t e = lane; e <= A.tmask; e += WAVE) {
+        const uint32_t v = A.t_slot[e];
+        if (v != KEY_NONE && (A.direct || A.t_key[e] != KEY_NONE)) pv.chunk_fill[v >> CH_SHIFT] = v & (CH_REC - 1u);
     }
-    for (uint32_t e = lane; e <= A.tmask; e += WAVE)
-        if (A.t_key[e] != KEY_NONE) { const uint32_t v = A.t_slot[e]; pv.chunk_fill[v >> CH_SHIFT] = v & (CH_REC - 1u); }
 }
 
 // diagonal streams (X == Y, cols == rows) pack 8-byte rows into the first half of their chunks
 __device__ __forceinline__ void rec_store_dense(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t w, uint32_t stream) {
-    ((ulonglong2*)pv.rec)[slot] = make_ulonglong2(rows, cols);
-    pv.recw[slot] = w;
-    pv.rkey[slot] = stream;
+    pv.wrec[slot] = WideRec{rows, cols, w, 0u};
+    pv.wkey[slot] = stream;
 }
 __device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t cls, uint32_t w, uint32_t stream) {
     if (pv.dense) { rec_store_dense(pv, slot, rows, rows, w, stream); return; }
@@ -410,16 +439,16 @@ struct NParams {
     const uint32_t* pair_ofs;
     const uint16_t* pair_blk;
     const unsigned long long* pair_mask;
-    ulonglong2* fn_mask;
-    uint32_t* fn_blk;
+    ulonglong2* fn_mask;           // written for the nodes with more than two blocks whose parent has at most two:
+    uint32_t* fn_blk;              // the parent's (blocks, masks)
     unsigned long long* widebits;
     uint32_t P, nseg_nodes, n_segs, chain_cap;
     uint32_t emit_lo, emit_hi;
-    uint32_t tbits;                // log2 of the open-chunk table
+    uint32_t tbits, n_states;      // log2 of the open-chunk table, streams
     PoolView pool;
 };
 constexpr int K1N_WAVES = 4;
-__host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tbits) { return (((size_t)chain_cap * 20 + 15) & ~(size_t)15) + ((size_t)8 << tbits); }
+__host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tbits, uint32_t n_states) { return (((size_t)chain_cap * 20 + 15) & ~(size_t)15) + arena_table_bytes(tbits, n_states); }
 
 __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -427,9 +456,9 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg = blockIdx.x * K1N_WAVES + wave;
     if (seg >= q.n_segs) return;
-    unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits) * wave;
-    uint32_t* table = (uint32_t*)wbase;                                                      // open chunks: [2 << tbits]
-    ulonglong2* chain_m = (ulonglong2*)(wbase + ((size_t)8 << q.tbits));                    // [chain_cap] one slot per depth:
+    unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits, q.n_states) * wave;
+    uint32_t* table = (uint32_t*)wbase;                                                      // open chunks
+    ulonglong2* chain_m = (ulonglong2*)(wbase + arena_table_bytes(q.tbits, q.n_states));    // [chain_cap] one slot per depth:
     uint32_t* chain_b = (uint32_t*)(chain_m + q.chain_cap);                                  // the latest node of that depth on the current root path
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t first = seg * q.nseg_nodes;
@@ -487,7 +516,7 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     };
     fetch(first);
     WaveArena A;
-    arena_init(A, table, q.tbits, seg, lane);
+    arena_init(A, table, q.tbits, q.n_states, seg, lane);
     for (uint32_t base = first; base < end; base += WAVE) {
         const uint32_t idx = base + lane;
         const bool valid = idx < end;
@@ -517,9 +546,17 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
             const unsigned long long wb = __ballot(wide);
             if (lane == 0) q.widebits[base >> 6] = wb;
         }
-        if (valid && !wide && (df >> 15)) {                       // a child with more blocks will start from here
-            q.fn_mask[idx] = make_ulonglong2(F0, F1);
-            q.fn_blk[idx] = (w0 == BNONE ? 0xFFFFu : w0) | ((w1 == BNONE ? 0xFFFFu : w1) << 16);
+        if (__ballot(wide)) {
+            // a node with more blocks whose parent still has at most two takes the parent's (blocks, masks) along: the wide
+            // kernel starts its list from them
+            const int pl0 = (valid && par >= (int32_t)base) ? (int)(par - (int32_t)base) : (int)lane;
+            NSum Pp = nsum_shfl(S, pl0);
+            if (valid && par >= 0 && par < (int32_t)base) { const ulonglong2 cm = chain_m[dep - 2u]; Pp = NSum{cm.x, cm.y, chain_b[dep - 2u]}; }
+            if (wide && par >= 0 && !((Pp.bw >> 30) & 1u)) {
+                const uint32_t pb0 = Pp.bw & 0x7FFFu, pb1 = (Pp.bw >> 15) & 0x7FFFu;
+                q.fn_mask[idx] = make_ulonglong2(Pp.m0, pb1 != BNONE ? Pp.m1 : 0ull);
+                q.fn_blk[idx] = (pb0 == BNONE ? 0xFFFFu : pb0) | ((pb1 == BNONE ? 0xFFFFu : pb1) << 16);
+            }
         }
         // ---- records (flat form): (w0, w0, F0), and with a second block (w1, w0, F1, F0) and (w1, w1, F1).  A diagonal
         // record needs two ids to have a pair.
@@ -626,14 +663,14 @@ struct GParams {
     const uint32_t* fn_blk;
     uint32_t emit_lo, emit_hi;
     uint32_t n_waves;              // waves of the launch, each with a run of consecutive batches of 64 wide nodes
-    uint32_t tbits;
+    uint32_t tbits, n_states;
     PoolView pool;
 };
-constexpr int K1G_WAVES = 4;
+constexpr int K1G_WAVES = 2;
 constexpr uint32_t K1G_ROW = 12;           // entries of a lane's row (lists with more blocks take the climbing path)
 constexpr uint32_t K1G_ENT = 64 * K1G_ROW; // the rows double as the entry pool of the climbing path
-constexpr uint32_t K1G_CH = 32;            // chain slots (by depth mod 32)
-constexpr uint32_t K1G_QCAP = 256;         // record descriptors queued per round
+constexpr uint32_t K1G_CH = 16;            // chain slots (by depth mod 16)
+constexpr uint32_t K1G_QCAP = 128;         // record descriptors queued per round
 struct K1GWave {
     unsigned long long ent_mask[K1G_ENT];
     unsigned long long ch_mask[K1G_CH * K1G_ROW];
@@ -650,7 +687,7 @@ struct K1GWave {
 // A wide node's parent is wide as well or has at most two blocks.  Its list = the parent's list + its own pairs:
 //   parent with <= 2 blocks: the (blocks, masks) the narrow kernel left in HBM;
 //   wide parent inside the batch: that lane's row in LDS (lanes resolve in rounds, parents first);
-//   wide parent before the batch: the wave's chain table (the latest wide node of every depth, by depth mod 32);
+//   wide parent before the batch: the wave's chain table (the latest wide node of every depth, by depth mod 16);
 //   anything else (the parent belongs to another wave's run, a list longer than a row): the lane climbs the parent links
 //   up to the nearest ancestor with <= 2 blocks and gathers the pairs on the way (the slow path, a few lanes per wave).
 __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) {
@@ -666,14 +703,14 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
     auto iswide = [&](uint32_t y) -> bool { return (q.widebits[y >> 6] >> (y & 63u)) & 1ull; };
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     WaveArena A;
-    arena_init(A, (uint32_t*)(lds_raw + ((size_t)8 << q.tbits) * wave), q.tbits, wid + 64u, lane);
+    arena_init(A, (uint32_t*)(lds_raw + arena_table_bytes(q.tbits, q.n_states) * wave), q.tbits, q.n_states, wid + 64u, lane);
     if (lane < K1G_CH) L.ch_node[lane] = 0xFFFFFFFFu;
     lds_sync();
 
     // record-parallel emission of the lanes in `on` (list of lane j: m entries from st_start[j]): a node with m blocks owns
     // m (m + 1) / 2 records (block pairs a >= b); the records are numbered by a prefix sum, every owner pushes one descriptor per
     // record into a queue, then the wave takes 64 descriptors at a time, one record per lane
-    auto emit = [&](bool on, uint32_t m, uint32_t wv) {
+    auto emit = [&](bool on, uint32_t m, uint32_t wv, uint32_t stride) {
         const uint32_t myrec = on ? m * (m + 1u) / 2u : 0u;
         const uint32_t rincl = wave_incl_scan(myrec, lane);
         const uint32_t T = bcast(rincl, WAVE - 1);
@@ -707,8 +744,8 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                     const uint32_t d = L.queue[t - q0];
                     const uint32_t own = d & 63u, a = (d >> 6) & 0x1FFFu, b = d >> 19;
                     const uint32_t st = L.st_start[own];
-                    FX = L.ent_mask[st + a]; FY = L.ent_mask[st + b];
-                    const uint32_t X = L.ent_blk[st + a], Y = L.ent_blk[st + b];
+                    FX = L.ent_mask[st + a * stride]; FY = L.ent_mask[st + b * stride];
+                    const uint32_t X = L.ent_blk[st + a * stride], Y = L.ent_blk[st + b * stride];
                     ww = L.st_w[own];
                     cl = weight_class(ww);
                     diag = a == b;
@@ -732,6 +769,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
         }
     };
 
+    uint32_t n_slow = 0;
     for (uint32_t batch = b_lo; batch < b_hi; ++batch) {
         const uint32_t k = batch * WAVE + lane;
         const bool valid = k < q.n_wide;
@@ -762,12 +800,12 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
             }
         }
         // ---- rows: the parent's entries, then the node's own pairs (ascending; an equal block at the seam merges)
-        const uint32_t row = lane * K1G_ROW;
+        const uint32_t row = lane;                              // rows are entry-major: entry e of this lane at row + 64 e (no bank conflicts)
         uint32_t len = 0;
         bool slow = valid && src == SRC_SLOW, done = !valid || src == SRC_NOW || src == SRC_CHAIN || src == SRC_SLOW;
         auto push = [&](uint32_t blk, unsigned long long mask) {
-            if (len && L.ent_blk[row + len - 1u] == blk) L.ent_mask[row + len - 1u] |= mask;
-            else if (len < K1G_ROW) { L.ent_blk[row + len] = (uint16_t)blk; L.ent_mask[row + len] = mask; ++len; }
+            if (len && L.ent_blk[row + 64u * (len - 1u)] == blk) L.ent_mask[row + 64u * (len - 1u)] |= mask;
+            else if (len < K1G_ROW) { L.ent_blk[row + 64u * len] = (uint16_t)blk; L.ent_mask[row + 64u * len] = mask; ++len; }
             else slow = true;                                   // longer than a row
         };
         auto push_own = [&]() {
@@ -777,8 +815,8 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
         if (valid && !slow) {
             if (src == SRC_NOW) {
                 if (par_narrow) {
-                    const uint32_t fb = q.fn_blk[par];
-                    const ulonglong2 fm = q.fn_mask[par];
+                    const uint32_t fb = q.fn_blk[node];
+                    const ulonglong2 fm = q.fn_mask[node];
                     if ((fb & 0xFFFFu) != 0xFFFFu) push(fb & 0xFFFFu, fm.x);
                     if ((fb >> 16) != 0xFFFFu) push(fb >> 16, fm.y);
                 }
@@ -786,7 +824,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
             } else if (src == SRC_CHAIN) {
                 const uint32_t cs = (dep - 1u) & (K1G_CH - 1u);
                 const uint32_t cl = L.ch_len[cs];
-                for (uint32_t e = 0; e < cl; ++e) { L.ent_blk[row + e] = L.ch_blk[cs * K1G_ROW + e]; L.ent_mask[row + e] = L.ch_mask[cs * K1G_ROW + e]; }
+                for (uint32_t e = 0; e < cl; ++e) { L.ent_blk[row + 64u * e] = L.ch_blk[cs * K1G_ROW + e]; L.ent_mask[row + 64u * e] = L.ch_mask[cs * K1G_ROW + e]; }
                 len = cl;
                 push_own();
             }
@@ -797,8 +835,8 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
             if (!done && (pstate & 1u)) {
                 if (pstate & 2u) slow = true;
                 else {
-                    const uint32_t pl = pstate >> 2, prow = plane * K1G_ROW;
-                    for (uint32_t e = 0; e < pl; ++e) { L.ent_blk[row + e] = L.ent_blk[prow + e]; L.ent_mask[row + e] = L.ent_mask[prow + e]; }
+                    const uint32_t pl = pstate >> 2, prow = plane;
+                    for (uint32_t e = 0; e < pl; ++e) { L.ent_blk[row + 64u * e] = L.ent_blk[prow + 64u * e]; L.ent_mask[row + 64u * e] = L.ent_mask[prow + 64u * e]; }
                     len = pl;
                     push_own();
                 }
@@ -816,17 +854,28 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
             }
             uint32_t later = (uint32_t)__shfl_down((int)mdep, 1, WAVE);
             if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
-            if (valid && dep < later) {
+            // two path nodes whose depths differ by a multiple of the table size share a slot: the deeper one keeps it
+            bool writer = valid && dep < later;
+            {
+                const uint32_t mycs = dep & (K1G_CH - 1u);
+#pragma unroll
+                for (uint32_t c2 = 0; c2 < K1G_CH; ++c2) {
+                    const unsigned long long wm = __ballot(writer && mycs == c2);
+                    if (writer && mycs == c2 && (wm >> lane) > 1ull) writer = false;      // a later (deeper) lane wants the slot
+                }
+            }
+            if (writer) {
                 const uint32_t cs = dep & (K1G_CH - 1u);
                 L.ch_node[cs] = node;
                 L.ch_len[cs] = slow ? (uint16_t)0xFFFFu : (uint16_t)len;
-                if (!slow) for (uint32_t e = 0; e < len; ++e) { L.ch_blk[cs * K1G_ROW + e] = L.ent_blk[row + e]; L.ch_mask[cs * K1G_ROW + e] = L.ent_mask[row + e]; }
+                if (!slow) for (uint32_t e = 0; e < len; ++e) { L.ch_blk[cs * K1G_ROW + e] = L.ent_blk[row + 64u * e]; L.ch_mask[cs * K1G_ROW + e] = L.ent_mask[row + 64u * e]; }
             }
         }
         L.st_start[lane] = (uint16_t)row;
         lds_sync();
-        emit(act && !slow, len, wv);
+        emit(act && !slow, len, wv, 64u);
         // ---- the slow path: climb to the nearest ancestor with at most two blocks, twice (count, then fill)
+        n_slow += (uint32_t)__popcll(__ballot(slow));
         if (__ballot(slow)) {
             uint32_t cnt = 0;
             if (slow) {
@@ -862,11 +911,12 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                             for (uint32_t t = ynp - 1; t-- > 0;) rpush(q.pair_blk[ypo + t], q.pair_mask[ypo + t]);
                         }
                         if (ynp) rpush(yi & 0xFFFFu, q.p0_mask[y]);
+                        const int32_t z = y;                      // the wide node whose parent may be the end of the climb
                         y = q.parent[y];
                         if (y < 0) break;
                         if (!iswide((uint32_t)y)) {
-                            const uint32_t fb = q.fn_blk[y];
-                            const ulonglong2 fm = q.fn_mask[y];
+                            const uint32_t fb = q.fn_blk[z];
+                            const ulonglong2 fm = q.fn_mask[z];
                             if ((fb >> 16) != 0xFFFFu) rpush(fb >> 16, fm.y);
                             if ((fb & 0xFFFFu) != 0xFFFFu) rpush(fb & 0xFFFFu, fm.x);
                             break;
@@ -876,12 +926,13 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                 }
                 L.st_start[lane] = (uint16_t)start;
                 lds_sync();
-                emit(on && act, m, wv);
+                emit(on && act, m, wv, 1u);
                 fin = hi;
             }
         }
     }
     arena_finish(A, q.pool, lane);
+    if (lane == 0 && n_slow) atomicAdd(&q.pool.counters[KCTR_SLOW], n_slow);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -933,32 +984,35 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
 
 struct K2Item {
     uint32_t X, Y, cls, count;             // block pair, weight class, wave steps (64 records each) of this stream in the window
-    const uint32_t* ids;                   // chunk mode: [count] chunk ids (LDS)
-    const uint32_t* fills;                 //             [count] records in every chunk (LDS)
-    const uint32_t* sslot;                 // gather mode (records sorted by stream): slots of the run, n_rec of them
+    const uint32_t* ids;                   // chunk mode: chunk ids of the run (LDS), CH_REC / 64 steps per chunk
+    const uint32_t* fills;                 //             records in every chunk (LDS)
+    const WideRec* srec;                   // sorted mode: the run's records, n_rec of them, contiguous
     uint32_t n_rec;
     const unsigned char* rec;              // record pool
     const uint32_t* recw;
 };
-// the 64 records of step ci, one per lane (lanes beyond the fill get an empty record)
-__device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t ci, uint32_t lane, bool weighted, unsigned long long& R,
+constexpr uint32_t CH_STEPS = CH_REC / 64u;
+// the 64 records of step st, one per lane (lanes beyond the fill get an empty record)
+__device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t st, uint32_t lane, bool weighted, unsigned long long& R,
                                          unsigned long long& Cc, uint32_t& W) {
     R = 0; Cc = 0; W = 0;
-    if (ci >= it.count) return;
-    if (it.sslot) {
-        const uint32_t p = ci * 64u + lane;
+    if (st >= it.count) return;
+    if (it.srec) {
+        const uint32_t p = st * 64u + lane;
         if (p < it.n_rec) {
-            const uint32_t slot = it.sslot[p];
-            const ulonglong2 rc = ((const ulonglong2*)it.rec)[slot];
-            R = rc.x; Cc = rc.y;
-            W = weighted ? it.recw[slot] : 1u;
+            const WideRec r = it.srec[p];
+            R = r.rows; Cc = r.cols;
+            W = weighted ? r.w : 1u;
         }
-    } else if (lane < it.fills[ci]) {
-        const uint32_t id = it.ids[ci];
-        const unsigned char* base = it.rec + ((size_t)id << (CH_SHIFT + 4));
-        if (diag) { R = ((const unsigned long long*)base)[lane]; Cc = R; }
-        else { const ulonglong2 rc = ((const ulonglong2*)base)[lane]; R = rc.x; Cc = rc.y; }
-        W = weighted ? it.recw[((size_t)id << CH_SHIFT) + lane] : 1u;
+    } else {
+        const uint32_t ci = st / CH_STEPS, j = (st % CH_STEPS) * 64u + lane;
+        if (j < it.fills[ci]) {
+            const uint32_t id = it.ids[ci];
+            const unsigned char* base = it.rec + ((size_t)id << (CH_SHIFT + 4));
+            if (diag) { R = ((const unsigned long long*)base)[j]; Cc = R; }
+            else { const ulonglong2 rc = ((const ulonglong2*)base)[j]; R = rc.x; Cc = rc.y; }
+            W = weighted ? it.recw[((size_t)id << CH_SHIFT) + j] : 1u;
+        }
     }
 }
 
@@ -988,6 +1042,7 @@ __device__ __forceinline__ void k2_apply_popc(const K2Item& it, uint32_t* __rest
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
         k2_fetch(it, DIAG, ci + 4, lane, true, nR, nC, nW);
+        if (!__ballot(R != 0)) continue;                           // the empty tail of a partly filled chunk
         const unsigned long long Ct = transpose64(C, lane);
         rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
         lds_sync();
@@ -1059,6 +1114,7 @@ __device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, u
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
         k2_fetch(it, DIAG, ci + 4, lane, WEIGHTED, nR, nC, nW);
+        if (!__ballot(R != 0)) continue;                           // the empty tail of a partly filled chunk
         const unsigned long long Ct = transpose64(C, lane);
         rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);
         if (!DIAG) ctbuf[wave][lane] = Ct;
@@ -1095,7 +1151,7 @@ __device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, u
     }
 }
 
-constexpr uint32_t K2_WIN = 128;           // sorted chunks per workgroup (8192 records)
+constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup (8192 records)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
                                                        const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
                                                        const uint32_t* __restrict__ chunk_fill, uint32_t n_states, uint32_t pool_cap,
@@ -1135,7 +1191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             while (tri32(X) > bucket) --X;
             while (tri32(X + 1u) <= bucket) ++X;
             it.X = X; it.Y = bucket - tri32(X);
-            it.count = b - a; it.ids = s_id + a; it.fills = s_fill + a; it.sslot = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw;
+            it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw;
         }
         for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
         __syncthreads();
@@ -1161,34 +1217,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
-// positions of the sorted chunk table: [0, lo) chunks of one stream each, [lo, raw_lo) never opened, [raw_lo, pool_cap) mixed
-__global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uint32_t pool_cap, uint32_t n_states, uint32_t* __restrict__ counters) {
+// opened chunks = the head of the sorted chunk table; slots of the wide pool in use = the busiest sub-pool's share of all
+__global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uint32_t pool_cap, uint32_t n_states, const uint32_t* __restrict__ wsub_cursor,
+                                    uint32_t* __restrict__ counters) {
     uint32_t lo = 0, hi = pool_cap;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_key[mid] < n_states) lo = mid + 1; else hi = mid; }
     counters[KCTR_CHUNKS] = lo;
-    hi = pool_cap;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_key[mid] <= n_states) lo = mid + 1; else hi = mid; }
-    counters[KCTR_RAW] = pool_cap - lo;
-}
-
-// dense mode: (stream, slot) of every record of the mixed chunks, never-written slots tagged n_states (they sort last)
-__global__ __launch_bounds__(64) void raw_expand_kernel(const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ chunk_fill,
-                                                        const uint32_t* __restrict__ rkey, const uint32_t* __restrict__ counters, uint32_t pool_cap,
-                                                        uint32_t n_states, uint32_t* __restrict__ wkey, uint32_t* __restrict__ wslot) {
-    const uint32_t n_raw = counters[KCTR_RAW];
-    if (blockIdx.x >= n_raw) return;
-    const uint32_t id = sorted_id[pool_cap - n_raw + blockIdx.x];
-    const uint32_t slot = (id << CH_SHIFT) + threadIdx.x;
-    const size_t o = (size_t)blockIdx.x * CH_REC + threadIdx.x;
-    wkey[o] = threadIdx.x < chunk_fill[id] ? rkey[slot] : n_states;
-    wslot[o] = slot;
+    uint32_t mx = 0;
+    for (uint32_t p = 0; p < KMDB_SUBPOOLS; ++p) mx = max(mx, wsub_cursor[p * 16u]);
+    counters[KCTR_RAW] = mx * KMDB_SUBPOOLS;                    // chunk ids below this bound cover every written record
 }
 
 // K2 over records sorted by stream (dense mode): a window of K2S_WIN sorted positions, one 64 x 64 tile per run of equal streams
 constexpr uint32_t K2S_WIN = 8192;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
-                                                        const uint32_t* __restrict__ swkey, const uint32_t* __restrict__ swslot,
-                                                        const uint32_t* __restrict__ counters, uint32_t n_states,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
+                                                        uint32_t total, uint32_t n_states,
                                                         uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
@@ -1197,7 +1240,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ unsigned long long lut_ff[256], lut_01[256];
     __shared__ uint16_t bnd[K2S_WIN + 2];          // run starts inside the window, then the end
     __shared__ uint32_t tcount[256];
-    const uint32_t total = counters[KCTR_RAW] * CH_REC;
     const uint32_t p0 = blockIdx.x * K2S_WIN;
     if (p0 >= total || swkey[p0] >= n_states) return;
     const uint32_t wend = total - p0 < K2S_WIN ? total - p0 : K2S_WIN;
@@ -1245,7 +1287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             while (tri32(X) > bucket) --X;
             while (tri32(X + 1u) <= bucket) ++X;
             it.X = X; it.Y = bucket - tri32(X);
-            it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.sslot = swslot + p0 + a; it.rec = rec; it.recw = recw;
+            it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.rec = nullptr; it.recw = nullptr;
         }
         for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
         __syncthreads();
@@ -1349,7 +1391,7 @@ __global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t*
 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
-                    (uint32_t)db->pool_cap, db->rkey, db->n_states + 1u, dense ? 1u : 0u};
+                    (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -1361,7 +1403,6 @@ struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) 
 int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->sort_tmp);
-    FREE_NULL(db->rkey); FREE_NULL(db->wkey); FREE_NULL(db->wslot); FREE_NULL(db->swkey); FREE_NULL(db->swslot); FREE_NULL(db->sort2_tmp);
     db->pool_cap = 0;
     chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB);
     if (chunks >= (1ull << 31) >> CH_SHIFT) return kmdb_set_error("kmdb: record pool would exceed 2^31 record slots");
@@ -1374,7 +1415,7 @@ int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipMalloc((void**)&db->recw, (chunks << CH_SHIFT) * 4));
     hipLaunchKernelGGL(iota_u32_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, db->stream, db->chunk_iota, (uint32_t)chunks);
     int key_bits = 1;
-    while ((1ull << key_bits) <= (uint64_t)db->n_states + 1) ++key_bits;          // streams, n_states = never opened, n_states + 1 = mixed
+    while ((1ull << key_bits) <= (uint64_t)db->n_states + 1) ++key_bits;          // streams; n_states = never opened; all-ones = never written
     db->key_bits = key_bits;
     size_t tb = 0, tb2 = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id, (int)chunks, 0, key_bits, db->stream));
@@ -1385,18 +1426,23 @@ int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     db->sort_tmp_bytes = std::max(tb, tb2);
     HIP_TRY(hipMalloc(&db->sort_tmp, std::max<size_t>(db->sort_tmp_bytes, 16)));
     db->pool_cap = chunks;
-    if (db->dense_wide || db->dense_narrow) {
-        // dense mode: every record slot carries its stream; the records of the mixed chunks are sorted by it
-        const uint64_t slots = chunks << CH_SHIFT;
-        HIP_TRY(hipMalloc((void**)&db->rkey, slots * 4));
-        HIP_TRY(hipMalloc((void**)&db->wkey, slots * 4));
-        HIP_TRY(hipMalloc((void**)&db->wslot, slots * 4));
-        HIP_TRY(hipMalloc((void**)&db->swkey, slots * 4));
-        HIP_TRY(hipMalloc((void**)&db->swslot, slots * 4));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, db->sort2_tmp_bytes, db->wkey, db->swkey, db->wslot, db->swslot, (int)std::min<uint64_t>(slots, 0x7FFFFFFF),
-                                                   0, key_bits, db->stream));
-        HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
-    }
+    return 0;
+}
+// the wide pool: records in arrival order + their stream keys, and the sorted copies
+int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
+    FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp);
+    db->wide_pool_cap = 0;
+    chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * WIDE_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * WIDE_GRAB) * ((uint64_t)KMDB_SUBPOOLS * WIDE_GRAB);
+    const uint64_t slots = chunks << WCH_SHIFT;
+    if (slots >= (1ull << 31)) return kmdb_set_error("kmdb: wide record pool would exceed 2^31 record slots");
+    HIP_TRY(hipMalloc((void**)&db->wkey, slots * 4));
+    HIP_TRY(hipMalloc(&db->wrec, slots * sizeof(WideRec)));
+    HIP_TRY(hipMalloc((void**)&db->swkey, slots * 4));
+    HIP_TRY(hipMalloc(&db->swrec, slots * sizeof(WideRec)));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, db->sort2_tmp_bytes, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)slots, 0, db->key_bits,
+                                               db->stream));
+    HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
+    db->wide_pool_cap = chunks;
     return 0;
 }
 int alloc_pair_pool(kmdb_db* db, uint64_t entries) {
@@ -1506,15 +1552,18 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     HIP_TRY(hipHostMalloc((void**)&db->h_counters, KCTR_COUNT * 4));
     if (alloc_pair_pool(db, std::max<uint64_t>(P + P / 2, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
     HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
-    // more streams than a wave's open-chunk table holds: the nodes with many blocks scatter their records over all of them,
-    // so the wide kernel writes them in arrival order and a device-wide sort groups them (the narrow kernel keeps its table:
-    // its records follow the clustering of the DFS stream; it switches too if its chunks turn out nearly empty)
-    db->dense_wide = db->n_states > (1u << ST_MAX_BITS);
+    HIP_TRY(hipMalloc((void**)&db->wsub_cursor, KMDB_SUBPOOLS * 16 * 4));
+    // The nodes with many blocks scatter their records over many streams, a few per stream and wave: the wide kernel writes them
+    // in arrival order into its own pool and a device-wide sort groups them (measured: 5 x faster than per-stream reservations).
+    // The narrow kernel keeps per-stream chunks: its records follow the clustering of the DFS stream.  With more streams than its
+    // open-chunk table holds it switches to the wide pool too, if its chunks turn out to be evicted nearly empty.
+    db->dense_wide = true;
     db->dense_narrow = false;
-    if (const char* e = getenv("KMDB_DENSE")) { db->dense_wide = atoi(e) >= 1; db->dense_narrow = atoi(e) >= 2; }
-    // chunks: the estimate at two thirds average fill, plus what the waves hold when they end (an unfinished grab, open chunks)
-    (void)est_n; (void)est_g;
-    if (alloc_record_pool(db, db->est_records * 3 / 2 / CH_REC + (uint64_t)(db->n_nsegs + K1G_MAX_WAVES) * (ARENA_GRAB + 8) + 4096)) return 1;
+    if (const char* e = getenv("KMDB_DENSE")) db->dense_narrow = atoi(e) >= 2;
+    // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
+    // unfinished grab); wide pool: the wide estimate and a grab per wave
+    if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 24 + 1024)) return 1;
+    if (alloc_wide_pool(db, est_g * 5 / 4 / WCH_REC + (uint64_t)(K1G_MAX_WAVES + 64) * (WIDE_GRAB + 2) + 1024)) return 1;
     return 0;
 }
 
@@ -1523,7 +1572,7 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->pair_cursor); FREE_NULL(db->fn_mask); FREE_NULL(db->fn_blk); FREE_NULL(db->widebits); FREE_NULL(db->wide_cnt);
     FREE_NULL(db->wide_base); FREE_NULL(db->widx); FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key);
     FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota); FREE_NULL(db->sort_tmp);
-    FREE_NULL(db->rkey); FREE_NULL(db->wkey); FREE_NULL(db->wslot); FREE_NULL(db->swkey); FREE_NULL(db->swslot); FREE_NULL(db->sort2_tmp);
+    FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
     db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
@@ -1531,7 +1580,8 @@ void kmdb_blocks_release(kmdb_db* db) {
 
 uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
     if (!db->counters) return 0;
-    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 20 + db->wide_cap * 4 + (db->P / 64) * 16;
+    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 20 + db->wide_cap * 4 + (db->P / 64) * 16 +
+           (db->wide_pool_cap << WCH_SHIFT) * 56;
 }
 
 namespace {
@@ -1554,6 +1604,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     HIP_TRY(hipMemsetAsync(db->counters, 0, KCTR_COUNT * 4, st));
     HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, KMDB_PAIR_REGIONS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->sub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
+    HIP_TRY(hipMemsetAsync(db->wsub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
+    {
+        // never-written slots of the wide pool sort last; only the part the previous call used has to be reset
+        const uint64_t wslots = db->have_counts ? std::min<uint64_t>((uint64_t)db->last_n_raw << WCH_SHIFT, db->wide_pool_cap << WCH_SHIFT) : db->wide_pool_cap << WCH_SHIFT;
+        HIP_TRY(hipMemsetAsync(db->wkey, 0xFF, wslots * 4, st));
+    }
     HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, st));
     hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, st, db->chunk_key, pool_cap, db->n_states);
     if (stage("init")) return 1;
@@ -1582,8 +1638,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.widebits = db->widebits;
         q.P = P; q.nseg_nodes = db->nseg_nodes; q.n_segs = db->n_nsegs; q.chain_cap = db->chain_cap;
-        q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.tbits = db->dense_narrow ? 0u : arena_table_bits(db->n_states); q.pool = pool_view(db, db->dense_narrow);
-        const size_t lds = k1n_wave_bytes(q.chain_cap, q.tbits) * K1N_WAVES;
+        q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.tbits = db->dense_narrow ? 0u : arena_table_bits(db->n_states); q.n_states = db->n_states;
+        q.pool = pool_view(db, db->dense_narrow);
+        const size_t lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_states) * K1N_WAVES;
         HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + K1N_WAVES - 1) / K1N_WAVES), dim3(WAVE * K1N_WAVES), lds, st, q);
         HIP_TRY(hipGetLastError());
@@ -1617,8 +1674,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
         const uint32_t batches = (n_wide + WAVE - 1) / WAVE;
         q.n_waves = std::min<uint32_t>(K1G_MAX_WAVES, batches);
-        q.tbits = db->dense_wide ? 0u : arena_table_bits(db->n_states);
-        const size_t lds = ((size_t)8 << q.tbits) * K1G_WAVES;
+        q.tbits = 0u; q.n_states = db->n_states;              // the wide kernel always writes into the wide pool: no open-chunk table
+        const size_t lds = arena_table_bytes(q.tbits, q.n_states) * K1G_WAVES;
         HIP_TRY(hipFuncSetAttribute((const void*)k1g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(K1GWave) * K1G_WAVES)));
         hipLaunchKernelGGL(k1g_kernel, dim3((q.n_waves + K1G_WAVES - 1) / K1G_WAVES), dim3(WAVE * K1G_WAVES), lds, st, q);
     }
@@ -1628,7 +1685,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     // ---- chunk table sorted by stream, K2 over windows of it
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort_tmp, db->sort_tmp_bytes, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id,
                                                (int)pool_cap, 0, db->key_bits, st));
-    hipLaunchKernelGGL(count_chunks_kernel, dim3(1), dim3(1), 0, st, db->sorted_key, pool_cap, db->n_states, db->counters);
+    hipLaunchKernelGGL(count_chunks_kernel, dim3(1), dim3(1), 0, st, db->sorted_key, pool_cap, db->n_states, db->wsub_cursor, db->counters);
     {
         hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
         HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, st));
@@ -1641,24 +1698,22 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                            pool_cap, M, (uint32_t)db->N, db->width);
     HIP_TRY(hipGetLastError());
     if (stage("apply")) return 1;
-    if (db->dense_wide || db->dense_narrow) {
-        // the mixed chunks: (stream, slot) of their records, sorted by stream, one tile per run
+    {
+        // the wide pool: records sorted by stream (the sort moves the 24-byte records with their keys), one tile per run
         uint32_t n_raw;
         if (db->have_counts) n_raw = db->last_n_raw;
         else {
             HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            n_raw = db->h_counters[KCTR_RAW];
+            n_raw = std::min<uint32_t>(db->h_counters[KCTR_RAW], (uint32_t)db->wide_pool_cap);
         }
         if (n_raw) {
-            hipLaunchKernelGGL(raw_expand_kernel, dim3(n_raw), dim3(64), 0, st, db->sorted_id, db->chunk_fill, db->rkey, db->counters, pool_cap, db->n_states,
-                               db->wkey, db->wslot);
             size_t tb = db->sort2_tmp_bytes;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, db->wslot, db->swslot, (int)((uint64_t)n_raw << CH_SHIFT), 0,
-                                                       db->key_bits, st));
-            const uint32_t g2 = (uint32_t)((((uint64_t)n_raw << CH_SHIFT) + K2S_WIN - 1) / K2S_WIN);
-            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->rec, db->recw, db->swkey, db->swslot, db->counters, db->n_states, M,
-                               (uint32_t)db->N, db->width);
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec,
+                                                       (int)((uint64_t)n_raw << WCH_SHIFT), 0, db->key_bits, st));
+            const uint32_t g2 = (uint32_t)((((uint64_t)n_raw << WCH_SHIFT) + K2S_WIN - 1) / K2S_WIN);
+            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, (uint32_t)((uint64_t)n_raw << WCH_SHIFT),
+                               db->n_states, M, (uint32_t)db->N, db->width);
             HIP_TRY(hipGetLastError());
         }
         if (stage("sorted apply")) return 1;
@@ -1672,26 +1727,38 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         db->fallback_reason = "a chain of more-than-two-block nodes does not fit the entry pool of the wide-node kernel";
         return 0;
     }
-    if (c[KCTR_PAIR_OVERFLOW] || c[KCTR_POOL_OVERFLOW]) {
+    if (c[KCTR_PAIR_OVERFLOW] || c[KCTR_POOL_OVERFLOW] || c[KCTR_WIDE_OVERFLOW]) {
         const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
         if (c[KCTR_PAIR_OVERFLOW]) {
             if (verbose) fprintf(stderr, "[kmdb] pair pool too small (%llu entries): doubling\n", (unsigned long long)db->pair_cap);
             if (alloc_pair_pool(db, db->pair_cap * 2)) return 1;
         }
+        if (c[KCTR_WIDE_OVERFLOW]) {
+            const uint64_t want = db->wide_pool_cap * 2;
+            if ((want << WCH_SHIFT) >= (1ull << 31)) {
+                db->fallback_reason = "more than 2^31 block records from the nodes with many blocks";
+                return 0;
+            }
+            if (verbose) fprintf(stderr, "[kmdb] wide record pool too small (%llu chunks): doubling\n", (unsigned long long)db->wide_pool_cap);
+            if (alloc_wide_pool(db, want)) return 1;
+        }
         if (c[KCTR_POOL_OVERFLOW]) {
             uint64_t want = db->pool_cap * 2;
-            if (!db->dense_narrow && db->n_states > (1u << ST_MAX_BITS) && db->pool_cap > 2 * (db->est_records / CH_REC + 65536)) {
-                // the estimate is long covered: the narrow kernel's chunks are being evicted nearly empty.  Dense mode for it as well.
+            if (!db->dense_narrow && db->n_states > (1u << ST_MAX_BITS) && (db->pool_cap << CH_SHIFT) > 8 * (db->est_records + (1u << 22))) {
+                // the estimate is long covered: the narrow kernel's chunks are being evicted nearly empty.  Wide pool for it as well.
                 db->dense_narrow = true;
-                want = db->est_records * 3 / 2 / CH_REC + (uint64_t)(db->n_nsegs + K1G_MAX_WAVES) * (ARENA_GRAB + 8) + 4096;
-                if (verbose) fprintf(stderr, "[kmdb] record chunks of the narrow kernel are evicted nearly empty: dense mode for it too\n");
-            } else if (want >= ((1ull << 31) >> CH_SHIFT) || (want << CH_SHIFT) * 48 > (160ull << 30)) {
+                if (verbose) fprintf(stderr, "[kmdb] record chunks of the narrow kernel are evicted nearly empty: its records go through the sort too\n");
+                if (alloc_wide_pool(db, db->wide_pool_cap + db->est_records * 5 / 4 / WCH_REC + (uint64_t)db->n_nsegs * (WIDE_GRAB + 2))) return 1;
+                want = 0;
+            } else if ((want << CH_SHIFT) >= (1ull << 31)) {
                 db->fallback_reason = "the record pool does not converge (" + std::to_string(db->n_states) + " streams, " +
                                       std::to_string(db->pool_cap) + " chunks were not enough)";
                 return 0;
             }
-            if (verbose) fprintf(stderr, "[kmdb] record pool too small (%llu chunks): %llu\n", (unsigned long long)db->pool_cap, (unsigned long long)want);
-            if (alloc_record_pool(db, want)) return 1;
+            if (want) {
+                if (verbose) fprintf(stderr, "[kmdb] record pool too small (%llu chunks): %llu\n", (unsigned long long)db->pool_cap, (unsigned long long)want);
+                if (alloc_record_pool(db, want)) return 1;
+            }
         }
         db->have_counts = false; *retry = true;
         return 0;
@@ -1701,7 +1768,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         db->have_counts = false; *retry = true;
         return 0;
     }
-    db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW];
+    db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW]; db->last_n_slow = c[KCTR_SLOW];
     db->last_records = (uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32);
     return 0;
 }

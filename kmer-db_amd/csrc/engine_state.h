@@ -26,9 +26,11 @@ enum : uint32_t {
     KCTR_PAIR_OVERFLOW,     // != 0: the pool of extra (block, mask) pairs was too small
     KCTR_NWIDE,             // nodes whose full list touches more than two blocks
     KCTR_LIST_OVERFLOW,     // != 0: a wide node's path did not fit the per-wave entry pool
-    KCTR_RAW = 5,           // dense mode: chunks with records of mixed streams
+    KCTR_RAW = 5,           // chunks of the wide pool in use (upper bound: busiest sub-pool x sub-pools)
     KCTR_RECORDS = 6,       // low word of the number of block records written (64-bit atomic: even index)
     KCTR_RECORDS_HI = 7,
+    KCTR_SLOW = 8,          // wide nodes that took the climbing path
+    KCTR_WIDE_OVERFLOW = 9, // != 0: the wide record pool was too small
     KCTR_COUNT = 16
 };
 constexpr uint32_t KMDB_PAIR_REGIONS = 4096;
@@ -69,8 +71,8 @@ struct kmdb_db {
     unsigned long long* pair_mask = nullptr;
     uint64_t pair_cap = 0;          // entries in total
     uint32_t* pair_cursor = nullptr;        // [KMDB_PAIR_REGIONS * 16] one cursor per region, a cache line apart
-    ulonglong2* fn_mask = nullptr;  // [P] (F0, F1) of the <= 2-block nodes that have children
-    uint32_t* fn_blk = nullptr;     // [P] their blocks: first | second << 16 (0xFFFF: none)
+    ulonglong2* fn_mask = nullptr;  // [P] for a node with more than two blocks whose parent has at most two: the parent's (F0, F1)
+    uint32_t* fn_blk = nullptr;     // [P] and its blocks: first | second << 16 (0xFFFF: none)
     unsigned long long* widebits = nullptr;  // [ceil(P / 64)] nodes with more than two blocks
     uint32_t* wide_cnt = nullptr;   // [words + 1] popcounts / their exclusive scan
     uint32_t* wide_base = nullptr;
@@ -88,10 +90,13 @@ struct kmdb_db {
     uint32_t* recw = nullptr;       // [pool_cap * 64] weights of the classes with w > 1
     uint64_t pool_cap = 0;          // chunks of 64 records, KMDB_SUBPOOLS interleaved sub-pools
     uint32_t* sub_cursor = nullptr; // [KMDB_SUBPOOLS * 16]
-    // dense mode (more streams than a wave's open-chunk table): records in arrival order + a device-wide sort by stream
+    // wide pool: records in arrival order + a device-wide sort by stream (the wide kernel always; the narrow kernel if its
+    // per-stream chunks do not work out)
     bool dense_wide = false, dense_narrow = false;
-    uint32_t* rkey = nullptr;       // [slots] stream of every record
-    uint32_t *wkey = nullptr, *wslot = nullptr, *swkey = nullptr, *swslot = nullptr;   // (stream, slot) of the mixed chunks' records, unsorted / sorted
+    uint32_t *wkey = nullptr, *swkey = nullptr;     // wide pool: stream of every record slot (0xFFFFFFFF = never written), and sorted
+    void *wrec = nullptr, *swrec = nullptr;         // wide pool: 24-byte records {rows, cols, w}, and sorted by stream
+    uint64_t wide_pool_cap = 0;     // chunks of 64 records
+    uint32_t* wsub_cursor = nullptr;
     void* sort2_tmp = nullptr;
     size_t sort2_tmp_bytes = 0;
     uint32_t* counters = nullptr;   // [KCTR_COUNT]
@@ -99,7 +104,7 @@ struct kmdb_db {
     uint64_t est_records = 0;       // sampled estimate for the chosen width
     // what the previous call found (the pipeline is deterministic per database: grid sizes of the next call)
     bool have_counts = false;
-    uint32_t last_n_wide = 0, last_n_chunks = 0, last_n_raw = 0;
+    uint32_t last_n_wide = 0, last_n_chunks = 0, last_n_raw = 0, last_n_slow = 0;
     uint64_t last_records = 0;
     uint32_t last_emit_lo = 0, last_emit_hi = 0;
     void* scan_tmp = nullptr;

@@ -26,7 +26,8 @@ for c in range(cases):
     max_local = int(rng.choice([1, 2, 5, 40, 200, 900]))
     width = int(rng.choice([0, 0, 32, 33, 47, 50, 63, 64]))
     nseg = int(rng.choice([0, 64, 192]))
-    pat = _random_forest(rng, N, P, max_local, heavy_frac=float(rng.random()) * 0.5, zero_frac=float(rng.random()) * 0.5)
+    chain = float(rng.choice([0.0, 0.0, 0.6, 0.9]))
+    pat = _random_forest(rng, N, P, max_local, heavy_frac=float(rng.random()) * 0.5, zero_frac=float(rng.random()) * 0.5, chain_frac=chain)
     arr = S.to_view_arrays(pat)
     view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
                        arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
@@ -49,7 +50,7 @@ for c in range(cases):
     d.close()
     if not ok:
         bad += 1
-        print("MISMATCH case", c, "N", N, "P", P, "max_local", max_local, "width", width, "nseg", nseg,
+        print("MISMATCH case", c, "N", N, "P", P, "max_local", max_local, "width", width, "nseg", nseg, "chain", chain,
               "diff cells", int((got != ref).sum()), flush=True)
 print("fuzz: %d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)

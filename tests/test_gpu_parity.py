@@ -403,10 +403,11 @@ def test_prefix_sharded_ranks_on_one_gpu(K, O, dev, tmp_path):
         assert np.array_equal(acc, full)
 
 
-def _random_forest(rng, N, P, max_local, heavy_frac=0.2, zero_frac=0.2):
+def _random_forest(rng, N, P, max_local, heavy_frac=0.2, zero_frac=0.2, chain_frac=0.0):
     """A random but valid pattern forest (not derived from genomes): pattern 0 is empty; every other
     pattern hangs under a random earlier pattern (or is a root) and owns 1..max_local ids larger than
-    everything above it.  Returns pattern dict in the format of synth.build_patterns."""
+    everything above it; with probability chain_frac the parent is the previous pattern (deep root paths that
+    cross many blocks).  Returns pattern dict in the format of synth.build_patterns."""
     import torch
     parent = np.full(P, -1, dtype=np.int64)
     nsam = np.zeros(P, dtype=np.int64)
@@ -414,8 +415,11 @@ def _random_forest(rng, N, P, max_local, heavy_frac=0.2, zero_frac=0.2):
     locs = [np.zeros(0, dtype=np.int64)]
     w = np.zeros(P, dtype=np.int64)
     for p in range(1, P):
-        for _ in range(20):
-            par = int(rng.integers(0, p)) if rng.random() < 0.85 else 0
+        for att in range(20):
+            if att == 0 and p > 1 and rng.random() < chain_frac:
+                par = p - 1
+            else:
+                par = int(rng.integers(0, p)) if rng.random() < 0.85 else 0
             lo = last[par] + 1 if par else 0
             if lo < N:
                 break
@@ -438,17 +442,18 @@ def _random_forest(rng, N, P, max_local, heavy_frac=0.2, zero_frac=0.2):
             "local_ptr": t(lp), "local_ids": t(np.concatenate(locs))}
 
 
-@pytest.mark.parametrize("seed,N,P,max_local", [(1, 2, 5, 1), (2, 64, 300, 5), (3, 65, 2000, 3), (4, 700, 6000, 40),
-                                                (5, 1024, 3000, 300), (6, 2048, 4000, 64), (7, 130, 20000, 2),
-                                                (8, 1500, 500, 1200)])
-def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local):
+@pytest.mark.parametrize("seed,N,P,max_local,chain", [(1, 2, 5, 1, 0), (2, 64, 300, 5, 0), (3, 65, 2000, 3, 0), (4, 700, 6000, 40, 0),
+                                                      (5, 1024, 3000, 300, 0), (6, 2048, 4000, 64, 0), (7, 130, 20000, 2, 0),
+                                                      (8, 1500, 500, 1200, 0), (9, 1000, 30000, 3, 0.9), (10, 1000, 60000, 2, 0.97),
+                                                      (11, 4000, 20000, 3, 0.95)])
+def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local, chain):
     """Fuzz: arbitrary valid pattern forests (deep chains, long local lists, zero and huge weights, lists
     longer than 1024 ids -> v1 fallback) through every all2all path, against the oracle's tree form AND
     flat form."""
     import importlib
     S = importlib.import_module("kmerdb_amd.synth")
     rng = np.random.default_rng(seed)
-    pat = _random_forest(rng, N, P, max_local)
+    pat = _random_forest(rng, N, P, max_local, chain_frac=chain)
     arr = S.to_view_arrays(pat)
     path = str(tmp_path / "f.db")
     S.write_db(path, 18, 1.0, ["s%d" % i for i in range(N)], [1] * N, arr)
