@@ -40,7 +40,7 @@
 
 namespace {
 
-constexpr uint32_t NCLS = 3;
+constexpr uint32_t NCLS = 1;               // streams per block pair (weights of all sizes share the stream, see K2)
 // weight classes: 0: w == 1 (no weight stored), 1: 2 <= w < 128 (one signed byte of an int8 MFMA operand),
 // 2: w >= 128 (rare: one popcount pass per bit plane)
 __host__ __device__ __forceinline__ uint32_t weight_class(uint32_t w) { return w == 1u ? 0u : w < 128u ? 1u : 2u; }
@@ -207,13 +207,15 @@ __device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot
     if (pv.dense) { rec_store_dense(pv, slot, rows, rows, w, stream); return; }
     const uint32_t ch = slot >> CH_SHIFT, r = slot & (CH_REC - 1u);
     ((unsigned long long*)(pv.rec + ((size_t)ch << (CH_SHIFT + 4))))[r] = rows;
-    if (cls) pv.recw[slot] = w;
+    (void)cls;
+    pv.recw[slot] = w;
 }
 __device__ __forceinline__ void rec_store_off(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t cls, uint32_t w,
                                               uint32_t stream) {
     if (pv.dense) { rec_store_dense(pv, slot, rows, cols, w, stream); return; }
     ((ulonglong2*)pv.rec)[slot] = make_ulonglong2(rows, cols);
-    if (cls) pv.recw[slot] = w;
+    (void)cls;
+    pv.recw[slot] = w;
 }
 
 __global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t n, uint32_t v) {
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         // ---- records (flat form): (w0, w0, F0), and with a second block (w1, w0, F1, F0) and (w1, w1, F1).  A diagonal
         // record needs two ids to have a pair.
         const bool act = valid && !wide && w != 0 && (nl & 0xFFFFu) >= 2u && w0 != BNONE && idx >= q.emit_lo && idx < q.emit_hi;
-        const uint32_t cls = weight_class(w);
+        const uint32_t cls = 0u;
         // the lanes of a batch mostly share the block: one reservation per block and weight class
         unsigned long long pend = __ballot(act && __popcll(F0) >= 2);
         while (pend) {
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                     FX = L.ent_mask[st + a * stride]; FY = L.ent_mask[st + b * stride];
                     const uint32_t X = L.ent_blk[st + a * stride], Y = L.ent_blk[st + b * stride];
                     ww = L.st_w[own];
-                    cl = weight_class(ww);
+                    cl = 0u;
                     diag = a == b;
                     rec_on = !diag || __popcll(FX) >= 2;           // a diagonal record needs two ids to have a pair
                     stream = (tri32(X) + Y) * NCLS + cl;
@@ -993,11 +995,12 @@ struct K2Item {
 };
 constexpr uint32_t CH_STEPS = CH_REC / 64u;
 // the 64 records of step st, one per lane (lanes beyond the fill get an empty record)
+template <bool SORTED>
 __device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t st, uint32_t lane, bool weighted, unsigned long long& R,
                                          unsigned long long& Cc, uint32_t& W) {
     R = 0; Cc = 0; W = 0;
     if (st >= it.count) return;
-    if (it.srec) {
+    if (SORTED) {
         const uint32_t p = st * 64u + lane;
         if (p < it.n_rec) {
             const WideRec r = it.srec[p];
@@ -1016,90 +1019,25 @@ __device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t s
     }
 }
 
-// Popcount form (weights >= 128 only).  A wave takes 64 records per step, one per lane, and turns them into bit
-// matrices over the records: lane c holds Ct = "which of the 64 records contain column c", and Rt_r = "which records
-// contain row r" is read from LDS.  cell(r, c) += popcount(Ct & Rt_r & plane_b) << b for every bit plane b of the
-// weights that occurs in the step.  The cells live in registers (lane c keeps column c of the 64 x 64 block, one
-// register per row) and are merged through LDS once per work item.
-// DIAG (X == Y, rows == cols): the block is symmetric and only c < r is wanted.  Lane c then takes the rows
-// (c + d) mod width for d = 1 .. width/2 instead of all rows: every unordered pair of samples exactly once (for an even
-// width the distance width/2 is kept by the lower half of the lanes) — half the row loop; the row mask is a per-lane
-// LDS read instead of a broadcast.
-template <bool DIAG>
-__device__ __forceinline__ void k2_apply_popc(const K2Item& it, uint32_t* __restrict__ M, uint32_t bwidth, uint32_t* acc, unsigned long long (*rtbuf)[64]) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t njs = DIAG ? bwidth / 2u : bwidth;                    // accumulators in use
-    const uint32_t wrapd = bwidth - lane;                                 // DIAG: row of accumulator j = lane + j + 1 (mod width)
-    uint32_t a[64];
-#pragma unroll
-    for (int r = 0; r < 64; ++r) a[r] = 0;
-    const unsigned long long* rt = rtbuf[wave];
-#define ROWMASK(j) (DIAG ? rt[((uint32_t)(j) + 1u < wrapd ? lane + (uint32_t)(j) + 1u : lane + (uint32_t)(j) + 1u - bwidth) & 63u] : rt[(j)])
-    unsigned long long nR = 0, nC = 0;
-    uint32_t nW = 0;
-    k2_fetch(it, DIAG, wave, lane, true, nR, nC, nW);
-    for (uint32_t ci = wave; ci < it.count; ci += 4) {
-        const unsigned long long R = nR, C = nC;
-        const uint32_t W = nW;
-        k2_fetch(it, DIAG, ci + 4, lane, true, nR, nC, nW);
-        if (!__ballot(R != 0)) continue;                           // the empty tail of a partly filled chunk
-        const unsigned long long Ct = transpose64(C, lane);
-        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
-        lds_sync();
-        uint32_t wor = W;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) wor |= (uint32_t)__shfl_xor((int)wor, d, WAVE);
-        wor = __builtin_amdgcn_readfirstlane(wor);
-        for (uint32_t wb = wor; wb; wb &= wb - 1) {
-            const uint32_t b = (uint32_t)__builtin_ctz(wb);
-            const unsigned long long Cb = Ct & __ballot(((W >> b) & 1u) != 0);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                if ((uint32_t)(g * 4) < njs) {
-                    asm volatile("" ::: "memory");    // keep a group's LDS reads together (register pressure)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { const int r = g * 4 + k; a[r] += (uint32_t)__popcll(Cb & ROWMASK(r)) << b; }
-                }
-            }
-        }
-        lds_sync();
-    }
-#undef ROWMASK
-    if (DIAG) {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const uint32_t d = (uint32_t)j + 1u;
-            if (d > njs || lane >= bwidth) continue;
-            if (2u * d == bwidth && lane >= d) continue;                 // even width: the opposite sample, once
-            const uint32_t r2 = d < wrapd ? lane + d : lane + d - bwidth;
-            const uint32_t row = r2 > lane ? r2 : lane, col = r2 > lane ? lane : r2;
-            if (a[j]) atomicAdd(&acc[row * 64 + col], a[j]);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 64; ++r)
-            if (a[r]) atomicAdd(&acc[r * 64 + lane], a[r]);
-    }
-}
-
-// The same accumulation on the matrix cores: over the 64 records of a step,
+// The accumulation of a run on the matrix cores: over the 64 records of a step,
 //     cell(r, c) += sum_k  w_k [r in rows_k] * [c in cols_k]    =  (A B)(r, c),   A = 64 x 64 int8 (rows x records, weighted),
 //                                                                                B = 64 x 64 int8 (records x cols, 0/1)
 // as eight v_mfma_i32_32x32x32_i8 (operand layout probed in profiles/r01_mfma_i8_layout_probe.hip: lane l holds
 // A[l & 31][16 (l >> 5) + j], B[16 (l >> 5) + j][l & 31], j < 16; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).
 // The bit matrices R^T / C^T of the step are parked in LDS; a lane turns 16 of their bits into 16 operand bytes with two
-// reads of a 256-entry byte-spreading table and ANDs the weights in.  The work does not depend on the weights, so
-// every weight below 128 costs the same as 1.  Exact: integer MACs, no rounding anywhere.
+// reads of a 256-entry byte-spreading table and ANDs the weights in.  An int8 operand holds a weight below 128: a larger
+// weight is split into base-128 digits, the run is accumulated once per digit that occurs (`digit`), and the digit's tile is
+// merged shifted left by 7 * digit — exact in the matrix's uint32 wrap-around arithmetic.  Almost every weight is below 128
+// (99.98 % at the benchmark database), so nearly every run takes one pass.  Returns (to every thread) the OR of the weights.
 typedef int k2_v4i __attribute__((ext_vector_type(4)));
 typedef int k2_v16i __attribute__((ext_vector_type(16)));
 
-template <bool WEIGHTED, bool DIAG>
-__device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
-                                              unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01) {
+template <bool DIAG, bool SORTED>
+__device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t digit, uint32_t* acc, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
+                                                  unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t half = lane >> 5, l31 = lane & 31u;
     k2_v16i c00 = {}, c01 = {}, c10 = {}, c11 = {};
-    const unsigned long long* lut_a = WEIGHTED ? lut_ff : lut_01;
     auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> k2_v4i {
         const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
         const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
@@ -1108,17 +1046,18 @@ __device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, u
         return r;
     };
     unsigned long long nR = 0, nC = 0;
-    uint32_t nW = 0;
-    k2_fetch(it, DIAG, wave, lane, WEIGHTED, nR, nC, nW);
+    uint32_t nW = 0, wor = 0;
+    k2_fetch<SORTED>(it, DIAG, wave, lane, true, nR, nC, nW);
     for (uint32_t ci = wave; ci < it.count; ci += 4) {
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
-        k2_fetch(it, DIAG, ci + 4, lane, WEIGHTED, nR, nC, nW);
+        k2_fetch<SORTED>(it, DIAG, ci + 4, lane, true, nR, nC, nW);
         if (!__ballot(R != 0)) continue;                           // the empty tail of a partly filled chunk
+        wor |= W;
         const unsigned long long Ct = transpose64(C, lane);
-        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);
+        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
         if (!DIAG) ctbuf[wave][lane] = Ct;
-        if (WEIGHTED) wbuf[wave][lane] = (unsigned char)W;
+        wbuf[wave][lane] = (unsigned char)((W >> (7u * digit)) & 127u);
         lds_sync();
         const unsigned long long* rtp = rtbuf[wave];
         const unsigned long long* ctp = DIAG ? rtbuf[wave] : ctbuf[wave];
@@ -1126,11 +1065,9 @@ __device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, u
 #pragma unroll
         for (uint32_t kh = 0; kh < 2; ++kh) {
             const uint32_t shift = 32u * kh + 16u * half;            // records 32 kh + 16 half .. + 15 of the step
-            k2_v4i a0 = spread(ra0, shift, lut_a), a1 = spread(ra1, shift, lut_a);
-            if (WEIGHTED) {
-                const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
-                a0 &= wv; a1 &= wv;
-            }
+            k2_v4i a0 = spread(ra0, shift, lut_ff), a1 = spread(ra1, shift, lut_ff);
+            const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
+            a0 &= wv; a1 &= wv;
             const k2_v4i b0 = spread(cb0, shift, lut_01), b1 = spread(cb1, shift, lut_01);
             c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
             c01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, c01, 0, 0, 0);
@@ -1140,19 +1077,50 @@ __device__ __forceinline__ void k2_apply_mfma(const K2Item& it, uint32_t* acc, u
         lds_sync();
     }
     // merge the four waves' tiles through the LDS block (on the diagonal only c < r)
+    const uint32_t sh = 7u * digit;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
-        const uint32_t v00 = (uint32_t)c00[r], v01 = (uint32_t)c01[r], v10 = (uint32_t)c10[r], v11 = (uint32_t)c11[r];
+        const uint32_t v00 = (uint32_t)c00[r] << sh, v01 = (uint32_t)c01[r] << sh, v10 = (uint32_t)c10[r] << sh, v11 = (uint32_t)c11[r] << sh;
         if (v00 && (!DIAG || l31 < row0)) atomicAdd(&acc[row0 * 64 + l31], v00);
         if (v01 && (!DIAG || 32u + l31 < row0)) atomicAdd(&acc[row0 * 64 + 32u + l31], v01);
         if (v10 && (!DIAG || l31 < 32u + row0)) atomicAdd(&acc[(32u + row0) * 64 + l31], v10);
         if (v11 && (!DIAG || l31 < row0)) atomicAdd(&acc[(32u + row0) * 64 + 32u + l31], v11);
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wor |= (uint32_t)__shfl_xor((int)wor, d, WAVE);
+    return wor;
+}
+
+// one run (the records of one block pair inside a window): accumulate, once per weight digit that occurs, and flush the tile
+template <bool SORTED>
+__device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t* wor_sh, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
+                                       unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01,
+                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
+    if (threadIdx.x == 0) *wor_sh = 0;
+    __syncthreads();
+    for (uint32_t digit = 0; digit < 5; ++digit) {
+        const uint32_t wor = it.X == it.Y ? k2_apply_mfma<true, SORTED>(it, digit, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01)
+                                          : k2_apply_mfma<false, SORTED>(it, digit, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        if ((threadIdx.x & 63u) == 0 && wor) atomicOr(wor_sh, wor);
+        __syncthreads();
+        if ((*wor_sh >> (7u * (digit + 1u))) == 0) break;           // no weight has a higher digit
+        __syncthreads();
+    }
+    // one HBM atomic per non-zero cell of the block
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
+        const uint32_t v = acc[k];
+        if (!v) continue;
+        const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
+        if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
+    }
+    __syncthreads();
 }
 
 constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup (8192 records)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
                                                        const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
                                                        const uint32_t* __restrict__ chunk_fill, uint32_t n_states, uint32_t pool_cap,
                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
@@ -1162,6 +1130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
     __shared__ uint32_t s_key[K2_WIN], s_id[K2_WIN], s_fill[K2_WIN];
+    __shared__ uint32_t wor_sh;
     // the window: K2_WIN chunks of the stream-sorted chunk table (never-opened chunks sort last)
     if (threadIdx.x < K2_WIN) {
         const uint32_t j = blockIdx.x * K2_WIN + threadIdx.x;
@@ -1193,26 +1162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             it.X = X; it.Y = bucket - tri32(X);
             it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw;
         }
-        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
-        __syncthreads();
-        if (it.X == it.Y) {
-            if (it.cls == 0) k2_apply_mfma<false, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else if (it.cls == 1) k2_apply_mfma<true, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else k2_apply_popc<true>(it, M, bwidth, acc, rtbuf);
-        } else {
-            if (it.cls == 0) k2_apply_mfma<false, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else if (it.cls == 1) k2_apply_mfma<true, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else k2_apply_popc<false>(it, M, bwidth, acc, rtbuf);
-        }
-        // one HBM atomic per non-zero cell of the block
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
-            const uint32_t v = acc[k];
-            if (!v) continue;
-            const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
-            if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
-        }
-        __syncthreads();
+        k2_run<false>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
         a = b;
     }
 }
@@ -1229,7 +1179,7 @@ __global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uin
 }
 
 // K2 over records sorted by stream (dense mode): a window of K2S_WIN sorted positions, one 64 x 64 tile per run of equal streams
-constexpr uint32_t K2S_WIN = 8192;
+constexpr uint32_t K2S_WIN = 4096;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
                                                         uint32_t total, uint32_t n_states,
                                                         uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
@@ -1239,6 +1189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];
     __shared__ uint16_t bnd[K2S_WIN + 2];          // run starts inside the window, then the end
+    __shared__ uint32_t wor_sh;
     __shared__ uint32_t tcount[256];
     const uint32_t p0 = blockIdx.x * K2S_WIN;
     if (p0 >= total || swkey[p0] >= n_states) return;
@@ -1255,10 +1206,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const uint32_t t0 = threadIdx.x * PER;
     uint32_t prev = (t0 == 0 || t0 >= wend) ? 0xFFFFFFFFu : swkey[p0 + t0 - 1];
     uint32_t mine = 0, flags = 0;
-    for (uint32_t i = 0; i < PER && t0 + i < wend; ++i) {
-        const uint32_t k = swkey[p0 + t0 + i];
-        if (k != prev) { flags |= 1u << i; ++mine; }               // the first never-written slot starts a last "run" that ends the loop below
-        prev = k;
+    uint32_t kk[PER];                                              // the thread's 32 keys: 8 loads of 16 bytes in flight together
+    if (t0 + PER <= wend) {
+#pragma unroll
+        for (uint32_t v = 0; v < PER / 4; ++v) {
+            const uint4 q4 = ((const uint4*)(swkey + p0 + t0))[v];
+            kk[4 * v] = q4.x; kk[4 * v + 1] = q4.y; kk[4 * v + 2] = q4.z; kk[4 * v + 3] = q4.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) kk[i] = t0 + i < wend ? swkey[p0 + t0 + i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+        if (t0 + i < wend && kk[i] != prev) { flags |= 1u << i; ++mine; }      // the first never-written slot starts a last "run" that ends the loop below
+        prev = kk[i];
     }
     tcount[threadIdx.x] = mine;
     __syncthreads();
@@ -1289,26 +1251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             it.X = X; it.Y = bucket - tri32(X);
             it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.rec = nullptr; it.recw = nullptr;
         }
-        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
-        __syncthreads();
-        // dense records always carry both masks: the off-diagonal code path reads them; the diagonal tile keeps c < r
-        if (it.X == it.Y) {
-            if (it.cls == 0) k2_apply_mfma<false, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else if (it.cls == 1) k2_apply_mfma<true, true>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else k2_apply_popc<true>(it, M, bwidth, acc, rtbuf);
-        } else {
-            if (it.cls == 0) k2_apply_mfma<false, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else if (it.cls == 1) k2_apply_mfma<true, false>(it, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
-            else k2_apply_popc<false>(it, M, bwidth, acc, rtbuf);
-        }
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
-            const uint32_t v = acc[k];
-            if (!v) continue;
-            const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
-            if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
-        }
-        __syncthreads();
+        k2_run<true>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
     }
 }
 
