@@ -1047,12 +1047,18 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
     };
     unsigned long long nR = 0, nC = 0;
     uint32_t nW = 0, wor = 0;
-    k2_fetch<SORTED>(it, DIAG, wave, lane, true, nR, nC, nW);
-    for (uint32_t ci = wave; ci < it.count; ci += 4) {
+    // this wave's steps: every fourth one; in chunk mode the steps past a chunk's fill are skipped without a fetch
+    auto next_step = [&](uint32_t st) -> uint32_t {
+        if (!SORTED) while (st < it.count && (st % CH_STEPS) * 64u >= it.fills[st / CH_STEPS]) st += 4;
+        return st;
+    };
+    uint32_t cur = next_step(wave);
+    k2_fetch<SORTED>(it, DIAG, cur, lane, true, nR, nC, nW);
+    while (cur < it.count) {
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
-        k2_fetch<SORTED>(it, DIAG, ci + 4, lane, true, nR, nC, nW);
-        if (!__ballot(R != 0)) continue;                           // the empty tail of a partly filled chunk
+        cur = next_step(cur + 4);
+        k2_fetch<SORTED>(it, DIAG, cur, lane, true, nR, nC, nW);
         wor |= W;
         const unsigned long long Ct = transpose64(C, lane);
         rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
@@ -1178,10 +1184,43 @@ __global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uin
     counters[KCTR_RAW] = mx * KMDB_SUBPOOLS;                    // chunk ids below this bound cover every written record
 }
 
+// Counting sort of the wide pool by stream, for up to CS_MAX_KEYS streams: per-block histograms in LDS (no device atomics),
+// one exclusive scan over the [stream][block] table, then every block moves its records to its own range of every stream.
+// The order inside a stream is arbitrary (uint32 adds commute).  Two reads of the keys, one read and one write of the records.
+constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, uint32_t n_keys, uint32_t per_block, uint32_t* __restrict__ H) {
+    extern __shared__ uint32_t cs_lds[];
+    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cs_lds[k] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
+    if (lo < n)
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) { const uint32_t key = wkey[i]; if (key < n_keys) atomicAdd(&cs_lds[key], 1u); }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) H[(size_t)k * CS_BLOCKS + blockIdx.x] = cs_lds[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)n_keys * CS_BLOCKS] = 0;          // the scan leaves the total here
+}
+__global__ __launch_bounds__(256) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
+                                                         uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
+                                                         WideRec* __restrict__ swrec) {
+    extern __shared__ uint32_t cs_lds[];
+    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cs_lds[k] = O[(size_t)k * CS_BLOCKS + blockIdx.x];
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
+    if (lo >= n) return;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint32_t key = wkey[i];
+        if (key < n_keys) {
+            const uint32_t pos = atomicAdd(&cs_lds[key], 1u);
+            swrec[pos] = wrec[i];
+            swkey[pos] = key;
+        }
+    }
+}
+
 // K2 over records sorted by stream (dense mode): a window of K2S_WIN sorted positions, one 64 x 64 tile per run of equal streams
 constexpr uint32_t K2S_WIN = 4096;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
-                                                        uint32_t total, uint32_t n_states,
+                                                        uint32_t limit, const uint32_t* __restrict__ total_ptr, uint32_t n_states,
                                                         uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
@@ -1191,6 +1230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ uint16_t bnd[K2S_WIN + 2];          // run starts inside the window, then the end
     __shared__ uint32_t wor_sh;
     __shared__ uint32_t tcount[256];
+    const uint32_t total = total_ptr ? (*total_ptr < limit ? *total_ptr : limit) : limit;      // counting sort: the valid records; radix sort: all slots
     const uint32_t p0 = blockIdx.x * K2S_WIN;
     if (p0 >= total || swkey[p0] >= n_states) return;
     const uint32_t wend = total - p0 < K2S_WIN ? total - p0 : K2S_WIN;
@@ -1385,6 +1425,13 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, db->sort2_tmp_bytes, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)slots, 0, db->key_bits,
                                                db->stream));
     HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
+    if (db->n_states <= CS_MAX_KEYS && !db->cs_hist) {
+        const size_t ne = (size_t)db->n_states * CS_BLOCKS + 1;
+        HIP_TRY(hipMalloc((void**)&db->cs_hist, ne * 4));
+        HIP_TRY(hipMalloc((void**)&db->cs_offs, ne * 4));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->cs_tmp_bytes, db->cs_hist, db->cs_offs, (int)ne, db->stream));
+        HIP_TRY(hipMalloc(&db->cs_tmp, std::max<size_t>(db->cs_tmp_bytes, 16)));
+    }
     db->wide_pool_cap = chunks;
     return 0;
 }
@@ -1515,7 +1562,7 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->pair_cursor); FREE_NULL(db->fn_mask); FREE_NULL(db->fn_blk); FREE_NULL(db->widebits); FREE_NULL(db->wide_cnt);
     FREE_NULL(db->wide_base); FREE_NULL(db->widx); FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key);
     FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota); FREE_NULL(db->sort_tmp);
-    FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor);
+    FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_tmp);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
     db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
@@ -1651,11 +1698,24 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             n_raw = std::min<uint32_t>(db->h_counters[KCTR_RAW], (uint32_t)db->wide_pool_cap);
         }
         if (n_raw) {
-            size_t tb = db->sort2_tmp_bytes;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec,
-                                                       (int)((uint64_t)n_raw << WCH_SHIFT), 0, db->key_bits, st));
-            const uint32_t g2 = (uint32_t)((((uint64_t)n_raw << WCH_SHIFT) + K2S_WIN - 1) / K2S_WIN);
-            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, (uint32_t)((uint64_t)n_raw << WCH_SHIFT),
+            const uint32_t nslots = (uint32_t)((uint64_t)n_raw << WCH_SHIFT);
+            const uint32_t* total_ptr = nullptr;
+            if (db->cs_hist) {
+                const uint32_t per_block = ((nslots + CS_BLOCKS - 1) / CS_BLOCKS + 255u) / 256u * 256u;
+                const size_t ne = (size_t)db->n_states * CS_BLOCKS + 1;
+                hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, per_block, db->cs_hist);
+                size_t tb = db->cs_tmp_bytes;
+                HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
+                hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(256), db->n_states * 4, st, db->wkey, (const WideRec*)db->wrec, nslots, db->n_states,
+                                   per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                total_ptr = db->cs_offs + (ne - 1);
+            } else {
+                size_t tb = db->sort2_tmp_bytes;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)nslots, 0,
+                                                           db->key_bits, st));
+            }
+            const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
+            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, nslots, total_ptr,
                                db->n_states, M, (uint32_t)db->N, db->width);
             HIP_TRY(hipGetLastError());
         }

@@ -1,30 +1,33 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs of collect_profiles.sh into the small files committed under profiles/:
-<tag>_kernel_stats.csv (our kernels only) and <tag>_traffic.json (HBM bytes per pass per kernel from the PMC
+<tag>_kernel_stats.csv (the kernels of the all2all call only) and <tag>_traffic.json (HBM bytes per call per kernel from the PMC
 counters FETCH_SIZE / WRITE_SIZE, which rocprofv3 reports in KB)."""
 import csv, json, os, sys
 from collections import defaultdict
 
 tag, fetch_csv, write_csv, out = sys.argv[1:5]
+CALLS = 1 + 1 + 2          # bench.py --steps 2 --warmup 1: the cold call, one warm-up, two timed calls
+OURS = ("k0_decode_kernel", "k1n_kernel", "k1g_kernel", "k2_apply_kernel", "k2_sorted_kernel", "wide_count_kernel", "wide_expand_kernel",
+        "count_chunks_kernel", "fill_u32_kernel")
 
 
 def short(name):
-    for k in ("b3_decode_kernel", "b3_narrow_kernel", "b3_emit_kernel", "b2_apply_kernel", "b2_emit_kernel"):
+    for k in OURS:
         if k in name:
             return k
+    if "rocprim" in name and ("radix" in name or "onesweep" in name):
+        return "rocprim radix sort (chunk table, wide records)"
+    if "rocprim" in name and ("scan" in name or "reduce" in name):
+        return "rocprim scan / reduce"
+    if "fillBuffer" in name:
+        return "memset (matrix, chunk table, wide-pool keys, cursors)"
+    if "cs_hist_kernel" in name or "cs_scatter_kernel" in name:
+        return "counting sort of the wide pool"
     return None
 
 
-def count_mode(name):
-    """upload-time instantiations: decode<true, *>, emit<*, false, *>, narrow<false>"""
-    return ("b3_decode_kernel<true" in name or "b3_narrow_kernel<false>" in name or
-            ("b3_emit_kernel<" in name and name.split("b3_emit_kernel<")[1].split(",")[1].strip() == "false") or
-            ("b2_emit_kernel<false>" in name))
-
-
 def per_kernel(path):
-    """bytes per kernel over the dispatches of the timed passes only: everything after the last upload-time
-    (count mode) dispatch"""
+    """KB per kernel over the dispatches of the all2all calls: everything after the last upload kernel (lay_* / width estimate)"""
     tot, cnt = defaultdict(float), defaultdict(int)
     if not os.path.exists(path):
         return tot, cnt
@@ -34,7 +37,8 @@ def per_kernel(path):
         rows.sort(key=lambda r: int(r[key]))
     last_upload = -1
     for i, row in enumerate(rows):
-        if count_mode(row.get("Kernel_Name", "")):
+        n = row.get("Kernel_Name", "")
+        if "lay_" in n or "width_estimate" in n or "iota_u32" in n:
             last_upload = i
     for row in rows[last_upload + 1:]:
         k = short(row.get("Kernel_Name", ""))
@@ -45,23 +49,30 @@ def per_kernel(path):
     return tot, cnt
 
 
-PASSES = 3      # --steps 2 --warmup 1
+stats_all = os.path.join(out, tag + "_kernel_stats_all.csv")
+if os.path.exists(stats_all):
+    rows = list(csv.DictReader(open(stats_all)))
+    keep = [r for r in rows if any(k in r["Name"] for k in OURS + ("lay_", "width_estimate")) or
+            ("rocprim" in r["Name"] and "at::" not in r["Name"] and 5 <= int(r["Calls"]) <= 64)]
+    with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as f:
+        wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        wr.writeheader()
+        for r in keep:
+            r = dict(r)
+            r["Name"] = r["Name"].replace("(anonymous namespace)::", "")[:160]
+            wr.writerow(r)
+
 fetch, nf = per_kernel(fetch_csv)
 write, nw = per_kernel(write_csv)
-res = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (--kernel-trace --kernel-include-regex 'b3_|b2_'), "
-                 "python bench.py --no-cpu-baseline --steps 2 --warmup 1, mean over the %d passes; counters are KB, x1024; FETCH_SIZE can "
-                 "under-count wide coalesced reads by up to 2x on gfx950 (MI355X_MICROARCH.md, HBM section), so this is a lower bound" % PASSES,
-       "fetch_bytes": {k: v * 1024 / PASSES for k, v in fetch.items()},
-       "write_bytes": {k: v * 1024 / PASSES for k, v in write.items()},
-       "dispatch_rows": {"fetch": dict(nf), "write": dict(nw)}}
-res["traffic_bytes_per_pass"] = sum(res["fetch_bytes"].values()) + sum(res["write_bytes"].values())
-json.dump(res, open(os.path.join(out, tag + "_traffic.json"), "w"), indent=1)
-print(json.dumps(res, indent=1))
-
-allstats = os.path.join(out, tag + "_kernel_stats_all.csv")
-if os.path.exists(allstats):
-    with open(allstats) as f, open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as g:
-        for i, line in enumerate(f):
-            if i == 0 or short(line):
-                g.write(line)
-    os.remove(allstats)
+if fetch or write:
+    res = {"pipeline": "r02",
+           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (--kernel-trace), python bench.py --no-cpu-baseline "
+                     "--steps 2 --warmup 1, mean over its %d all2all calls (the dispatches after the last upload kernel); counters are KB, "
+                     "x1024; FETCH_SIZE can under-count wide coalesced reads by up to 2x on gfx950 (MI355X_MICROARCH.md, HBM section), so this "
+                     "is a lower bound" % CALLS,
+           "fetch_bytes": {k: v * 1024 / CALLS for k, v in fetch.items()},
+           "write_bytes": {k: v * 1024 / CALLS for k, v in write.items()},
+           "dispatch_rows": {"fetch": dict(nf), "write": dict(nw)}}
+    res["traffic_bytes_per_pass"] = sum(res["fetch_bytes"].values()) + sum(res["write_bytes"].values())
+    json.dump(res, open(os.path.join(out, tag + "_traffic.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1))
