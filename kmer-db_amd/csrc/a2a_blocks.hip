@@ -40,10 +40,6 @@
 
 namespace {
 
-constexpr uint32_t NCLS = 1;               // streams per block pair (weights of all sizes share the stream, see K2)
-// weight classes: 0: w == 1 (no weight stored), 1: 2 <= w < 128 (one signed byte of an int8 MFMA operand),
-// 2: w >= 128 (rare: one popcount pass per bit plane)
-__host__ __device__ __forceinline__ uint32_t weight_class(uint32_t w) { return w == 1u ? 0u : w < 128u ? 1u : 2u; }
 __host__ __device__ __forceinline__ uint32_t tri32(uint32_t x) { return x * (x + 1u) / 2u; }
 
 __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
@@ -96,8 +92,9 @@ struct WaveArena {
     uint32_t tmask;
     uint32_t direct;
     uint32_t sub;                  // this wave's sub-pool
-    uint32_t stock, next;          // wave-uniform: chunks left of the last grab, the next of them (index inside the sub-pool)
-    uint32_t dslot;                // dense mode: next slot of the wave's one open chunk (0 with dopen == 0: none)
+    uint32_t stock, next;          // wave-uniform: stream chunks left of the last grab, the next of them (index inside the sub-pool)
+    uint32_t wstock, wnext;        // the same for the wide pool
+    uint32_t dslot;                // wide pool: next slot of the wave's one open chunk (dopen == 0: none)
     uint32_t dopen;
 };
 constexpr uint32_t ARENA_GRAB = 4;         // stream chunks (256 records) per grab
@@ -107,14 +104,15 @@ __host__ __device__ inline uint32_t arena_table_bits(uint32_t n_states) {
     while (b < ST_MAX_BITS && (1u << b) < n_states) ++b;
     return b;
 }
-__host__ __device__ inline size_t arena_table_bytes(uint32_t tbits, uint32_t n_states) {
+// the table is indexed by block: only the records (X, X) of a list's first block go through stream chunks
+__host__ __device__ inline size_t arena_table_bytes(uint32_t tbits, uint32_t n_keys) {
     if (tbits == 0) return 16;
-    return ((size_t)4 << tbits) * (n_states <= (1u << tbits) ? 1 : 2);
+    return ((size_t)4 << tbits) * (n_keys <= (1u << tbits) ? 1 : 2);
 }
 __device__ __forceinline__ void arena_init(WaveArena& A, uint32_t* lds, uint32_t tbits, uint32_t n_states, uint32_t wave_id, uint32_t lane) {
     A.direct = n_states <= (1u << tbits) ? 1u : 0u;
     A.t_slot = lds; A.t_key = lds + (1u << tbits); A.tmask = (1u << tbits) - 1u;
-    A.sub = wave_id % KMDB_SUBPOOLS; A.stock = 0; A.next = 0; A.dslot = 0; A.dopen = 0;
+    A.sub = wave_id % KMDB_SUBPOOLS; A.stock = 0; A.next = 0; A.wstock = 0; A.wnext = 0; A.dslot = 0; A.dopen = 0;
     if (tbits == 0) return;                                   // dense mode: no table
     for (uint32_t e = lane; e <= A.tmask; e += WAVE) { A.t_slot[e] = KEY_NONE; if (!A.direct) A.t_key[e] = KEY_NONE; }
     lds_sync();
@@ -137,7 +135,7 @@ __device__ __forceinline__ uint32_t arena_take(WaveArena& A, const PoolView& pv,
 }
 // next chunk of the wide pool
 __device__ __forceinline__ uint32_t arena_take_wide(WaveArena& A, const PoolView& pv, uint32_t lane) {
-    if (A.stock == 0) {
+    if (A.wstock == 0) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&pv.wsub_cursor[A.sub * 16u], WIDE_GRAB);
         base = bcast(base, 0);
@@ -145,25 +143,26 @@ __device__ __forceinline__ uint32_t arena_take_wide(WaveArena& A, const PoolView
             if (lane == 0) atomicOr(&pv.counters[KCTR_WIDE_OVERFLOW], 1u);
             base = pv.wsub_cap - WIDE_GRAB;
         }
-        A.next = base; A.stock = WIDE_GRAB;
+        A.wnext = base; A.wstock = WIDE_GRAB;
     }
-    const uint32_t id = A.next * KMDB_SUBPOOLS + A.sub;
-    ++A.next; --A.stock;
+    const uint32_t id = A.wnext * KMDB_SUBPOOLS + A.sub;
+    ++A.wnext; --A.wstock;
     return id;
 }
 // cnt (1..64) slots of stream s; s and cnt wave-uniform, every lane of the wave calls
-__device__ __forceinline__ Resv arena_reserve(WaveArena& A, const PoolView& pv, uint32_t s, uint32_t cnt, uint32_t lane) {
-    if (pv.dense) {
-        // records of all streams share the wave's one open chunk; they are grouped by a device-wide sort afterwards
-        if (!A.dopen) { A.dslot = arena_take_wide(A, pv, lane) << WCH_SHIFT; A.dopen = 1; }
-        const uint32_t v = A.dslot, rem = WCH_REC - (v & (WCH_REC - 1u));
-        if (cnt < rem) { A.dslot = v + cnt; return Resv{v, cnt, 0u}; }
-        if (cnt == rem) { A.dopen = 0; return Resv{v, cnt, 0u}; }
-        const uint32_t nv = arena_take_wide(A, pv, lane) << WCH_SHIFT;
-        A.dslot = nv + (cnt - rem);
-        return Resv{v, rem, nv};
-    }
-    const uint32_t e = s & A.tmask;
+// cnt (1..64) slots of the wide pool: records of all streams share the wave's one open chunk, a device-wide sort groups them
+__device__ __forceinline__ Resv arena_reserve_wide(WaveArena& A, const PoolView& pv, uint32_t cnt, uint32_t lane) {
+    if (!A.dopen) { A.dslot = arena_take_wide(A, pv, lane) << WCH_SHIFT; A.dopen = 1; }
+    const uint32_t v = A.dslot, rem = WCH_REC - (v & (WCH_REC - 1u));
+    if (cnt < rem) { A.dslot = v + cnt; return Resv{v, cnt, 0u}; }
+    if (cnt == rem) { A.dopen = 0; return Resv{v, cnt, 0u}; }
+    const uint32_t nv = arena_take_wide(A, pv, lane) << WCH_SHIFT;
+    A.dslot = nv + (cnt - rem);
+    return Resv{v, rem, nv};
+}
+// cnt (1..64) slots of stream s, whose open chunk lives in table entry `ent`; all arguments wave-uniform, every lane calls
+__device__ __forceinline__ Resv arena_reserve(WaveArena& A, const PoolView& pv, uint32_t ent, uint32_t s, uint32_t cnt, uint32_t lane) {
+    const uint32_t e = ent & A.tmask;
     uint32_t v = A.t_slot[e];
     if (A.direct) {
         if (v == KEY_NONE) v = arena_take(A, pv, s, lane) << CH_SHIFT;
@@ -191,7 +190,7 @@ __device__ __forceinline__ Resv arena_reserve(WaveArena& A, const PoolView& pv, 
     return r;
 }
 __device__ __forceinline__ void arena_finish(const WaveArena& A, const PoolView& pv, uint32_t lane) {
-    if (pv.dense) return;                                       // never-written slots of the wide pool keep their 0xFFFFFFFF key
+    if (A.tmask == 0) return;                                   // no stream table (never-written slots of the wide pool keep their 0xFFFFFFFF key)
     for (uint32_t e = lane; e <= A.tmask; e += WAVE) {
         const uint32_t v = A.t_slot[e];
         if (v != KEY_NONE && (A.direct || A.t_key[e] != KEY_NONE)) pv.chunk_fill[v >> CH_SHIFT] = v & (CH_REC - 1u);
@@ -199,22 +198,14 @@ __device__ __forceinline__ void arena_finish(const WaveArena& A, const PoolView&
 }
 
 // diagonal streams (X == Y, cols == rows) pack 8-byte rows into the first half of their chunks
-__device__ __forceinline__ void rec_store_dense(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t w, uint32_t stream) {
+__device__ __forceinline__ void rec_store_wide(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t w, uint32_t stream) {
     pv.wrec[slot] = WideRec{rows, cols, w, 0u};
     pv.wkey[slot] = stream;
 }
-__device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t cls, uint32_t w, uint32_t stream) {
-    if (pv.dense) { rec_store_dense(pv, slot, rows, rows, w, stream); return; }
+// stream chunks hold the records (X, X, rows) of one block X: 8-byte rows in the first half of the chunk, weights beside
+__device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t w) {
     const uint32_t ch = slot >> CH_SHIFT, r = slot & (CH_REC - 1u);
     ((unsigned long long*)(pv.rec + ((size_t)ch << (CH_SHIFT + 4))))[r] = rows;
-    (void)cls;
-    pv.recw[slot] = w;
-}
-__device__ __forceinline__ void rec_store_off(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t cls, uint32_t w,
-                                              uint32_t stream) {
-    if (pv.dense) { rec_store_dense(pv, slot, rows, cols, w, stream); return; }
-    ((ulonglong2*)pv.rec)[slot] = make_ulonglong2(rows, cols);
-    (void)cls;
     pv.recw[slot] = w;
 }
 
@@ -446,7 +437,8 @@ struct NParams {
     unsigned long long* widebits;
     uint32_t P, nseg_nodes, n_segs, chain_cap;
     uint32_t emit_lo, emit_hi;
-    uint32_t tbits, n_states;      // log2 of the open-chunk table, streams
+    uint32_t tbits, n_keys;        // log2 of the open-chunk table, blocks
+    uint32_t all_wide;             // 1: every record through the wide pool (the stream chunks did not work out)
     PoolView pool;
 };
 constexpr int K1N_WAVES = 4;
@@ -458,9 +450,9 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg = blockIdx.x * K1N_WAVES + wave;
     if (seg >= q.n_segs) return;
-    unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits, q.n_states) * wave;
+    unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys) * wave;
     uint32_t* table = (uint32_t*)wbase;                                                      // open chunks
-    ulonglong2* chain_m = (ulonglong2*)(wbase + arena_table_bytes(q.tbits, q.n_states));    // [chain_cap] one slot per depth:
+    ulonglong2* chain_m = (ulonglong2*)(wbase + arena_table_bytes(q.tbits, q.n_keys));      // [chain_cap] one slot per depth:
     uint32_t* chain_b = (uint32_t*)(chain_m + q.chain_cap);                                  // the latest node of that depth on the current root path
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t first = seg * q.nseg_nodes;
@@ -518,7 +510,7 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     };
     fetch(first);
     WaveArena A;
-    arena_init(A, table, q.tbits, q.n_states, seg, lane);
+    arena_init(A, table, q.tbits, q.n_keys, seg, lane);
     for (uint32_t base = first; base < end; base += WAVE) {
         const uint32_t idx = base + lane;
         const bool valid = idx < end;
@@ -563,45 +555,41 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         // ---- records (flat form): (w0, w0, F0), and with a second block (w1, w0, F1, F0) and (w1, w1, F1).  A diagonal
         // record needs two ids to have a pair.
         const bool act = valid && !wide && w != 0 && (nl & 0xFFFFu) >= 2u && w0 != BNONE && idx >= q.emit_lo && idx < q.emit_hi;
-        const uint32_t cls = 0u;
-        // the lanes of a batch mostly share the block: one reservation per block and weight class
-        unsigned long long pend = __ballot(act && __popcll(F0) >= 2);
-        while (pend) {
-            const uint32_t X0 = bcast(w0, (uint32_t)__builtin_ctzll(pend));
-            const bool mine = act && __popcll(F0) >= 2 && w0 == X0;
-            const uint32_t sb = (tri32(X0) + X0) * NCLS;
-#pragma unroll
-            for (uint32_t c3 = 0; c3 < NCLS; ++c3) {
-                const unsigned long long bc = __ballot(mine && cls == c3);
-                if (bc) {
-                    const Resv r = arena_reserve(A, q.pool, sb + c3, (uint32_t)__popcll(bc), lane);
-                    if (mine && cls == c3) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, cls, w, sb + c3);
-                }
+        // (w0, w0, F0): the lanes of a batch mostly share the block — one reservation per block in that block's open chunk.
+        // (In wide mode, q.all_wide, these records take the wide pool as well.)
+        const bool d0 = act && __popcll(F0) >= 2;
+        if (!q.all_wide) {
+            unsigned long long pend = __ballot(d0);
+            while (pend) {
+                const uint32_t X0 = bcast(w0, (uint32_t)__builtin_ctzll(pend));
+                const bool mine = d0 && w0 == X0;
+                const unsigned long long bc = __ballot(mine);
+                const Resv r = arena_reserve(A, q.pool, X0, tri32(X0) + X0, (uint32_t)__popcll(bc), lane);
+                if (mine) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, w);
+                pend &= ~bc;
             }
-            pend &= ~__ballot(mine);
+        } else {
+            const unsigned long long bc = __ballot(d0);
+            if (bc) {
+                const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(bc), lane);
+                if (d0) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, F0, w, tri32(w0) + w0);
+            }
         }
-        // second blocks: one round per distinct (w0, w1) of the batch
-        const bool act2 = act && F1 != 0;
-        unsigned long long pend2 = __ballot(act2);
-        while (pend2) {
-            const uint32_t key = bcast(S.bw & 0x3FFFFFFFu, (uint32_t)__builtin_ctzll(pend2));
-            const uint32_t Y0 = key & 0x7FFFu, X1 = key >> 15;
-            const bool mine = act2 && (S.bw & 0x3FFFFFFFu) == key;
-            const bool dg = mine && __popcll(F1) >= 2;
-#pragma unroll
-            for (uint32_t c3 = 0; c3 < NCLS; ++c3) {
-                const unsigned long long bc = __ballot(mine && cls == c3);
-                if (bc) {
-                    const Resv r = arena_reserve(A, q.pool, (tri32(X1) + Y0) * NCLS + c3, (uint32_t)__popcll(bc), lane);
-                    if (mine && cls == c3) rec_store_off(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F1, F0, cls, w, (tri32(X1) + Y0) * NCLS + c3);
-                }
-                const unsigned long long dc = __ballot(dg && cls == c3);
+        // second blocks, (w1, w0, F1, F0) and (w1, w1, F1): the pairs differ from lane to lane, so these records go to the wide
+        // pool in arrival order (one reservation for all lanes) and are grouped by the sort
+        {
+            const bool act2 = act && F1 != 0;
+            const unsigned long long ac = __ballot(act2);
+            if (ac) {
+                const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(ac), lane);
+                if (act2) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(ac & lt_mask)), F1, F0, w, tri32(w1) + w0);
+                const bool dg = act2 && __popcll(F1) >= 2;
+                const unsigned long long dc = __ballot(dg);
                 if (dc) {
-                    const Resv r = arena_reserve(A, q.pool, (tri32(X1) + X1) * NCLS + c3, (uint32_t)__popcll(dc), lane);
-                    if (dg && cls == c3) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(dc & lt_mask)), F1, cls, w, (tri32(X1) + X1) * NCLS + c3);
+                    const Resv r2 = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(dc), lane);
+                    if (dg) rec_store_wide(q.pool, resv_slot(r2, (uint32_t)__popcll(dc & lt_mask)), F1, F1, w, tri32(w1) + w1);
                 }
             }
-            pend2 &= ~__ballot(mine);
         }
         // ---- chain slots for the next batch: the nodes on the root path of this batch's last node, i.e. the
         // lanes whose depth is smaller than the depth of every later lane
@@ -740,7 +728,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
             for (uint32_t t0 = q0; t0 < tend; t0 += WAVE) {
                 const uint32_t t = t0 + lane;
                 bool rec_on = false, diag = false;
-                uint32_t stream = 0, ww = 0, cl = 0;
+                uint32_t stream = 0, ww = 0;
                 unsigned long long FX = 0, FY = 0;
                 if (t < tend) {
                     const uint32_t d = L.queue[t - q0];
@@ -749,22 +737,15 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                     FX = L.ent_mask[st + a * stride]; FY = L.ent_mask[st + b * stride];
                     const uint32_t X = L.ent_blk[st + a * stride], Y = L.ent_blk[st + b * stride];
                     ww = L.st_w[own];
-                    cl = 0u;
                     diag = a == b;
                     rec_on = !diag || __popcll(FX) >= 2;           // a diagonal record needs two ids to have a pair
-                    stream = (tri32(X) + Y) * NCLS + cl;
+                    stream = tri32(X) + Y;
                 }
-                // one reservation per distinct stream of the step (the records of neighbouring nodes share their streams)
-                unsigned long long pend = __ballot(rec_on);
-                while (pend) {
-                    const uint32_t s0 = bcast(stream, (uint32_t)__builtin_ctzll(pend));
-                    const unsigned long long grp = q.pool.dense ? pend : __ballot(rec_on && stream == s0);     // dense: the whole step at once
-                    const Resv r = arena_reserve(A, q.pool, s0, (uint32_t)__popcll(grp), lane);
-                    if ((grp >> lane) & 1ull) {
-                        const uint32_t slot = resv_slot(r, (uint32_t)__popcll(grp & lt_mask));
-                        if (diag) rec_store_diag(q.pool, slot, FX, cl, ww, stream); else rec_store_off(q.pool, slot, FX, FY, cl, ww, stream);
-                    }
-                    pend &= ~grp;
+                // the step's records go to the wide pool in arrival order: one reservation for all lanes
+                const unsigned long long grp = __ballot(rec_on);
+                if (grp) {
+                    const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(grp), lane);
+                    if (rec_on) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(grp & lt_mask)), FX, diag ? FX : FY, ww, stream);
                 }
             }
             lds_sync();
@@ -985,7 +966,7 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
 }
 
 struct K2Item {
-    uint32_t X, Y, cls, count;             // block pair, weight class, wave steps (64 records each) of this stream in the window
+    uint32_t X, Y, count;                  // block pair, wave steps (64 records each) of this stream in the window
     const uint32_t* ids;                   // chunk mode: chunk ids of the run (LDS), CH_REC / 64 steps per chunk
     const uint32_t* fills;                 //             records in every chunk (LDS)
     const WideRec* srec;                   // sorted mode: the run's records, n_rec of them, contiguous
@@ -1160,8 +1141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         while (b < K2_WIN && s_key[b] == key) ++b;
         K2Item it;
         {
-            const uint32_t bucket = key / NCLS;
-            it.cls = key - bucket * NCLS;
+            const uint32_t bucket = key;
             uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)bucket + 1.0f) - 1.0f) * 0.5f);
             while (tri32(X) > bucket) --X;
             while (tri32(X + 1u) <= bucket) ++X;
@@ -1199,21 +1179,73 @@ __global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict
     for (uint32_t k = threadIdx.x; k < n_keys; k += 256) H[(size_t)k * CS_BLOCKS + blockIdx.x] = cs_lds[k];
     if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)n_keys * CS_BLOCKS] = 0;          // the scan leaves the total here
 }
+// The scatter stages tiles of CS_TILE records in LDS sorted by stream, so that the records of one stream leave the tile as one
+// contiguous burst (a record-by-record scatter of 24-byte records is bound by the number of write transactions: measured 2 ms
+// for 62 M records).  LDS: the staged records, their destinations, and three per-stream arrays (tile histogram = rank source,
+// tile offsets, the block's running global cursor).
+constexpr uint32_t CS_TILE = 2048;
+__host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + 1024 + 64; }
 __global__ __launch_bounds__(256) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
                                                          uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
                                                          WideRec* __restrict__ swrec) {
-    extern __shared__ uint32_t cs_lds[];
-    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cs_lds[k] = O[(size_t)k * CS_BLOCKS + blockIdx.x];
-    __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
+    WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
+    uint32_t* st_dst = (uint32_t*)(st_rec + CS_TILE);                     // [CS_TILE] global destination
+    uint32_t* st_key = st_dst + CS_TILE;                                  // [CS_TILE]
+    uint32_t* hist = st_key + CS_TILE;                                    // [n_keys] records of the tile per stream
+    uint32_t* toff = hist + n_keys;                                       // [n_keys] first staging position of the stream
+    uint32_t* cursor = toff + n_keys;                                     // [n_keys] next global position of the stream for this block
+    uint32_t* part = cursor + n_keys;                                     // [256] scan scratch
+    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cursor[k] = O[(size_t)k * CS_BLOCKS + blockIdx.x];
     const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
     if (lo >= n) return;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const uint32_t key = wkey[i];
-        if (key < n_keys) {
-            const uint32_t pos = atomicAdd(&cs_lds[key], 1u);
-            swrec[pos] = wrec[i];
-            swkey[pos] = key;
+    constexpr uint32_t PER = CS_TILE / 256;
+    const uint32_t kper = (n_keys + 255u) / 256u;                          // streams per thread in the scan
+    for (uint32_t t0 = lo; t0 < hi; t0 += CS_TILE) {
+        for (uint32_t k = threadIdx.x; k < n_keys; k += 256) hist[k] = 0;
+        __syncthreads();
+        uint32_t key[PER], rank[PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t i = t0 + j * 256u + threadIdx.x;
+            key[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
+            rank[j] = key[j] < n_keys ? atomicAdd(&hist[key[j]], 1u) : 0u;
         }
+        __syncthreads();
+        // exclusive scan of the tile histogram: kper consecutive streams per thread, then the 256 partial sums
+        uint32_t sum = 0;
+        for (uint32_t k = threadIdx.x * kper; k < n_keys && k < (threadIdx.x + 1u) * kper; ++k) sum += hist[k];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256; d <<= 1) {
+            const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = part[threadIdx.x] - sum;
+        for (uint32_t k = threadIdx.x * kper; k < n_keys && k < (threadIdx.x + 1u) * kper; ++k) { toff[k] = run; run += hist[k]; }
+        __syncthreads();
+        const uint32_t tile_n = part[255];
+        // stage: record -> its stream's run inside the tile, with its global destination
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            if (key[j] < n_keys) {
+                const uint32_t i = t0 + j * 256u + threadIdx.x;
+                const uint32_t p = toff[key[j]] + rank[j];
+                st_rec[p] = wrec[i];
+                st_dst[p] = cursor[key[j]] + rank[j];
+                st_key[p] = key[j];
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cursor[k] += hist[k];
+        for (uint32_t p = threadIdx.x; p < tile_n; p += 256) {
+            const uint32_t d = st_dst[p];
+            swrec[d] = st_rec[p];
+            swkey[d] = st_key[p];
+        }
+        __syncthreads();
     }
 }
 
@@ -1283,8 +1315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (key >= n_states) break;
         K2Item it;
         {
-            const uint32_t bucket = key / NCLS;
-            it.cls = key - bucket * NCLS;
+            const uint32_t bucket = key;
             uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)bucket + 1.0f) - 1.0f) * 0.5f);
             while (tri32(X) > bucket) --X;
             while (tri32(X + 1u) <= bucket) ++X;
@@ -1351,8 +1382,10 @@ __global__ void width_estimate_kernel(const EstParams q) {
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (int c = 0; c < EST_NW; ++c) {
-        unsigned long long rn = on && nblk[c] <= 2u ? (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u : 0ull;
-        unsigned long long rg = on && nblk[c] > 2u ? (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u : 0ull;
+        // a node with at most two blocks sends one record to its first block's stream chunk; all other records take the wide pool
+        const unsigned long long recs = (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u;
+        unsigned long long rn = on && nblk[c] >= 1u && nblk[c] <= 2u ? 1ull : 0ull;
+        unsigned long long rg = on ? recs - rn : 0ull;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { rn += shfl64(rn, (int)(lane ^ (uint32_t)d)); rg += shfl64(rg, (int)(lane ^ (uint32_t)d)); }
         if (lane == 0) { if (rn) atomicAdd(&q.out[c], rn); if (rg) atomicAdd(&q.out[EST_NW + c], rg); }
@@ -1522,7 +1555,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
         }
     }
     db->NB = (uint32_t)((N + db->width - 1) / db->width);
-    const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2 * NCLS;
+    const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2;          // streams = block pairs
     if (n_states >= (1ull << 30)) { db->fallback_reason = "too many block pairs"; return 0; }
     db->n_states = (uint32_t)n_states;
     // ---- working set
@@ -1628,9 +1661,10 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.widebits = db->widebits;
         q.P = P; q.nseg_nodes = db->nseg_nodes; q.n_segs = db->n_nsegs; q.chain_cap = db->chain_cap;
-        q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.tbits = db->dense_narrow ? 0u : arena_table_bits(db->n_states); q.n_states = db->n_states;
+        q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.tbits = db->dense_narrow ? 0u : arena_table_bits(db->NB); q.n_keys = db->NB;
+        q.all_wide = db->dense_narrow ? 1u : 0u;
         q.pool = pool_view(db, db->dense_narrow);
-        const size_t lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_states) * K1N_WAVES;
+        const size_t lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys) * K1N_WAVES;
         HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + K1N_WAVES - 1) / K1N_WAVES), dim3(WAVE * K1N_WAVES), lds, st, q);
         HIP_TRY(hipGetLastError());
@@ -1706,8 +1740,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                 hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, per_block, db->cs_hist);
                 size_t tb = db->cs_tmp_bytes;
                 HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
-                hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(256), db->n_states * 4, st, db->wkey, (const WideRec*)db->wrec, nslots, db->n_states,
-                                   per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
+                hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(256), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                                   db->n_states, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
                 total_ptr = db->cs_offs + (ne - 1);
             } else {
                 size_t tb = db->sort2_tmp_bytes;
