@@ -1167,7 +1167,7 @@ __global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uin
 // Counting sort of the wide pool by stream, for up to CS_MAX_KEYS streams: per-block histograms in LDS (no device atomics),
 // one exclusive scan over the [stream][block] table, then every block moves its records to its own range of every stream.
 // The order inside a stream is arbitrary (uint32 adds commute).  Two reads of the keys, one read and one write of the records.
-constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 1024;
+constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 2048;
 __global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, uint32_t n_keys, uint32_t per_block, uint32_t* __restrict__ H) {
     extern __shared__ uint32_t cs_lds[];
     for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cs_lds[k] = 0;
@@ -1183,9 +1183,9 @@ __global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict
 // contiguous burst (a record-by-record scatter of 24-byte records is bound by the number of write transactions: measured 2 ms
 // for 62 M records).  LDS: the staged records, their destinations, and three per-stream arrays (tile histogram = rank source,
 // tile offsets, the block's running global cursor).
-constexpr uint32_t CS_TILE = 2048;
-__host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + 1024 + 64; }
-__global__ __launch_bounds__(256) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
+constexpr uint32_t CS_TILE = 1024, CS_THREADS = 256;
+__host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + CS_THREADS * 4 + 64; }
+__global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
                                                          uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
                                                          WideRec* __restrict__ swrec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
@@ -1195,19 +1195,19 @@ __global__ __launch_bounds__(256) void cs_scatter_kernel(const uint32_t* __restr
     uint32_t* hist = st_key + CS_TILE;                                    // [n_keys] records of the tile per stream
     uint32_t* toff = hist + n_keys;                                       // [n_keys] first staging position of the stream
     uint32_t* cursor = toff + n_keys;                                     // [n_keys] next global position of the stream for this block
-    uint32_t* part = cursor + n_keys;                                     // [256] scan scratch
-    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cursor[k] = O[(size_t)k * CS_BLOCKS + blockIdx.x];
+    uint32_t* part = cursor + n_keys;                                     // [CS_THREADS] scan scratch
+    for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) cursor[k] = O[(size_t)k * CS_BLOCKS + blockIdx.x];
     const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
     if (lo >= n) return;
-    constexpr uint32_t PER = CS_TILE / 256;
-    const uint32_t kper = (n_keys + 255u) / 256u;                          // streams per thread in the scan
+    constexpr uint32_t PER = CS_TILE / CS_THREADS;
+    const uint32_t kper = (n_keys + CS_THREADS - 1u) / CS_THREADS;                          // streams per thread in the scan
     for (uint32_t t0 = lo; t0 < hi; t0 += CS_TILE) {
-        for (uint32_t k = threadIdx.x; k < n_keys; k += 256) hist[k] = 0;
+        for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) hist[k] = 0;
         __syncthreads();
         uint32_t key[PER], rank[PER];
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
-            const uint32_t i = t0 + j * 256u + threadIdx.x;
+            const uint32_t i = t0 + j * CS_THREADS + threadIdx.x;
             key[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
             rank[j] = key[j] < n_keys ? atomicAdd(&hist[key[j]], 1u) : 0u;
         }
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256) void cs_scatter_kernel(const uint32_t* __restr
         for (uint32_t k = threadIdx.x * kper; k < n_keys && k < (threadIdx.x + 1u) * kper; ++k) sum += hist[k];
         part[threadIdx.x] = sum;
         __syncthreads();
-        for (uint32_t d = 1; d < 256; d <<= 1) {
+        for (uint32_t d = 1; d < CS_THREADS; d <<= 1) {
             const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
             __syncthreads();
             part[threadIdx.x] += v;
@@ -1226,12 +1226,12 @@ __global__ __launch_bounds__(256) void cs_scatter_kernel(const uint32_t* __restr
         uint32_t run = part[threadIdx.x] - sum;
         for (uint32_t k = threadIdx.x * kper; k < n_keys && k < (threadIdx.x + 1u) * kper; ++k) { toff[k] = run; run += hist[k]; }
         __syncthreads();
-        const uint32_t tile_n = part[255];
+        const uint32_t tile_n = part[CS_THREADS - 1];
         // stage: record -> its stream's run inside the tile, with its global destination
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
             if (key[j] < n_keys) {
-                const uint32_t i = t0 + j * 256u + threadIdx.x;
+                const uint32_t i = t0 + j * CS_THREADS + threadIdx.x;
                 const uint32_t p = toff[key[j]] + rank[j];
                 st_rec[p] = wrec[i];
                 st_dst[p] = cursor[key[j]] + rank[j];
@@ -1239,8 +1239,8 @@ __global__ __launch_bounds__(256) void cs_scatter_kernel(const uint32_t* __restr
             }
         }
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cursor[k] += hist[k];
-        for (uint32_t p = threadIdx.x; p < tile_n; p += 256) {
+        for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) cursor[k] += hist[k];
+        for (uint32_t p = threadIdx.x; p < tile_n; p += CS_THREADS) {
             const uint32_t d = st_dst[p];
             swrec[d] = st_rec[p];
             swkey[d] = st_key[p];
@@ -1741,7 +1741,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                 size_t tb = db->cs_tmp_bytes;
                 HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
                 HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
-                hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(256), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
                                    db->n_states, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
                 total_ptr = db->cs_offs + (ne - 1);
             } else {
