@@ -10,8 +10,9 @@ Reported:
   wall.upload_s         kmdb_db_upload: host conversion + H2D + device layout   (the reference's deserialize)
   wall.cold_call_ms     first call after upload, host matrix out (H2D/D2H inclusive)
   wall.cold_total_s     upload + first call = what one `all2all` run costs end to end, next to cpu_baseline.seconds
-Workloads (--workload): c2 = BASELINE.json configs[1], 1000 x 5 Mbp; c3shard = the per-GPU share of configs[2],
-10 000 samples x 625 kbp.  With --gpus N the k-mer space is sharded by prefix bucket (kmer >> 32, reference
+Workloads (--workload): c2 = BASELINE.json configs[1], 1000 x 5 Mbp; c3part = the sample count of configs[2] on one GPU,
+10 000 samples x 300 kbp (about half of one GPU's 625 kbp share of configs[2]: the synthetic generator's torch sorts stop at
+2^31 local ids, which 10 000 x 625 kbp exceeds).  With --gpus N the k-mer space is sharded by prefix bucket (kmer >> 32, reference
 src/types.h:25-27): --scaling weak (default) keeps per-GPU work fixed (genomes N x longer, rank r owns the buckets
 congruent to r mod N); --scaling strong shards ONE database of the workload's size (kmdb_db_upload_shard).  The
 partial matrices are summed with one RCCL reduce.  `python bench.py --gpus N` starts its own N ranks.
@@ -37,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E p
 
 WORKLOADS = {
     "c2": dict(samples=1000, clade_size=50, length=5_000_000),
-    "c3shard": dict(samples=10000, clade_size=50, length=625_000),
+    "c3part": dict(samples=10000, clade_size=50, length=300_000),
 }
 
 

@@ -701,6 +701,39 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
     // m (m + 1) / 2 records (block pairs a >= b); the records are numbered by a prefix sum, every owner pushes one descriptor per
     // record into a queue, then the wave takes 64 descriptors at a time, one record per lane
     auto emit = [&](bool on, uint32_t m, uint32_t wv, uint32_t stride) {
+        // a node with many blocks (66 records and more) is taken by the whole wave: lane t builds pair t of the node
+        {
+            unsigned long long hb = __ballot(on && m >= 11u);
+            while (hb) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(hb);
+                hb &= hb - 1ull;
+                const uint32_t mj = bcast(m, j), wj = bcast(wv, j), stj = L.st_start[j];
+                const uint32_t Tj = mj * (mj + 1u) / 2u;
+                for (uint32_t t0 = 0; t0 < Tj; t0 += WAVE) {
+                    const uint32_t t = t0 + lane;
+                    bool rec_on = false;
+                    uint32_t stream = 0;
+                    unsigned long long FX = 0, FY = 0;
+                    if (t < Tj) {
+                        uint32_t a = (uint32_t)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                        while (tri32(a) > t) --a;
+                        while (tri32(a + 1u) <= t) ++a;
+                        const uint32_t b = t - tri32(a);
+                        FX = L.ent_mask[stj + a * stride]; FY = L.ent_mask[stj + b * stride];
+                        const uint32_t X = L.ent_blk[stj + a * stride], Y = L.ent_blk[stj + b * stride];
+                        rec_on = a != b || __popcll(FX) >= 2;
+                        if (a == b) FY = FX;
+                        stream = tri32(X) + Y;
+                    }
+                    const unsigned long long grp = __ballot(rec_on);
+                    if (grp) {
+                        const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(grp), lane);
+                        if (rec_on) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(grp & lt_mask)), FX, FY, wj, stream);
+                    }
+                }
+            }
+            on = on && m < 11u;
+        }
         const uint32_t myrec = on ? m * (m + 1u) / 2u : 0u;
         const uint32_t rincl = wave_incl_scan(myrec, lane);
         const uint32_t T = bcast(rincl, WAVE - 1);
@@ -1394,6 +1427,29 @@ __global__ void width_estimate_kernel(const EstParams q) {
     if (lane == 0 && nb) atomicAdd(&q.out[2 * EST_NW], (unsigned long long)__popcll(nb));
 }
 
+// upload-time: sampled estimate of the extra (block, mask) pairs K0 reserves (one node in `stride`, its own list only)
+__global__ void pair_estimate_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ bitrel, const uint64_t* __restrict__ blkbase,
+                                     const uint64_t* __restrict__ bits, uint32_t P, uint32_t stride, BlockMap bm, unsigned long long* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i0 = (uint64_t)t * stride + (t * 2654435761u) % stride;
+    unsigned long long need = 0;
+    if (i0 < P) {
+        const uint2 km = k0in[i0];
+        const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16;
+        if (l > 1) {
+            BitCursor c(bits, blkbase[(uint32_t)i0 >> 8] + bitrel[i0]);
+            uint32_t span = 0;
+            for (uint32_t k = 0; k + 1 < l; ++k) span += c.next();
+            const uint32_t nb = bm.blk(last) - bm.blk(last - span);
+            need = nb < l - 1u ? nb : l - 1u;
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) need += shfl64(need, (int)(lane ^ (uint32_t)d));
+    if (lane == 0 && need) atomicAdd(out, need);
+}
+
 // v1 / new2all node arrays from the compact layout
 __global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ bitrel, const uint64_t* __restrict__ blkbase,
                                  const uint32_t* __restrict__ nl, uint32_t P, uint4* __restrict__ meta, uint64_t* __restrict__ bitpos) {
@@ -1415,6 +1471,7 @@ void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 
 constexpr uint32_t K1G_MAX_WAVES = 4096;
 struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
+struct ValidKey { uint32_t n_states; __host__ __device__ uint32_t operator()(uint32_t k) const { return k < n_states ? 1u : 0u; } };
 
 int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota);
@@ -1573,7 +1630,23 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     HIP_TRY(hipMalloc(&db->scan_tmp, std::max<size_t>(db->scan_tmp_bytes, 16)));
     HIP_TRY(hipMalloc((void**)&db->counters, KCTR_COUNT * 4));
     HIP_TRY(hipHostMalloc((void**)&db->h_counters, KCTR_COUNT * 4));
-    if (alloc_pair_pool(db, std::max<uint64_t>(P + P / 2, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
+    {
+        // extra pairs: sampled with the chosen width (K0 reserves min(l - 1, blocks spanned) per list that is not a single short run)
+        unsigned long long* d_need = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_need, 8));
+        HIP_TRY(hipMemsetAsync(d_need, 0, 8, db->stream));
+        const BlockMap bm{db->width, (uint32_t)((1ull << 32) / db->width) + 1u};
+        const uint64_t nthreads = (P + stride - 1) / stride;
+        hipLaunchKernelGGL(pair_estimate_kernel, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, db->stream, db->k0in, db->bitrel, db->blkbase, db->bits,
+                           (uint32_t)P, stride, bm, d_need);
+        unsigned long long h_need = 0;
+        HIP_TRY(hipMemcpyAsync(&h_need, d_need, 8, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        (void)hipFree(d_need);
+        const uint64_t est_pairs = h_need * stride;
+        if (verbose) fprintf(stderr, "[kmdb] extra (block, mask) pairs, sampled: %llu\n", (unsigned long long)est_pairs);
+        if (alloc_pair_pool(db, std::max<uint64_t>(est_pairs * 3 / 2 + P / 8, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
+    }
     HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->wsub_cursor, KMDB_SUBPOOLS * 16 * 4));
     // The nodes with many blocks scatter their records over many streams, a few per stream and wave: the wide kernel writes them
@@ -1586,7 +1659,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide pool: the wide estimate and a grab per wave
     if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 24 + 1024)) return 1;
-    if (alloc_wide_pool(db, est_g * 5 / 4 / WCH_REC + (uint64_t)(K1G_MAX_WAVES + 64) * (WIDE_GRAB + 2) + 1024)) return 1;
+    if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1G_MAX_WAVES + 64) * (WIDE_GRAB + 2) + 1024)) return 1;
     return 0;
 }
 
@@ -1744,7 +1817,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                 hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
                                    db->n_states, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
                 total_ptr = db->cs_offs + (ne - 1);
+                HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
             } else {
+                {
+                    // records in the wide pool (statistics): the slots whose key is a stream
+                    hipcub::TransformInputIterator<uint32_t, ValidKey, uint32_t*> it(db->wkey, ValidKey{db->n_states});
+                    size_t tbv = db->sort2_tmp_bytes;
+                    HIP_TRY(hipcub::DeviceReduce::Sum(db->sort2_tmp, tbv, it, db->counters + KCTR_WIDE_RECORDS, (int)nslots, st));
+                }
                 size_t tb = db->sort2_tmp_bytes;
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)nslots, 0,
                                                            db->key_bits, st));
@@ -1807,7 +1887,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         return 0;
     }
     db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW]; db->last_n_slow = c[KCTR_SLOW];
-    db->last_records = (uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32);
+    db->last_records = ((uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32)) + c[KCTR_WIDE_RECORDS];
     return 0;
 }
 

@@ -31,6 +31,7 @@ enum : uint32_t {
     KCTR_RECORDS_HI = 7,
     KCTR_SLOW = 8,          // wide nodes that took the climbing path
     KCTR_WIDE_OVERFLOW = 9, // != 0: the wide record pool was too small
+    KCTR_WIDE_RECORDS = 10, // records written to the wide pool
     KCTR_COUNT = 16
 };
 constexpr uint32_t KMDB_PAIR_REGIONS = 4096;
