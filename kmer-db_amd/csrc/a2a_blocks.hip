@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     const uint2 km = live ? q.k0in[i] : make_uint2(0u, 0u);
     const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16, nbits = km.y;
     if (!q.perm && kmdb_long_node(l, nbits)) live = false;
-    using Cursor = RunCursor<LONG ? 8 : 3, LONG>;
+    using Cursor = RunCursor32<LONG ? 16 : 6, LONG>;
     uint32_t npairs = 0, blk0 = 0, need = 0, span = 0, bit0 = 0;
     unsigned long long mask0 = 0, m1 = 0, m2 = 0;
     bool second_pass = false;
@@ -1186,12 +1186,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 }
 
-// opened chunks = the head of the sorted chunk table; slots of the wide pool in use = the busiest sub-pool's share of all
-__global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uint32_t pool_cap, uint32_t n_states, const uint32_t* __restrict__ wsub_cursor,
-                                    uint32_t* __restrict__ counters) {
+// opened chunks = the head of the sorted chunk table
+__global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uint32_t pool_cap, uint32_t n_states, uint32_t* __restrict__ counters) {
     uint32_t lo = 0, hi = pool_cap;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_key[mid] < n_states) lo = mid + 1; else hi = mid; }
     counters[KCTR_CHUNKS] = lo;
+}
+// slots of the wide pool in use = the busiest sub-pool's share of all
+__global__ void count_raw_kernel(const uint32_t* __restrict__ wsub_cursor, uint32_t* __restrict__ counters) {
     uint32_t mx = 0;
     for (uint32_t p = 0; p < KMDB_SUBPOOLS; ++p) mx = max(mx, wsub_cursor[p * 16u]);
     counters[KCTR_RAW] = mx * KMDB_SUBPOOLS;                    // chunk ids below this bound cover every written record
@@ -1744,6 +1746,27 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     }
     if (stage("narrow emit")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[1], st));
+    // ---- on the side stream, next to the wide kernel: the stream chunks (all written by now) sorted by stream and applied
+    hipStream_t s2 = db->stream2;
+    HIP_TRY(hipEventRecord(db->ev_side[0], st));
+    HIP_TRY(hipStreamWaitEvent(s2, db->ev_side[0], 0));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort_tmp, db->sort_tmp_bytes, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id,
+                                               (int)pool_cap, 0, db->key_bits, s2));
+    hipLaunchKernelGGL(count_chunks_kernel, dim3(1), dim3(1), 0, s2, db->sorted_key, pool_cap, db->n_states, db->counters);
+    {
+        hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
+        HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
+    }
+    {
+        uint32_t grid = (pool_cap + K2_WIN - 1) / K2_WIN;
+        if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + K2_WIN - 1) / K2_WIN);
+        if (grid)
+            hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, s2, db->rec, db->recw, db->sorted_key, db->sorted_id, db->chunk_fill, db->n_states,
+                               pool_cap, M, (uint32_t)db->N, db->width);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(db->ev_side[1], s2));
+    if (sync_debug) { const hipError_t e = hipStreamSynchronize(s2); fprintf(stderr, "[kmdb] stage %-14s %s\n", "chunk apply", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
     // ---- wide list
     hipLaunchKernelGGL(wide_count_kernel, dim3((n_words + 1 + 255) / 256), dim3(256), 0, st, db->widebits, n_words, db->wide_cnt);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->scan_tmp, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1), st));
@@ -1779,22 +1802,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     HIP_TRY(hipGetLastError());
     if (stage("wide emit")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[2], st));
-    // ---- chunk table sorted by stream, K2 over windows of it
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort_tmp, db->sort_tmp_bytes, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id,
-                                               (int)pool_cap, 0, db->key_bits, st));
-    hipLaunchKernelGGL(count_chunks_kernel, dim3(1), dim3(1), 0, st, db->sorted_key, pool_cap, db->n_states, db->wsub_cursor, db->counters);
-    {
-        hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
-        HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, st));
-    }
-    if (stage("chunk sort")) return 1;
-    uint32_t grid = (pool_cap + K2_WIN - 1) / K2_WIN;
-    if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + K2_WIN - 1) / K2_WIN);
-    if (grid)
-        hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, st, db->rec, db->recw, db->sorted_key, db->sorted_id, db->chunk_fill, db->n_states,
-                           pool_cap, M, (uint32_t)db->N, db->width);
-    HIP_TRY(hipGetLastError());
-    if (stage("apply")) return 1;
+    hipLaunchKernelGGL(count_raw_kernel, dim3(1), dim3(1), 0, st, db->wsub_cursor, db->counters);
     {
         // the wide pool: records sorted by stream (the sort moves the 24-byte records with their keys), one tile per run
         uint32_t n_raw;
@@ -1836,6 +1844,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         }
         if (stage("sorted apply")) return 1;
     }
+    HIP_TRY(hipStreamWaitEvent(st, db->ev_side[1], 0));          // the side stream's tiles are in the matrix too
     HIP_TRY(hipEventRecord(db->ev_k[3], st));
     // ---- what the call found
     HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));

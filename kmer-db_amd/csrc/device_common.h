@@ -186,6 +186,61 @@ struct RunCursor {
     }
 };
 
+// The same reader on 32-bit units: ids are below 2^16, so a gamma code has at most 31 bits and one 32-bit window holds a run
+// of "0" codes and, when it fits behind them, the code that follows — with v_alignbit_b32 and a 32-bit count-leading-zeros
+// instead of 64-bit shifts (the decode loop is bound by VALU issue).  Unit u of the stream (MSB-first inside little-endian
+// uint64 words: a word's high half comes first) is the uint32 at index u ^ 1.  NU units are fetched together before the loop;
+// RELOAD: when two are left, the next NU - 2 are fetched in one go.
+template <int NU, bool RELOAD>
+struct RunCursor32 {
+    const uint32_t* __restrict__ b32;
+    uint64_t u0;                                   // stream unit held in c[0]
+    uint32_t c[NU + 1];
+    uint32_t s;                                    // bit offset inside c[0]
+    uint32_t left;                                 // units of c[] that hold stream data (RELOAD)
+    __device__ __forceinline__ RunCursor32(const uint64_t* __restrict__ b, uint64_t pos) : b32((const uint32_t*)b) {
+        u0 = pos >> 5;
+        s = (uint32_t)pos & 31u;
+#pragma unroll
+        for (int k = 0; k < NU; ++k) c[k] = b32[(u0 + k) ^ 1ull];
+        c[NU] = 0;
+        left = NU;
+    }
+    __device__ __forceinline__ void shift_unit() {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) c[k] = c[k + 1];
+        ++u0;
+        if (RELOAD) {
+            if (--left == 2u) {
+#pragma unroll
+                for (int k = 2; k < NU; ++k) c[k] = b32[(u0 + k) ^ 1ull];
+                left = NU;
+            }
+        }
+    }
+    // One step of the run-aware decoder: z consecutive "0" codes (deltas of 1, at most `limit`) and, when it is complete inside
+    // the 32-bit window, the code that follows them (value >= 2; 0 = none taken).
+    __device__ __forceinline__ void step(uint32_t limit, uint32_t& z, uint32_t& v) {
+        const uint32_t win = s ? __builtin_amdgcn_alignbit(c[0], c[1], 32u - s) : c[0];
+        z = win ? (uint32_t)__clz((int)win) : 32u;
+        z = z < limit ? z : limit;
+        v = 0;
+        uint32_t used = z;
+        if (z < limit && z < 32u) {
+            const uint32_t rest = win << z;                          // starts with a 1 bit
+            uint32_t ones = (uint32_t)__clz((int)~rest);
+            ones = ones > 15u ? 15u : ones;                          // a valid code of an id below 2^16 has at most 15 leading ones
+            const uint32_t len = 2u * ones + 1u;
+            if (z + len <= 32u) {
+                v = ((rest << ones) >> (31u - ones)) | (1u << ones);
+                used += len;
+            }
+        }
+        s += used;
+        if (s >= 32u) { s -= 32u; shift_unit(); }
+    }
+};
+
 // Decode the l local ids of one node into out[0..l) (ascending).  pattern_t::decodeSamples
 // (reference src/pattern.cpp:99-109): l-1 gamma-coded deltas in append order, last id explicit.
 template <class T>

@@ -115,6 +115,8 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     if (hipStreamCreate(&db->stream) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
     for (auto& e : db->ev) if (hipEventCreate(&e) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
     for (auto& e : db->ev_k) if (hipEventCreate(&e) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
+    if (hipStreamCreate(&db->stream2) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
+    for (auto& e : db->ev_side) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
     if (kmdb_layout_upload(db, v, with_hashtables, shard_index, shard_count)) return fail();
     // the working set of all2all: now for an all2all upload, on the first all2all call for a new2all / db2db upload
     if (!with_hashtables && kmdb_blocks_prepare(db)) return fail();
@@ -148,6 +150,8 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_k) if (e) (void)hipEventDestroy(e);
+    for (auto& e : db->ev_side) if (e) (void)hipEventDestroy(e);
+    if (db->stream2) (void)hipStreamDestroy(db->stream2);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;
 }

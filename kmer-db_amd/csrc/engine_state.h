@@ -130,6 +130,8 @@ struct kmdb_db {
     uint64_t* slots = nullptr;
     uint32_t* pid2dfs = nullptr;    // original pattern id -> DFS index
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // side stream: the stream chunks are sorted and applied next to the wide kernel
+    hipEvent_t ev_side[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // after decode / narrow / wide / apply
     kmdb_stats stats{};
