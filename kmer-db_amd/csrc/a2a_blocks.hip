@@ -235,7 +235,7 @@ struct K0Params {
     uint16_t* pair_blk;
     unsigned long long* pair_mask;
     uint32_t* pair_cursor;         // [KMDB_PAIR_REGIONS * 16]
-    uint32_t n_regions, region_cap;
+    uint32_t n_regions, region_cap, spill_cap;   // sub-pools of region_cap entries each, then a shared spill area
     uint32_t* counters;
 };
 
@@ -343,10 +343,18 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
             uint32_t base = 0;
             if (lane == WAVE - 1) base = atomicAdd(&q.pair_cursor[region * 16u], total);
             base = bcast(base, WAVE - 1);
-            if (base + total > q.region_cap) {
-                if (lane == 0) atomicOr(&q.counters[KCTR_PAIR_OVERFLOW], 1u);
-                need = 0; second_pass = false; npairs = npairs ? 1u : 0u; m1 = m2 = 0;        // results invalid; the call is repeated with a larger pool
-            } else out = region * q.region_cap + base + (incl - need);
+            if (base + total <= q.region_cap) out = region * q.region_cap + base + (incl - need);
+            else {
+                // the wave's sub-pool is full: the shared spill area behind the sub-pools (one cursor, rarely used)
+                uint32_t sb = 0;
+                if (lane == WAVE - 1) sb = atomicAdd(&q.pair_cursor[q.n_regions * 16u], total);
+                sb = bcast(sb, WAVE - 1);
+                if (sb + total <= q.spill_cap) out = q.n_regions * q.region_cap + sb + (incl - need);
+                else {
+                    if (lane == 0) atomicOr(&q.counters[KCTR_PAIR_OVERFLOW], 1u);
+                    need = 0; second_pass = false; npairs = npairs ? 1u : 0u; m1 = m2 = 0;    // results invalid; the call is repeated with a larger pool
+                }
+            }
         }
     }
     if (!live) return;
@@ -1621,7 +1629,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->p0_mask, P * 8));
     HIP_TRY(hipMalloc((void**)&db->p0_info, P * 4));
     HIP_TRY(hipMalloc((void**)&db->pair_ofs, P * 4));
-    HIP_TRY(hipMalloc((void**)&db->pair_cursor, KMDB_PAIR_REGIONS * 16 * 4));
+    HIP_TRY(hipMalloc((void**)&db->pair_cursor, (KMDB_PAIR_REGIONS + 1) * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->fn_mask, P * 16));
     HIP_TRY(hipMalloc((void**)&db->fn_blk, P * 4));
     const uint64_t n_words = (P + 63) / 64;
@@ -1647,7 +1655,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
         (void)hipFree(d_need);
         const uint64_t est_pairs = h_need * stride;
         if (verbose) fprintf(stderr, "[kmdb] extra (block, mask) pairs, sampled: %llu\n", (unsigned long long)est_pairs);
-        if (alloc_pair_pool(db, std::max<uint64_t>(est_pairs * 3 / 2 + P / 8, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
+        if (alloc_pair_pool(db, std::max<uint64_t>(est_pairs * 2 + P / 4, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
     }
     HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->wsub_cursor, KMDB_SUBPOOLS * 16 * 4));
@@ -1700,7 +1708,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     const uint32_t n_words = (P + 63) / 64;
     const uint32_t pool_cap = (uint32_t)db->pool_cap;
     HIP_TRY(hipMemsetAsync(db->counters, 0, KCTR_COUNT * 4, st));
-    HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, KMDB_PAIR_REGIONS * 16 * 4, st));
+    HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, (KMDB_PAIR_REGIONS + 1) * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->sub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->wsub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     {
@@ -1719,7 +1727,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         // sub-pools of the pair pool: enough of them that their cursors are not hot, few enough that one wave's need fits a share
         uint32_t nreg = 1;
         while (nreg < KMDB_PAIR_REGIONS && (uint64_t)nreg * 16384 < P) nreg <<= 1;
-        q.pair_cursor = db->pair_cursor; q.n_regions = nreg; q.region_cap = (uint32_t)(db->pair_cap / nreg); q.counters = db->counters;
+        // three quarters of the pool in sub-pools, the rest shared
+        q.pair_cursor = db->pair_cursor; q.n_regions = nreg; q.region_cap = (uint32_t)(db->pair_cap * 3 / 4 / nreg);
+        q.spill_cap = (uint32_t)(db->pair_cap - (uint64_t)q.region_cap * nreg); q.counters = db->counters;
         hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
         if (db->n_long) {
             q.perm = db->long_nodes; q.P = db->n_long;
