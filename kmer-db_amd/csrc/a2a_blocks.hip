@@ -58,7 +58,10 @@ __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, in
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t CH_SHIFT = 8, CH_REC = 1u << CH_SHIFT;      // records per stream chunk: four wave steps of K2, 4 KB contiguous
 constexpr uint32_t WCH_SHIFT = 6, WCH_REC = 1u << WCH_SHIFT;   // records per chunk of the wide pool (grouped by a sort, not by chunk)
-struct WideRec { unsigned long long rows, cols; uint32_t w, pad; };      // record of the wide pool: moved by the sort next to its stream key
+// Record of the wide pool: 16 bytes of masks, moved by the sort next to its 4-byte key word.  The key word holds the stream in
+// its low `kbits` bits, above it one base-2^dbits digit of the weight and the digit's index (2 bits): a weight of more than
+// dbits bits becomes one record per non-zero digit (exact: the matrix is uint32 wrap-around arithmetic, shifted digits add up).
+struct __attribute__((aligned(16))) WideRec { unsigned long long rows, cols; };
 struct PoolView {
     uint32_t* counters;            // KCTR_*
     uint32_t* chunk_key;           // [pool_cap] stream of the chunk (n_states: never opened)
@@ -73,7 +76,8 @@ struct PoolView {
     WideRec* wrec;                 // [wide slots]
     uint32_t* wsub_cursor;         // [KMDB_SUBPOOLS * 16]
     uint32_t wsub_cap;             // chunks per sub-pool of the wide pool
-    uint32_t dense;                // 1: this kernel writes into the wide pool
+    uint32_t dense;
+    uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
@@ -93,7 +97,7 @@ struct WaveArena {
     uint32_t direct;
     uint32_t sub;                  // this wave's sub-pool
     uint32_t stock, next;          // wave-uniform: stream chunks left of the last grab, the next of them (index inside the sub-pool)
-    uint32_t wstock, wnext;        // the same for the wide pool
+    uint32_t wstock, wnext, wsub;  // the same for the wide pool (its sub-pool changes with every grab)
     uint32_t dslot;                // wide pool: next slot of the wave's one open chunk (dopen == 0: none)
     uint32_t dopen;
 };
@@ -112,7 +116,7 @@ __host__ __device__ inline size_t arena_table_bytes(uint32_t tbits, uint32_t n_k
 __device__ __forceinline__ void arena_init(WaveArena& A, uint32_t* lds, uint32_t tbits, uint32_t n_states, uint32_t wave_id, uint32_t lane) {
     A.direct = n_states <= (1u << tbits) ? 1u : 0u;
     A.t_slot = lds; A.t_key = lds + (1u << tbits); A.tmask = (1u << tbits) - 1u;
-    A.sub = wave_id % KMDB_SUBPOOLS; A.stock = 0; A.next = 0; A.wstock = 0; A.wnext = 0; A.dslot = 0; A.dopen = 0;
+    A.sub = wave_id % KMDB_SUBPOOLS; A.wsub = A.sub; A.stock = 0; A.next = 0; A.wstock = 0; A.wnext = 0; A.dslot = 0; A.dopen = 0;
     if (tbits == 0) return;                                   // dense mode: no table
     for (uint32_t e = lane; e <= A.tmask; e += WAVE) { A.t_slot[e] = KEY_NONE; if (!A.direct) A.t_key[e] = KEY_NONE; }
     lds_sync();
@@ -137,7 +141,8 @@ __device__ __forceinline__ uint32_t arena_take(WaveArena& A, const PoolView& pv,
 __device__ __forceinline__ uint32_t arena_take_wide(WaveArena& A, const PoolView& pv, uint32_t lane) {
     if (A.wstock == 0) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&pv.wsub_cursor[A.sub * 16u], WIDE_GRAB);
+        A.wsub = (A.wsub + 61u) % KMDB_SUBPOOLS;                     // every grab from another sub-pool: waves with much output do not drain one
+        if (lane == 0) base = atomicAdd(&pv.wsub_cursor[A.wsub * 16u], WIDE_GRAB);
         base = bcast(base, 0);
         if (base + WIDE_GRAB > pv.wsub_cap) {                     // stays in range; the call is repeated with a larger pool
             if (lane == 0) atomicOr(&pv.counters[KCTR_WIDE_OVERFLOW], 1u);
@@ -145,7 +150,7 @@ __device__ __forceinline__ uint32_t arena_take_wide(WaveArena& A, const PoolView
         }
         A.wnext = base; A.wstock = WIDE_GRAB;
     }
-    const uint32_t id = A.wnext * KMDB_SUBPOOLS + A.sub;
+    const uint32_t id = A.wnext * KMDB_SUBPOOLS + A.wsub;
     ++A.wnext; --A.wstock;
     return id;
 }
@@ -198,9 +203,30 @@ __device__ __forceinline__ void arena_finish(const WaveArena& A, const PoolView&
 }
 
 // diagonal streams (X == Y, cols == rows) pack 8-byte rows into the first half of their chunks
-__device__ __forceinline__ void rec_store_wide(const PoolView& pv, uint32_t slot, unsigned long long rows, unsigned long long cols, uint32_t w, uint32_t stream) {
-    pv.wrec[slot] = WideRec{rows, cols, w, 0u};
-    pv.wkey[slot] = stream;
+// the records `on` of a wave step into the wide pool: one reservation for all lanes per weight digit (nearly always one digit).
+// Every lane of the wave calls.
+__device__ __forceinline__ void wide_emit(WaveArena& A, const PoolView& pv, bool on, unsigned long long rows, unsigned long long cols, uint32_t w, uint32_t stream,
+                                          uint32_t lane, unsigned long long lt_mask) {
+    const uint32_t dmask = (1u << pv.dbits) - 1u;
+    uint32_t j = 0;
+    for (;;) {
+        const unsigned long long grp = __ballot(on);
+        if (!grp) break;
+        const Resv r = arena_reserve_wide(A, pv, (uint32_t)__popcll(grp), lane);
+        if (on) {
+            const uint32_t slot = resv_slot(r, (uint32_t)__popcll(grp & lt_mask));
+            pv.wrec[slot] = WideRec{rows, cols};
+            pv.wkey[slot] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
+        }
+        w >>= pv.dbits; ++j;
+        on = on && w != 0;
+    }
+}
+// weight of a sorted wide record from its key word
+__device__ __forceinline__ uint32_t wide_weight(uint32_t key, uint32_t kbits, uint32_t dbits) {
+    const uint32_t f = key >> kbits, dig = f & ((1u << dbits) - 1u), j = f >> dbits;
+    const uint32_t sh = j * dbits;
+    return sh < 32u ? dig << sh : 0u;
 }
 // stream chunks hold the records (X, X, rows) of one block X: 8-byte rows in the first half of the chunk, weights beside
 __device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t w) {
@@ -577,26 +603,15 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
                 pend &= ~bc;
             }
         } else {
-            const unsigned long long bc = __ballot(d0);
-            if (bc) {
-                const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(bc), lane);
-                if (d0) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, F0, w, tri32(w0) + w0);
-            }
+            wide_emit(A, q.pool, d0, F0, F0, w, tri32(w0) + w0, lane, lt_mask);
         }
         // second blocks, (w1, w0, F1, F0) and (w1, w1, F1): the pairs differ from lane to lane, so these records go to the wide
         // pool in arrival order (one reservation for all lanes) and are grouped by the sort
         {
             const bool act2 = act && F1 != 0;
-            const unsigned long long ac = __ballot(act2);
-            if (ac) {
-                const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(ac), lane);
-                if (act2) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(ac & lt_mask)), F1, F0, w, tri32(w1) + w0);
-                const bool dg = act2 && __popcll(F1) >= 2;
-                const unsigned long long dc = __ballot(dg);
-                if (dc) {
-                    const Resv r2 = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(dc), lane);
-                    if (dg) rec_store_wide(q.pool, resv_slot(r2, (uint32_t)__popcll(dc & lt_mask)), F1, F1, w, tri32(w1) + w1);
-                }
+            if (__ballot(act2)) {
+                wide_emit(A, q.pool, act2, F1, F0, w, tri32(w1) + w0, lane, lt_mask);
+                wide_emit(A, q.pool, act2 && __popcll(F1) >= 2, F1, F1, w, tri32(w1) + w1, lane, lt_mask);
             }
         }
         // ---- chain slots for the next batch: the nodes on the root path of this batch's last node, i.e. the
@@ -733,11 +748,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                         if (a == b) FY = FX;
                         stream = tri32(X) + Y;
                     }
-                    const unsigned long long grp = __ballot(rec_on);
-                    if (grp) {
-                        const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(grp), lane);
-                        if (rec_on) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(grp & lt_mask)), FX, FY, wj, stream);
-                    }
+                    wide_emit(A, q.pool, rec_on, FX, FY, wj, stream, lane, lt_mask);
                 }
             }
             on = on && m < 11u;
@@ -783,11 +794,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                     stream = tri32(X) + Y;
                 }
                 // the step's records go to the wide pool in arrival order: one reservation for all lanes
-                const unsigned long long grp = __ballot(rec_on);
-                if (grp) {
-                    const Resv r = arena_reserve_wide(A, q.pool, (uint32_t)__popcll(grp), lane);
-                    if (rec_on) rec_store_wide(q.pool, resv_slot(r, (uint32_t)__popcll(grp & lt_mask)), FX, diag ? FX : FY, ww, stream);
-                }
+                wide_emit(A, q.pool, rec_on, FX, diag ? FX : FY, ww, stream, lane, lt_mask);
             }
             lds_sync();
         }
@@ -1011,6 +1018,8 @@ struct K2Item {
     const uint32_t* ids;                   // chunk mode: chunk ids of the run (LDS), CH_REC / 64 steps per chunk
     const uint32_t* fills;                 //             records in every chunk (LDS)
     const WideRec* srec;                   // sorted mode: the run's records, n_rec of them, contiguous
+    const uint32_t* skey;                  //              their key words (weight digits)
+    uint32_t kbits, dbits;
     uint32_t n_rec;
     const unsigned char* rec;              // record pool
     const uint32_t* recw;
@@ -1027,7 +1036,7 @@ __device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t s
         if (p < it.n_rec) {
             const WideRec r = it.srec[p];
             R = r.rows; Cc = r.cols;
-            W = weighted ? r.w : 1u;
+            W = weighted ? wide_weight(it.skey[p], it.kbits, it.dbits) : 1u;
         }
     } else {
         const uint32_t ci = st / CH_STEPS, j = (st % CH_STEPS) * 64u + lane;
@@ -1210,17 +1219,22 @@ __global__ void count_raw_kernel(const uint32_t* __restrict__ wsub_cursor, uint3
 // Counting sort of the wide pool by stream, for up to CS_MAX_KEYS streams: per-block histograms in LDS (no device atomics),
 // one exclusive scan over the [stream][block] table, then every block moves its records to its own range of every stream.
 // The order inside a stream is arbitrary (uint32 adds commute).  Two reads of the keys, one read and one write of the records.
+// Between CS_MAX_KEYS and CSL_MAX_KEYS streams (up to about 13 500 samples at width 50) the same scheme runs with one large
+// workgroup per CU (the per-stream tables fill most of its LDS) and a direct scatter: with tens of thousands of streams a tile
+// holds less than one record per stream, staging would not merge any writes.  Beyond that: rocprim's radix sort.
 constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 2048;
-__global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, uint32_t n_keys, uint32_t per_block, uint32_t* __restrict__ H) {
+constexpr uint32_t CSL_MAX_KEYS = 36864, CSL_BLOCKS = 512, CSL_THREADS = 1024;
+__global__ __launch_bounds__(1024) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, uint32_t n_keys, uint32_t kmask, uint32_t per_block,
+                                                      uint32_t* __restrict__ H) {
     extern __shared__ uint32_t cs_lds[];
-    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) cs_lds[k] = 0;
+    for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) cs_lds[k] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
     if (lo < n)
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) { const uint32_t key = wkey[i]; if (key < n_keys) atomicAdd(&cs_lds[key], 1u); }
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const uint32_t key = wkey[i] & kmask; if (key < n_keys) atomicAdd(&cs_lds[key], 1u); }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_keys; k += 256) H[(size_t)k * CS_BLOCKS + blockIdx.x] = cs_lds[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)n_keys * CS_BLOCKS] = 0;          // the scan leaves the total here
+    for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) H[(size_t)k * gridDim.x + blockIdx.x] = cs_lds[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)n_keys * gridDim.x] = 0;          // the scan leaves the total here
 }
 // The scatter stages tiles of CS_TILE records in LDS sorted by stream, so that the records of one stream leave the tile as one
 // contiguous burst (a record-by-record scatter of 24-byte records is bound by the number of write transactions: measured 2 ms
@@ -1229,7 +1243,7 @@ __global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict
 constexpr uint32_t CS_TILE = 1024, CS_THREADS = 256;
 __host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + CS_THREADS * 4 + 64; }
 __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
-                                                         uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
+                                                         uint32_t kmask, uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
                                                          WideRec* __restrict__ swrec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
     WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
@@ -1247,11 +1261,12 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
     for (uint32_t t0 = lo; t0 < hi; t0 += CS_TILE) {
         for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) hist[k] = 0;
         __syncthreads();
-        uint32_t key[PER], rank[PER];
+        uint32_t key[PER], kw[PER], rank[PER];                     // stream, whole key word (stream + weight digit), rank in the tile
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
             const uint32_t i = t0 + j * CS_THREADS + threadIdx.x;
-            key[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
+            kw[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
+            key[j] = kw[j] & kmask;
             rank[j] = key[j] < n_keys ? atomicAdd(&hist[key[j]], 1u) : 0u;
         }
         __syncthreads();
@@ -1278,7 +1293,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
                 const uint32_t p = toff[key[j]] + rank[j];
                 st_rec[p] = wrec[i];
                 st_dst[p] = cursor[key[j]] + rank[j];
-                st_key[p] = key[j];
+                st_key[p] = kw[j];
             }
         }
         __syncthreads();
@@ -1292,11 +1307,41 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
     }
 }
 
+// many streams: the block's cursor of every stream in LDS, records written one by one
+__global__ __launch_bounds__(CSL_THREADS) void csl_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
+                                                           uint32_t kmask, uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
+                                                           WideRec* __restrict__ swrec) {
+    extern __shared__ uint32_t csl_cursor[];
+    for (uint32_t k = threadIdx.x; k < n_keys; k += CSL_THREADS) csl_cursor[k] = O[(size_t)k * CSL_BLOCKS + blockIdx.x];
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
+    if (lo >= n) return;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 4u * CSL_THREADS) {
+        uint32_t kw[4];
+        WideRec r[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t i = i0 + j * CSL_THREADS + threadIdx.x;
+            kw[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
+            if ((kw[j] & kmask) < n_keys) r[j] = wrec[i];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t key = kw[j] & kmask;
+            if (key < n_keys) {
+                const uint32_t d = atomicAdd(&csl_cursor[key], 1u);
+                swrec[d] = r[j];
+                swkey[d] = kw[j];
+            }
+        }
+    }
+}
+
 // K2 over records sorted by stream (dense mode): a window of K2S_WIN sorted positions, one 64 x 64 tile per run of equal streams
 constexpr uint32_t K2S_WIN = 4096;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
                                                         uint32_t limit, const uint32_t* __restrict__ total_ptr, uint32_t n_states,
-                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
@@ -1307,7 +1352,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ uint32_t tcount[256];
     const uint32_t total = total_ptr ? (*total_ptr < limit ? *total_ptr : limit) : limit;      // counting sort: the valid records; radix sort: all slots
     const uint32_t p0 = blockIdx.x * K2S_WIN;
-    if (p0 >= total || swkey[p0] >= n_states) return;
+    const uint32_t kmask = (1u << kbits) - 1u;
+    if (p0 >= total || (swkey[p0] & kmask) >= n_states) return;
     const uint32_t wend = total - p0 < K2S_WIN ? total - p0 : K2S_WIN;
     {
         unsigned long long v = 0;
@@ -1319,18 +1365,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // run starts: every thread scans 32 consecutive positions; a block scan puts them in order
     constexpr uint32_t PER = K2S_WIN / 256;
     const uint32_t t0 = threadIdx.x * PER;
-    uint32_t prev = (t0 == 0 || t0 >= wend) ? 0xFFFFFFFFu : swkey[p0 + t0 - 1];
+    uint32_t prev = (t0 == 0 || t0 >= wend) ? 0xFFFFFFFFu : (swkey[p0 + t0 - 1] & kmask);
     uint32_t mine = 0, flags = 0;
     uint32_t kk[PER];                                              // the thread's 32 keys: 8 loads of 16 bytes in flight together
     if (t0 + PER <= wend) {
 #pragma unroll
         for (uint32_t v = 0; v < PER / 4; ++v) {
             const uint4 q4 = ((const uint4*)(swkey + p0 + t0))[v];
-            kk[4 * v] = q4.x; kk[4 * v + 1] = q4.y; kk[4 * v + 2] = q4.z; kk[4 * v + 3] = q4.w;
+            kk[4 * v] = q4.x & kmask; kk[4 * v + 1] = q4.y & kmask; kk[4 * v + 2] = q4.z & kmask; kk[4 * v + 3] = q4.w & kmask;
         }
     } else {
 #pragma unroll
-        for (uint32_t i = 0; i < PER; ++i) kk[i] = t0 + i < wend ? swkey[p0 + t0 + i] : 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < PER; ++i) kk[i] = t0 + i < wend ? (swkey[p0 + t0 + i] & kmask) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (uint32_t i = 0; i < PER; ++i) {
@@ -1354,7 +1400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __syncthreads();
     for (uint32_t r = 0; r < nb; ++r) {
         const uint32_t a = bnd[r], b = bnd[r + 1];
-        const uint32_t key = swkey[p0 + a];
+        const uint32_t key = swkey[p0 + a] & kmask;
         if (key >= n_states) break;
         K2Item it;
         {
@@ -1363,7 +1409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             while (tri32(X) > bucket) --X;
             while (tri32(X + 1u) <= bucket) ++X;
             it.X = X; it.Y = bucket - tri32(X);
-            it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.rec = nullptr; it.recw = nullptr;
+            it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.skey = swkey + p0 + a; it.kbits = kbits; it.dbits = dbits; it.rec = nullptr; it.recw = nullptr;
         }
         k2_run<true>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
     }
@@ -1471,9 +1517,12 @@ __global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t*
     bitpos[i] = blkbase[i >> 8] + bitrel[i];
 }
 
+// weight digit bits of the wide pool's key word: what the stream bits and the two digit-index bits leave (four digits cover 32 bits)
+inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits - 2); }
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
-                    (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u};
+                    (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits)};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -1481,7 +1530,7 @@ void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 
 constexpr uint32_t K1G_MAX_WAVES = 4096;
 struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
-struct ValidKey { uint32_t n_states; __host__ __device__ uint32_t operator()(uint32_t k) const { return k < n_states ? 1u : 0u; } };
+struct ValidKey { uint32_t n_states, kmask; __host__ __device__ uint32_t operator()(uint32_t k) const { return (k & kmask) < n_states ? 1u : 0u; } };
 
 int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota);
@@ -1525,8 +1574,9 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, db->sort2_tmp_bytes, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)slots, 0, db->key_bits,
                                                db->stream));
     HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
-    if (db->n_states <= CS_MAX_KEYS && !db->cs_hist) {
-        const size_t ne = (size_t)db->n_states * CS_BLOCKS + 1;
+    if (db->n_states <= CSL_MAX_KEYS && !db->cs_hist) {
+        db->cs_blocks = db->n_states <= CS_MAX_KEYS ? CS_BLOCKS : CSL_BLOCKS;
+        const size_t ne = (size_t)db->n_states * db->cs_blocks + 1;
         HIP_TRY(hipMalloc((void**)&db->cs_hist, ne * 4));
         HIP_TRY(hipMalloc((void**)&db->cs_offs, ne * 4));
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->cs_tmp_bytes, db->cs_hist, db->cs_offs, (int)ne, db->stream));
@@ -1623,7 +1673,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     }
     db->NB = (uint32_t)((N + db->width - 1) / db->width);
     const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2;          // streams = block pairs
-    if (n_states >= (1ull << 30)) { db->fallback_reason = "too many block pairs"; return 0; }
+    if (n_states + 1 >= (1ull << 22)) { db->fallback_reason = "too many block pairs"; return 0; }          // 22 stream bits + 8-bit weight digits in a key word
     db->n_states = (uint32_t)n_states;
     // ---- working set
     HIP_TRY(hipMalloc((void**)&db->p0_mask, P * 8));
@@ -1687,7 +1737,7 @@ void kmdb_blocks_release(kmdb_db* db) {
 uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
     if (!db->counters) return 0;
     return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 20 + db->wide_cap * 4 + (db->P / 64) * 16 +
-           (db->wide_pool_cap << WCH_SHIFT) * 56;
+           (db->wide_pool_cap << WCH_SHIFT) * 40;
 }
 
 namespace {
@@ -1825,21 +1875,32 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         if (n_raw) {
             const uint32_t nslots = (uint32_t)((uint64_t)n_raw << WCH_SHIFT);
             const uint32_t* total_ptr = nullptr;
+            const uint32_t kmask = (1u << db->key_bits) - 1u;
             if (db->cs_hist) {
-                const uint32_t per_block = ((nslots + CS_BLOCKS - 1) / CS_BLOCKS + 255u) / 256u * 256u;
-                const size_t ne = (size_t)db->n_states * CS_BLOCKS + 1;
-                hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, per_block, db->cs_hist);
+                const uint32_t nblk = db->cs_blocks;
+                const bool large = nblk == CSL_BLOCKS;
+                const uint32_t per_block = ((nslots + nblk - 1) / nblk + 1023u) / 1024u * 1024u;
+                const size_t ne = (size_t)db->n_states * nblk + 1;
+                HIP_TRY(hipFuncSetAttribute((const void*)cs_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(db->n_states * 4)));
+                hipLaunchKernelGGL(cs_hist_kernel, dim3(nblk), dim3(large ? CSL_THREADS : 256), db->n_states * 4, st, db->wkey, nslots, db->n_states, kmask, per_block,
+                                   db->cs_hist);
                 size_t tb = db->cs_tmp_bytes;
                 HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
-                HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
-                hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
-                                   db->n_states, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                if (large) {
+                    HIP_TRY(hipFuncSetAttribute((const void*)csl_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(db->n_states * 4)));
+                    hipLaunchKernelGGL(csl_scatter_kernel, dim3(nblk), dim3(CSL_THREADS), db->n_states * 4, st, db->wkey, (const WideRec*)db->wrec, nslots, db->n_states,
+                                       kmask, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                } else {
+                    HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
+                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                                       db->n_states, kmask, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                }
                 total_ptr = db->cs_offs + (ne - 1);
                 HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
             } else {
                 {
                     // records in the wide pool (statistics): the slots whose key is a stream
-                    hipcub::TransformInputIterator<uint32_t, ValidKey, uint32_t*> it(db->wkey, ValidKey{db->n_states});
+                    hipcub::TransformInputIterator<uint32_t, ValidKey, uint32_t*> it(db->wkey, ValidKey{db->n_states, (1u << db->key_bits) - 1u});
                     size_t tbv = db->sort2_tmp_bytes;
                     HIP_TRY(hipcub::DeviceReduce::Sum(db->sort2_tmp, tbv, it, db->counters + KCTR_WIDE_RECORDS, (int)nslots, st));
                 }
@@ -1849,7 +1910,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             }
             const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
             hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, nslots, total_ptr,
-                               db->n_states, M, (uint32_t)db->N, db->width);
+                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width);
             HIP_TRY(hipGetLastError());
         }
         if (stage("sorted apply")) return 1;

@@ -433,7 +433,7 @@ def _random_forest(rng, N, P, max_local, heavy_frac=0.2, zero_frac=0.2, chain_fr
         last[p] = ids[-1]
         locs.append(ids.astype(np.int64))
         r = rng.random()
-        w[p] = 0 if r < zero_frac else (int(rng.integers(2, 1 << 20)) if r < zero_frac + heavy_frac else int(rng.integers(1, 4)))
+        w[p] = 0 if r < zero_frac else (int(rng.integers(2, 1 << int(rng.integers(8, 33)))) if r < zero_frac + heavy_frac else int(rng.integers(1, 4)))
     num_local = np.array([len(x) for x in locs], dtype=np.int64)
     lp = np.zeros(P + 1, dtype=np.int64)
     lp[1:] = np.cumsum(num_local)
