@@ -39,7 +39,12 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E p
 WORKLOADS = {
     "c2": dict(samples=1000, clade_size=50, length=5_000_000),
     "c3part": dict(samples=10000, clade_size=50, length=300_000),
+    # secondary modes (--mode), sized so that the synthetic generator and the reference finish in minutes
+    "c4part": dict(samples=20000, clade_size=50, length=100_000, k=25, fraction=0.1),      # configs[3] is 50 000 samples: --samples 50000
+    "c5part": dict(samples=10000, clade_size=50, length=100_000, queries=1000),            # configs[4]: 1000 queries vs a 10 000-sample database
+    "parts": dict(samples=2000, clade_size=50, length=300_000),                            # all2all-parts cell: two halves of one collection
 }
+MODE_WORKLOAD = {"all2all": "c2", "all2all-sp": "c4part", "new2all": "c5part", "db2db": "parts"}
 
 
 def log(*a):
@@ -127,6 +132,165 @@ def cpu_baseline(K, S, O, args, device, arr, names, counts, nk, gpu_matrix):
                           % (args.workload, arr["num_kmers"].size, thr, buf, len(tried), max(1, args.length // L), m.size)}
 
 
+def pattern_bytes(arr):
+    """B_pat of SURVEY 8(d): the on-disk pattern section, 40 B header + 16 B per 128 stream bits"""
+    return int((40 + 16 * ((arr["num_bits"].astype(np.int64) + 127) // 128)).sum())
+
+
+def secondary_mode(args, K, S, device):
+    """--mode all2all-sp | new2all | db2db: the rows of SURVEY 8 beside the dense all2all, one JSON line each in the same contract.
+    `value` is on device time (HIP events around the call's kernels, kmdb_stats.kernel_ms); these entry points take and return
+    HOST buffers, so the PCIe-inclusive wall time of one call is reported beside it (wall.call_ms)."""
+    from oracle import oracle as O
+    dev_index = device.index or 0
+    N, cs, L, k, f = args.samples, args.clade_size, args.length, args.k, args.fraction
+    g = S.CladeGenomes(N, cs, L, seed=args.seed, device=device)
+    t0 = time.time()
+
+    def make(ids, with_tables):
+        pat = S.build_patterns(lambda i: S.kmers_of(g.sample(ids[i]), k, f), len(ids), device, progress=None)
+        arr = S.to_view_arrays(pat)
+        tables = S.build_hashtables(pat["dictionary"], pat["kmer_pid"], k) if with_tables else None
+        return pat, arr, tables
+
+    def up(arr, n, tables):
+        view = K.make_view(k, n, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                           arr["data_offset"], arr["data"], bucket_offset=None if tables is None else tables[0],
+                           slots=None if tables is None else tables[1])
+        t1 = time.perf_counter()
+        d = K.DeviceDB(view, device=dev_index, with_hashtables=tables is not None)
+        return d, time.perf_counter() - t1
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        dev_ms, t1 = [], time.perf_counter()
+        for _ in range(args.steps):
+            res, d = fn()
+            dev_ms.append(d.stats()["kernel_ms"])
+        return res, float(np.mean(dev_ms)), (time.perf_counter() - t1) / args.steps * 1e3
+
+    cores = os.cpu_count() or 1
+    desc = "%d synthetic %g Mbp genomes (clade-mutation model, clades of %d), k=%d f=%g" % (N, L / 1e6, cs, k, f)
+    with tempfile.TemporaryDirectory(dir=args.tmp) as td:
+        if args.mode == "all2all-sp":
+            pat, arr, _ = make(list(range(N)), False)
+            log("synth db: %d k-mers, %d patterns in %.1f s" % (pat["dictionary"].numel(), arr["num_kmers"].size, time.time() - t0))
+            d, upload_s = up(arr, N, None)
+            sp, dev_ms, call_ms = timed(lambda: (d.all2all_sparse(), d))
+            st = d.stats()
+            alg = pattern_bytes(arr) + 8 * int(sp.nnz)
+            units, metric, unit = float(st["sum_pairs"]), "all2all-sp k-mer pair-comparisons/sec", "kmer-pair-comparisons/s"
+            # identity over the whole output: the non-zeros sum to sum_p w_p C(n_p, 2) (mod 2^32 per cell is not hit at these sizes)
+            assert int(sp.val.astype(np.uint64).sum()) == int(st["sum_pairs"]), "sparse output checksum mismatch"
+            cpu = None
+            if not args.no_cpu_baseline and O.have_ref():
+                path = os.path.join(td, "db.db")
+                S.write_db_fast(path, k, f, [g.name(i) for i in range(N)], pat["sample_counts"], arr, kmers_count=int(pat["dictionary"].numel()), device=device)
+                txt, info = O.ref_all2all_sp(path, os.path.join(td, "sp.txt"), threads=min(cores, 16))
+                lines = txt.split(b"\n")
+                for i in range(N):
+                    c, v = sp.row(i)
+                    assert "".join("%d:%d," % (a + 1, b) for a, b in zip(c, v)).encode() == lines[i], "row %d differs from the reference" % i
+                cpu = {"value": units / info["seconds"], "unit": unit, "cores": min(cores, 16), "host_cores": cores, "kind": "reference", "seconds": info["seconds"],
+                       "sample": "the same database, reference all2all_sp compute interval; all %d rows of the sparse output compared equal" % N}
+            cfg = {"workload": "%s: %s, all2all-sp" % (args.workload, desc), "nnz": int(sp.nnz), "patterns": int(d.P)}
+            kernel = "kmdb_all2all_sparse: block-record pipeline into the dense triangle + row_nnz / row_compact (CSR)"
+        elif args.mode == "new2all":
+            NQ = args.queries
+            pat, arr, tables = make(list(range(N)), True)
+            log("synth db + hashtables: %d k-mers, %d patterns in %.1f s" % (pat["dictionary"].numel(), arr["num_kmers"].size, time.time() - t0))
+            d, upload_s = up(arr, N, tables)
+            # queries = fresh strains of 20 clades of the collection (SURVEY 8d, C5)
+            n_clades = max(1, N // cs)
+            chosen = [int(c) for c in np.random.default_rng(args.seed + 1000).choice(n_clades, size=min(20, n_clades), replace=False)]
+            qs_dev = [S.kmers_of(g.strain(chosen[i * len(chosen) // NQ], N + i), k, f) for i in range(NQ)]
+            qs = [q.cpu().numpy().view(np.uint64) for q in qs_dev]
+            got, dev_ms, call_ms = timed(lambda: (d.new2all(qs), d))
+            # algorithmic bytes (SURVEY 8d): 16 B per looked-up k-mer + the root-path bytes of every distinct hit pattern + 4 N per query
+            node_b = torch.from_numpy(40 + 16 * ((arr["num_bits"].astype(np.int64) + 127) // 128)).to(device)
+            par = torch.from_numpy(arr["parent_id"].astype(np.int64)).to(device)
+            path_b, hop = node_b.clone(), par.clone()
+            while bool((hop >= 0).any()):
+                live = hop >= 0
+                path_b[live] += path_b[hop[live]]
+                hop[live] = hop[hop[live]]
+            dic, kp = pat["dictionary"], pat["kmer_pid"]
+            alg, hits_total = 0, 0
+            for q in qs_dev:
+                idx = torch.searchsorted(dic, q).clamp_(max=dic.numel() - 1)
+                hit = dic[idx] == q
+                pids = torch.unique(kp[idx[hit]].to(torch.int64))
+                hits_total += int(hit.sum())
+                alg += 16 * int(q.numel()) + int(path_b[pids].sum()) + 4 * N
+            # identity over the whole output: row sums == sum over hit k-mers of the number of samples of their pattern
+            ns = torch.from_numpy(arr["num_samples"].astype(np.int64)).to(device)
+            for i in (0, NQ // 2, NQ - 1):
+                idx = torch.searchsorted(dic, qs_dev[i]).clamp_(max=dic.numel() - 1)
+                hit = dic[idx] == qs_dev[i]
+                assert int(ns[kp[idx[hit]].to(torch.int64)].sum()) == int(got[i].astype(np.uint64).sum()), "row %d checksum mismatch" % i
+            units, metric, unit = float(NQ), "new2all queries/sec (k-mer sets resident on the host, %d-sample database)" % N, "queries/s"
+            cpu = None
+            if not args.no_cpu_baseline and O.have_ref():
+                path = os.path.join(td, "db.db")
+                S.write_db(path, k, f, [g.name(i) for i in range(N)], pat["sample_counts"], arr, kmers_count=int(pat["dictionary"].numel()), tables=tables)
+                nref = min(NQ, 16)
+                O.write_kmers_bin(os.path.join(td, "q.bin"), k, f, [("q%d" % i, q) for i, q in enumerate(qs[:nref])])
+                rows, info = O.ref_one2all(path, os.path.join(td, "q.bin"), os.path.join(td, "o.u32"), 1)
+                assert np.array_equal(rows.reshape(nref, N), got[:nref]), "new2all rows differ from the reference"
+                cpu = {"value": nref / info["seconds"], "unit": unit, "cores": 1, "host_cores": cores, "kind": "reference", "seconds": info["seconds"],
+                       "sample": "the same database, the first %d queries through the reference's one2all<false> on one thread (the reference's new2all "
+                                 "runs one such call per query, src/console_new2all.cpp); rows compared equal" % nref}
+            cfg = {"workload": "%s: %d fresh strains (%d k-mers each) against %s, new2all dense" % (args.workload, NQ, int(np.mean([q.size for q in qs])), desc),
+                   "queries": NQ, "kmers_found": hits_total, "patterns": int(d.P)}
+            kernel = "kmdb_new2all_batch: n2a_probe_kernel + pattern climb + row accumulation"
+        else:
+            ids_a, ids_b = list(range(0, N, 2)), list(range(1, N, 2))
+            pa, arr_a, tab_a = make(ids_a, True)
+            pb, arr_b, tab_b = make(ids_b, True)
+            log("synth parts + hashtables: %d + %d k-mers in %.1f s" % (pa["dictionary"].numel(), pb["dictionary"].numel(), time.time() - t0))
+            da, ua = up(arr_a, len(ids_a), tab_a)
+            d, ub = up(arr_b, len(ids_b), tab_b)
+            upload_s = ua + ub
+            got, dev_ms, call_ms = timed(lambda: (d.db2db(da), d))
+            # algorithmic bytes: every stored k-mer of the row database looked up in the column database (8 B item read + 8 B item probed),
+            # both pattern sections once, the result once
+            alg = 16 * int(pb["dictionary"].numel()) + pattern_bytes(arr_a) + pattern_bytes(arr_b) + 4 * len(ids_a) * len(ids_b)
+            units, metric, unit = float(got.astype(np.uint64).sum()), "db2db (all2all-parts cell) shared k-mer pair-comparisons/sec", "kmer-pair-comparisons/s"
+            # identity over the whole output: the cell of the union matrix — sum == sum over shared k-mers of n_a(p) * n_b(q)
+            common = torch.isin(pb["dictionary"], pa["dictionary"])
+            ia = torch.searchsorted(pa["dictionary"], pb["dictionary"][common])
+            na = torch.from_numpy(arr_a["num_samples"].astype(np.int64)).to(device)[pa["kmer_pid"][ia].to(torch.int64)]
+            nb_ = torch.from_numpy(arr_b["num_samples"].astype(np.int64)).to(device)[pb["kmer_pid"][common].to(torch.int64)]
+            assert int((na * nb_).sum()) == int(units), "db2db checksum mismatch"
+            cpu = None
+            if not args.no_cpu_baseline and O.have_ref():
+                fa, fb = os.path.join(td, "a.db"), os.path.join(td, "b.db")
+                S.write_db(fa, k, f, [g.name(i) for i in ids_a], pa["sample_counts"], arr_a, kmers_count=int(pa["dictionary"].numel()), tables=tab_a)
+                S.write_db(fb, k, f, [g.name(i) for i in ids_b], pb["sample_counts"], arr_b, kmers_count=int(pb["dictionary"].numel()), tables=tab_b)
+                txt, info = O.ref_db2db_sp(fb, fa, os.path.join(td, "o.txt"), threads=min(cores, 16))
+                lines = txt.split(b"\n")
+                for r in range(got.shape[0]):
+                    assert "".join("%d:%d," % (c + 1, v) for c, v in enumerate(got[r]) if v).encode() == lines[r], "row %d differs from the reference" % r
+                cpu = {"value": units / info["seconds"], "unit": unit, "cores": min(cores, 16), "host_cores": cores, "kind": "reference", "seconds": info["seconds"],
+                       "sample": "the same two databases, reference db2db_sp compute interval; all %d rows compared equal" % got.shape[0]}
+            cfg = {"workload": "%s: %s split into two databases of %d / %d samples (even / odd ids), db2db" % (args.workload, desc, len(ids_b), len(ids_a)),
+                   "patterns": [int(d.P), int(da.P)]}
+            kernel = "kmdb_db2db_dense: item probe of the row database's tables in the column database's + pair-of-paths accumulation"
+    achieved = alg / (dev_ms * 1e-3) / 1e9
+    out = {"metric": metric, "value": units / (dev_ms * 1e-3), "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dev_ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": dict(cfg, samples=N, genome_length_bp=L, k=k, fraction=f, mode=args.mode),
+           "wall": {"upload_s": upload_s, "call_ms": call_ms,
+                    "note": "ms_per_step / value: device time of one call (HIP events); call_ms: the same call as the host sees it, host buffers in "
+                            "and out (H2D / D2H inclusive)"},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": kernel, "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg}}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out), flush=True)
+
+
 def respawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run"""
     port = 29500 + (os.getpid() % 2000)
@@ -143,11 +307,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--clade-size", type=int, default=None)
     ap.add_argument("--length", type=int, default=None, help="genome length (bp); per GPU with --scaling weak")
-    ap.add_argument("--k", type=int, default=18)
+    ap.add_argument("--mode", default="all2all", choices=sorted(MODE_WORKLOAD),
+                    help="all2all (default, the headline line) or one of the secondary rows: all2all-sp, new2all, db2db (1 GPU)")
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--fraction", type=float, default=None)
+    ap.add_argument("--queries", type=int, default=None)
     ap.add_argument("--seed", type=int, default=20260928 + 1)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample-length", type=int, default=100_000)
@@ -157,7 +325,9 @@ def main():
                     help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the matrix reduce goes through host memory); never used for reported numbers")
     args = ap.parse_args()
-    for key, val in WORKLOADS[args.workload].items():
+    if args.workload is None:
+        args.workload = MODE_WORKLOAD[args.mode]
+    for key, val in dict(dict(k=18, fraction=1.0, queries=0), **WORKLOADS[args.workload]).items():
         if getattr(args, key) is None:
             setattr(args, key, val)
 
@@ -185,6 +355,13 @@ def main():
     import importlib
     S = importlib.import_module("kmerdb_amd.synth")
 
+    if args.mode != "all2all":
+        if world != 1:
+            raise SystemExit("bench.py: --mode %s runs on one GPU" % args.mode)
+        secondary_mode(args, K, S, device)
+        return
+    if args.fraction != 1.0:
+        raise SystemExit("bench.py: the all2all mode runs at f = 1.0 (use --mode all2all-sp for minhash databases)")
     strong = world > 1 and args.scaling == "strong"
     total_len = args.length if (world == 1 or strong) else args.length * world
     if strong:

@@ -79,6 +79,10 @@ class CladeGenomes:
         c = i // self.clade_size
         return self._mutate(self.clade_ancestor(c), 1_000_003 + i, self.r2)
 
+    def strain(self, c, stream_id):
+        """a fresh strain of clade c (a query genome that is not in the collection): stream_id >= n_samples"""
+        return self._mutate(self.clade_ancestor(c), 1_000_003 + stream_id, self.r2)
+
     def name(self, i):
         return "g%05d" % i
 

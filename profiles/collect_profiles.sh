@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the per-round profile evidence on the GPU box (run from the repo root):
-#   bash profiles/collect_profiles.sh <tag> [all|stats|pmc]        e.g. r02_v3
+#   bash profiles/collect_profiles.sh <tag> [all|stats|pmc]        e.g. r02_v3        (BENCH_ARGS="--workload c3part" for another workload)
 # 1. bench line (with cpu_baseline)   2. rocprofv3 kernel stats of the same command
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (never combined with other trace domains)
 set -u
@@ -10,16 +10,17 @@ OUT=$PWD/gpurun_out
 R=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
+BA=${BENCH_ARGS:-}
 if [ "$WHAT" = "all" ]; then
-python bench.py 2> $OUT/${TAG}_bench.err | tee $OUT/${TAG}_bench.json
+python bench.py $BA 2> $OUT/${TAG}_bench.err | tee $OUT/${TAG}_bench.json
 fi
 if [ "$WHAT" != "pmc" ]; then
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $OUT/${TAG}_bench_profiled.json 2> /tmp/prof_stats.err )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py $BA --no-cpu-baseline --steps 5 --warmup 2 > $OUT/${TAG}_bench_profiled.json 2> /tmp/prof_stats.err )
 find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_all.csv \;
 fi
 if [ "$WHAT" != "stats" ]; then
 for C in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> /tmp/prof_$C.err )
+  ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- python $R/bench.py $BA --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> /tmp/prof_$C.err )
   find /tmp/prof_$C -name '*counter_collection.csv' -exec cp {} /tmp/${C}.csv \;
 done
 fi

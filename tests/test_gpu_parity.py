@@ -548,6 +548,27 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
         assert abs(d2["value"] * d2["ms_per_step"] - d["value"] * d["ms_per_step"]) / (d["value"] * d["ms_per_step"]) < 1e-9
 
 
+@pytest.mark.parametrize("mode", ["all2all-sp", "new2all", "db2db"])
+def test_bench_secondary_modes(dev, mode):
+    """`bench.py --mode`: the all2all-sp / new2all / db2db rows as driver-runnable lines in the same contract; each run checks a
+    whole-output identity and (oracle/_ref present) compares every row with the real reference's output."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", mode, "--samples", "600", "--length", "20000", "--queries", "24",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "wall"):
+        assert k in d, k
+    assert d["config"]["mode"] == mode and d["value"] > 0 and d["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_driver")):
+        assert d["cpu_baseline"]["kind"] == "reference" and "compared equal" in d["cpu_baseline"]["sample"]
+
+
 def test_new2all_synthetic_scale(K, O, dev, tmp_path):
     """new2all on a bench-shaped database (1000 samples) with synthetic hashtables: members, fresh strains of
     known clades, an unrelated genome and an empty query, dense and sparse, against the oracle and the
