@@ -675,7 +675,8 @@ struct GParams {
     const ulonglong2* fn_mask;
     const uint32_t* fn_blk;
     uint32_t emit_lo, emit_hi;
-    uint32_t n_waves;              // waves of the launch, each with a run of consecutive batches of 64 wide nodes
+    uint32_t run;                  // consecutive batches per run
+    uint32_t n_waves;              // waves of the launch, each with runs of consecutive batches of 64 wide nodes
     uint32_t tbits, n_states;
     PoolView pool;
 };
@@ -684,6 +685,7 @@ constexpr uint32_t K1G_ROW = 12;           // entries of a lane's row (lists wit
 constexpr uint32_t K1G_ENT = 64 * K1G_ROW; // the rows double as the entry pool of the climbing path
 constexpr uint32_t K1G_CH = 16;            // chain slots (by depth mod 16)
 constexpr uint32_t K1G_QCAP = 128;         // record descriptors queued per round
+constexpr uint32_t K1G_RUN = 8;            // consecutive batches per run of a wave
 struct K1GWave {
     unsigned long long ent_mask[K1G_ENT];
     unsigned long long ch_mask[K1G_CH * K1G_ROW];
@@ -694,6 +696,8 @@ struct K1GWave {
     uint16_t ch_blk[K1G_CH * K1G_ROW];
     uint16_t st_start[64];
     uint16_t ch_len[K1G_CH];
+    unsigned long long co_mask[64];         // the list of the node the whole wave emits, contiguous (a lane's row is strided: one bank)
+    uint16_t co_blk[64];
 };
 
 // One lane per wide node, batches of 64 consecutive nodes of the (DFS-ordered) wide list, a run of batches per wave.
@@ -712,7 +716,10 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
     const uint32_t wid = blockIdx.x * K1G_WAVES + wave;          // every wave takes a run of consecutive batches
     if (wid >= q.n_waves) return;
     const uint32_t n_batches = (q.n_wide + WAVE - 1) / WAVE;
-    const uint32_t b_lo = (uint32_t)((uint64_t)n_batches * wid / q.n_waves), b_hi = (uint32_t)((uint64_t)n_batches * (wid + 1) / q.n_waves);
+    // runs of K1G_RUN consecutive batches, dealt round-robin: the records per node differ by orders of magnitude (3 blocks: 6
+    // records, 200 blocks: 20 100) and heavy nodes sit together in the DFS order — equal contiguous shares left a few waves
+    // with most of the work.  (A shared work counter is no alternative: same-address device atomics run at a few million per second.)
+    const uint32_t n_runs = (n_batches + q.run - 1u) / q.run;
     auto iswide = [&](uint32_t y) -> bool { return (q.widebits[y >> 6] >> (y & 63u)) & 1ull; };
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     WaveArena A;
@@ -730,7 +737,16 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
             while (hb) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(hb);
                 hb &= hb - 1ull;
-                const uint32_t mj = bcast(m, j), wj = bcast(wv, j), stj = L.st_start[j];
+                const uint32_t mj = bcast(m, j), wj = bcast(wv, j);
+                uint32_t stj = L.st_start[j];
+                const unsigned long long* cmask = L.ent_mask + stj;
+                const uint16_t* cblk = L.ent_blk + stj;
+                if (stride != 1u) {
+                    lds_sync();
+                    if (lane < mj) { L.co_mask[lane] = L.ent_mask[stj + lane * stride]; L.co_blk[lane] = L.ent_blk[stj + lane * stride]; }
+                    lds_sync();
+                    cmask = L.co_mask; cblk = L.co_blk;
+                }
                 const uint32_t Tj = mj * (mj + 1u) / 2u;
                 for (uint32_t t0 = 0; t0 < Tj; t0 += WAVE) {
                     const uint32_t t = t0 + lane;
@@ -742,8 +758,8 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                         while (tri32(a) > t) --a;
                         while (tri32(a + 1u) <= t) ++a;
                         const uint32_t b = t - tri32(a);
-                        FX = L.ent_mask[stj + a * stride]; FY = L.ent_mask[stj + b * stride];
-                        const uint32_t X = L.ent_blk[stj + a * stride], Y = L.ent_blk[stj + b * stride];
+                        FX = cmask[a]; FY = cmask[b];
+                        const uint32_t X = cblk[a], Y = cblk[b];
                         rec_on = a != b || __popcll(FX) >= 2;
                         if (a == b) FY = FX;
                         stream = tri32(X) + Y;
@@ -801,7 +817,8 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
     };
 
     uint32_t n_slow = 0;
-    for (uint32_t batch = b_lo; batch < b_hi; ++batch) {
+    for (uint32_t run = wid; run < n_runs; run += q.n_waves)
+    for (uint32_t batch = run * q.run; batch < (run + 1u) * q.run && batch < n_batches; ++batch) {
         const uint32_t k = batch * WAVE + lane;
         const bool valid = k < q.n_wide;
         const uint32_t node = valid ? q.widx[k] : 0u;
@@ -1224,14 +1241,33 @@ __global__ void count_raw_kernel(const uint32_t* __restrict__ wsub_cursor, uint3
 // holds less than one record per stream, staging would not merge any writes.  Beyond that: rocprim's radix sort.
 constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 2048;
 constexpr uint32_t CSL_MAX_KEYS = 36864, CSL_BLOCKS = 512, CSL_THREADS = 1024;
-__global__ __launch_bounds__(1024) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, uint32_t n_keys, uint32_t kmask, uint32_t per_block,
-                                                      uint32_t* __restrict__ H) {
+// block row X of stream s = tri32(X) + Y
+__device__ __forceinline__ uint32_t stream_row(uint32_t s) {
+    uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)s + 1.0f) - 1.0f) * 0.5f);
+    while (tri32(X) > s) --X;
+    while (tri32(X + 1u) <= s) ++X;
+    return X;
+}
+// the records [0, n) in equal shares of whole 1024-record tiles; n_ptr: the count comes from an earlier kernel (<= n)
+__device__ __forceinline__ void cs_range(uint32_t n, const uint32_t* n_ptr, uint32_t& lo, uint32_t& hi) {
+    if (n_ptr) { const uint32_t m = *n_ptr; n = m < n ? m : n; }
+    const uint32_t per_block = ((n + gridDim.x - 1u) / gridDim.x + 1023u) / 1024u * 1024u;
+    lo = blockIdx.x * per_block;
+    hi = n - lo < per_block ? n : lo + per_block;
+    if (lo >= n) { lo = 0; hi = 0; }
+}
+// n_valid streams; bins = the streams themselves, or (byrow) their block rows
+__global__ __launch_bounds__(1024) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, const uint32_t* __restrict__ n_ptr, uint32_t n_valid, uint32_t n_keys,
+                                                      uint32_t byrow, uint32_t kmask, uint32_t* __restrict__ H) {
     extern __shared__ uint32_t cs_lds[];
     for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) cs_lds[k] = 0;
     __syncthreads();
-    const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
-    if (lo < n)
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const uint32_t key = wkey[i] & kmask; if (key < n_keys) atomicAdd(&cs_lds[key], 1u); }
+    uint32_t lo, hi;
+    cs_range(n, n_ptr, lo, hi);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t key = wkey[i] & kmask;
+        if (key < n_valid) atomicAdd(&cs_lds[byrow ? stream_row(key) : key], 1u);
+    }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) H[(size_t)k * gridDim.x + blockIdx.x] = cs_lds[k];
     if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)n_keys * gridDim.x] = 0;          // the scan leaves the total here
@@ -1242,9 +1278,9 @@ __global__ __launch_bounds__(1024) void cs_hist_kernel(const uint32_t* __restric
 // tile offsets, the block's running global cursor).
 constexpr uint32_t CS_TILE = 1024, CS_THREADS = 256;
 __host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + CS_THREADS * 4 + 64; }
-__global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
-                                                         uint32_t kmask, uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
-                                                         WideRec* __restrict__ swrec) {
+__global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_valid,
+                                                         uint32_t n_keys, uint32_t byrow, uint32_t kmask, const uint32_t* __restrict__ O,
+                                                         uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
     WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
     uint32_t* st_dst = (uint32_t*)(st_rec + CS_TILE);                     // [CS_TILE] global destination
@@ -1254,8 +1290,8 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
     uint32_t* cursor = toff + n_keys;                                     // [n_keys] next global position of the stream for this block
     uint32_t* part = cursor + n_keys;                                     // [CS_THREADS] scan scratch
     for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) cursor[k] = O[(size_t)k * CS_BLOCKS + blockIdx.x];
-    const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
-    if (lo >= n) return;
+    uint32_t lo, hi;
+    cs_range(n, nullptr, lo, hi);
     constexpr uint32_t PER = CS_TILE / CS_THREADS;
     const uint32_t kper = (n_keys + CS_THREADS - 1u) / CS_THREADS;                          // streams per thread in the scan
     for (uint32_t t0 = lo; t0 < hi; t0 += CS_TILE) {
@@ -1267,6 +1303,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
             const uint32_t i = t0 + j * CS_THREADS + threadIdx.x;
             kw[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
             key[j] = kw[j] & kmask;
+            key[j] = key[j] < n_valid ? (byrow ? stream_row(key[j]) : key[j]) : 0xFFFFFFFFu;
             rank[j] = key[j] < n_keys ? atomicAdd(&hist[key[j]], 1u) : 0u;
         }
         __syncthreads();
@@ -1308,14 +1345,14 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
 }
 
 // many streams: the block's cursor of every stream in LDS, records written one by one
-__global__ __launch_bounds__(CSL_THREADS) void csl_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_keys,
-                                                           uint32_t kmask, uint32_t per_block, const uint32_t* __restrict__ O, uint32_t* __restrict__ swkey,
-                                                           WideRec* __restrict__ swrec) {
+__global__ __launch_bounds__(CSL_THREADS) void csl_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n,
+                                                           const uint32_t* __restrict__ n_ptr, uint32_t n_keys, uint32_t kmask, const uint32_t* __restrict__ O,
+                                                           uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec) {
     extern __shared__ uint32_t csl_cursor[];
     for (uint32_t k = threadIdx.x; k < n_keys; k += CSL_THREADS) csl_cursor[k] = O[(size_t)k * CSL_BLOCKS + blockIdx.x];
     __syncthreads();
-    const uint32_t lo = blockIdx.x * per_block, hi = n - lo < per_block ? n : lo + per_block;
-    if (lo >= n) return;
+    uint32_t lo, hi;
+    cs_range(n, n_ptr, lo, hi);
     for (uint32_t i0 = lo; i0 < hi; i0 += 4u * CSL_THREADS) {
         uint32_t kw[4];
         WideRec r[4];
@@ -1853,7 +1890,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
         const uint32_t batches = (n_wide + WAVE - 1) / WAVE;
-        q.n_waves = std::min<uint32_t>(K1G_MAX_WAVES, batches);
+        q.run = K1G_RUN;
+        if (const char* e = getenv("KMDB_K1G_RUN")) q.run = std::max(1, atoi(e));
+        q.n_waves = std::min<uint32_t>(K1G_MAX_WAVES, (batches + q.run - 1) / q.run);
         q.tbits = 0u; q.n_states = db->n_states;              // the wide kernel always writes into the wide pool: no open-chunk table
         const size_t lds = arena_table_bytes(q.tbits, q.n_states) * K1G_WAVES;
         HIP_TRY(hipFuncSetAttribute((const void*)k1g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(K1GWave) * K1G_WAVES)));
@@ -1876,24 +1915,44 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             const uint32_t nslots = (uint32_t)((uint64_t)n_raw << WCH_SHIFT);
             const uint32_t* total_ptr = nullptr;
             const uint32_t kmask = (1u << db->key_bits) - 1u;
+            const uint32_t* sorted_key = db->swkey;
+            const WideRec* sorted_rec = (const WideRec*)db->swrec;
             if (db->cs_hist) {
                 const uint32_t nblk = db->cs_blocks;
                 const bool large = nblk == CSL_BLOCKS;
-                const uint32_t per_block = ((nslots + nblk - 1) / nblk + 1023u) / 1024u * 1024u;
-                const size_t ne = (size_t)db->n_states * nblk + 1;
                 HIP_TRY(hipFuncSetAttribute((const void*)cs_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(db->n_states * 4)));
-                hipLaunchKernelGGL(cs_hist_kernel, dim3(nblk), dim3(large ? CSL_THREADS : 256), db->n_states * 4, st, db->wkey, nslots, db->n_states, kmask, per_block,
-                                   db->cs_hist);
-                size_t tb = db->cs_tmp_bytes;
-                HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
+                size_t ne;
                 if (large) {
+                    // many streams: first the records grouped by block row (NB bins, staged scatter), then every row's records by stream with
+                    // the direct scatter — a workgroup of the second pass then writes to a few hundred streams, which its L2 merges
+                    const size_t ne1 = (size_t)db->NB * CS_BLOCKS + 1;
+                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), db->NB * 4, st, db->wkey, nslots, (const uint32_t*)nullptr, db->n_states, db->NB, 1u,
+                                       kmask, db->cs_hist);
+                    size_t tb = db->cs_tmp_bytes;
+                    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne1, st));
+                    HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->NB)));
+                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->NB), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                                       db->n_states, db->NB, 1u, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                    HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, db->cs_offs + (ne1 - 1), 4, hipMemcpyDeviceToDevice, st));
+                    const uint32_t* n_ptr = db->counters + KCTR_WIDE_RECORDS;
+                    ne = (size_t)db->n_states * nblk + 1;
+                    hipLaunchKernelGGL(cs_hist_kernel, dim3(nblk), dim3(CSL_THREADS), db->n_states * 4, st, db->swkey, nslots, n_ptr, db->n_states, db->n_states, 0u,
+                                       kmask, db->cs_hist);
+                    tb = db->cs_tmp_bytes;
+                    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
                     HIP_TRY(hipFuncSetAttribute((const void*)csl_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(db->n_states * 4)));
-                    hipLaunchKernelGGL(csl_scatter_kernel, dim3(nblk), dim3(CSL_THREADS), db->n_states * 4, st, db->wkey, (const WideRec*)db->wrec, nslots, db->n_states,
-                                       kmask, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                    hipLaunchKernelGGL(csl_scatter_kernel, dim3(nblk), dim3(CSL_THREADS), db->n_states * 4, st, db->swkey, (const WideRec*)db->swrec, nslots, n_ptr,
+                                       db->n_states, kmask, db->cs_offs, db->wkey, (WideRec*)db->wrec);
+                    sorted_key = db->wkey; sorted_rec = (const WideRec*)db->wrec;
                 } else {
+                    ne = (size_t)db->n_states * nblk + 1;
+                    hipLaunchKernelGGL(cs_hist_kernel, dim3(nblk), dim3(256), db->n_states * 4, st, db->wkey, nslots, (const uint32_t*)nullptr, db->n_states, db->n_states, 0u,
+                                       kmask, db->cs_hist);
+                    size_t tb = db->cs_tmp_bytes;
+                    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
                     HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
                     hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
-                                       db->n_states, kmask, per_block, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                                       db->n_states, db->n_states, 0u, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
                 }
                 total_ptr = db->cs_offs + (ne - 1);
                 HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
@@ -1909,7 +1968,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                                                            db->key_bits, st));
             }
             const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
-            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, nslots, total_ptr,
+            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, sorted_key, sorted_rec, nslots, total_ptr,
                                db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width);
             HIP_TRY(hipGetLastError());
         }
