@@ -13,6 +13,7 @@
 // Everything below the three kmdb_* compute calls runs on the GPU; there is no CPU engine here.
 #include "kmdb_amd.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -615,6 +616,149 @@ int run_one2all(std::vector<std::string>& args, Common& c) {
     return 0;
 }
 
+// ---- distance (console_distance.cpp:7-213, params.cpp:603-668) ----------------------------------------
+// Text in, text out: the table of common k-mer counts that all2all / all2all-sp / new2all wrote -> one similarity / distance
+// measure per cell.  Same row semantics as the reference: a dense triangle (first row named like the first sample, no counts
+// in it) keeps i values in row i, any other dense table whole rows; sparse input or -sparse give "column:value" pairs of the
+// non-zero counts that pass the filters; a bound without a criterion filters the chosen measure.
+
+// a measure in the reference's fixed notation (conversion.h:167-219, 262-268): exactly 0 is "0", everything else has six
+// decimals, rounded half up on the magnitude
+size_t put_measure(double v, char* out) {
+    if (v == 0) { *out = '0'; return 1; }
+    char* p = out;
+    if (v < 0) { *p++ = '-'; v = -v; }
+    const unsigned long long x = (unsigned long long)(v * 1000000.0 + 0.5);
+    p += std::snprintf(p, 40, "%llu.%06llu", x / 1000000ull, x % 1000000ull);
+    return (size_t)(p - out);
+}
+size_t put_uint(unsigned long long v, char* out) { return (size_t)std::snprintf(out, 24, "%llu", v); }
+
+int run_distance(std::vector<std::string>& args) {
+    bool sparse_out = take_switch(args, "-sparse");
+    const bool phylip = take_switch(args, "-phylip-out");
+    if (phylip) sparse_out = false;
+    auto avail = metrics();
+    struct Bound { metric_fn fn; double lo = std::numeric_limits<double>::lowest(), hi = std::numeric_limits<double>::max(); };
+    std::map<std::string, Bound> bounds;
+    long kmer_lo = 0, kmer_hi = std::numeric_limits<uint32_t>::max();
+    const char* names[2] = {"-min", "-max"};
+    for (int which = 0; which < 2; ++which) {
+        std::string v;
+        while (take_option(args, names[which], v)) {
+            std::string crit = "?", num = v;
+            const auto sep = v.rfind(':');
+            if (sep != std::string::npos) { crit = v.substr(0, sep); num = v.substr(sep + 1); }
+            std::istringstream iss(num);
+            double value;
+            if (!(iss >> value)) throw std::runtime_error("Filtering error - unable to parse numerical value: " + v);
+            if (crit == "num-kmers") (which == 0 ? kmer_lo : kmer_hi) = std::lrint(value);
+            else if (crit == "?" || avail.count(crit)) (which == 0 ? bounds[crit].lo : bounds[crit].hi) = value;
+            else throw std::runtime_error("Filtering error - unknown metric: " + crit);
+        }
+    }
+    if (args.empty()) throw std::runtime_error("No distance/similarity metric specified");
+    const std::string measure_name = args.front();
+    args.erase(args.begin());
+    if (args.size() < 2) throw usage_error("distance");
+    if (!avail.count(measure_name)) throw std::runtime_error("unknown measure: " + measure_name);
+    if (bounds.count("?")) {                                   // a bare bound belongs to the chosen measure
+        const Bound b = bounds["?"];
+        bounds.erase("?");
+        bounds[measure_name] = b;
+    }
+    for (auto& kv : bounds) kv.second.fn = avail[kv.first];
+    const metric_fn measure = avail[measure_name];
+
+    std::ifstream in(args[0]);
+    if (!in) throw std::runtime_error("Cannot open common k-mers table: " + args[0]);
+    std::ofstream out(args[1]);
+    std::string tok, rest;
+    uint32_t k = 0;
+    double fraction = 0;
+    in >> tok >> k >> tok >> fraction >> tok;                  // "kmer-length: K fraction: F db-samples"
+    std::getline(in, rest);                                    // ",name,name,..."
+    if (!phylip) out << "kmer-length: " << k << " fraction: " << fraction << rest << std::endl;
+    std::vector<std::string> sample_names;
+    {
+        std::string t = rest;
+        std::replace(t.begin(), t.end(), ',', ' ');
+        std::istringstream iss(t);
+        for (std::string w; iss >> w;) sample_names.push_back(w);
+    }
+    std::vector<uint32_t> db_counts;
+    {
+        std::getline(in, rest);                                // "query-samples,total-kmers,c0,c1,..."
+        std::replace(rest.begin(), rest.end(), ',', ' ');
+        std::istringstream iss(rest);
+        iss >> tok >> tok;
+        for (unsigned long long c; iss >> c;) db_counts.push_back((uint32_t)c);
+    }
+    const size_t n = db_counts.size();
+    if (phylip) out << n << std::endl;
+
+    auto pass = [&](uint32_t common, uint32_t qcnt, size_t col) {
+        for (auto& kv : bounds) {
+            const double x = kv.second.fn(common, qcnt, db_counts[col], (int)k);
+            if (!(x >= kv.second.lo && x <= kv.second.hi)) return false;
+        }
+        return (long)common >= kmer_lo && (long)common <= kmer_hi;
+    };
+    auto read_uint = [](const char*& p) { unsigned long long v = 0; while (*p >= '0' && *p <= '9') v = v * 10 + (unsigned)(*p++ - '0'); return v; };
+
+    std::vector<uint32_t> dense(n, 0);
+    std::vector<std::pair<size_t, uint32_t>> hits;
+    std::vector<char> obuf;
+    bool triangle = false;
+    std::string line;
+    for (size_t row = 0; std::getline(in, line); ++row) {
+        const char* p = line.c_str();
+        const char* end = p + line.size();
+        const char* comma = std::find(p, end, ',');
+        const std::string qname(p, comma);
+        p = comma < end ? comma + 1 : end;
+        const uint32_t qcnt = (uint32_t)read_uint(p);
+        if (p < end) ++p;
+        size_t n_read = 0;
+        for (; end - p > 1; ++n_read) {
+            const unsigned long long v = read_uint(p);
+            if (*p == ':') {                                   // sparse input: 1-based column, count
+                ++p;
+                const uint32_t common = (uint32_t)read_uint(p);
+                if (phylip) { if (v >= 1 && v <= n) dense[v - 1] = common; }
+                else {
+                    sparse_out = true;                         // sparse input always gives sparse output
+                    if (common > 0 && v >= 1 && v <= n && pass(common, qcnt, v - 1)) hits.emplace_back(v - 1, common);
+                }
+            } else if (sparse_out) {
+                if (v > 0 && n_read < n && pass((uint32_t)v, qcnt, n_read)) hits.emplace_back(n_read, (uint32_t)v);
+            } else if (n_read < n) dense[n_read] = (uint32_t)v;
+            if (p < end) ++p;
+        }
+        const bool empty_first = sparse_out ? hits.empty() : (n == 0 || dense[0] == 0);
+        if (row == 0 && !sample_names.empty() && qname == sample_names[0] && empty_first) triangle = true;
+        const size_t n_proc = sparse_out ? hits.size() : (triangle ? std::min(row, n) : n);
+        obuf.resize(qname.size() + 64 + (phylip ? n_read : n_proc) * 48);
+        char* o = obuf.data();
+        std::memcpy(o, qname.data(), qname.size());
+        o += qname.size();
+        if (phylip) {
+            *o++ = ' ';
+            for (size_t c = 0; c < n_read && c < n; ++c) { o += put_measure(c < n_proc ? measure(dense[c], qcnt, db_counts[c], (int)k) : 0.0, o); *o++ = ' '; }
+        } else {
+            *o++ = ',';
+            if (sparse_out)
+                for (auto& h : hits) { o += put_uint(h.first + 1, o); *o++ = ':'; o += put_measure(measure(h.second, qcnt, db_counts[h.first], (int)k), o); *o++ = ','; }
+            else
+                for (size_t c = 0; c < n_proc; ++c) { o += put_measure(measure(dense[c], qcnt, db_counts[c], (int)k), o); *o++ = ','; }
+        }
+        out.write(obuf.data(), o - obuf.data());
+        out << std::endl;
+        if (sparse_out && !phylip) hits.clear(); else std::fill(dense.begin(), dense.end(), 0u);
+    }
+    return 0;
+}
+
 void usage() {
     std::cerr << "kmer-db-amd (MI355X engine for kmer-db's all2all / all2all-sp / new2all)\n"
                  "USAGE\n"
@@ -623,6 +767,7 @@ void usage() {
                  "    kmer-db-amd new2all [-multisample-fasta] [-sparse [-min ...] [-max ...]] <database> <sample_list> <common_table>\n"
                  "    kmer-db-amd one2all <database> <sample> <similarity_vector>\n"
                  "    kmer-db-amd all2all-parts [-min ...] [-max ...] <db_list> <common_table>\n"
+                 "    kmer-db-amd distance [-sparse] [-phylip-out] [-min [<criterion>:]<v>]* [-max [<criterion>:]<v>]* <measure> <common_table> <output>\n"
                  "Common options: -t <threads>, -gpu <device>\n";
 }
 
@@ -646,6 +791,7 @@ int main(int argc, char** argv) {
         if (mode == "new2all") return run_new2all(args, c);
         if (mode == "one2all") return run_one2all(args, c);
         if (mode == "all2all-parts") return run_all2all_parts(args, c);
+        if (mode == "distance") return run_distance(args);
         usage();
         return -1;
     } catch (usage_error&) {

@@ -185,3 +185,48 @@ def test_cli_usage_and_open_errors(golden_dir):
     assert r.returncode != 0 and "ERROR: Cannot open k-mer database /nonexistent.db" in r.stderr
     r = subprocess.run([exe, "all2all", "onlyone"], capture_output=True, text=True)
     assert r.returncode != 0 and "USAGE" in r.stderr
+
+
+DISTANCE_CASES = [
+    # the reference's own distance tests (.github/workflows/self-hosted.yml:146-234, main.yml:99-110): arguments, input, golden
+    (["mash"], "synth.a2a", "synth.a2a.mash"),
+    (["ani"], "synth.a2a", "synth.a2a.ani"),
+    (["-sparse", "ani"], "synth.a2a", "synth.a2a-sparse.ani"),
+    (["-sparse", "-max", "1.0", "-min", "-1.0", "mash"], "synth.a2a", "synth.a2a-sparse.mash"),
+    (["mash"], "synth.a2a-sparse", "synth.a2a-sparse.mash"),
+    (["ani"], "synth.a2a-sparse", "synth.a2a-sparse.ani"),
+    (["-sparse", "mash", "-min", "0.03", "-max", "mash:1.0"], "synth.a2a-sparse", "synth.a2a.mash.above-below"),
+    (["-sparse", "-min", "0.03", "-max", "mash:1.0", "-min", "num-kmers:36", "mash"], "synth.a2a", "synth.a2a.mash-sparse-min2max"),
+    (["mash"], "synth.n2a", "synth.n2a.mash"),
+    (["ani"], "synth.n2a", "synth.n2a.ani"),
+    (["-sparse", "ani"], "synth.n2a", "synth.n2a-sparse.ani"),
+    (["-sparse", "-max", "1.0", "-min", "-1.0", "mash"], "synth.n2a", "synth.n2a-sparse.mash"),
+    (["mash"], "synth.n2a-sparse", "synth.n2a-sparse.mash"),
+    (["ani"], "synth.n2a-sparse", "synth.n2a-sparse.ani"),
+    (["cosine"], "virus.k18.csv", "virus.k18.csv.cosine"),
+    (["jaccard"], "virus.k18.csv", "virus.k18.csv.jaccard"),
+    (["mash"], "virus.k18.csv", "virus.k18.csv.mash"),
+    (["max"], "virus.k18.csv", "virus.k18.csv.max"),
+    (["min"], "virus.k18.csv", "virus.k18.csv.min"),
+]
+
+
+@pytest.mark.parametrize("case", DISTANCE_CASES, ids=lambda c: c[2] + ":" + "_".join(c[0]))
+def test_cli_distance_matches_reference_goldens(golden_dir, tmp_path, case):
+    """`distance` (console_distance.cpp:7-213): byte-identical with every golden the reference's workflows compare."""
+    opts, src, want = case
+    out = tmp_path / "out"
+    r = subprocess.run([os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd"), "distance"] + opts + [os.path.join(golden_dir, src), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == open(os.path.join(golden_dir, want), "rb").read()
+
+
+def test_cli_distance_errors(golden_dir, tmp_path):
+    exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
+    src = os.path.join(golden_dir, "synth.a2a")
+    for argv in (["distance", src, str(tmp_path / "o")],                                   # no measure: the first file name is taken for one
+                 ["distance", "-min", "nosuch:1", "mash", src, str(tmp_path / "o")],
+                 ["distance", "mash", str(tmp_path / "missing"), str(tmp_path / "o")]):
+        r = subprocess.run([exe] + argv, capture_output=True, text=True)
+        assert r.returncode != 0 and ("ERROR" in r.stderr or "USAGE" in r.stderr)
