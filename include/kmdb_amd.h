@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KMDB_ABI_VERSION 2
+#define KMDB_ABI_VERSION 3
 
 /* ---------------------------------------------------------------------------------------
  * Host-side view of a loaded database = what the reference hands to SimilarityCalculator:
@@ -94,7 +94,27 @@ typedef struct kmdb_sparse_rows {
     uint64_t* row_ptr;             /* [n_rows+1] */
     uint32_t* col;                 /* [nnz] 0-based */
     uint32_t* val;                 /* [nnz] */
+    double*   measure;             /* [nnz] or NULL: kmdb_all2all_sparse_filtered with a measure */
 } kmdb_sparse_rows;
+
+/* Similarity / distance measures of a cell (common k-mers c, k-mer counts a of the row sample and b of the column sample,
+ * k-mer length k): the functions of Params::availableMetrics (params.cpp:14-42), in that order. */
+#define KMDB_METRIC_JACCARD     0
+#define KMDB_METRIC_MIN         1
+#define KMDB_METRIC_MAX         2
+#define KMDB_METRIC_COSINE      3
+#define KMDB_METRIC_MASH        4
+#define KMDB_METRIC_ANI         5
+#define KMDB_METRIC_ANI_SHORTER 6
+#define KMDB_METRIC_MASH_QUERY  7
+#define KMDB_METRIC_NUM_KMERS   8
+#define KMDB_METRIC_COUNT       9
+/* One bound pair of a CombinedFilter (sparse_filters.h:12-61): the cell passes when lo <= metric(cell) <= hi. */
+typedef struct kmdb_cell_filter {
+    int32_t metric;                /* KMDB_METRIC_* */
+    int32_t reserved;
+    double  lo, hi;
+} kmdb_cell_filter;
 
 typedef struct kmdb_stats {        /* measurements of the LAST call on this db handle */
     double   kernel_ms;            /* HIP-event time of the whole device pipeline of the call */
@@ -152,6 +172,19 @@ int  kmdb_all2all_dense_device(kmdb_db* db, void* out_lower_tri_dev, const kmdb_
  * array.h:391-446; call sites console_all2all_sparse.cpp:44,79). */
 int  kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmdb_opts* opts);
 void kmdb_sparse_free(kmdb_sparse_rows* rows);
+/* the same with the -min / -max filters applied before the result leaves HBM, and optionally one measure per
+ * kept cell.  Replaces all2all_sp + SparseMatrix::compact2 with a CombinedFilter (array.h:391-446, sparse_filters.h:38-61;
+ * call site console_all2all_sparse.cpp:44-79) and, with measure >= 0, the `distance -sparse` pass over the written table
+ * (console_distance.cpp:96-171).  sample_kmers[i] = k-mer count of sample i (the table's total-kmers row; num_kmers_t =
+ * uint32 in the reference).  The device drops the cells that miss a bound by more than a safety margin; the remaining
+ * cells are decided, and the measures computed, by kmdbh_metric on the host — bit-identical with the reference's double
+ * arithmetic (incl. its libm log).  measure: KMDB_METRIC_* or -1. */
+int  kmdb_all2all_sparse_filtered(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers,
+                                  int measure, kmdb_sparse_rows* out, const kmdb_opts* opts);
+/* the measure itself (params.cpp:14-42): uint32 wrap-around integer parts, double arithmetic */
+double kmdbh_metric(int metric, uint32_t common, uint32_t cnt_row, uint32_t cnt_col, int kmer_length);
+/* KMDB_METRIC_* of a criterion name ("jaccard", "min", ..., "num-kmers"), -1 if unknown */
+int    kmdbh_metric_id(const char* name);
 
 /* Replaces T concurrent calls of SimilarityCalculator::one2all<false>
  * (similarity_calculator.cpp:809-925; call site console_new2all.cpp:82): nq queries, each a

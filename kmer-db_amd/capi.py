@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -39,7 +39,14 @@ class _Opts(C.Structure):
 
 class _Sparse(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("nnz", C.c_uint64), ("row_ptr", C.POINTER(C.c_uint64)),
-                ("col", C.POINTER(C.c_uint32)), ("val", C.POINTER(C.c_uint32))]
+                ("col", C.POINTER(C.c_uint32)), ("val", C.POINTER(C.c_uint32)), ("measure", C.POINTER(C.c_double))]
+
+
+class _CellFilter(C.Structure):
+    _fields_ = [("metric", C.c_int32), ("reserved", C.c_int32), ("lo", C.c_double), ("hi", C.c_double)]
+
+
+METRICS = ["jaccard", "min", "max", "cosine", "mash", "ani", "ani-shorter", "mash-query", "num-kmers"]
 
 
 class _Stats(C.Structure):
@@ -61,7 +68,7 @@ PATH_NONE, PATH_RECORDS, PATH_TILE, PATH_GLOBAL = 0, 1, 2, 3
 # every symbol include/kmdb_amd.h declares
 EXPORTS = [
     "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_stats",
-    "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_sparse_free",
+    "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
     "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
     "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
     "kmdbh_db_start_fraction", "kmdbh_db_alphabet", "kmdbh_db_n_samples", "kmdbh_db_sample_name",
@@ -94,6 +101,10 @@ def lib():
     L.kmdb_all2all_dense.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_all2all_dense_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_all2all_sparse.argtypes = [C.c_void_p, C.POINTER(_Sparse), C.POINTER(_Opts)]
+    L.kmdb_all2all_sparse_filtered.argtypes = [C.c_void_p, C.POINTER(_CellFilter), C.c_size_t, C.c_void_p, C.c_int, C.POINTER(_Sparse), C.POINTER(_Opts)]
+    L.kmdbh_metric.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.kmdbh_metric.restype = C.c_double
+    L.kmdbh_metric_id.argtypes = [C.c_char_p]
     L.kmdb_sparse_free.argtypes = [C.POINTER(_Sparse)]
     L.kmdb_new2all_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_new2all_batch_sparse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(_Sparse), C.POINTER(_Opts)]
@@ -246,6 +257,7 @@ class SparseRows:
         self.col = np.ctypeslib.as_array(raw.col, shape=(max(nnz, 1),))[:nnz].copy()
         self.val = np.ctypeslib.as_array(raw.val, shape=(max(nnz, 1),))[:nnz].copy()
         self.n_rows, self.nnz = n, nnz
+        self.measure = np.ctypeslib.as_array(raw.measure, shape=(max(nnz, 1),))[:nnz].copy() if raw.measure else None
 
     def row(self, i):
         a, b = int(self.row_ptr[i]), int(self.row_ptr[i + 1])
@@ -295,6 +307,23 @@ class DeviceDB:
         raw = _Sparse()
         o = _opts(self.device, shard)
         _check(lib().kmdb_all2all_sparse(self._d, C.byref(raw), C.byref(o)))
+        try:
+            return SparseRows(raw)
+        finally:
+            lib().kmdb_sparse_free(C.byref(raw))
+
+    def all2all_sparse_filtered(self, filters, sample_kmers, measure=None):
+        """filters: [(criterion name, lo, hi)], None = unbounded; measure: a criterion name whose value is returned for every kept cell"""
+        raw = _Sparse()
+        o = _opts(self.device)
+        fs = (_CellFilter * max(1, len(filters)))()
+        for i, (name, lo, hi) in enumerate(filters):
+            fs[i].metric = METRICS.index(name)
+            fs[i].lo = -np.finfo(np.float64).max if lo is None else lo
+            fs[i].hi = np.finfo(np.float64).max if hi is None else hi
+        cnt = np.ascontiguousarray(sample_kmers, np.uint32)
+        _check(lib().kmdb_all2all_sparse_filtered(self._d, fs, len(filters), cnt.ctypes.data, -1 if measure is None else METRICS.index(measure),
+                                                  C.byref(raw), C.byref(o)))
         try:
             return SparseRows(raw)
         finally:

@@ -12,7 +12,10 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
+#include <limits>
 #include <thread>
+#include <vector>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,11 +44,39 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // dense -> CSR compaction for the sparse entry point
 // ------------------------------------------------------------------------------------------
-__global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t N, unsigned long long* __restrict__ row_nnz) {
+// Device side of the -min / -max filters: every bound is brought to one of six plain ratios of the cell
+// (log-based measures are monotone in theirs) and widened by a safety margin on the host; a cell that misses a widened bound is
+// dropped here, the rest is decided on the host with the reference's own arithmetic.
+enum { RATIO_JACCARD = 0, RATIO_MIN, RATIO_MAX, RATIO_COSINE, RATIO_QUERY, RATIO_NUM };
+struct DevFilter {
+    int n;                          // bounds in use (0: keep every non-zero cell)
+    int kind[8];
+    double lo[8], hi[8];
+    const uint32_t* counts;         // [N] k-mer counts of the samples
+};
+__device__ __forceinline__ bool dev_keep(const DevFilter& f, uint32_t c, uint32_t row, uint32_t col) {
+    if (c == 0) return false;
+    if (f.n == 0) return true;
+    const uint32_t a = f.counts[row], b = f.counts[col];
+    for (int i = 0; i < f.n; ++i) {
+        double x;
+        switch (f.kind[i]) {
+        case RATIO_JACCARD: x = (double)c / (double)(uint32_t)(a + b - c); break;
+        case RATIO_MIN:     x = (double)c / (double)(a < b ? a : b); break;
+        case RATIO_MAX:     x = (double)c / (double)(a > b ? a : b); break;
+        case RATIO_COSINE:  x = (double)c / sqrt((double)(uint32_t)(a * b)); break;
+        case RATIO_QUERY:   x = (double)c / (double)a; break;
+        default:            x = (double)c; break;
+        }
+        if (!(x >= f.lo[i] && x <= f.hi[i])) return false;      // NaN fails, as on the host
+    }
+    return true;
+}
+__global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t N, unsigned long long* __restrict__ row_nnz, const DevFilter f) {
     const uint64_t row = blockIdx.x;
     const uint32_t* r = M + tri64(row);
     uint32_t c = 0;
-    for (uint64_t j = threadIdx.x; j < row; j += blockDim.x) c += r[j] != 0;
+    for (uint64_t j = threadIdx.x; j < row; j += blockDim.x) c += dev_keep(f, r[j], (uint32_t)row, (uint32_t)j) ? 1u : 0u;
     __shared__ uint32_t red[256];
     red[threadIdx.x] = c;
     __syncthreads();
@@ -58,7 +89,7 @@ __global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t N, unsig
 
 // one block per row, ordered compaction with a block-wide running offset
 __global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t N, const unsigned long long* __restrict__ row_ptr,
-                                   uint32_t* __restrict__ col, uint32_t* __restrict__ val) {
+                                   uint32_t* __restrict__ col, uint32_t* __restrict__ val, const DevFilter f) {
     const uint64_t row = blockIdx.x;
     const uint32_t* r = M + tri64(row);
     __shared__ uint32_t wave_cnt[4];
@@ -68,7 +99,8 @@ __global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t N, c
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint64_t j0 = 0; j0 < row; j0 += blockDim.x) {
         const uint64_t j = j0 + threadIdx.x;
-        const uint32_t v = j < row ? r[j] : 0u;
+        uint32_t v = j < row ? r[j] : 0u;
+        if (!dev_keep(f, v, (uint32_t)row, (uint32_t)j)) v = 0u;
         const unsigned long long bal = __ballot(v != 0);
         if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
@@ -300,7 +332,61 @@ extern "C" int kmdb_all2all_dense(kmdb_db* db, uint32_t* out, const kmdb_opts* o
 // (reference src/bubble_helper.h) only exist to spare the CPU hash maps; their contributions are part
 // of the same sums, so bubble_size does not change the result.
 // ------------------------------------------------------------------------------------------
+namespace {
+// one host bound -> the device's widened bound on a plain ratio.  mash = -(1/k) log(2 j / (1 + j)) falls with j:
+// mash <= m  <=>  j >= E / (2 - E), E = exp(-k m); ani = 1 - mash.
+struct RatioBound { int kind; double lo, hi; };
+RatioBound ratio_bound(const kmdb_cell_filter& f, int k) {
+    const double inf = std::numeric_limits<double>::infinity();
+    auto j_of_mash = [k](double m) {                       // the j whose mash distance is m (0 .. inf)
+        const double E = std::exp(-(double)k * m);
+        if (std::isnan(E)) return std::numeric_limits<double>::quiet_NaN();
+        if (E >= 2.0) return std::numeric_limits<double>::infinity();
+        return E / (2.0 - E);
+    };
+    RatioBound r{RATIO_NUM, f.lo, f.hi};
+    double mlo = f.lo, mhi = f.hi;                          // bounds on the mash distance, for the log-based measures
+    bool logm = false;
+    switch (f.metric) {
+    case KMDB_METRIC_JACCARD: r.kind = RATIO_JACCARD; break;
+    case KMDB_METRIC_MIN: r.kind = RATIO_MIN; break;
+    case KMDB_METRIC_MAX: r.kind = RATIO_MAX; break;
+    case KMDB_METRIC_COSINE: r.kind = RATIO_COSINE; break;
+    case KMDB_METRIC_NUM_KMERS: r.kind = RATIO_NUM; break;
+    case KMDB_METRIC_MASH: r.kind = RATIO_JACCARD; logm = true; break;
+    case KMDB_METRIC_MASH_QUERY: r.kind = RATIO_QUERY; logm = true; break;
+    case KMDB_METRIC_ANI: r.kind = RATIO_JACCARD; logm = true; mlo = 1.0 - f.hi; mhi = 1.0 - f.lo; break;
+    case KMDB_METRIC_ANI_SHORTER: r.kind = RATIO_MIN; logm = true; mlo = 1.0 - f.hi; mhi = 1.0 - f.lo; break;
+    default: break;
+    }
+    if (logm) { r.lo = j_of_mash(mhi); r.hi = j_of_mash(mlo); }
+    // the margin: 1e-6 relative and a little absolute — far above any rounding difference between the two sides, far below
+    // anything that costs transfer volume; a NaN bound keeps everything (the host decides)
+    if (std::isnan(r.lo)) r.lo = -inf; else r.lo = r.lo - std::fabs(r.lo) * 1e-6 - 1e-300;
+    if (std::isnan(r.hi)) r.hi = inf; else r.hi = r.hi + std::fabs(r.hi) * 1e-6 + 1e-300;
+    return r;
+}
+}  // namespace
+
+static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure, kmdb_sparse_rows* out,
+                       const kmdb_opts* opts);
+
 extern "C" int kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmdb_opts* opts) {
+    return sparse_impl(db, nullptr, 0, nullptr, -1, out, opts);
+}
+
+extern "C" int kmdb_all2all_sparse_filtered(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure,
+                                            kmdb_sparse_rows* out, const kmdb_opts* opts) {
+    if ((n_filters && !filters) || ((n_filters || measure >= 0) && !sample_kmers)) return kmdb_set_error("kmdb_all2all_sparse_filtered: null argument");
+    if (measure >= KMDB_METRIC_COUNT) return kmdb_set_error("kmdb_all2all_sparse_filtered: unknown measure");
+    if (n_filters > 8) return kmdb_set_error("kmdb_all2all_sparse_filtered: more than 8 bounds");
+    for (size_t i = 0; i < n_filters; ++i)
+        if (filters[i].metric < 0 || filters[i].metric >= KMDB_METRIC_COUNT) return kmdb_set_error("kmdb_all2all_sparse_filtered: unknown metric in a filter");
+    return sparse_impl(db, filters, n_filters, sample_kmers, measure, out, opts);
+}
+
+static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure, kmdb_sparse_rows* out,
+                       const kmdb_opts* opts) {
     if (!db || !out) return kmdb_set_error("kmdb_all2all_sparse: null argument");
     std::memset(out, 0, sizeof *out);
     HIP_TRY(hipSetDevice(db->device));
@@ -308,21 +394,31 @@ extern "C" int kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmd
     const uint64_t cells = N ? N * (N - 1) / 2 : 0;
     uint32_t* M = nullptr;
     unsigned long long *row_nnz = nullptr, *row_ptr = nullptr;
-    uint32_t *col = nullptr, *val = nullptr;
+    uint32_t *col = nullptr, *val = nullptr, *d_counts = nullptr;
     void* tmp = nullptr;
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : db->stream;
     int rc = 0;
     auto cleanup = [&]() {
-        for (void* p : {(void*)M, (void*)row_nnz, (void*)row_ptr, (void*)col, (void*)val, tmp}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)M, (void*)row_nnz, (void*)row_ptr, (void*)col, (void*)val, (void*)d_counts, tmp}) if (p) (void)hipFree(p);
     };
+    DevFilter df{};
 #define SP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     SP_TRY(hipMalloc((void**)&M, std::max<uint64_t>(cells, 1) * 4));
     SP_TRY(hipMalloc((void**)&row_nnz, (N + 1) * 8));
     SP_TRY(hipMalloc((void**)&row_ptr, (N + 1) * 8));
+    if (n_filters) {
+        SP_TRY(hipMalloc((void**)&d_counts, std::max<uint64_t>(N, 1) * 4));
+        SP_TRY(hipMemcpyAsync(d_counts, sample_kmers, N * 4, hipMemcpyHostToDevice, st));
+        df.n = (int)n_filters; df.counts = d_counts;
+        for (size_t i = 0; i < n_filters; ++i) {
+            const RatioBound rb = ratio_bound(filters[i], (int)db->kmer_length);
+            df.kind[i] = rb.kind; df.lo[i] = rb.lo; df.hi[i] = rb.hi;
+        }
+    }
     rc = run_dense(db, M, opts, st);
     if (rc) { cleanup(); return rc; }
     SP_TRY(hipMemsetAsync(row_nnz, 0, (N + 1) * 8, st));
-    if (N) hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_nnz);
+    if (N) hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_nnz, df);
     size_t tmp_bytes = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st);
     SP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
@@ -333,7 +429,7 @@ extern "C" int kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmd
     const uint64_t nnz = h_ptr[N];
     SP_TRY(hipMalloc((void**)&col, std::max<uint64_t>(nnz, 1) * 4));
     SP_TRY(hipMalloc((void**)&val, std::max<uint64_t>(nnz, 1) * 4));
-    if (N) hipLaunchKernelGGL(row_compact_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_ptr, col, val);
+    if (N) hipLaunchKernelGGL(row_compact_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_ptr, col, val, df);
     rc = finish_stats(db, st);
     if (rc) { cleanup(); return rc; }
     out->n_rows = N;
@@ -348,12 +444,54 @@ extern "C" int kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmd
     }
 #undef SP_TRY
     cleanup();
+    if (n_filters || measure >= 0) {
+        // the host side: every surviving cell decided by the reference's own arithmetic, rows compacted in place, measures computed
+        const int k = (int)db->kmer_length;
+        const unsigned nthr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        std::vector<uint64_t> kept(N + 1, 0);
+        auto rows_of = [&](unsigned t, auto&& fn) { for (uint64_t i = (uint64_t)N * t / nthr; i < (uint64_t)N * (t + 1) / nthr; ++i) fn(i); };
+        auto parallel = [&](auto&& fn) {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nthr; ++t) th.emplace_back([&, t]() { rows_of(t, fn); });
+            for (auto& x : th) x.join();
+        };
+        parallel([&](uint64_t i) {                             // pass 1: filter every row in place (write position <= read position)
+            uint64_t w = out->row_ptr[i];
+            for (uint64_t e = out->row_ptr[i]; e < out->row_ptr[i + 1]; ++e) {
+                const uint32_t c = out->val[e], cj = out->col[e];
+                bool ok = true;
+                for (size_t q = 0; q < n_filters && ok; ++q) {
+                    const double x = kmdbh_metric(filters[q].metric, c, sample_kmers[i], sample_kmers[cj], k);
+                    ok = x >= filters[q].lo && x <= filters[q].hi;
+                }
+                if (ok) { out->col[w] = cj; out->val[w] = c; ++w; }
+            }
+            kept[i + 1] = w - out->row_ptr[i];
+        });
+        std::vector<uint64_t> new_ptr(N + 1, 0);
+        for (uint64_t i = 0; i < N; ++i) new_ptr[i + 1] = new_ptr[i] + kept[i + 1];
+        // pass 2: close the gaps (ascending rows; a row never moves right)
+        for (uint64_t i = 0; i < N; ++i)
+            if (new_ptr[i] != out->row_ptr[i] && kept[i + 1]) {
+                std::memmove(out->col + new_ptr[i], out->col + out->row_ptr[i], kept[i + 1] * 4);
+                std::memmove(out->val + new_ptr[i], out->val + out->row_ptr[i], kept[i + 1] * 4);
+            }
+        for (uint64_t i = 0; i <= N; ++i) out->row_ptr[i] = new_ptr[i];
+        out->nnz = new_ptr[N];
+        if (measure >= 0) {
+            out->measure = (double*)std::malloc(std::max<uint64_t>(out->nnz, 1) * 8);
+            parallel([&](uint64_t i) {
+                for (uint64_t e = out->row_ptr[i]; e < out->row_ptr[i + 1]; ++e)
+                    out->measure[e] = kmdbh_metric(measure, out->val[e], sample_kmers[i], sample_kmers[out->col[e]], k);
+            });
+        }
+    }
     return 0;
 }
 
 extern "C" void kmdb_sparse_free(kmdb_sparse_rows* rows) {
     if (!rows) return;
-    std::free(rows->row_ptr); std::free(rows->col); std::free(rows->val);
+    std::free(rows->row_ptr); std::free(rows->col); std::free(rows->val); std::free(rows->measure);
     std::memset(rows, 0, sizeof *rows);
 }
 

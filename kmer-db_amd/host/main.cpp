@@ -203,7 +203,17 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     std::cerr << "Calculating matrix of common k-mers...";
     auto t0 = clk::now();
     kmdb_sparse_rows sp{};
-    check(kmdb_all2all_sparse(db.d, &sp, &o));
+    {
+        // the -min / -max filters go with the call: cells that miss a bound never leave the device
+        std::vector<kmdb_cell_filter> fl;
+        for (auto& kv : c.filters.metric) fl.push_back(kmdb_cell_filter{kmdbh_metric_id(kv.first.c_str()), 0, kv.second.lo, kv.second.hi});
+        if (c.filters.kmer_lo != 0 || c.filters.kmer_hi != std::numeric_limits<uint32_t>::max())
+            fl.push_back(kmdb_cell_filter{KMDB_METRIC_NUM_KMERS, 0, (double)c.filters.kmer_lo, (double)c.filters.kmer_hi});
+        std::vector<uint32_t> counts(n);
+        for (uint64_t i = 0; i < n; ++i) counts[i] = (uint32_t)kmdbh_db_sample_kmers(db.h, i);
+        if (fl.empty() || fl.size() > 8) check(kmdb_all2all_sparse(db.d, &sp, &o));
+        else check(kmdb_all2all_sparse_filtered(db.d, fl.data(), fl.size(), counts.data(), -1, &sp, &o));
+    }
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
     std::cerr << "Storing matrix of common k-mers in " << args[1] << "...";
     t0 = clk::now();

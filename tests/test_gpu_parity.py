@@ -1,5 +1,6 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and
 the committed outputs of the real reference, bit-exact (all arithmetic is uint32 / integer)."""
+import math
 import os
 import subprocess
 import sys
@@ -64,6 +65,69 @@ def test_shards_sum_to_full_matrix(K, golden_dir, dev, stem, shards):
         acc += d.all2all_dense(shard=(s, shards))
         assert d.stats()["path"] == K.capi.PATH_RECORDS          # slices of the pattern stream stay on the fast path
     assert np.array_equal(acc, _ref_dense(golden_dir, stem))
+
+
+def _np_metric(name, c, a, b, k):
+    """the measures of params.cpp:14-42 restated with numpy (uint32 wrap-around integer parts, float64)"""
+    c, a, b = c.astype(np.uint32), a.astype(np.uint32), b.astype(np.uint32)
+    with np.errstate(all="ignore"):
+        def mash(j):
+            # math.log = the C library's log, as in the reference (numpy's vectorised log may differ in the last bit)
+            r = (2 * j) / (j + 1)
+            lg = np.array([math.log(x) if x > 0 and np.isfinite(x) else (float("-inf") if x == 0 else float("nan")) for x in r.tolist()])
+            return np.where(j == 0, 1.0, (-1.0 / k) * lg)
+        jac = c.astype(np.float64) / (a + b - c).astype(np.float64)
+        mn = c.astype(np.float64) / np.minimum(a, b).astype(np.float64)
+        return {"jaccard": jac, "min": mn, "max": c.astype(np.float64) / np.maximum(a, b).astype(np.float64),
+                "cosine": c.astype(np.float64) / np.sqrt((a * b).astype(np.float64)), "mash": mash(jac), "ani": 1.0 - mash(jac),
+                "ani-shorter": 1.0 - mash(mn), "mash-query": mash(c.astype(np.float64) / a.astype(np.float64)),
+                "num-kmers": c.astype(np.float64)}[name]
+
+
+@pytest.mark.parametrize("stem", ["virus_k18", "synth_k21", "clade64", "clade64_k25_f01"])
+def test_all2all_sparse_filtered_on_device(K, golden_dir, dev, stem):
+    """-min / -max bounds applied before the result leaves HBM, measures for the kept cells.  Against the
+    unfiltered result filtered here with the restated measures: bounds taken FROM the data (so that cells sit exactly on
+    them), every criterion, pairs of criteria, one-sided bounds, bounds nothing / everything passes."""
+    h = K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True)
+    d = K.DeviceDB(h, device=dev)
+    k = h.k
+    cnt = h.sample_kmers.astype(np.uint32)
+    full = d.all2all_sparse()
+    rows = np.repeat(np.arange(d.N), np.diff(full.row_ptr).astype(np.int64))
+    rng = np.random.default_rng(7)
+    names = K.capi.METRICS
+    # kmdbh_metric == the numpy restatement on every cell (libm log on both sides)
+    L = K.capi.lib()
+    for name in names:
+        want = _np_metric(name, full.val, cnt[rows], cnt[full.col], k)
+        pick = rng.integers(0, full.nnz, size=min(200, full.nnz))
+        got = np.array([L.kmdbh_metric(names.index(name), int(full.val[e]), int(cnt[rows[e]]), int(cnt[full.col[e]]), k) for e in pick])
+        assert np.array_equal(got, want[pick], equal_nan=True), name
+    cases = []
+    for name in names:
+        vals = _np_metric(name, full.val, cnt[rows], cnt[full.col], k)
+        fin = np.sort(vals[np.isfinite(vals)])
+        if fin.size == 0:
+            continue
+        q = [float(fin[int(x * (fin.size - 1))]) for x in (0.0, 0.25, 0.5, 0.9, 1.0)]
+        cases += [[(name, q[1], q[3])], [(name, q[2], None)], [(name, None, q[2])], [(name, q[2], q[2])], [(name, q[4] + 1.0, None)], [(name, None, None)]]
+        other = names[(names.index(name) + 3) % len(names)]
+        ov = _np_metric(other, full.val, cnt[rows], cnt[full.col], k)
+        of = np.sort(ov[np.isfinite(ov)])
+        cases.append([(name, q[1], None), (other, None, float(of[int(0.8 * (of.size - 1))]))])
+    for ci, filters in enumerate(cases):
+        keep = np.ones(full.nnz, dtype=bool)
+        for name, lo, hi in filters:
+            x = _np_metric(name, full.val, cnt[rows], cnt[full.col], k)
+            with np.errstate(invalid="ignore"):
+                keep &= (x >= (-np.finfo(np.float64).max if lo is None else lo)) & (x <= (np.finfo(np.float64).max if hi is None else hi))
+        measure = names[ci % len(names)]
+        sp = d.all2all_sparse_filtered(filters, cnt, measure=measure)
+        assert sp.nnz == int(keep.sum()), (filters, sp.nnz, int(keep.sum()))
+        assert np.array_equal(sp.col, full.col[keep]) and np.array_equal(sp.val, full.val[keep])
+        assert np.array_equal(np.diff(sp.row_ptr), np.bincount(rows[keep], minlength=d.N))
+        assert np.array_equal(sp.measure, _np_metric(measure, full.val, cnt[rows], cnt[full.col], k)[keep], equal_nan=True)
 
 
 @pytest.mark.parametrize("stem", ["virus_k18", "synth_k21", "clade64", "clade64_k25_f01"])
