@@ -30,6 +30,7 @@
 // with a ballot look-up.  After the emit kernels the chunk table (stream of every chunk) is radix-sorted, and K2 walks
 // windows of 128 sorted chunks: all records of a stream meet in one 64 x 64 LDS tile per window.
 #include "device_common.h"
+#include "engine_internal.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -1637,6 +1638,32 @@ int alloc_pair_pool(kmdb_db* db, uint64_t entries) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// list index for new2all / db2db (engine_state.h): checkpoints of the long local lists
+__global__ void ck_count_kernel(const uint2* __restrict__ k0in, uint32_t P, uint32_t* __restrict__ cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > P) return;
+    const uint32_t l = i < P ? (k0in[i].x & 0xFFFFu) : 0u;
+    cnt[i] = l > KMDB_CK_IDS ? (l + KMDB_CK_IDS - 1u) / KMDB_CK_IDS : 0u;
+}
+__global__ void ck_fill_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ bitrel, const uint64_t* __restrict__ blkbase,
+                               const uint64_t* __restrict__ bits, uint32_t P, const uint32_t* __restrict__ ck_ofs, uint64_t* __restrict__ ck_bit,
+                               uint32_t* __restrict__ ck_id) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint2 km = k0in[i];
+    const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16;
+    if (l <= KMDB_CK_IDS) return;
+    const uint64_t pos = blkbase[i >> 8] + bitrel[i];
+    uint32_t sum = 0;
+    { BitCursor c(bits, pos); for (uint32_t t = 0; t + 1 < l; ++t) sum += c.next(); }
+    BitCursor c(bits, pos);
+    uint32_t id = last - sum, o = ck_ofs[i];
+    for (uint32_t t = 0; t < l; ++t) {
+        if (t % KMDB_CK_IDS == 0) { ck_id[o] = id; ck_bit[o] = c.wi * 64u + c.s; ++o; }      // element t and the position of the code after it
+        if (t + 1 < l) id += c.next();
+    }
+}
+
 int kmdb_ensure_v1_arrays(kmdb_db* db) {
     if (db->meta) return 0;
     const uint64_t P = db->P;
@@ -1657,6 +1684,27 @@ int kmdb_ensure_v1_arrays(kmdb_db* db) {
     db->n_segs = (uint32_t)segs.size();
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1)));
     HIP_TRY(hipMalloc(&db->v1_scan_tmp, std::max<size_t>(db->v1_scan_tmp_bytes, 16)));
+    {
+        const uint64_t P1 = P + 1;
+        uint32_t* cnt = nullptr;
+        void* tmp = nullptr;
+        size_t tb = 0;
+        HIP_TRY(hipMalloc((void**)&cnt, P1 * 4));
+        HIP_TRY(hipMalloc((void**)&db->ck_ofs, P1 * 4));
+        hipLaunchKernelGGL(ck_count_kernel, dim3((unsigned)((P1 + 255) / 256)), dim3(256), 0, db->stream, db->k0in, (uint32_t)P, cnt);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, db->ck_ofs, (int)P1, db->stream));
+        HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, db->ck_ofs, (int)P1, db->stream));
+        uint32_t n_ck = 0;
+        HIP_TRY(hipMemcpyAsync(&n_ck, db->ck_ofs + P, 4, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        (void)hipFree(cnt); (void)hipFree(tmp);
+        HIP_TRY(hipMalloc((void**)&db->ck_bit, std::max<uint64_t>(n_ck, 1) * 8));
+        HIP_TRY(hipMalloc((void**)&db->ck_id, std::max<uint64_t>(n_ck, 1) * 4));
+        if (P) hipLaunchKernelGGL(ck_fill_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, db->stream, db->k0in, db->bitrel, db->blkbase, db->bits,
+                                  (uint32_t)P, db->ck_ofs, db->ck_bit, db->ck_id);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(db->stream));
     return 0;
 }

@@ -177,7 +177,7 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     (void)hipSetDevice(db->device);
     kmdb_blocks_release(db);
     void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
-                    db->nseg_anc_n, db->meta, db->bitpos, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,
+                    db->nseg_anc_n, db->meta, db->bitpos, db->ck_ofs, db->ck_bit, db->ck_id, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,
                     db->bucket_offset, db->slots, db->pid2dfs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
@@ -193,6 +193,7 @@ int kmdb_engine_get(kmdb_db* db, kmdb_engine_view* o) {
     if (kmdb_ensure_v1_arrays(db)) return 1;
     o->device = db->device; o->N = db->N; o->P = db->P; o->kmer_length = db->kmer_length;
     o->meta = db->meta; o->bitpos = db->bitpos; o->parent = db->parent; o->w = db->w; o->sub_end = db->sub_end;
+    o->ck_ofs = db->ck_ofs; o->ck_bit = db->ck_bit; o->ck_id = db->ck_id;
     o->bits = db->bits; o->n_buckets = db->n_buckets; o->bucket_offset = db->bucket_offset; o->slots = db->slots;
     o->pid2dfs = db->pid2dfs; o->stream = db->stream;
     for (int i = 0; i < 4; ++i) o->ev[i] = db->ev[i];

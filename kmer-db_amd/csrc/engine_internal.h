@@ -6,6 +6,8 @@
 
 struct kmdb_db;
 
+constexpr uint32_t KMDB_CK_IDS = 32;   // list index of new2all: one checkpoint per 32 local ids of a long list
+
 struct kmdb_engine_view {
     int device;
     uint64_t N, P;
@@ -16,6 +18,9 @@ struct kmdb_engine_view {
     const uint32_t* w;
     const uint32_t* sub_end;
     const uint64_t* bits;
+    const uint32_t* ck_ofs;        // list index of the long local lists (engine_state.h)
+    const uint64_t* ck_bit;
+    const uint32_t* ck_id;
     uint64_t n_buckets;
     const uint64_t* bucket_offset;
     const uint64_t* slots;

@@ -117,6 +117,11 @@ struct kmdb_db {
     // ---- v1 kernels (A/B reference, fallback) and new2all: built lazily on the device from the arrays above
     uint4* meta = nullptr;          // {n, l, last_id, nbits} per node, DFS order
     uint64_t* bitpos = nullptr;     // absolute bit offset of the node's gamma stream
+    // new2all: index into the gamma streams of the nodes with more than KMDB_CK_IDS local ids — every KMDB_CK_IDS-th id and
+    // the bit position of the code after it, so that the lanes of a workgroup decode one long list in pieces
+    uint32_t* ck_ofs = nullptr;     // [P + 1] first checkpoint of the node (a node with a short list has none)
+    uint64_t* ck_bit = nullptr;
+    uint32_t* ck_id = nullptr;
     uint32_t* wprefix = nullptr;    // P+1, exclusive scan of w (recomputed by every call)
     Segment* segs = nullptr;
     uint32_t n_segs = 0;

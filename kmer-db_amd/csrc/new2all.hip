@@ -111,14 +111,24 @@ struct N2Cursor {                                                 // gamma strea
     }
 };
 
-// (4) walk: one thread per distinct (query, hit pattern)
+// (4) walk: one thread per distinct (query, hit pattern).  A thread climbs from its hit towards the root until it meets the
+// previous hit's path, so every node on the union of the root paths is visited once per query; the node's local ids get H =
+// the number of hit k-mers below it.  Local lists of up to KMDB_CK_IDS ids are decoded by the visiting thread; longer ones
+// (a few nodes near the root carry thousands of ids) go to a queue in LDS and are decoded afterwards by ALL threads of the
+// workgroup in pieces of KMDB_CK_IDS ids, each piece starting from a checkpoint of the list index (engine_state.h) —
+// measured before that: 8 % of the lanes active, the others waiting for a neighbour's long list.
+constexpr uint32_t N2_QCAP = 512;
 template <bool LDS_HIST>
 __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long* __restrict__ uniq, const uint32_t* __restrict__ csum,
                                                        const uint32_t* __restrict__ qstart, uint32_t nruns, uint32_t nq,
                                                        const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
                                                        const int32_t* __restrict__ parent, const uint32_t* __restrict__ sub_end,
-                                                       const uint64_t* __restrict__ bits, uint32_t N, uint32_t* __restrict__ sim) {
+                                                       const uint64_t* __restrict__ bits, const uint32_t* __restrict__ ck_ofs,
+                                                       const uint64_t* __restrict__ ck_bit, const uint32_t* __restrict__ ck_id, uint32_t N,
+                                                       uint32_t* __restrict__ sim) {
     extern __shared__ uint32_t hist[];
+    __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[256];
+    __shared__ uint32_t q_n;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < nruns && uniq[i] != N2_INVALID;
     const uint32_t myq = live ? (uint32_t)(uniq[i] >> 32) : 0xFFFFFFFFu;
@@ -130,10 +140,10 @@ __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long*
     __syncthreads();
     if (q_lo == 0xFFFFFFFFu) return;
     for (uint32_t q = q_lo; q <= q_hi; ++q) {
-        if (LDS_HIST) {
+        if (LDS_HIST)
             for (uint32_t s = threadIdx.x; s < N; s += blockDim.x) hist[s] = 0;
-            __syncthreads();
-        }
+        if (threadIdx.x == 0) q_n = 0;
+        __syncthreads();
         uint32_t* acc = LDS_HIST ? hist : (sim + (size_t)q * N);
         if (live && myq == q) {
             const uint32_t qs = qstart[q], qe = qstart[q + 1];
@@ -141,15 +151,25 @@ __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long*
             const int64_t prev = i > qs ? (int64_t)(uint32_t)uniq[i - 1] : -1;
             const uint32_t cbase = csum[i];
             int64_t r = h;
+            uint32_t ub = i + 1;                               // grows while climbing: an ancestor's subtree contains the node's
             while (r > prev) {
-                // hits below r: indices [i, ub), ub = first run of this query whose pattern is >= sub_end[r]
+                // hits below r: indices [i, ub), ub = first run of this query whose pattern is >= sub_end[r].  Searched from the
+                // previous ub in doubling steps: near the leaves a subtree holds a handful of hits, one or two probes find its end
                 const uint32_t se = sub_end[r];
-                uint32_t lo = i + 1, hi = qe;
+                uint32_t lo = ub, hi = ub, step = 1;
+                while (hi < qe && (uint32_t)uniq[hi] < se) { lo = hi + 1; hi += step; step <<= 1; }
+                if (hi > qe) hi = qe;
                 while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)uniq[mid] < se) lo = mid + 1; else hi = mid; }
+                ub = lo;
                 const uint32_t H = csum[lo] - cbase;
                 const uint4 m = meta[r];
                 const uint32_t l = m.y;
-                if (l) {
+                bool inl = l != 0;
+                if (l > KMDB_CK_IDS) {
+                    const uint32_t slot = atomicAdd(&q_n, 1u);
+                    if (slot < N2_QCAP) { q_node[slot] = (uint32_t)r; q_h[slot] = H; q_l[slot] = l; inl = false; }      // a full queue: decoded here
+                }
+                if (inl) {
                     uint32_t id = m.z;
                     if (l > 1) {
                         // pattern_t::decodeSamples (src/pattern.cpp:99-109): first id = last - sum of the deltas
@@ -165,13 +185,45 @@ __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long*
                 r = parent[r];
             }
         }
+        __syncthreads();
+        // ---- the queued long lists, KMDB_CK_IDS ids per thread and step
+        const uint32_t nt = q_n < N2_QCAP ? q_n : N2_QCAP;
+        if (nt) {
+            constexpr uint32_t PER = N2_QCAP / 256;
+            uint32_t sum = 0;
+            for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) sum += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS;
+            part[threadIdx.x] = sum;
+            __syncthreads();
+            for (uint32_t d = 1; d < 256; d <<= 1) {
+                const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+                __syncthreads();
+                part[threadIdx.x] += v;
+                __syncthreads();
+            }
+            uint32_t run = part[threadIdx.x] - sum;
+            for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) { q_pre[t] = run; run += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS; }
+            if (threadIdx.x == 255) q_pre[nt] = part[255];
+            __syncthreads();
+            const uint32_t S = q_pre[nt];
+            for (uint32_t g = threadIdx.x; g < S; g += 256) {
+                uint32_t lo = 0, hi = nt;                       // the task whose pieces contain g: last t with q_pre[t] <= g
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (q_pre[mid] <= g) lo = mid; else hi = mid; }
+                const uint32_t piece = g - q_pre[lo], r = q_node[lo], H = q_h[lo], l = q_l[lo];
+                const uint32_t o = ck_ofs[r] + piece;
+                uint32_t id = ck_id[o];
+                const uint32_t left = l - piece * KMDB_CK_IDS, cnt = left < KMDB_CK_IDS ? left : KMDB_CK_IDS;
+                atomicAdd(&acc[id], H);
+                N2Cursor c(bits, ck_bit[o]);
+                for (uint32_t t = 1; t < cnt; ++t) { id += c.next(); atomicAdd(&acc[id], H); }
+            }
+        }
         if (LDS_HIST) {
             __syncthreads();
             uint32_t* out = sim + (size_t)q * N;
             for (uint32_t s = threadIdx.x; s < N; s += blockDim.x)
                 if (hist[s]) atomicAdd(&out[s], hist[s]);
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -236,14 +288,14 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
                            d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
         if (nruns) {
             const unsigned wblocks = (nruns + 255) / 256;
-            if (N * 4 + 256 <= 64 * 1024)
+            if (N * 4 + 12 * 1024 <= 64 * 1024)                     // the per-query histogram next to the kernel's 10 KB of static LDS
                 hipLaunchKernelGGL(n2a_walk_kernel<true>, dim3(wblocks), dim3(256), N * 4, st, d_uniq.as<unsigned long long>(),
                                    d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent,
-                                   e.sub_end, e.bits, (uint32_t)N, d_sim.as<uint32_t>());
+                                   e.sub_end, e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>());
             else
                 hipLaunchKernelGGL(n2a_walk_kernel<false>, dim3(wblocks), dim3(256), 0, st, d_uniq.as<unsigned long long>(),
                                    d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent,
-                                   e.sub_end, e.bits, (uint32_t)N, d_sim.as<uint32_t>());
+                                   e.sub_end, e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>());
         }
         N2_TRY(hipGetLastError());
     }
