@@ -1151,11 +1151,8 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
 template <bool SORTED>
 __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t* wor_sh, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
                                        unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01,
-                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, bool zero = true, bool flush = true) {
-    // zero / flush: a run that continues in the workgroup's next window keeps its tile in LDS (one merge into the matrix per run
-    // and workgroup instead of one per window)
-    if (zero)
-        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
+                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     if (threadIdx.x == 0) *wor_sh = 0;
     __syncthreads();
     for (uint32_t digit = 0; digit < 5; ++digit) {
@@ -1168,7 +1165,6 @@ __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t
     }
     // one HBM atomic per non-zero cell of the block
     __syncthreads();
-    if (flush)
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) {
         const uint32_t v = acc[k];
         if (!v) continue;
@@ -1383,7 +1379,7 @@ __global__ __launch_bounds__(CSL_THREADS) void csl_scatter_kernel(const uint32_t
 constexpr uint32_t K2S_WIN = 4096;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
                                                         uint32_t limit, const uint32_t* __restrict__ total_ptr, uint32_t n_states,
-                                                        uint32_t kbits, uint32_t dbits, uint32_t span, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
@@ -1393,7 +1389,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ uint32_t wor_sh;
     __shared__ uint32_t tcount[256];
     const uint32_t total = total_ptr ? (*total_ptr < limit ? *total_ptr : limit) : limit;      // counting sort: the valid records; radix sort: all slots
+    const uint32_t p0 = blockIdx.x * K2S_WIN;
     const uint32_t kmask = (1u << kbits) - 1u;
+    if (p0 >= total || (swkey[p0] & kmask) >= n_states) return;
+    const uint32_t wend = total - p0 < K2S_WIN ? total - p0 : K2S_WIN;
     {
         unsigned long long v = 0;
 #pragma unroll
@@ -1401,12 +1400,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         lut_ff[threadIdx.x] = v;
         lut_01[threadIdx.x] = v & 0x0101010101010101ull;
     }
-    bool carried = false;                                          // the previous window's last run is still in the tile
-    for (uint32_t wi = 0; wi < span; ++wi) {
-    const uint32_t p0 = (blockIdx.x * span + wi) * K2S_WIN;
-    if (p0 >= total || (swkey[p0] & kmask) >= n_states) break;     // (a carried run was flushed: it ends where the valid records end)
-    const uint32_t wend = total - p0 < K2S_WIN ? total - p0 : K2S_WIN;
-    __syncthreads();
     // run starts: every thread scans 32 consecutive positions; a block scan puts them in order
     constexpr uint32_t PER = K2S_WIN / 256;
     const uint32_t t0 = threadIdx.x * PER;
@@ -1443,16 +1436,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const uint32_t nb = tcount[255];
     if (threadIdx.x == 0) bnd[nb] = (uint16_t)wend;
     __syncthreads();
-    // does the window's last run go on in this workgroup's next window?
-    uint32_t next_key = 0xFFFFFFFFu;
-    if (wi + 1u < span && p0 + K2S_WIN < total) next_key = swkey[p0 + K2S_WIN] & kmask;
     for (uint32_t r = 0; r < nb; ++r) {
         const uint32_t a = bnd[r], b = bnd[r + 1];
         const uint32_t key = swkey[p0 + a] & kmask;
         if (key >= n_states) break;
-        const bool zero = !(r == 0 && carried);                    // a carried run is the same stream: the sorted order has no gap
-        const bool flush = !(b == K2S_WIN && key == next_key);
-        carried = !flush;
         K2Item it;
         {
             const uint32_t bucket = key;
@@ -1462,8 +1449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             it.X = X; it.Y = bucket - tri32(X);
             it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.skey = swkey + p0 + a; it.kbits = kbits; it.dbits = dbits; it.rec = nullptr; it.recw = nullptr;
         }
-        k2_run<true>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth, zero, flush);
-    }
+        k2_run<true>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
     }
 }
 
@@ -2029,12 +2015,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)nslots, 0,
                                                            db->key_bits, st));
             }
-            // windows per workgroup: as many as still leave every CU a dozen workgroups
-            const uint32_t nwin = (nslots + K2S_WIN - 1) / K2S_WIN;
-            const uint32_t span = std::max(1u, std::min(8u, nwin / 4096u));
-            const uint32_t g2 = (nwin + span - 1) / span;
+            const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
             hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, sorted_key, sorted_rec, nslots, total_ptr,
-                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), span, M, (uint32_t)db->N, db->width);
+                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width);
             HIP_TRY(hipGetLastError());
         }
         if (stage("sorted apply")) return 1;
