@@ -1234,14 +1234,16 @@ __global__ void count_raw_kernel(const uint32_t* __restrict__ wsub_cursor, uint3
     counters[KCTR_RAW] = mx * KMDB_SUBPOOLS;                    // chunk ids below this bound cover every written record
 }
 
-// Counting sort of the wide pool by stream, for up to CS_MAX_KEYS streams: per-block histograms in LDS (no device atomics),
-// one exclusive scan over the [stream][block] table, then every block moves its records to its own range of every stream.
-// The order inside a stream is arbitrary (uint32 adds commute).  Two reads of the keys, one read and one write of the records.
-// Between CS_MAX_KEYS and CSL_MAX_KEYS streams (up to about 13 500 samples at width 50) the same scheme runs with one large
-// workgroup per CU (the per-stream tables fill most of its LDS) and a direct scatter: with tens of thousands of streams a tile
-// holds less than one record per stream, staging would not merge any writes.  Beyond that: rocprim's radix sort.
-constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 2048;
-constexpr uint32_t CSL_MAX_KEYS = 36864, CSL_BLOCKS = 512, CSL_THREADS = 1024;
+// Counting sort of the wide pool by stream: per-workgroup histograms in LDS (no device atomics), one exclusive scan over the
+// table of counts, then every workgroup moves its records to its own range of every stream.  The order inside a stream is
+// arbitrary (uint32 adds commute).  Two reads of the keys, one read and one write of the records per pass.
+// Up to CS_MAX_KEYS streams: one pass, bins = streams.  More (10 000 samples at width 50 are 20 100 streams): two passes —
+// first by block row X (bins = rows), then every row by itself, cut into chunks of whole tiles, bins = the row's X + 1 streams.
+// A scatter straight to 20 100 destinations is bound by the number of write requests (measured: 25.8 ms for 495 M records, a
+// tile holds less than one record per stream); the two staged passes write bursts (6.3 ms + the same again).
+// More than CS_MAX_ROWS block rows (25 600 samples at width 50): rocprim's radix sort — a tile of 1024 records then holds about one
+// record per bin of its row, the staged passes stop writing bursts (measured at 782 rows: 27.7 ms against 22.6 with rocprim).
+constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 2048, CS_MAX_ROWS = 512;
 // block row X of stream s = tri32(X) + Y
 __device__ __forceinline__ uint32_t stream_row(uint32_t s) {
     uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)s + 1.0f) - 1.0f) * 0.5f);
@@ -1249,68 +1251,105 @@ __device__ __forceinline__ uint32_t stream_row(uint32_t s) {
     while (tri32(X + 1u) <= s) ++X;
     return X;
 }
-// the records [0, n) in equal shares of whole 1024-record tiles; n_ptr: the count comes from an earlier kernel (<= n)
-__device__ __forceinline__ void cs_range(uint32_t n, const uint32_t* n_ptr, uint32_t& lo, uint32_t& hi) {
-    if (n_ptr) { const uint32_t m = *n_ptr; n = m < n ? m : n; }
-    const uint32_t per_block = ((n + gridDim.x - 1u) / gridDim.x + 1023u) / 1024u * 1024u;
-    lo = blockIdx.x * per_block;
-    hi = n - lo < per_block ? n : lo + per_block;
-    if (lo >= n) { lo = 0; hi = 0; }
+// the second pass's view of the row-sorted records: where every row starts, its first workgroup, its first table entry
+struct CsRows {
+    const uint32_t* row_start;      // [NB + 1]
+    const uint32_t* row_blk;        // [NB + 1] workgroups before the row (a row of n records has ceil(n / chunk))
+    const uint32_t* row_tab;        // [NB + 1] table entries before the row (its (X + 1) streams x its workgroups)
+    uint32_t NB, chunk;
+};
+enum { CS_BY_STREAM = 0, CS_BY_ROW = 1, CS_IN_ROW = 2 };
+// what one workgroup sorts: records [lo, hi), bin of a key = row(key) or key - sub, count / offset of bin k at table[tab + k * stride]
+struct CsJob { uint32_t lo, hi, n_bins, sub, tab, stride; };
+__device__ __forceinline__ CsJob cs_job(int mode, uint32_t n, uint32_t n_keys, const CsRows& rows) {
+    CsJob j{0u, 0u, n_keys, 0u, blockIdx.x, gridDim.x};
+    if (mode != CS_IN_ROW) {
+        // equal shares of whole 1024-record tiles
+        const uint32_t per_block = ((n + gridDim.x - 1u) / gridDim.x + 1023u) / 1024u * 1024u;
+        const uint32_t lo = blockIdx.x * per_block;
+        if (lo < n) { j.lo = lo; j.hi = n - lo < per_block ? n : lo + per_block; }
+        return j;
+    }
+    j.n_bins = 0;
+    if (blockIdx.x >= rows.row_blk[rows.NB]) return j;
+    uint32_t a = 0, b = rows.NB;                             // last row whose first workgroup is <= this one and that has workgroups
+    while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if (rows.row_blk[mid] <= blockIdx.x) a = mid; else b = mid; }
+    const uint32_t X = a, c = blockIdx.x - rows.row_blk[X];
+    j.lo = rows.row_start[X] + c * rows.chunk;
+    j.hi = rows.row_start[X + 1];
+    if (j.hi - j.lo > rows.chunk) j.hi = j.lo + rows.chunk;
+    j.n_bins = X + 1u; j.sub = tri32(X); j.tab = rows.row_tab[X] + c; j.stride = rows.row_blk[X + 1] - rows.row_blk[X];
+    return j;
 }
-// n_valid streams; bins = the streams themselves, or (byrow) their block rows
-__global__ __launch_bounds__(1024) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, const uint32_t* __restrict__ n_ptr, uint32_t n_valid, uint32_t n_keys,
-                                                      uint32_t byrow, uint32_t kmask, uint32_t* __restrict__ H) {
-    extern __shared__ uint32_t cs_lds[];
-    for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) cs_lds[k] = 0;
+__device__ __forceinline__ uint32_t cs_bin(int mode, uint32_t key, uint32_t n_valid, uint32_t sub) {
+    if (key >= n_valid) return 0xFFFFFFFFu;
+    return mode == CS_BY_ROW ? stream_row(key) : key - sub;
+}
+// row tables of the second pass from the first pass's offsets O1[row][workgroup] (+ total)
+__global__ void cs_rows_kernel(const uint32_t* __restrict__ O1, uint32_t NB, uint32_t chunk, uint32_t* __restrict__ row_start, uint32_t* __restrict__ row_blk,
+                               uint32_t* __restrict__ row_tab) {
+    for (uint32_t X = threadIdx.x; X <= NB; X += blockDim.x) row_start[X] = O1[(size_t)X * CS_BLOCKS];      // entry [NB][0] is the total
     __syncthreads();
-    uint32_t lo, hi;
-    cs_range(n, n_ptr, lo, hi);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t key = wkey[i] & kmask;
-        if (key < n_valid) atomicAdd(&cs_lds[byrow ? stream_row(key) : key], 1u);
+    if (threadIdx.x == 0) {
+        uint32_t blk = 0, tab = 0;
+        for (uint32_t X = 0; X < NB; ++X) {
+            row_blk[X] = blk; row_tab[X] = tab;
+            const uint32_t nch = (row_start[X + 1] - row_start[X] + chunk - 1u) / chunk;
+            blk += nch; tab += nch * (X + 1u);
+        }
+        row_blk[NB] = blk; row_tab[NB] = tab;
+    }
+}
+__global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict__ wkey, uint32_t n, uint32_t n_valid, uint32_t n_keys, int mode, const CsRows rows,
+                                                     uint32_t kmask, uint32_t* __restrict__ H) {
+    extern __shared__ uint32_t cs_lds[];
+    const CsJob job = cs_job(mode, n, n_keys, rows);
+    for (uint32_t k = threadIdx.x; k < job.n_bins; k += blockDim.x) cs_lds[k] = 0;
+    __syncthreads();
+    for (uint32_t i = job.lo + threadIdx.x; i < job.hi; i += blockDim.x) {
+        const uint32_t bin = cs_bin(mode, wkey[i] & kmask, n_valid, job.sub);
+        if (bin < job.n_bins) atomicAdd(&cs_lds[bin], 1u);
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) H[(size_t)k * gridDim.x + blockIdx.x] = cs_lds[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)n_keys * gridDim.x] = 0;          // the scan leaves the total here
+    for (uint32_t k = threadIdx.x; k < job.n_bins; k += blockDim.x) H[(size_t)job.tab + (size_t)k * job.stride] = cs_lds[k];
+    if (mode != CS_IN_ROW && blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)n_keys * gridDim.x] = 0;          // the scan leaves the total here
 }
-// The scatter stages tiles of CS_TILE records in LDS sorted by stream, so that the records of one stream leave the tile as one
-// contiguous burst (a record-by-record scatter of 24-byte records is bound by the number of write transactions: measured 2 ms
-// for 62 M records).  LDS: the staged records, their destinations, and three per-stream arrays (tile histogram = rank source,
-// tile offsets, the block's running global cursor).
+// The scatter stages tiles of CS_TILE records in LDS sorted by bin, so that the records of one stream leave the tile as one
+// contiguous burst.  LDS: the staged records, their destinations, and three per-bin arrays (tile histogram = rank source,
+// tile offsets, the workgroup's running global cursor).
 constexpr uint32_t CS_TILE = 1024, CS_THREADS = 256;
 __host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + CS_THREADS * 4 + 64; }
 __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_valid,
-                                                         uint32_t n_keys, uint32_t byrow, uint32_t kmask, const uint32_t* __restrict__ O,
+                                                         uint32_t n_keys, int mode, const CsRows rows, uint32_t kmask, const uint32_t* __restrict__ O,
                                                          uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
     WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
     uint32_t* st_dst = (uint32_t*)(st_rec + CS_TILE);                     // [CS_TILE] global destination
     uint32_t* st_key = st_dst + CS_TILE;                                  // [CS_TILE]
-    uint32_t* hist = st_key + CS_TILE;                                    // [n_keys] records of the tile per stream
-    uint32_t* toff = hist + n_keys;                                       // [n_keys] first staging position of the stream
-    uint32_t* cursor = toff + n_keys;                                     // [n_keys] next global position of the stream for this block
+    uint32_t* hist = st_key + CS_TILE;                                    // [n_keys] records of the tile per bin
+    uint32_t* toff = hist + n_keys;                                       // [n_keys] first staging position of the bin
+    uint32_t* cursor = toff + n_keys;                                     // [n_keys] next global position of the bin for this workgroup
     uint32_t* part = cursor + n_keys;                                     // [CS_THREADS] scan scratch
-    for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) cursor[k] = O[(size_t)k * CS_BLOCKS + blockIdx.x];
-    uint32_t lo, hi;
-    cs_range(n, nullptr, lo, hi);
+    const CsJob job = cs_job(mode, n, n_keys, rows);
+    const uint32_t nb = job.n_bins, lo = job.lo, hi = job.hi;
+    for (uint32_t k = threadIdx.x; k < nb; k += CS_THREADS) cursor[k] = O[(size_t)job.tab + (size_t)k * job.stride];
     constexpr uint32_t PER = CS_TILE / CS_THREADS;
-    const uint32_t kper = (n_keys + CS_THREADS - 1u) / CS_THREADS;                          // streams per thread in the scan
+    const uint32_t kper = (nb + CS_THREADS - 1u) / CS_THREADS;                              // bins per thread in the scan
     for (uint32_t t0 = lo; t0 < hi; t0 += CS_TILE) {
-        for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) hist[k] = 0;
+        for (uint32_t k = threadIdx.x; k < nb; k += CS_THREADS) hist[k] = 0;
         __syncthreads();
-        uint32_t key[PER], kw[PER], rank[PER];                     // stream, whole key word (stream + weight digit), rank in the tile
+        uint32_t key[PER], kw[PER], rank[PER];                     // bin, whole key word (stream + weight digit), rank in the tile
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
             const uint32_t i = t0 + j * CS_THREADS + threadIdx.x;
             kw[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
-            key[j] = kw[j] & kmask;
-            key[j] = key[j] < n_valid ? (byrow ? stream_row(key[j]) : key[j]) : 0xFFFFFFFFu;
-            rank[j] = key[j] < n_keys ? atomicAdd(&hist[key[j]], 1u) : 0u;
+            key[j] = cs_bin(mode, kw[j] & kmask, n_valid, job.sub);
+            rank[j] = key[j] < nb ? atomicAdd(&hist[key[j]], 1u) : 0u;
         }
         __syncthreads();
-        // exclusive scan of the tile histogram: kper consecutive streams per thread, then the 256 partial sums
+        // exclusive scan of the tile histogram: kper consecutive bins per thread, then the 256 partial sums
         uint32_t sum = 0;
-        for (uint32_t k = threadIdx.x * kper; k < n_keys && k < (threadIdx.x + 1u) * kper; ++k) sum += hist[k];
+        for (uint32_t k = threadIdx.x * kper; k < nb && k < (threadIdx.x + 1u) * kper; ++k) sum += hist[k];
         part[threadIdx.x] = sum;
         __syncthreads();
         for (uint32_t d = 1; d < CS_THREADS; d <<= 1) {
@@ -1320,13 +1359,13 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
             __syncthreads();
         }
         uint32_t run = part[threadIdx.x] - sum;
-        for (uint32_t k = threadIdx.x * kper; k < n_keys && k < (threadIdx.x + 1u) * kper; ++k) { toff[k] = run; run += hist[k]; }
+        for (uint32_t k = threadIdx.x * kper; k < nb && k < (threadIdx.x + 1u) * kper; ++k) { toff[k] = run; run += hist[k]; }
         __syncthreads();
         const uint32_t tile_n = part[CS_THREADS - 1];
-        // stage: record -> its stream's run inside the tile, with its global destination
+        // stage: record -> its bin's run inside the tile, with its global destination
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
-            if (key[j] < n_keys) {
+            if (key[j] < nb) {
                 const uint32_t i = t0 + j * CS_THREADS + threadIdx.x;
                 const uint32_t p = toff[key[j]] + rank[j];
                 st_rec[p] = wrec[i];
@@ -1335,43 +1374,13 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
             }
         }
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n_keys; k += CS_THREADS) cursor[k] += hist[k];
+        for (uint32_t k = threadIdx.x; k < nb; k += CS_THREADS) cursor[k] += hist[k];
         for (uint32_t p = threadIdx.x; p < tile_n; p += CS_THREADS) {
             const uint32_t d = st_dst[p];
             swrec[d] = st_rec[p];
             swkey[d] = st_key[p];
         }
         __syncthreads();
-    }
-}
-
-// many streams: the block's cursor of every stream in LDS, records written one by one
-__global__ __launch_bounds__(CSL_THREADS) void csl_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n,
-                                                           const uint32_t* __restrict__ n_ptr, uint32_t n_keys, uint32_t kmask, const uint32_t* __restrict__ O,
-                                                           uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec) {
-    extern __shared__ uint32_t csl_cursor[];
-    for (uint32_t k = threadIdx.x; k < n_keys; k += CSL_THREADS) csl_cursor[k] = O[(size_t)k * CSL_BLOCKS + blockIdx.x];
-    __syncthreads();
-    uint32_t lo, hi;
-    cs_range(n, n_ptr, lo, hi);
-    for (uint32_t i0 = lo; i0 < hi; i0 += 4u * CSL_THREADS) {
-        uint32_t kw[4];
-        WideRec r[4];
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t i = i0 + j * CSL_THREADS + threadIdx.x;
-            kw[j] = i < hi ? wkey[i] : 0xFFFFFFFFu;
-            if ((kw[j] & kmask) < n_keys) r[j] = wrec[i];
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t key = kw[j] & kmask;
-            if (key < n_keys) {
-                const uint32_t d = atomicAdd(&csl_cursor[key], 1u);
-                swrec[d] = r[j];
-                swkey[d] = kw[j];
-            }
-        }
     }
 }
 
@@ -1612,11 +1621,12 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, db->sort2_tmp_bytes, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)slots, 0, db->key_bits,
                                                db->stream));
     HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
-    if (db->n_states <= CSL_MAX_KEYS && !db->cs_hist) {
-        db->cs_blocks = db->n_states <= CS_MAX_KEYS ? CS_BLOCKS : CSL_BLOCKS;
-        const size_t ne = (size_t)db->n_states * db->cs_blocks + 1;
+    if ((db->n_states <= CS_MAX_KEYS || db->NB <= CS_MAX_ROWS) && !db->cs_hist) {
+        // one pass: [stream][workgroup]; two passes: [row][workgroup], then per row [stream of the row][chunk of the row]
+        const size_t ne = db->n_states <= CS_MAX_KEYS ? (size_t)db->n_states * CS_BLOCKS + 1 : (size_t)(2 * CS_BLOCKS + db->NB + 2) * db->NB + 1;
         HIP_TRY(hipMalloc((void**)&db->cs_hist, ne * 4));
         HIP_TRY(hipMalloc((void**)&db->cs_offs, ne * 4));
+        HIP_TRY(hipMalloc((void**)&db->cs_rows, (size_t)3 * (db->NB + 1) * 4));
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->cs_tmp_bytes, db->cs_hist, db->cs_offs, (int)ne, db->stream));
         HIP_TRY(hipMalloc(&db->cs_tmp, std::max<size_t>(db->cs_tmp_bytes, 16)));
     }
@@ -1813,7 +1823,7 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->pair_cursor); FREE_NULL(db->fn_mask); FREE_NULL(db->fn_blk); FREE_NULL(db->widebits); FREE_NULL(db->wide_cnt);
     FREE_NULL(db->wide_base); FREE_NULL(db->widx); FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key);
     FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota); FREE_NULL(db->sort_tmp);
-    FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_tmp);
+    FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_rows); FREE_NULL(db->cs_tmp);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
     db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
@@ -1966,41 +1976,41 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             const uint32_t* sorted_key = db->swkey;
             const WideRec* sorted_rec = (const WideRec*)db->swrec;
             if (db->cs_hist) {
-                const uint32_t nblk = db->cs_blocks;
-                const bool large = nblk == CSL_BLOCKS;
-                HIP_TRY(hipFuncSetAttribute((const void*)cs_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(db->n_states * 4)));
+                const bool large = db->n_states > CS_MAX_KEYS;
+                const CsRows no_rows{};
                 size_t ne;
                 if (large) {
-                    // many streams: first the records grouped by block row (NB bins, staged scatter), then every row's records by stream with
-                    // the direct scatter — a workgroup of the second pass then writes to a few hundred streams, which its L2 merges
-                    const size_t ne1 = (size_t)db->NB * CS_BLOCKS + 1;
-                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), db->NB * 4, st, db->wkey, nslots, (const uint32_t*)nullptr, db->n_states, db->NB, 1u,
-                                       kmask, db->cs_hist);
+                    // many streams: the records grouped by block row first (bins = rows), then every row by itself (bins = its streams)
+                    const uint32_t NB = db->NB;
+                    const size_t ne1 = (size_t)NB * CS_BLOCKS + 1;
+                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), NB * 4, st, db->wkey, nslots, db->n_states, NB, (int)CS_BY_ROW, no_rows, kmask, db->cs_hist);
                     size_t tb = db->cs_tmp_bytes;
                     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne1, st));
-                    HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->NB)));
-                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->NB), st, db->wkey, (const WideRec*)db->wrec, nslots,
-                                       db->n_states, db->NB, 1u, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
-                    HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, db->cs_offs + (ne1 - 1), 4, hipMemcpyDeviceToDevice, st));
-                    const uint32_t* n_ptr = db->counters + KCTR_WIDE_RECORDS;
-                    ne = (size_t)db->n_states * nblk + 1;
-                    hipLaunchKernelGGL(cs_hist_kernel, dim3(nblk), dim3(CSL_THREADS), db->n_states * 4, st, db->swkey, nslots, n_ptr, db->n_states, db->n_states, 0u,
-                                       kmask, db->cs_hist);
+                    HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(NB)));
+                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(NB), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                                       db->n_states, NB, (int)CS_BY_ROW, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                    // second pass: rows cut into chunks of whole tiles, about CS_BLOCKS workgroups in all
+                    const uint32_t chunk = std::max<uint32_t>(16u * CS_TILE, ((nslots + CS_BLOCKS - 1) / CS_BLOCKS + CS_TILE - 1) / CS_TILE * CS_TILE);
+                    const uint32_t blocks2 = nslots / chunk + NB + 1;                            // >= sum over the rows of ceil(n_row / chunk)
+                    const CsRows rows{db->cs_rows, db->cs_rows + (NB + 1), db->cs_rows + 2 * (NB + 1), NB, chunk};
+                    hipLaunchKernelGGL(cs_rows_kernel, dim3(1), dim3(256), 0, st, db->cs_offs, NB, chunk, db->cs_rows, db->cs_rows + (NB + 1), db->cs_rows + 2 * (NB + 1));
+                    ne = (size_t)blocks2 * NB + 1;                                                // >= table entries in use; the rest stays zero
+                    HIP_TRY(hipMemsetAsync(db->cs_hist, 0, ne * 4, st));
+                    hipLaunchKernelGGL(cs_hist_kernel, dim3(blocks2), dim3(256), NB * 4, st, db->swkey, nslots, db->n_states, NB, (int)CS_IN_ROW, rows, kmask, db->cs_hist);
                     tb = db->cs_tmp_bytes;
                     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
-                    HIP_TRY(hipFuncSetAttribute((const void*)csl_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(db->n_states * 4)));
-                    hipLaunchKernelGGL(csl_scatter_kernel, dim3(nblk), dim3(CSL_THREADS), db->n_states * 4, st, db->swkey, (const WideRec*)db->swrec, nslots, n_ptr,
-                                       db->n_states, kmask, db->cs_offs, db->wkey, (WideRec*)db->wrec);
+                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(blocks2), dim3(CS_THREADS), cs_scatter_lds(NB), st, db->swkey, (const WideRec*)db->swrec, nslots,
+                                       db->n_states, NB, (int)CS_IN_ROW, rows, kmask, db->cs_offs, db->wkey, (WideRec*)db->wrec);
                     sorted_key = db->wkey; sorted_rec = (const WideRec*)db->wrec;
                 } else {
-                    ne = (size_t)db->n_states * nblk + 1;
-                    hipLaunchKernelGGL(cs_hist_kernel, dim3(nblk), dim3(256), db->n_states * 4, st, db->wkey, nslots, (const uint32_t*)nullptr, db->n_states, db->n_states, 0u,
-                                       kmask, db->cs_hist);
+                    ne = (size_t)db->n_states * CS_BLOCKS + 1;
+                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, db->n_states, (int)CS_BY_STREAM,
+                                       no_rows, kmask, db->cs_hist);
                     size_t tb = db->cs_tmp_bytes;
                     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
                     HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
                     hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
-                                       db->n_states, db->n_states, 0u, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+                                       db->n_states, db->n_states, (int)CS_BY_STREAM, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
                 }
                 total_ptr = db->cs_offs + (ne - 1);
                 HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));

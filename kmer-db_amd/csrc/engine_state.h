@@ -98,7 +98,7 @@ struct kmdb_db {
     void *wrec = nullptr, *swrec = nullptr;         // wide pool: 24-byte records {rows, cols, w}, and sorted by stream
     uint64_t wide_pool_cap = 0;     // chunks of 64 records
     uint32_t* wsub_cursor = nullptr;
-    uint32_t cs_blocks = 0;                            // workgroups of the counting sort (its tables are [stream][block])
+    uint32_t* cs_rows = nullptr;                       // two-pass sort: row starts / first workgroup / first table entry, [3][NB + 1]
     uint32_t *cs_hist = nullptr, *cs_offs = nullptr;   // counting sort of the wide pool: [stream][block] counts / offsets (+ total)
     void* cs_tmp = nullptr;
     size_t cs_tmp_bytes = 0;
