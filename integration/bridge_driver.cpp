@@ -6,6 +6,7 @@
 //                                               query is the keys of bucket 0 instead (hash lookups through the
 //                                               slot-exact tables), one row of N counts
 #include "kmdb_bridge.h"
+#include "params.h"
 #include "similarity_calculator.h"
 
 #include <cstdio>
@@ -13,7 +14,7 @@
 #include <string>
 
 int main(int argc, char** argv) {
-    if (argc < 4) { fprintf(stderr, "usage: bridge_driver all2all|all2all_sp|new2all <db> <out>\n"); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: bridge_driver all2all|all2all_sp|all2all_sp_filtered|new2all <db> <out> [-min/-max options]\n"); return 2; }
     const std::string cmd = argv[1];
     try {
         std::ifstream f(argv[2], std::ios::binary);
@@ -44,6 +45,42 @@ int main(int argc, char** argv) {
             }
             fclose(out);
             kmdb_sparse_free(&sp);
+        } else if (cmd == "all2all_sp_filtered") {
+            // bridge_driver all2all_sp_filtered <db> <out.txt> [-min [crit:]v]* [-max [crit:]v]*: the options go through the reference's
+            // own Params::parse (params.cpp:59-139); the engine's filtered rows must equal the reference's CombinedFilter
+            // (sparse_filters.h:38-61) applied to the unfiltered rows
+            std::vector<std::string> av = {"kmer-db", "all2all-sp"};
+            for (int i = 4; i < argc; ++i) av.push_back(argv[i]);
+            av.push_back(argv[2]); av.push_back(argv[3]);
+            std::vector<char*> avp;
+            for (auto& a : av) avp.push_back(a.data());
+            Params params;
+            if (!params.parse((int)avp.size(), avp.data())) { fprintf(stderr, "Params::parse rejected the options\n"); kmdb_db_free(gpu); return 2; }
+            kmdb_sparse_rows sp{}, all{};
+            kmdb_bridge_all2all_sp(gpu, db, params.metricFilters, params.kmerFilter, &sp, &o);
+            kmdb_check(kmdb_all2all_sparse(gpu, &all, &o));
+            const auto& counts = db.getSampleKmersCount();
+            CombinedFilter<num_kmers_t> filter(params.metricFilters, params.kmerFilter, counts, counts, (int)db.getKmerLength());
+            uint64_t w = 0, kept = 0;
+            bool same = true;
+            for (uint64_t r = 0; r < all.n_rows && same; ++r) {
+                for (uint64_t e = all.row_ptr[r]; e < all.row_ptr[r + 1]; ++e)
+                    if (filter(all.val[e], (int)r, (int)all.col[e])) {
+                        same = same && w < sp.nnz && sp.col[w] == all.col[e] && sp.val[w] == all.val[e];
+                        ++w; ++kept;
+                    }
+                same = same && sp.row_ptr[r + 1] == w;
+            }
+            FILE* out = fopen(argv[3], "wb");
+            for (uint64_t r = 0; r < sp.n_rows; ++r) {
+                for (uint64_t e = sp.row_ptr[r]; e < sp.row_ptr[r + 1]; ++e) fprintf(out, "%u:%u,", sp.col[e] + 1, sp.val[e]);
+                fputc('\n', out);
+            }
+            fclose(out);
+            const uint64_t nnz = sp.nnz, total = all.nnz;
+            kmdb_sparse_free(&sp); kmdb_sparse_free(&all);
+            if (!same || kept != nnz) { fprintf(stderr, "all2all_sp_filtered: engine rows differ from CombinedFilter on the unfiltered rows\n"); kmdb_db_free(gpu); return 3; }
+            printf("all2all_sp_filtered: %llu of %llu cells kept, identical to the reference's CombinedFilter\n", (unsigned long long)nnz, (unsigned long long)total);
         } else if (cmd == "new2all") {
             // query = every key stored in bucket 0's table, widened back to a k-mer (bucket << 32 | key): all of them hit
             std::vector<uint64_t> q;

@@ -9,6 +9,7 @@
 #pragma once
 #include "kmdb_amd.h"
 #include "prefix_kmer_db.h"
+#include "sparse_filters.h"
 
 #include <cstring>
 #include <stdexcept>
@@ -79,4 +80,27 @@ inline void kmdb_bridge_all2all(const PrefixKmerDb& db, LowerTriangularMatrix<ui
     const int rc = kmdb_all2all_dense(gpu, matrix.getData().data(), &o);
     kmdb_db_free(gpu);
     kmdb_check(rc);
+}
+
+// The -min / -max filters of the reference's Params (params.h:99-100, filled by Params::parse, params.cpp:418-455) as the
+// bounds kmdb_all2all_sparse_filtered takes: one entry per criterion, the k-mer count filter as KMDB_METRIC_NUM_KMERS.
+inline std::vector<kmdb_cell_filter> kmdb_bridge_filters(const std::map<std::string, MetricFilter>& metricFilters, const KmerFilter& kmerFilter) {
+    std::vector<kmdb_cell_filter> out;
+    for (const auto& kv : metricFilters) {
+        const int id = kmdbh_metric_id(kv.first.c_str());
+        if (id < 0) throw std::runtime_error("kmdb bridge: unknown criterion " + kv.first);
+        out.push_back(kmdb_cell_filter{id, 0, kv.second.bounds[0], kv.second.bounds[1]});
+    }
+    const KmerFilter all;
+    if (kmerFilter.bounds[0] != all.bounds[0] || kmerFilter.bounds[1] != all.bounds[1])
+        out.push_back(kmdb_cell_filter{KMDB_METRIC_NUM_KMERS, 0, (double)kmerFilter.bounds[0], (double)kmerFilter.bounds[1]});
+    return out;
+}
+
+// drop-in for `calculator.all2all_sp(...)` + `matrix.compact2(filter)` (console_all2all_sparse.cpp:44-79): the filtered rows
+inline void kmdb_bridge_all2all_sp(kmdb_db* gpu, const PrefixKmerDb& db, const std::map<std::string, MetricFilter>& metricFilters, const KmerFilter& kmerFilter,
+                                   kmdb_sparse_rows* rows, const kmdb_opts* o) {
+    const std::vector<kmdb_cell_filter> fl = kmdb_bridge_filters(metricFilters, kmerFilter);
+    if (fl.empty()) kmdb_check(kmdb_all2all_sparse(gpu, rows, o));
+    else kmdb_check(kmdb_all2all_sparse_filtered(gpu, fl.data(), fl.size(), db.getSampleKmersCount().data(), -1, rows, o));
 }

@@ -723,6 +723,15 @@ def test_integration_glue_inside_the_reference(golden_dir, tmp_path):
     assert open(out, "rb").read() == open(os.path.join(golden_dir, "clade64.a2a_sp.ref.txt"), "rb").read()
     r = subprocess.run([exe, "new2all", os.path.join(golden_dir, "clade64.db"), str(tmp_path / "row.u32")], capture_output=True, text=True)
     assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr[-2000:]
+    # the -min / -max options parsed by the reference's own Params, translated by the bridge, applied on the device; the driver
+    # compares the rows with the reference's CombinedFilter on the unfiltered rows, and the synth case equals the reference's golden
+    for stem, opts in (("clade64", ["-min", "jaccard:0.02", "-max", "mash:0.2"]), ("virus_k18", ["-min", "ani-shorter:0.9", "-min", "num-kmers:100"]),
+                       ("clade64_k25_f01", ["-max", "cosine:0.5", "-min", "min:0.01"]), ("synth_k21", ["-max", "39", "-min", "num-kmers:31"])):
+        out = str(tmp_path / (stem + ".flt.txt"))
+        r = subprocess.run([exe, "all2all_sp_filtered", os.path.join(golden_dir, stem + ".db"), out] + opts, capture_output=True, text=True)
+        assert r.returncode == 0 and "identical to the reference's CombinedFilter" in r.stdout, r.stdout + r.stderr[-2000:]
+    want = [ln.split(b",", 2)[2] for ln in open(os.path.join(golden_dir, "synth.a2a.sparse.above-below"), "rb").read().split(b"\n")[2:] if ln]
+    assert open(out, "rb").read().split(b"\n")[:len(want)] == want
 
 
 @pytest.mark.gpu
