@@ -56,10 +56,7 @@ def build_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, 
     g = S.CladeGenomes(n_samples, clade_size, length, seed=seed, device=device)
 
     def kmers(i):
-        km = S.kmers_of(g.sample(i), k)
-        if world > 1:
-            km = km[((km >> 32) % world) == rank]
-        return km
+        return S.kmers_of(g.sample(i), k, prefix_shard=(rank, world))
     t0 = time.time()
     pat = S.build_patterns(kmers, n_samples, device, progress=progress)
     arr = S.to_view_arrays(pat)

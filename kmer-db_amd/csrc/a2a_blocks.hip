@@ -483,7 +483,7 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t seg = blockIdx.x * K1N_WAVES + wave;
+    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + wave;            // 1 .. K1N_WAVES waves per workgroup, by the LDS a wave needs
     if (seg >= q.n_segs) return;
     unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys) * wave;
     uint32_t* table = (uint32_t*)wbase;                                                      // open chunks
@@ -1894,9 +1894,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.tbits = db->dense_narrow ? 0u : arena_table_bits(db->NB); q.n_keys = db->NB;
         q.all_wide = db->dense_narrow ? 1u : 0u;
         q.pool = pool_view(db, db->dense_narrow);
-        const size_t lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys) * K1N_WAVES;
+        // a wave's chain table grows with the depth of the tree: as many waves per workgroup as 144 KB of LDS hold
+        const size_t wave_lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys);
+        const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(K1N_WAVES, (144u << 10) / wave_lds));
+        const size_t lds = wave_lds * waves;
         HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + K1N_WAVES - 1) / K1N_WAVES), dim3(WAVE * K1N_WAVES), lds, st, q);
+        hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
         HIP_TRY(hipGetLastError());
     }
     if (stage("narrow emit")) return 1;

@@ -150,7 +150,8 @@ struct kmdb_db {
 // registers; the others (a few percent) go to a second launch, longest list first.
 constexpr uint32_t KMDB_SHORT_MAX_IDS = 32, KMDB_SHORT_MAX_BITS = 128;
 __host__ __device__ inline bool kmdb_long_node(uint32_t l, uint32_t num_bits) { return l > KMDB_SHORT_MAX_IDS || num_bits > KMDB_SHORT_MAX_BITS; }
-constexpr int KMDB_CHAIN_MAX = 512;   // longest root path (in nodes) the chain table of the emit kernel holds
+constexpr int KMDB_CHAIN_MAX = 4096;  // longest root path (in nodes) the chain table of the narrow kernel holds (20 B of LDS per node and wave:
+                                      // the deeper the tree, the fewer waves share a workgroup)
 
 // ---- layout.hip: host conversion + device layout of the view (fills the structural arrays and stats)
 int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count);

@@ -91,9 +91,10 @@ class CladeGenomes:
         return ">%s\n%s\n" % (self.name(i), np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode())
 
 
-def kmers_of(codes, k, fraction=1.0, start_fraction=0.0):
+def kmers_of(codes, k, fraction=1.0, start_fraction=0.0, prefix_shard=None):
     """Sorted, duplicate-free k-mer words of one genome (torch int64 holding the uint64 bit pattern;
-    all words are < 2^62 so signed order == unsigned order)."""
+    all words are < 2^62 so signed order == unsigned order).  prefix_shard=(index, count): only the k-mers whose prefix
+    bucket (kmer >> 32) is congruent to index modulo count (dropped before the sort)."""
     L = codes.numel()
     if L < k:
         return torch.zeros(0, dtype=torch.int64, device=codes.device)
@@ -133,6 +134,8 @@ def kmers_of(codes, k, fraction=1.0, start_fraction=0.0):
         sign = _i64(1 << 63)
         keep = ((hv ^ sign) >= _i64(lo ^ (1 << 63))) & ((hv ^ sign) < _i64(min(hi, _M64) ^ (1 << 63)))
         can = can[keep]
+    if prefix_shard is not None and prefix_shard[1] > 1:
+        can = can[((can >> 32) % prefix_shard[1]) == prefix_shard[0]]
     return torch.unique(can)           # sorted
 
 

@@ -509,7 +509,7 @@ def _random_forest(rng, N, P, max_local, heavy_frac=0.2, zero_frac=0.2, chain_fr
 @pytest.mark.parametrize("seed,N,P,max_local,chain", [(1, 2, 5, 1, 0), (2, 64, 300, 5, 0), (3, 65, 2000, 3, 0), (4, 700, 6000, 40, 0),
                                                       (5, 1024, 3000, 300, 0), (6, 2048, 4000, 64, 0), (7, 130, 20000, 2, 0),
                                                       (8, 1500, 500, 1200, 0), (9, 1000, 30000, 3, 0.9), (10, 1000, 60000, 2, 0.97),
-                                                      (11, 4000, 20000, 3, 0.95)])
+                                                      (11, 4000, 20000, 3, 0.95), (12, 3000, 40000, 2, 0.995)])
 def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local, chain):
     """Fuzz: arbitrary valid pattern forests (deep chains, long local lists, zero and huge weights, lists
     longer than 1024 ids -> v1 fallback) through every all2all path, against the oracle's tree form AND
@@ -528,6 +528,9 @@ def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local, ch
                        arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
     d = K.DeviceDB(view, device=dev)
     assert np.array_equal(d.all2all_dense(), exp)
+    if chain and max_local <= 3:
+        # root paths of hundreds to thousands of nodes stay on the block-record pipeline (chain table sized by the depth)
+        assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp) and d.stats()["path"] == K.capi.PATH_RECORDS
     for fl in (K.capi.FLAG_FORCE_TILE, K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT):
         assert np.array_equal(d.all2all_dense(flags=fl), exp), fl
     acc = np.zeros_like(exp)
