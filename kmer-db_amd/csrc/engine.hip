@@ -383,6 +383,8 @@ extern "C" int kmdb_all2all_sparse_filtered(kmdb_db* db, const kmdb_cell_filter*
     if (n_filters > 8) return kmdb_set_error("kmdb_all2all_sparse_filtered: more than 8 bounds");
     for (size_t i = 0; i < n_filters; ++i)
         if (filters[i].metric < 0 || filters[i].metric >= KMDB_METRIC_COUNT) return kmdb_set_error("kmdb_all2all_sparse_filtered: unknown metric in a filter");
+    // bounds are conditions on the whole cell: a slice of the pattern stream (opts->shard_*) holds partial sums only
+    if ((n_filters || measure >= 0) && opts && opts->shard_count > 1) return kmdb_set_error("kmdb_all2all_sparse_filtered: filters need the whole database (shard_count must be 1)");
     return sparse_impl(db, filters, n_filters, sample_kmers, measure, out, opts);
 }
 
