@@ -1038,6 +1038,7 @@ struct K2Item {
     const WideRec* srec;                   // sorted mode: the run's records, n_rec of them, contiguous
     const uint32_t* skey;                  //              their key words (weight digits)
     uint32_t kbits, dbits;
+    uint32_t rect_cols;                    // 0: lower-triangular matrix of N samples; else a dense n_rows x rect_cols matrix (db2db), N = n_rows
     uint32_t n_rec;
     const unsigned char* rec;              // record pool
     const uint32_t* recw;
@@ -1156,7 +1157,7 @@ __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t
     if (threadIdx.x == 0) *wor_sh = 0;
     __syncthreads();
     for (uint32_t digit = 0; digit < 5; ++digit) {
-        const uint32_t wor = it.X == it.Y ? k2_apply_mfma<true, SORTED>(it, digit, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01)
+        const uint32_t wor = (it.X == it.Y && !it.rect_cols) ? k2_apply_mfma<true, SORTED>(it, digit, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01)
                                           : k2_apply_mfma<false, SORTED>(it, digit, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
         if ((threadIdx.x & 63u) == 0 && wor) atomicOr(wor_sh, wor);
         __syncthreads();
@@ -1169,7 +1170,8 @@ __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t
         const uint32_t v = acc[k];
         if (!v) continue;
         const uint64_t row = (uint64_t)it.X * bwidth + (k >> 6), col = (uint64_t)it.Y * bwidth + (k & 63u);
-        if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
+        if (it.rect_cols) { if (row < N && col < it.rect_cols) atomicAdd(&M[row * it.rect_cols + col], v); }
+        else if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
     }
     __syncthreads();
 }
@@ -1214,7 +1216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             while (tri32(X) > bucket) --X;
             while (tri32(X + 1u) <= bucket) ++X;
             it.X = X; it.Y = bucket - tri32(X);
-            it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw;
+            it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw; it.rect_cols = 0;
         }
         k2_run<false>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
         a = b;
@@ -1388,7 +1390,8 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
 constexpr uint32_t K2S_WIN = 4096;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
                                                         uint32_t limit, const uint32_t* __restrict__ total_ptr, uint32_t n_states,
-                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth,
+                                                        uint32_t rect_nbc, uint32_t rect_cols) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
@@ -1452,10 +1455,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         K2Item it;
         {
             const uint32_t bucket = key;
-            uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)bucket + 1.0f) - 1.0f) * 0.5f);
-            while (tri32(X) > bucket) --X;
-            while (tri32(X + 1u) <= bucket) ++X;
-            it.X = X; it.Y = bucket - tri32(X);
+            if (rect_nbc) { it.X = bucket / rect_nbc; it.Y = bucket - it.X * rect_nbc; }      // db2db: stream = row block x column blocks + column block
+            else { it.X = stream_row(bucket); it.Y = bucket - tri32(it.X); }
+            it.rect_cols = rect_cols;
             it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.skey = swkey + p0 + a; it.kbits = kbits; it.dbits = dbits; it.rec = nullptr; it.recw = nullptr;
         }
         k2_run<true>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
@@ -1716,6 +1718,50 @@ int kmdb_ensure_v1_arrays(kmdb_db* db) {
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(db->stream));
+    return 0;
+}
+
+// db2db (csrc/db2db.hip): records (row block, column block, row mask, column mask, weight digit in the key word) of the pairs of
+// patterns that share k-mers, in arrival order in [0, nslots) with never-written slots keyed all-ones -> sorted by stream and
+// accumulated into the dense n_rows x n_cols matrix M by the same sort and matrix-core kernels as the all2all's wide pool.
+int kmdb_rect_sort_apply(hipStream_t st, uint32_t* wkey, void* wrec, uint32_t nslots, uint32_t nbr, uint32_t nbc, int key_bits, uint32_t* M, uint32_t n_rows,
+                         uint32_t n_cols) {
+    if (!nslots) return 0;
+    const uint32_t n_states = nbr * nbc, kmask = (1u << key_bits) - 1u;
+    uint32_t *swkey = nullptr, *hist = nullptr, *offs = nullptr;
+    WideRec* swrec = nullptr;
+    void* tmp = nullptr;
+    auto cleanup = [&]() { for (void* p : {(void*)swkey, (void*)swrec, (void*)hist, (void*)offs, tmp}) if (p) (void)hipFree(p); };
+#define RS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    RS_TRY(hipMalloc((void**)&swkey, (size_t)nslots * 4));
+    RS_TRY(hipMalloc((void**)&swrec, (size_t)nslots * sizeof(WideRec)));
+    const uint32_t* total_ptr = nullptr;
+    if (n_states <= CS_MAX_KEYS) {
+        const size_t ne = (size_t)n_states * CS_BLOCKS + 1;
+        size_t tb = 0;
+        RS_TRY(hipMalloc((void**)&hist, ne * 4));
+        RS_TRY(hipMalloc((void**)&offs, ne * 4));
+        RS_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hist, offs, (int)ne, st));
+        RS_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+        const CsRows no_rows{};
+        hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), n_states * 4, st, wkey, nslots, n_states, n_states, (int)CS_BY_STREAM, no_rows, kmask, hist);
+        RS_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, hist, offs, (int)ne, st));
+        RS_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(n_states)));
+        hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(n_states), st, wkey, (const WideRec*)wrec, nslots, n_states, n_states,
+                           (int)CS_BY_STREAM, no_rows, kmask, offs, swkey, swrec);
+        total_ptr = offs + (ne - 1);
+    } else {
+        size_t tb = 0;
+        RS_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, wkey, swkey, (WideRec*)wrec, swrec, (int)nslots, 0, key_bits, st));
+        RS_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+        RS_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, wkey, swkey, (WideRec*)wrec, swrec, (int)nslots, 0, key_bits, st));
+    }
+    hipLaunchKernelGGL(k2_sorted_kernel, dim3((nslots + K2S_WIN - 1) / K2S_WIN), dim3(256), 0, st, swkey, (const WideRec*)swrec, nslots, total_ptr, n_states,
+                       (uint32_t)key_bits, wide_digit_bits(key_bits), M, n_rows, 64u, nbc, n_cols);
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(st));
+#undef RS_TRY
+    cleanup();
     return 0;
 }
 
@@ -2030,7 +2076,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             }
             const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
             hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, sorted_key, sorted_rec, nslots, total_ptr,
-                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width);
+                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u);
             HIP_TRY(hipGetLastError());
         }
         if (stage("sorted apply")) return 1;

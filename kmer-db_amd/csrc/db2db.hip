@@ -19,12 +19,13 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 namespace {
 
 constexpr unsigned long long D2_INVALID = ~0ull;
-constexpr uint32_t D2_MAXN = 2048;            // longest full list the scatter kernel stages in LDS
 
 __device__ __forceinline__ uint32_t d2_fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
@@ -90,9 +91,9 @@ struct D2Cursor {                               // gamma stream reader (src/elia
     }
 };
 
-// full list of the pattern with DFS index `node` into out[0..n): lane d decodes the d-th node of the root path
-__device__ __forceinline__ uint32_t d2_decode_list(const D2Db& db, uint32_t node, uint16_t* out, uint32_t lane) {
-    const uint32_t n = db.meta[node].x;
+// full list of the pattern with DFS index `node` as a bit set over the sample ids (64 per word): lane d decodes the d-th
+// node of the root path and ORs its local ids in (pattern_t::decodeSamples, src/pattern.cpp:99-109: first id = last - sum of the deltas)
+__device__ __forceinline__ void d2_list_bits(const D2Db& db, uint32_t node, unsigned long long* set, uint32_t lane) {
     int64_t r = node;
     uint32_t d = 0;
     while (r >= 0) {                             // every lane walks the path; lane (d mod 64) decodes node d
@@ -101,47 +102,110 @@ __device__ __forceinline__ uint32_t d2_decode_list(const D2Db& db, uint32_t node
             const uint32_t l = m.y;
             if (l) {
                 uint32_t id = m.z;
-                if (l > 1) {                     // pattern_t::decodeSamples (src/pattern.cpp:99-109)
+                if (l > 1) {
                     D2Cursor c1(db.bits, db.bitpos[r]);
                     uint32_t sum = 0;
                     for (uint32_t t = 0; t + 1 < l; ++t) sum += c1.next();
                     id = m.z - sum;
                     D2Cursor c2(db.bits, db.bitpos[r]);
-                    uint32_t pos = m.x - l;
-                    for (uint32_t t = 0; t + 1 < l; ++t) { out[pos++] = (uint16_t)id; id += c2.next(); }
+                    for (uint32_t t = 0; t + 1 < l; ++t) { atomicOr(&set[id >> 6], 1ull << (id & 63u)); id += c2.next(); }
                 }
-                out[m.x - 1] = (uint16_t)id;
+                atomicOr(&set[id >> 6], 1ull << (id & 63u));
             }
         }
         r = db.parent[r];
         ++d;
     }
-    return n;
 }
 
-__global__ __launch_bounds__(256) void d2_scatter_kernel(D2Db row, D2Db col, const unsigned long long* __restrict__ pairs,
-                                                         const uint32_t* __restrict__ counts, uint32_t npairs, uint32_t n_col,
-                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ too_long) {
-    __shared__ uint16_t lists[4][2][D2_MAXN];
+// Pattern pairs -> block records.  A pair (row pattern, column pattern, c shared k-mers) adds c to every cell (sample of the
+// row pattern, sample of the column pattern): with both lists as bit sets over blocks of 64 ids that is one record
+// (row block, column block, row mask, column mask, c) per pair of non-empty blocks — the record form of the all2all pipeline
+// (a2a_blocks.hip), sorted by block pair and accumulated on the matrix cores by the same kernels.  (Round 1 added the cells
+// one by one with HBM atomics: 100 ms for two 1000-sample databases.)
+// One wave per pair, persistent waves.  COUNT: only the number of records (sizes the pool); else: records into the pool in
+// arrival order, slots taken GRAB at a time from one of 256 cursors (a shared cursor would serialise: same-address atomics).
+constexpr uint32_t D2_GRAB = 512, D2_CURSORS = 256;
+struct D2Pool { uint32_t* wkey; ulonglong2* wrec; uint32_t* cursor; uint32_t region; uint32_t kbits, dbits; uint32_t* overflow; };
+template <bool COUNT>
+__global__ __launch_bounds__(256) void d2_emit_kernel(D2Db row, D2Db col, const unsigned long long* __restrict__ pairs, const uint32_t* __restrict__ counts,
+                                                      uint32_t npairs, uint32_t nbr, uint32_t nbc, D2Pool pool, unsigned long long* __restrict__ n_records) {
+    extern __shared__ unsigned long long d2_lds[];          // per wave: row set [nbr], column set [nbc], then the non-empty blocks of each
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t i = blockIdx.x * 4 + wave;
-    if (i >= npairs) return;
-    const unsigned long long key = pairs[i];
-    if (key == D2_INVALID) return;
-    const uint32_t pr = (uint32_t)(key >> 32), pc = (uint32_t)key, c = counts[i];
-    if (row.meta[pr].x > D2_MAXN || col.meta[pc].x > D2_MAXN) { if (lane == 0) atomicAdd(too_long, 1u); return; }
-    uint16_t* A = lists[wave][0];
-    uint16_t* B = lists[wave][1];
-    const uint32_t n1 = d2_decode_list(row, pr, A, lane);
-    const uint32_t n2 = d2_decode_list(col, pc, B, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint32_t total = n1 * n2;
-    for (uint32_t t = lane; t < total; t += 64) {
-        const uint32_t a = t / n2, b = t - a * n2;
-        atomicAdd(&out[(size_t)A[a] * n_col + B[b]], c);
+    const uint32_t per_wave = 2u * (nbr + nbc);
+    unsigned long long* rset = d2_lds + (size_t)wave * per_wave;
+    unsigned long long* cset = rset + nbr;
+    unsigned long long* rmask = cset + nbc;                   // compacted: mask of the a-th non-empty row block
+    unsigned long long* cmask = rmask + nbr;
+    __shared__ uint16_t blkidx[4][2][1024];                   // ... and its block index (N <= 65535: at most 1024 blocks)
+    uint16_t* ridx = blkidx[wave][0];
+    uint16_t* cidx = blkidx[wave][1];
+    const uint32_t wid = blockIdx.x * 4u + wave, nwaves = gridDim.x * 4u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long mine = 0;
+    uint32_t next = 0, left = 0, sub = wid % D2_CURSORS;      // the wave's current grab of pool slots
+    // the pairs are sorted by row pattern: a wave takes a contiguous share and keeps the row pattern's list while it repeats
+    const uint32_t i_lo = (uint32_t)((uint64_t)npairs * wid / nwaves), i_hi = (uint32_t)((uint64_t)npairs * (wid + 1u) / nwaves);
+    uint32_t cached_pr = 0xFFFFFFFFu, na = 0;
+    for (uint32_t i = i_lo; i < i_hi; ++i) {
+        const unsigned long long key = pairs[i];
+        if (key == D2_INVALID) continue;
+        const uint32_t pr = (uint32_t)(key >> 32), pc = (uint32_t)key;
+        uint32_t c = counts[i];
+        const bool new_row = pr != cached_pr;
+        for (uint32_t k = lane + (new_row ? 0u : nbr); k < nbr + nbc; k += 64u) rset[k] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (new_row) d2_list_bits(row, pr, rset, lane);
+        d2_list_bits(col, pc, cset, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the non-empty blocks of both lists, compacted in order
+        uint32_t nb = 0;
+        if (new_row) {
+            na = 0; cached_pr = pr;
+            for (uint32_t k0 = 0; k0 < nbr; k0 += 64u) {
+                const uint32_t k = k0 + lane;
+                const unsigned long long m = k < nbr ? rset[k] : 0ull;
+                const unsigned long long bal = __ballot(m != 0);
+                if (m) { const uint32_t o = na + (uint32_t)__popcll(bal & lt_mask); rmask[o] = m; ridx[o] = (uint16_t)k; }
+                na += (uint32_t)__popcll(bal);
+            }
+        }
+        for (uint32_t k0 = 0; k0 < nbc; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            const unsigned long long m = k < nbc ? cset[k] : 0ull;
+            const unsigned long long bal = __ballot(m != 0);
+            if (m) { const uint32_t o = nb + (uint32_t)__popcll(bal & lt_mask); cmask[o] = m; cidx[o] = (uint16_t)k; }
+            nb += (uint32_t)__popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // one record per block pair and per base-2^dbits digit of c (exact: shifted digits add up in uint32 wrap-around arithmetic)
+        uint32_t nd = 0;
+        for (uint32_t w = c; w; w >>= pool.dbits) ++nd;
+        const uint32_t T = na * nb * nd;
+        if (COUNT) { if (lane == 0) mine += T; continue; }
+        const uint32_t dmask = (1u << pool.dbits) - 1u;
+        for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+            const uint32_t cnt = T - t0 < 64u ? T - t0 : 64u;
+            if (left < cnt) {                                  // a fresh grab from the next cursor (the tail of the old one stays unwritten)
+                sub = (sub + 61u) % D2_CURSORS;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&pool.cursor[sub * 16u], D2_GRAB);
+                base = (uint32_t)__shfl((int)base, 0, 64);
+                if (base + D2_GRAB > pool.region) { if (lane == 0) atomicOr(pool.overflow, 1u); base = pool.region - D2_GRAB; }
+                next = sub * pool.region + base; left = D2_GRAB;
+            }
+            const uint32_t t = t0 + lane;
+            if (t < T) {
+                const uint32_t j = t % nd, ab = t / nd, a = ab / nb, b = ab - a * nb;
+                const uint32_t digit = (c >> (j * pool.dbits)) & dmask;
+                const uint32_t stream = (uint32_t)ridx[a] * nbc + cidx[b];
+                pool.wrec[next + lane] = make_ulonglong2(rmask[a], cmask[b]);
+                pool.wkey[next + lane] = stream | ((digit | (j << pool.dbits)) << pool.kbits);
+            }
+            next += cnt; left -= cnt;
+        }
     }
+    if (COUNT && lane == 0 && mine) atomicAdd(&n_records[(wid % 64u) * 8u], mine);
 }
 
 struct DevBuf {
@@ -206,9 +270,60 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
         D2_TRY(hipMemcpyAsync(&nruns, d_nruns.p, 4, hipMemcpyDeviceToHost, st));
         D2_TRY(hipStreamSynchronize(st));
         if (nruns) {
-            hipLaunchKernelGGL(d2_scatter_kernel, dim3((nruns + 3) / 4), dim3(256), 0, st, vr, vc, d_uniq.as<unsigned long long>(),
-                               d_cnt.as<uint32_t>(), nruns, (uint32_t)nc, d_out.as<uint32_t>(), d_flag.as<uint32_t>());
-            D2_TRY(hipGetLastError());
+            // pairs -> block records -> sorted by block pair -> accumulated on the matrix cores (a2a_blocks.hip)
+            const uint32_t nbr = (uint32_t)((nr + 63) / 64), nbc = (uint32_t)((nc + 63) / 64);
+            int key_bits = 1;
+            while ((1ull << key_bits) <= (uint64_t)nbr * nbc + 1) ++key_bits;
+            const uint32_t dbits = (uint32_t)(32 - key_bits - 2);
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nruns + 3) / 4, 256 * 8);
+            const size_t lds = (size_t)4 * 2 * (nbr + nbc) * 8;
+            DevBuf d_nrec, d_cursor;
+            D2_TRY(d_nrec.alloc(64 * 8 * 8)); D2_TRY(d_cursor.alloc(D2_CURSORS * 16 * 4));
+            D2_TRY(hipMemsetAsync(d_nrec.p, 0, 64 * 8 * 8, st));
+            D2_TRY(hipMemsetAsync(d_cursor.p, 0, D2_CURSORS * 16 * 4, st));
+            D2Pool pool{nullptr, nullptr, d_cursor.as<uint32_t>(), 0u, (uint32_t)key_bits, dbits, d_flag.as<uint32_t>() + 1};
+            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // the pool: sized for six records per pair first; if that overflows, the
+            // records are counted and the pool is made to measure
+            DevBuf d_wkey, d_wrec;
+            uint64_t slots = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                unsigned long long total = 6ull * nruns;
+                if (attempt) {
+                    D2_TRY(hipMemsetAsync(d_nrec.p, 0, 64 * 8 * 8, st));
+                    hipLaunchKernelGGL(d2_emit_kernel<true>, dim3(grid), dim3(256), lds, st, vr, vc, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(), nruns, nbr,
+                                       nbc, pool, d_nrec.as<unsigned long long>());
+                    D2_TRY(hipGetLastError());
+                    unsigned long long h_nrec[64 * 8];
+                    D2_TRY(hipMemcpyAsync(h_nrec, d_nrec.p, sizeof h_nrec, hipMemcpyDeviceToHost, st));
+                    D2_TRY(hipStreamSynchronize(st));
+                    total = 0;
+                    for (int q = 0; q < 64; ++q) total += h_nrec[q * 8];
+                }
+                // per cursor: its share of the records and of the grab tails (up to 63 slots per grab), one unfinished grab per wave
+                // that ends there, and room for the uneven ends of the waves' round-robin over the cursors
+                const uint64_t grabs = (total + total / 8) / D2_GRAB / D2_CURSORS + (uint64_t)grid * 4 / D2_CURSORS + 130;
+                const uint64_t region = grabs * D2_GRAB;
+                slots = region * D2_CURSORS;
+                if (slots >= (1ull << 31)) return kmdb_set_error("kmdb_db2db_dense: more than 2^31 block records");
+                if (d_wkey.p) { (void)hipFree(d_wkey.p); d_wkey.p = nullptr; (void)hipFree(d_wrec.p); d_wrec.p = nullptr; }
+                D2_TRY(d_wkey.alloc(slots * 4)); D2_TRY(d_wrec.alloc(slots * 16));
+                D2_TRY(hipMemsetAsync(d_wkey.p, 0xFF, slots * 4, st));
+                D2_TRY(hipMemsetAsync(d_cursor.p, 0, D2_CURSORS * 16 * 4, st));
+                D2_TRY(hipMemsetAsync(d_flag.as<uint32_t>() + 1, 0, 4, st));
+                pool.wkey = d_wkey.as<uint32_t>(); pool.wrec = d_wrec.as<ulonglong2>(); pool.region = (uint32_t)region;
+                hipLaunchKernelGGL(d2_emit_kernel<false>, dim3(grid), dim3(256), lds, st, vr, vc, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(), nruns, nbr, nbc,
+                                   pool, d_nrec.as<unsigned long long>());
+                D2_TRY(hipGetLastError());
+                uint32_t ovf = 0;
+                D2_TRY(hipMemcpyAsync(&ovf, d_flag.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, st));
+                D2_TRY(hipStreamSynchronize(st));
+                if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] db2db: %u pattern pairs, pool for %llu records (%s)%s\n", nruns, total, attempt ? "counted" : "estimate", ovf ? ": too small" : "");
+                if (!ovf) break;
+                if (attempt) return kmdb_set_error("kmdb_db2db_dense: internal error (record pool overflow)");
+            }
+            if (kmdb_rect_sort_apply(st, d_wkey.as<uint32_t>(), d_wrec.p, (uint32_t)slots, nbr, nbc, key_bits, d_out.as<uint32_t>(), (uint32_t)nr, (uint32_t)nc)) return 1;
         }
     }
     D2_TRY(hipEventRecord(ev3, st));
@@ -218,7 +333,7 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
     kmdb_engine_set_times(db_row, ms, ms);
     uint32_t too_long = 0;
     D2_TRY(hipMemcpy(&too_long, d_flag.p, 4, hipMemcpyDeviceToHost));
-    if (too_long) return kmdb_set_error("kmdb_db2db_dense: a pattern with more than 2048 samples is not supported yet");
+    if (too_long) return kmdb_set_error("kmdb_db2db_dense: internal error");
     if (nr * nc) D2_TRY(hipMemcpy(out, d_out.p, nr * nc * 4, hipMemcpyDeviceToHost));
     return 0;
 }

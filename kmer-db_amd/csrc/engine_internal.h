@@ -32,3 +32,9 @@ struct kmdb_engine_view {
 // also builds the v1 / new2all node arrays on first use; non-zero on failure
 int kmdb_engine_get(kmdb_db* db, kmdb_engine_view* out);
 void kmdb_engine_set_times(kmdb_db* db, double kernel_ms, double dominant_ms);
+
+// sort + matrix-core accumulation of block records into a dense n_rows x n_cols matrix (a2a_blocks.hip; used by db2db.hip).
+// Record = 16 bytes {row mask, column mask} + key word {stream = row block * nbc + column block | (weight digit | digit index << d) << key_bits},
+// d = 32 - key_bits - 2; slots never written carry the key 0xFFFFFFFF.
+int kmdb_rect_sort_apply(hipStream_t st, uint32_t* wkey, void* wrec, uint32_t nslots, uint32_t nbr, uint32_t nbc, int key_bits, uint32_t* M, uint32_t n_rows,
+                         uint32_t n_cols);
