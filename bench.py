@@ -191,6 +191,19 @@ def secondary_mode(args, K, S, device):
                     assert "".join("%d:%d," % (a + 1, b) for a, b in zip(c, v)).encode() == lines[i], "row %d differs from the reference" % i
                 cpu = {"value": units / info["seconds"], "unit": unit, "cores": min(cores, 16), "host_cores": cores, "kind": "reference", "seconds": info["seconds"],
                        "sample": "the same database, reference all2all_sp compute interval; all %d rows of the sparse output compared equal" % N}
+            # the same call with a bound on a measure: cells that miss it never leave the device
+            cnt32 = np.asarray(pat["sample_counts"], dtype=np.uint64).astype(np.uint32)
+            rows_of = np.repeat(np.arange(N), np.diff(sp.row_ptr).astype(np.int64))
+            a_, b_, c_ = cnt32[rows_of].astype(np.uint32), cnt32[sp.col].astype(np.uint32), sp.val.astype(np.uint32)
+            jac = c_.astype(np.float64) / (a_ + b_ - c_).astype(np.float64)
+            thr = float(np.quantile(jac, 0.99)) if jac.size else 0.0
+            t1 = time.perf_counter()
+            spf = d.all2all_sparse_filtered([("jaccard", thr, None)], cnt32, measure="jaccard")
+            filt_ms = (time.perf_counter() - t1) * 1e3
+            keep = jac >= thr
+            assert spf.nnz == int(keep.sum()) and np.array_equal(spf.col, sp.col[keep]) and np.array_equal(spf.val, sp.val[keep]) \
+                and np.array_equal(spf.measure, jac[keep]), "filtered sparse output differs"
+            extra_wall = {"filtered_call_ms": filt_ms, "filtered_nnz": int(spf.nnz), "filter": "jaccard >= %.6g (the 99th percentile), measure = jaccard" % thr}
             cfg = {"workload": "%s: %s, all2all-sp" % (args.workload, desc), "nnz": int(sp.nnz), "patterns": int(d.P)}
             kernel = "kmdb_all2all_sparse: block-record pipeline into the dense triangle + row_nnz / row_compact (CSR)"
         elif args.mode == "new2all":
@@ -278,7 +291,7 @@ def secondary_mode(args, K, S, device):
     out = {"metric": metric, "value": units / (dev_ms * 1e-3), "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dev_ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
            "config": dict(cfg, samples=N, genome_length_bp=L, k=k, fraction=f, mode=args.mode),
-           "wall": {"upload_s": upload_s, "call_ms": call_ms,
+           "wall": {"upload_s": upload_s, "call_ms": call_ms, **(extra_wall if args.mode == "all2all-sp" else {}),
                     "note": "ms_per_step / value: device time of one call (HIP events); call_ms: the same call as the host sees it, host buffers in "
                             "and out (H2D / D2H inclusive)"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
