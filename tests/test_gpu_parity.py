@@ -225,29 +225,35 @@ def test_db2db_bit_exact(K, O, golden_dir, dev):
         d1.db2db(K.DeviceDB(K.HostDB(os.path.join(golden_dir, "virus_k25_f01_part1.db")), device=dev, with_hashtables=True))
 
 
-def test_db2db_patterns_of_thousands_of_samples(K, O, dev, tmp_path):
-    """db2db with patterns that list more samples than any fixed per-pattern buffer (round 1 refused > 2048): two parts of
-    2600 samples; every row of the cell equals the corresponding part of the all2all matrix of the whole collection."""
+@pytest.mark.parametrize("N,L,near", [(5200, 1500, True), (9000, 400, False)])
+def test_db2db_large_parts(K, O, dev, tmp_path, N, L, near):
+    """db2db beyond round 1's limits.  near: near-identical genomes, patterns that list more samples than any fixed per-pattern
+    buffer (round 1 refused > 2048); every row of the cell equals the corresponding part of the all2all matrix of the whole
+    collection.  Otherwise: 4500 x 4500 samples = 71 x 71 block pairs, more than the one-pass counting sort takes (radix sort
+    path of kmdb_rect_sort_apply), against the oracle."""
     import importlib
     import torch
     S = importlib.import_module("kmerdb_amd.synth")
-    N, cs, L, k = 5200, 50, 1500, 18
+    cs, k = 50, 18
     device = torch.device("cuda", dev)
-    g = S.CladeGenomes(N, cs, L, r1=0.005, r2=0.0005, seed=11, device=device)       # near-identical genomes: k-mers shared by most samples
+    g = S.CladeGenomes(N, cs, L, r1=0.005 if near else 0.10, r2=0.0005 if near else 0.01, seed=11, device=device)
     ids_a, ids_b = list(range(0, N, 2)), list(range(1, N, 2))
     pa, pb, pall = str(tmp_path / "a.db"), str(tmp_path / "b.db"), str(tmp_path / "all.db")
     _synth_part(S, g, ids_a, k, pa, device)
     _synth_part(S, g, ids_b, k, pb, device)
-    _synth_part(S, g, ids_a + ids_b, k, pall, device)
     ha = K.HostDB(pa)
-    assert int(ha.view_arrays()["num_samples"].max()) > 2048          # the case this test is about
     da = K.DeviceDB(ha, device=dev, with_hashtables=True)
     db_ = K.DeviceDB(K.HostDB(pb), device=dev, with_hashtables=True)
     got = db_.db2db(da)
-    full = K.DeviceDB(K.HostDB(pall, skip_hashtables=True), device=dev).all2all_dense()
-    na = len(ids_a)
-    for r in range(0, len(ids_b), 97):
-        assert np.array_equal(got[r], O.tri_row(full, na + r)[:na]), r
+    if near:
+        assert int(ha.view_arrays()["num_samples"].max()) > 2048          # the case this test is about
+        _synth_part(S, g, ids_a + ids_b, k, pall, device)
+        full = K.DeviceDB(K.HostDB(pall, skip_hashtables=True), device=dev).all2all_dense()
+        na = len(ids_a)
+        for r in range(0, len(ids_b), 97):
+            assert np.array_equal(got[r], O.tri_row(full, na + r)[:na]), r
+    else:
+        assert np.array_equal(got, O.OracleDB(pb).db2db(O.OracleDB(pa))) and got.any()
     assert np.array_equal(da.db2db(db_), got.T)
 
 
