@@ -358,7 +358,10 @@ def main():
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
-            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+            try:
+                rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:                                      # reporting only
+                rccl = "unknown"
         else:
             dist.init_process_group("gloo")
     K = import_kmerdb_amd()
