@@ -129,6 +129,24 @@ def cpu_baseline(K, S, O, args, device, arr, names, counts, nk, gpu_matrix):
                           % (args.workload, arr["num_kmers"].size, thr, buf, len(tried), max(1, args.length // L), m.size)}
 
 
+def measured_copy_gbs(device, gib=2):
+    """achievable HBM bandwidth on this box: a device-to-device copy of `gib` GiB (read + write counted), best of 5"""
+    n = gib << 28
+    a = torch.empty(n, dtype=torch.int32, device=device)
+    b = torch.ones(n, dtype=torch.int32, device=device)
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        a.copy_(b)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
+
+
 def pattern_bytes(arr):
     """B_pat of SURVEY 8(d): the on-disk pattern section, 40 B header + 16 B per 128 stream bits"""
     return int((40 + 16 * ((arr["num_bits"].astype(np.int64) + 127) // 128)).sum())
@@ -501,6 +519,7 @@ def main():
                 "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3]),
                                   "whole_call": kern_ms},
                 "cold_call_frac": alg / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "measured_copy_GBs": measured_copy_gbs(device),      # what a plain copy reaches on this box (peak above is the nominal figure)
                 "block_records_per_launch": stl["n_records"], "wide_nodes": stl["n_wide"], "wide_nodes_climbing": stl["n_slow_wide"],
                 "record_chunks": stl["n_chunks"],
             },
