@@ -509,7 +509,9 @@ def main():
                 "upload_s": upload_s, "cold_call_ms": cold_ms, "cold_total_s": upload_s + cold_ms * 1e-3, "warm_ms": ms_per_step,
                 "note": "upload = kmdb_db_upload (format conversion: host narrowing + H2D + device DFS layout; no sample id decoded except "
                         "the 1-in-%d sample of the block-width estimate); cold call = first kmdb_all2all_dense incl. D2H of the matrix; every "
-                        "call, warm or cold, decodes, places and accumulates everything itself" % max(1, min(1024, db.P // 65536)),
+                        "call, warm or cold, decodes, places and accumulates everything itself; the upload's host staging buffers (3.5 GB at c2) are "
+                        "unmapped by a helper thread after the first call, not inside upload (0.3 s of address-space work that blocks nothing "
+                        "the calls need)" % max(1, min(1024, db.P // 65536)),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -1859,8 +1859,8 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     if (const char* e = getenv("KMDB_DENSE")) db->dense_narrow = atoi(e) >= 2;
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide pool: the wide estimate and a grab per wave
-    if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 24 + 1024)) return 1;
-    if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1G_MAX_WAVES + 64) * (WIDE_GRAB + 2) + 1024)) return 1;
+    if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
+    if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1G_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;
     return 0;
 }
 

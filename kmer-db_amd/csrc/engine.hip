@@ -175,6 +175,7 @@ extern "C" int kmdb_db_upload_shard(const kmdb_db_view* v, const kmdb_opts* opts
 extern "C" void kmdb_db_free(kmdb_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
+    kmdb_release_staging(db);
     kmdb_blocks_release(db);
     void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
                     db->nseg_anc_n, db->meta, db->bitpos, db->ck_ofs, db->ck_bit, db->ck_id, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,
@@ -201,6 +202,7 @@ int kmdb_engine_get(kmdb_db* db, kmdb_engine_view* o) {
 }
 
 void kmdb_engine_set_times(kmdb_db* db, double kernel_ms, double dominant_ms) {
+    kmdb_release_staging(db);                                   // (end of a new2all / db2db call)
     db->stats.kernel_ms = kernel_ms;
     db->stats.dominant_kernel_ms = dominant_ms;
 }
@@ -309,7 +311,9 @@ extern "C" int kmdb_all2all_dense_device(kmdb_db* db, void* out_dev, const kmdb_
     HIP_TRY(hipSetDevice(db->device));
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : db->stream;
     if (run_dense(db, (uint32_t*)out_dev, opts, st)) return 1;
-    return finish_stats(db, st);
+    const int rc = finish_stats(db, st);
+    kmdb_release_staging(db);                                   // the upload's host buffers, once the first call is through
+    return rc;
 }
 
 extern "C" int kmdb_all2all_dense(kmdb_db* db, uint32_t* out, const kmdb_opts* opts) {
@@ -324,6 +328,7 @@ extern "C" int kmdb_all2all_dense(kmdb_db* db, uint32_t* out, const kmdb_opts* o
     if (!rc && cells && hipMemcpy(out, M, cells * 4, hipMemcpyDeviceToHost) != hipSuccess)
         rc = kmdb_set_error("kmdb_all2all_dense: copy back failed");
     (void)hipFree(M);
+    kmdb_release_staging(db);
     return rc;
 }
 
@@ -447,6 +452,7 @@ static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_fi
     }
 #undef SP_TRY
     cleanup();
+    kmdb_release_staging(db);
     if (n_filters || measure >= 0) {
         // the host side: every surviving cell decided by the reference's own arithmetic, rows compacted in place, measures computed
         const int k = (int)db->kmer_length;

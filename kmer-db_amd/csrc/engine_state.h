@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #define HIP_TRY(expr)                                                                          \
@@ -115,6 +116,9 @@ struct kmdb_db {
     void* scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     // ---- v1 kernels (A/B reference, fallback) and new2all: built lazily on the device from the arrays above
+    // host staging buffers of the upload, given back by a helper thread after the first call (or when the handle is freed):
+    // unmapping them costs 0.3 s (the HIP runtime had them registered for the copies) and blocks every hipMalloc meanwhile
+    std::vector<std::pair<void*, size_t>> staging;
     uint4* meta = nullptr;          // {n, l, last_id, nbits} per node, DFS order
     uint64_t* bitpos = nullptr;     // absolute bit offset of the node's gamma stream
     // new2all: index into the gamma streams of the nodes with more than KMDB_CK_IDS local ids — every KMDB_CK_IDS-th id and
@@ -168,3 +172,6 @@ void kmdb_blocks_release(kmdb_db* db);
 uint64_t kmdb_blocks_device_bytes(const kmdb_db* db);
 // v1 / new2all node arrays, derived on the device from the compact layout
 int kmdb_ensure_v1_arrays(kmdb_db* db);
+
+// layout.hip: unmap db->staging piece by piece on a detached thread
+void kmdb_release_staging(kmdb_db* db);

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <thread>
 
 namespace {
@@ -204,12 +205,25 @@ __global__ void lay_shard_weights_kernel(const uint64_t* __restrict__ slots, con
     }
 }
 
+// Host staging buffers of the upload: anonymous mappings, handed to the database handle and given back piece by piece by a helper
+// thread after the first call (kmdb_release_staging).  Unmapping them right after the copies took 0.31 s of a 0.63 s upload
+// (the HIP runtime has the ranges registered for its DMA), and a thread that does it meanwhile blocks every hipMalloc of the
+// main thread for as long (both need the address-space lock).  (Transparent huge pages cut both the faults and
+// the munmap 3 x, but one upload in ten on a fresh box then stalled 5 s in the kernel's page compaction: not used.)
+struct HostRegion { void* p; size_t bytes; };
 template <class T>
 struct HostBuf {
     T* p = nullptr;
-    explicit HostBuf(size_t n, bool zero = false) { p = (T*)(zero ? std::calloc(std::max<size_t>(n, 1), sizeof(T)) : std::malloc(std::max<size_t>(n, 1) * sizeof(T))); }
-    ~HostBuf() { std::free(p); }
-    void reset() { std::free(p); p = nullptr; }
+    size_t bytes = 0;
+    explicit HostBuf(size_t n, bool zero = false) {
+        (void)zero;                                             // anonymous mappings are zero-filled
+        bytes = (std::max<size_t>(n, 1) * sizeof(T) + 4095) & ~(size_t)4095;
+        void* q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        p = q == MAP_FAILED ? nullptr : (T*)q;
+    }
+    ~HostBuf() { reset(); }
+    void reset() { if (p) (void)munmap(p, bytes); p = nullptr; }
+    HostRegion release() { HostRegion r{p, bytes}; p = nullptr; return r; }
     T& operator[](size_t i) { return p[i]; }
     HostBuf(const HostBuf&) = delete;
     HostBuf& operator=(const HostBuf&) = delete;
@@ -224,6 +238,17 @@ struct DevTmp {
 };
 
 }  // namespace
+
+void kmdb_release_staging(kmdb_db* db) {
+    if (db->staging.empty()) return;
+    std::vector<std::pair<void*, size_t>> regions;
+    regions.swap(db->staging);
+    std::thread([regions]() {
+        const size_t step = (size_t)32 << 20;
+        for (const auto& r : regions)
+            for (size_t o = 0; o < r.second; o += step) (void)munmap((char*)r.first + o, std::min(step, r.second - o));
+    }).detach();
+}
 
 int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count) {
     const uint64_t P = v->n_patterns, N = v->n_samples;
@@ -340,17 +365,21 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     }
     HIP_TRY(hipStreamSynchronize(st));
     phase("H2D");
-    h_parent.reset(); h_ll.reset(); h_n.reset(); h_nbits.reset(); h_w.reset(); h_bits.reset();
+    for (HostRegion r : {h_parent.release(), h_ll.release(), h_n.release(), h_nbits.release(), h_w.release(), h_bits.release()})
+        if (r.p) db->staging.emplace_back(r.p, r.bytes);
 
     // ---- device: DFS pre-order
     DevTmp<uint32_t> cnt, cstart, size, keys, vals, skeys, schild, ssz, S, acc[2], dep[2], order, flags;
     DevTmp<int32_t> anc[2];
     if (cnt.alloc(P + 2) || cstart.alloc(P + 2) || size.alloc(P) || flags.alloc(4)) return 1;
+    phase("  first device temporaries");
     HIP_TRY(hipMemsetAsync(cnt.p, 0, (P + 2) * 4, st));
     HIP_TRY(hipMemsetAsync(cstart.p, 0, (P + 2) * 4, st));
     HIP_TRY(hipMemsetAsync(flags.p, 0, 16, st));
     // children grouped by parent, pid order inside a family
     if (keys.alloc(P) || vals.alloc(P) || skeys.alloc(P) || schild.alloc(P)) return 1;
+    HIP_TRY(hipStreamSynchronize(st));
+    phase("  temporaries (hipMalloc)");
     hipLaunchKernelGGL(lay_keys_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, keys.p, vals.p);
     {
         int end_bit = 1;
@@ -359,8 +388,11 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
+        HIP_TRY(hipStreamSynchronize(st));
+        phase("  keys + sort temporaries");
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
         HIP_TRY(hipStreamSynchronize(st));
+        phase("  radix sort");
     }
     keys.reset(); vals.reset();
     hipLaunchKernelGGL(lay_child_runs_kernel, dim3(G), dim3(B), 0, st, skeys.p, (uint32_t)P, cstart.p, cnt.p);
@@ -491,10 +523,12 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     db->max_n = hs.max_n; db->max_depth = hs.max_depth;
     db->chain_ok = hs.max_depth <= (uint32_t)KMDB_CHAIN_MAX;
     db->chain_cap = std::min<uint32_t>(KMDB_CHAIN_MAX, std::max<uint32_t>(8, (hs.max_depth + 7) / 8 * 8));
-    // one wave per slice, and every wave keeps its own open record chunks: about 8192 slices (two waves per SIMD
-    // on the whole chip), never shorter than 2048 nodes
-    db->nseg_nodes = (uint32_t)std::max<uint64_t>(2048, ((P + 8191) / 8192 + 63) / 64 * 64);
-    if (const char* e = getenv("KMDB_NSEG")) db->nseg_nodes = (uint32_t)std::max<uint64_t>(64, strtoull(e, nullptr, 10) / 64 * 64);
+    // one wave per slice of 2048 nodes.  (Round 1 used about 8192 slices in all, 12 544 nodes each at the benchmark database,
+    // because every wave left its open record chunks half empty; since only the first block's diagonal records go through
+    // stream chunks that costs little — measured: narrow kernel 1.83 -> 1.37 ms, chunks 186 k -> 208 k, whole call -0.3 ms;
+    // 1024 nodes: no faster, more chunks.)
+    db->nseg_nodes = 2048;
+    if (const char* e = getenv("KMDB_NSEG")) if (*e) db->nseg_nodes = (uint32_t)std::max<uint64_t>(64, strtoull(e, nullptr, 10) / 64 * 64);
     db->n_nsegs = (uint32_t)((P + db->nseg_nodes - 1) / db->nseg_nodes);
     HIP_TRY(hipMalloc((void**)&db->nseg_anc, std::max<size_t>((size_t)db->n_nsegs * db->chain_cap, 1) * 4));
     HIP_TRY(hipMalloc((void**)&db->nseg_anc_n, std::max<size_t>(db->n_nsegs, 1) * 4));
