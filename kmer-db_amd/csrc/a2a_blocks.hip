@@ -682,7 +682,7 @@ struct GParams {
     PoolView pool;
 };
 constexpr int K1G_WAVES = 2;
-constexpr uint32_t K1G_ROW = 12;           // entries of a lane's row (lists with more blocks take the climbing path)
+constexpr uint32_t K1G_ROW = 8;            // entries of a lane's row (lists with more blocks take the climbing path); 12 cost a third of the occupancy
 constexpr uint32_t K1G_ENT = 64 * K1G_ROW; // the rows double as the entry pool of the climbing path
 constexpr uint32_t K1G_CH = 16;            // chain slots (by depth mod 16)
 constexpr uint32_t K1G_QCAP = 128;         // record descriptors queued per round
@@ -1577,7 +1577,7 @@ PoolView pool_view(const kmdb_db* db, bool dense) {
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 #define FREE_NULL(x) free_and_null((void**)&(x))
 
-constexpr uint32_t K1G_MAX_WAVES = 4096;
+constexpr uint32_t K1G_MAX_WAVES = 8192;
 struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
 struct ValidKey { uint32_t n_states, kmask; __host__ __device__ uint32_t operator()(uint32_t k) const { return (k & kmask) < n_states ? 1u : 0u; } };
 
