@@ -686,7 +686,7 @@ constexpr uint32_t K1G_ROW = 8;            // entries of a lane's row (lists wit
 constexpr uint32_t K1G_ENT = 64 * K1G_ROW; // the rows double as the entry pool of the climbing path
 constexpr uint32_t K1G_CH = 16;            // chain slots (by depth mod 16)
 constexpr uint32_t K1G_QCAP = 128;         // record descriptors queued per round
-constexpr uint32_t K1G_RUN = 8;            // consecutive batches per run of a wave
+constexpr uint32_t K1G_RUN = 4;            // consecutive batches per run of a wave
 struct K1GWave {
     unsigned long long ent_mask[K1G_ENT];
     unsigned long long ch_mask[K1G_CH * K1G_ROW];
