@@ -103,7 +103,8 @@ struct WaveArena {
     uint32_t dopen;
 };
 constexpr uint32_t ARENA_GRAB = 4;         // stream chunks (256 records) per grab
-constexpr uint32_t WIDE_GRAB = 16;         // wide-pool chunks (64 records) per grab
+constexpr uint32_t WIDE_GRAB = 4;          // wide-pool chunks (64 records) per grab: every wave leaves an unfinished grab behind, and the
+                                           // sort reads all slots up to the busiest sub-pool's cursor (16 -> 4: -0.35 ms at the benchmark database)
 __host__ __device__ inline uint32_t arena_table_bits(uint32_t n_states) {
     uint32_t b = 4;
     while (b < ST_MAX_BITS && (1u << b) < n_states) ++b;
@@ -1176,11 +1177,11 @@ __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t
     __syncthreads();
 }
 
-constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup (8192 records)
+constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup at most; the launch picks 16 (few streams: measured better) or 32
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
                                                        const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
                                                        const uint32_t* __restrict__ chunk_fill, uint32_t n_states, uint32_t pool_cap,
-                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, uint32_t win) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
@@ -1189,8 +1190,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     __shared__ uint32_t s_key[K2_WIN], s_id[K2_WIN], s_fill[K2_WIN];
     __shared__ uint32_t wor_sh;
     // the window: K2_WIN chunks of the stream-sorted chunk table (never-opened chunks sort last)
-    if (threadIdx.x < K2_WIN) {
-        const uint32_t j = blockIdx.x * K2_WIN + threadIdx.x;
+    if (threadIdx.x < win) {
+        const uint32_t j = blockIdx.x * win + threadIdx.x;
         const uint32_t key = j < pool_cap ? sorted_key[j] : n_states;
         const uint32_t id = key < n_states ? sorted_id[j] : 0u;
         s_key[threadIdx.x] = key; s_id[threadIdx.x] = id; s_fill[threadIdx.x] = key < n_states ? chunk_fill[id] : 0u;
@@ -1204,11 +1205,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
     __syncthreads();
     uint32_t a = 0;
-    while (a < K2_WIN && s_key[a] < n_states) {
+    while (a < win && s_key[a] < n_states) {
         // one run of the window = the chunks of one stream
         const uint32_t key = s_key[a];
         uint32_t b = a + 1;
-        while (b < K2_WIN && s_key[b] == key) ++b;
+        while (b < win && s_key[b] == key) ++b;
         K2Item it;
         {
             const uint32_t bucket = key;
@@ -1246,6 +1247,7 @@ __global__ void count_raw_kernel(const uint32_t* __restrict__ wsub_cursor, uint3
 // More than CS_MAX_ROWS block rows (25 600 samples at width 50): rocprim's radix sort — a tile of 1024 records then holds about one
 // record per bin of its row, the staged passes stop writing bursts (measured at 782 rows: 27.7 ms against 22.6 with rocprim).
 constexpr uint32_t CS_MAX_KEYS = 2048, CS_BLOCKS = 2048, CS_MAX_ROWS = 512;
+constexpr uint32_t CS_BLOCKS_ONE = 3072;   // workgroups of the one-pass sort (two full rounds on the chip measured better than 2048; the two-pass sort keeps 2048)
 // block row X of stream s = tri32(X) + Y
 __device__ __forceinline__ uint32_t stream_row(uint32_t s) {
     uint32_t X = (uint32_t)((__fsqrt_rn(8.0f * (float)s + 1.0f) - 1.0f) * 0.5f);
@@ -1625,7 +1627,7 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
     if ((db->n_states <= CS_MAX_KEYS || db->NB <= CS_MAX_ROWS) && !db->cs_hist) {
         // one pass: [stream][workgroup]; two passes: [row][workgroup], then per row [stream of the row][chunk of the row]
-        const size_t ne = db->n_states <= CS_MAX_KEYS ? (size_t)db->n_states * CS_BLOCKS + 1 : (size_t)(2 * CS_BLOCKS + db->NB + 2) * db->NB + 1;
+        const size_t ne = db->n_states <= CS_MAX_KEYS ? (size_t)db->n_states * CS_BLOCKS_ONE + 1 : (size_t)(2 * CS_BLOCKS + db->NB + 2) * db->NB + 1;
         HIP_TRY(hipMalloc((void**)&db->cs_hist, ne * 4));
         HIP_TRY(hipMalloc((void**)&db->cs_offs, ne * 4));
         HIP_TRY(hipMalloc((void**)&db->cs_rows, (size_t)3 * (db->NB + 1) * 4));
@@ -1737,17 +1739,17 @@ int kmdb_rect_sort_apply(hipStream_t st, uint32_t* wkey, void* wrec, uint32_t ns
     RS_TRY(hipMalloc((void**)&swrec, (size_t)nslots * sizeof(WideRec)));
     const uint32_t* total_ptr = nullptr;
     if (n_states <= CS_MAX_KEYS) {
-        const size_t ne = (size_t)n_states * CS_BLOCKS + 1;
+        const size_t ne = (size_t)n_states * CS_BLOCKS_ONE + 1;
         size_t tb = 0;
         RS_TRY(hipMalloc((void**)&hist, ne * 4));
         RS_TRY(hipMalloc((void**)&offs, ne * 4));
         RS_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hist, offs, (int)ne, st));
         RS_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
         const CsRows no_rows{};
-        hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), n_states * 4, st, wkey, nslots, n_states, n_states, (int)CS_BY_STREAM, no_rows, kmask, hist);
+        hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS_ONE), dim3(256), n_states * 4, st, wkey, nslots, n_states, n_states, (int)CS_BY_STREAM, no_rows, kmask, hist);
         RS_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, hist, offs, (int)ne, st));
         RS_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(n_states)));
-        hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(n_states), st, wkey, (const WideRec*)wrec, nslots, n_states, n_states,
+        hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(n_states), st, wkey, (const WideRec*)wrec, nslots, n_states, n_states,
                            (int)CS_BY_STREAM, no_rows, kmask, offs, swkey, swrec);
         total_ptr = offs + (ne - 1);
     } else {
@@ -1962,11 +1964,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
     }
     {
-        uint32_t grid = (pool_cap + K2_WIN - 1) / K2_WIN;
-        if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + K2_WIN - 1) / K2_WIN);
+        const uint32_t win = db->n_states <= CS_MAX_KEYS ? K2_WIN / 2 : K2_WIN;
+        uint32_t grid = (pool_cap + win - 1) / win;
+        if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + win - 1) / win);
         if (grid)
             hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, s2, db->rec, db->recw, db->sorted_key, db->sorted_id, db->chunk_fill, db->n_states,
-                               pool_cap, M, (uint32_t)db->N, db->width);
+                               pool_cap, M, (uint32_t)db->N, db->width, win);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(db->ev_side[1], s2));
@@ -2052,13 +2055,13 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                                        db->n_states, NB, (int)CS_IN_ROW, rows, kmask, db->cs_offs, db->wkey, (WideRec*)db->wrec);
                     sorted_key = db->wkey; sorted_rec = (const WideRec*)db->wrec;
                 } else {
-                    ne = (size_t)db->n_states * CS_BLOCKS + 1;
-                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, db->n_states, (int)CS_BY_STREAM,
+                    ne = (size_t)db->n_states * CS_BLOCKS_ONE + 1;
+                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS_ONE), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, db->n_states, (int)CS_BY_STREAM,
                                        no_rows, kmask, db->cs_hist);
                     size_t tb = db->cs_tmp_bytes;
                     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
                     HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
-                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
                                        db->n_states, db->n_states, (int)CS_BY_STREAM, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
                 }
                 total_ptr = db->cs_offs + (ne - 1);
