@@ -67,13 +67,32 @@ def build_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, 
     return arr, names, pat["sample_counts"], int(pat["dictionary"].numel()), items
 
 
+def release_generator_memory(rank):
+    """The synthetic generator is done: its cached VRAM goes back to the driver, and the driver gets a moment before the timed
+    upload starts.  Twice in about 27 first-in-process uploads on this pool kmdb_db_upload took 5.8 s instead of 0.45 s right after
+    torch.cuda.empty_cache() had handed back the generator's memory (a constant 5.4 s extra, phase unknown: the breakdown was
+    not being printed) — apparently the driver's clean-up of freed VRAM, which is the generator's cost, not the upload's.
+    (Keeping torch's cache instead made every phase of the upload that allocates 2-10 x slower: 1.27 s.)"""
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    time.sleep(3.0)
+    free, total = torch.cuda.mem_get_info()
+    log("[rank %d] device memory before the upload: %.0f of %.0f GB free" % (rank, free / 1e9, total / 1e9))
+
+
 def upload(K, arr, n_samples, k, device_index, items=None, prefix_shard=None):
     view = K.make_view(k, n_samples, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
                        arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"],
                        bucket_offset=None if items is None else items[0], slots=None if items is None else items[1])
+    had = os.environ.get("KMDB_VERBOSE")
+    os.environ["KMDB_VERBOSE"] = "1"                      # the phases of the upload go to stderr (a slow one shows where)
     t0 = time.perf_counter()
     d = K.DeviceDB(view, device=device_index, prefix_shard=prefix_shard)
-    return d, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if had is None:
+        os.environ.pop("KMDB_VERBOSE", None)
+    return d, dt
 
 
 def cpu_baseline(K, S, O, args, device, arr, names, counts, nk, gpu_matrix):
@@ -399,12 +418,12 @@ def main():
         # every rank derives the same database and keeps its prefix shard of it
         arr, names, counts, nk, items = build_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device, rank, 1,
                                                  progress=100 if rank == 0 else None, with_items=True)
-        torch.cuda.empty_cache()
+        release_generator_memory(rank)
         db, upload_s = upload(K, arr, args.samples, args.k, dev_index, items=items, prefix_shard=(rank, world))
     else:
         arr, names, counts, nk, items = build_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device, rank, world,
                                                  progress=100 if rank == 0 else None)
-        torch.cuda.empty_cache()
+        release_generator_memory(rank)
         db, upload_s = upload(K, arr, args.samples, args.k, dev_index)
     st0 = db.stats()
     log("[rank %d] upload %.2f s; block width %d" % (rank, upload_s, st0["width"]))
