@@ -230,3 +230,45 @@ def test_cli_distance_errors(golden_dir, tmp_path):
                  ["distance", "mash", str(tmp_path / "missing"), str(tmp_path / "o")]):
         r = subprocess.run([exe] + argv, capture_output=True, text=True)
         assert r.returncode != 0 and ("ERROR" in r.stderr or "USAGE" in r.stderr)
+
+
+def test_metrics_match_the_reference_formulas(K):
+    """kmdbh_metric / kmdbh_metric_id (params.cpp:14-42): names, uint32 wrap-around integer parts, libm log."""
+    import math
+    L = K.capi.lib()
+    names = K.capi.METRICS
+    assert [L.kmdbh_metric_id(n.encode()) for n in names] == list(range(len(names))) and L.kmdbh_metric_id(b"nosuch") == -1
+    rng = np.random.default_rng(3)
+    u32 = lambda x: x & 0xFFFFFFFF        # noqa: E731
+
+    def mash(j, k):
+        return 1.0 if j == 0 else (-1.0 / k) * math.log((2 * j) / (j + 1))
+    for _ in range(300):
+        a, b = int(rng.integers(1, 1 << 22)), int(rng.integers(1, 1 << 22))
+        c = int(rng.integers(1, min(a, b) + 1))
+        k = int(rng.integers(10, 31))
+        want = {"jaccard": c / u32(a + b - c), "min": c / min(a, b), "max": c / max(a, b), "cosine": c / math.sqrt(u32(a * b)),
+                "mash": mash(c / u32(a + b - c), k), "ani": 1.0 - mash(c / u32(a + b - c), k), "ani-shorter": 1.0 - mash(c / min(a, b), k),
+                "mash-query": mash(c / a, k), "num-kmers": float(c)}
+        for i, n in enumerate(names):
+            assert L.kmdbh_metric(i, c, a, b, k) == want[n], (n, c, a, b, k)
+    # products that wrap in uint32, as in the reference's num_kmers_t arithmetic
+    assert L.kmdbh_metric(names.index("cosine"), 5, 70000, 70000, 18) == 5 / math.sqrt(u32(70000 * 70000))
+
+
+def test_filtered_sparse_call_validates_its_arguments(K):
+    """kmdb_all2all_sparse_filtered rejects bad filter lists before it touches a device."""
+    import ctypes as C
+    L = K.capi.lib()
+    F = K.capi._CellFilter
+    raw = K.capi._Sparse()
+    cnt = np.ones(4, np.uint32)
+    one = (F * 1)(); one[0].metric = 0; one[0].lo = 0.0; one[0].hi = 1.0
+    bad = (F * 1)(); bad[0].metric = 99
+    nine = (F * 9)()
+    cases = [((None, 1, cnt.ctypes.data, -1), "null argument"), ((one, 1, None, -1), "null argument"), ((None, 0, None, 3), "null argument"),
+             ((one, 1, cnt.ctypes.data, 99), "unknown measure"), ((nine, 9, cnt.ctypes.data, -1), "more than 8"),
+             ((bad, 1, cnt.ctypes.data, -1), "unknown metric")]
+    for (fl, n, counts, measure), msg in cases:
+        rc = L.kmdb_all2all_sparse_filtered(None, fl, n, counts, measure, C.byref(raw), None)
+        assert rc != 0 and msg in L.kmdb_last_error().decode(), (msg, L.kmdb_last_error())
