@@ -117,9 +117,9 @@ struct N2Cursor {                                                 // gamma strea
 // (a few nodes near the root carry thousands of ids) go to a queue in LDS and are decoded afterwards by ALL threads of the
 // workgroup in pieces of KMDB_CK_IDS ids, each piece starting from a checkpoint of the list index (engine_state.h) —
 // measured before that: 8 % of the lanes active, the others waiting for a neighbour's long list.
-constexpr uint32_t N2_QCAP = 512;
+constexpr uint32_t N2_QCAP = 1024, N2_THREADS = 512;      // 512 threads share one per-query histogram: twice the waves per byte of LDS
 template <bool LDS_HIST>
-__global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long* __restrict__ uniq, const uint32_t* __restrict__ csum,
+__global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned long long* __restrict__ uniq, const uint32_t* __restrict__ csum,
                                                        const uint32_t* __restrict__ qstart, uint32_t nruns, uint32_t nq,
                                                        const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
                                                        const int32_t* __restrict__ parent, const uint32_t* __restrict__ sub_end,
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long*
                                                        const uint64_t* __restrict__ ck_bit, const uint32_t* __restrict__ ck_id, uint32_t N,
                                                        uint32_t* __restrict__ sim) {
     extern __shared__ uint32_t hist[];
-    __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[256];
+    __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[N2_THREADS];
     __shared__ uint32_t q_n;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < nruns && uniq[i] != N2_INVALID;
@@ -189,12 +189,12 @@ __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long*
         // ---- the queued long lists, KMDB_CK_IDS ids per thread and step
         const uint32_t nt = q_n < N2_QCAP ? q_n : N2_QCAP;
         if (nt) {
-            constexpr uint32_t PER = N2_QCAP / 256;
+            constexpr uint32_t PER = N2_QCAP / N2_THREADS;
             uint32_t sum = 0;
             for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) sum += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS;
             part[threadIdx.x] = sum;
             __syncthreads();
-            for (uint32_t d = 1; d < 256; d <<= 1) {
+            for (uint32_t d = 1; d < N2_THREADS; d <<= 1) {
                 const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
                 __syncthreads();
                 part[threadIdx.x] += v;
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(256) void n2a_walk_kernel(const unsigned long long*
             }
             uint32_t run = part[threadIdx.x] - sum;
             for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) { q_pre[t] = run; run += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS; }
-            if (threadIdx.x == 255) q_pre[nt] = part[255];
+            if (threadIdx.x == N2_THREADS - 1u) q_pre[nt] = part[N2_THREADS - 1u];
             __syncthreads();
             const uint32_t S = q_pre[nt];
-            for (uint32_t g = threadIdx.x; g < S; g += 256) {
+            for (uint32_t g = threadIdx.x; g < S; g += N2_THREADS) {
                 uint32_t lo = 0, hi = nt;                       // the task whose pieces contain g: last t with q_pre[t] <= g
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (q_pre[mid] <= g) lo = mid; else hi = mid; }
                 const uint32_t piece = g - q_pre[lo], r = q_node[lo], H = q_h[lo], l = q_l[lo];
@@ -287,13 +287,13 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
         hipLaunchKernelGGL(n2a_query_ranges_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st,
                            d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
         if (nruns) {
-            const unsigned wblocks = (nruns + 255) / 256;
-            if (N * 4 + 12 * 1024 <= 64 * 1024)                     // the per-query histogram next to the kernel's 10 KB of static LDS
-                hipLaunchKernelGGL(n2a_walk_kernel<true>, dim3(wblocks), dim3(256), N * 4, st, d_uniq.as<unsigned long long>(),
+            const unsigned wblocks = (nruns + N2_THREADS - 1) / N2_THREADS;
+            if (N * 4 + 20 * 1024 <= 64 * 1024)                     // the per-query histogram next to the kernel's 19 KB of static LDS
+                hipLaunchKernelGGL(n2a_walk_kernel<true>, dim3(wblocks), dim3(N2_THREADS), N * 4, st, d_uniq.as<unsigned long long>(),
                                    d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent,
                                    e.sub_end, e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>());
             else
-                hipLaunchKernelGGL(n2a_walk_kernel<false>, dim3(wblocks), dim3(256), 0, st, d_uniq.as<unsigned long long>(),
+                hipLaunchKernelGGL(n2a_walk_kernel<false>, dim3(wblocks), dim3(N2_THREADS), 0, st, d_uniq.as<unsigned long long>(),
                                    d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent,
                                    e.sub_end, e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>());
         }
