@@ -1,4 +1,4 @@
-// a2a_blocks.hip — the block-record pipeline of the dense all2all path (any N up to 65535).
+// a2a_blocks.hip — the block-record pipeline of the dense all2all path (up to about 185 000 samples: 2^22 block pairs).
 //
 // Replaces SimilarityCalculator::all2all (reference src/similarity_calculator.cpp:42-438, inner loop row_add
 // src/simd/row_add_avx2.cpp:30-124) with a design for gfx950.  The N x N matrix is cut into blocks (X, Y), X >= Y,
@@ -9,26 +9,29 @@
 // Flat form (all2all_sp semantics, reference similarity_calculator.cpp:596-638): every pattern with w > 0 adds its
 // on-disk w to all pairs of its FULL list, i.e. one record per pair of blocks X >= Y the full list touches.
 //
-// Everything that depends on a decoded sample id happens inside the call (kmdb_blocks_run), on one stream:
-//   K0  k0_decode_kernel   gamma streams -> the LOCAL ids of every node as (block, 64-bit mask) pairs   (thread per node)
-//   K1n k1n_kernel         walks the DFS stream, 64 nodes per wave step, one lane each.  A full list is the union of
-//                          the local lists on the root path and ids ascend along it, so the list of a node with at most
-//                          TWO blocks is two registers; in-batch parents by pointer doubling across lanes, earlier ones
-//                          from a chain table in LDS (one slot per depth).  Emits the records of those nodes, leaves
-//                          (blocks, masks) of the ones with children in HBM, and flags the nodes with more blocks.
-//       wide list          the flagged nodes, compacted (popcount + scan + expand)
-//   K1g k1g_kernel         one lane per wide node: climbs to the nearest ancestor with at most two blocks, collecting
-//                          the (block, mask) pairs on the way into a per-wave entry pool in LDS; records of the batch are
-//                          numbered by a prefix sum and emitted one per lane from a descriptor queue.
-//   K2  k2_apply_kernel    one workgroup per record chunk: 64 records per wave step as bit matrices, int8 MFMA
-//                          accumulate into a 64 x 64 LDS tile (popcount passes per bit plane for weights >= 128),
-//                          one HBM atomic per non-zero cell.
-// Records are grouped by (block pair, weight class) = "stream" WITHOUT a counting pass and WITHOUT global atomics
-// (same-address device atomics run at a few million per second on this part: measured, profiles/README.md): every
-// emitting wave owns an arena of 64-record chunks (chunk ids w, w + W, w + 2W, ...) and keeps up to 64 open chunks, one
-// per stream, in registers (lane e holds entry e: stream, next slot, end of chunk); a group of lanes reserves its slots
-// with a ballot look-up.  After the emit kernels the chunk table (stream of every chunk) is radix-sorted, and K2 walks
-// windows of 128 sorted chunks: all records of a stream meet in one 64 x 64 LDS tile per window.
+// Everything that depends on a decoded sample id happens inside the call (kmdb_blocks_run):
+//   K0  k0_decode_kernel x2  gamma streams -> the LOCAL ids of every node as (block, 64-bit mask) pairs (thread per node; the
+//                            nodes with long streams in a second launch, most work first)
+//   K1n k1n_kernel           walks the DFS stream in slices of 2048 nodes, 64 nodes per wave step, one lane each.  A full list is
+//                            the union of the local lists on the root path and ids ascend along it, so the list of a node with
+//                            at most TWO blocks is a summary of five registers; in-batch parents by pointer doubling across
+//                            lanes, earlier ones from a chain table in LDS (one slot per depth).  Emits the records of those
+//                            nodes (first-block diagonal records into per-block stream chunks, the others into the wide pool),
+//                            flags the nodes with more blocks and leaves them their parent's summary.
+//       wide list            the flagged nodes, compacted (popcount + scan + expand)
+//   K1g k1g_kernel           one lane per wide node: list = parent's list (row in LDS, chain table, or a climb) + own pairs;
+//                            the records of a batch are numbered by a prefix sum and emitted one per lane from a descriptor
+//                            queue into the wide pool, in arrival order; heavy nodes by the whole wave.
+//   sort cs_hist / cs_scatter  the wide pool (16-byte records + a key word: stream | weight digit) grouped by stream: counting
+//                            sort with per-workgroup LDS histograms and staged tiles, one pass (<= 2048 streams) or two
+//                            (by block row, then inside the rows); rocprim radix sort beyond 512 block rows.
+//   K2  k2_apply_kernel      stream chunks (side stream, next to K1g), k2_sorted_kernel: the sorted wide pool.  64 records per
+//                            wave step as bit matrices, int8 MFMA into a 64 x 64 LDS tile (weights >= 128 as base-128 digit
+//                            passes), one HBM atomic per non-zero cell.
+// Records are placed WITHOUT a counting pass and WITHOUT hot global atomics (same-address device atomics run at a few million
+// per second on this part: measured, profiles/README.md): waves take chunks from 256 sub-pool cursors a few at a time, keep
+// their open stream chunks in an LDS table indexed by block, and reserve slots for a group of lanes with a ballot.  The pools are
+// sized from a sampled estimate; a pool that turns out too small is enlarged and the call repeated.
 #include "device_common.h"
 #include "engine_internal.h"
 
@@ -2013,7 +2016,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     HIP_TRY(hipEventRecord(db->ev_k[2], st));
     hipLaunchKernelGGL(count_raw_kernel, dim3(1), dim3(1), 0, st, db->wsub_cursor, db->counters);
     {
-        // the wide pool: records sorted by stream (the sort moves the 24-byte records with their keys), one tile per run
+        // the wide pool: records sorted by stream (the sort moves the 16-byte records with their key words), one tile per run
         uint32_t n_raw;
         if (db->have_counts) n_raw = db->last_n_raw;
         else {

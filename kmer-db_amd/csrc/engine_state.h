@@ -96,7 +96,7 @@ struct kmdb_db {
     // per-stream chunks do not work out)
     bool dense_wide = false, dense_narrow = false;
     uint32_t *wkey = nullptr, *swkey = nullptr;     // wide pool: stream of every record slot (0xFFFFFFFF = never written), and sorted
-    void *wrec = nullptr, *swrec = nullptr;         // wide pool: 24-byte records {rows, cols, w}, and sorted by stream
+    void *wrec = nullptr, *swrec = nullptr;         // wide pool: 16-byte records {rows, cols} (weight digit in the key word), and sorted by stream
     uint64_t wide_pool_cap = 0;     // chunks of 64 records
     uint32_t* wsub_cursor = nullptr;
     uint32_t* cs_rows = nullptr;                       // two-pass sort: row starts / first workgroup / first table entry, [3][NB + 1]
