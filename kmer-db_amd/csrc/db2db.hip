@@ -8,9 +8,11 @@
 //            table of the same prefix (murmur3 fmix32 probe, src/hashmap_lp.h:53-64,308-333);
 //            key = DFS index of the row pattern << 32 | DFS index of the column pattern, or ~0
 //   count    radix sort + run-length encode of the keys: (pattern pair, number of shared k-mers)
-//   scatter  one wave per pattern pair: the full sample lists of both patterns are decoded into LDS (every node of
-//            a root path writes its local ids at positions [n - l, n) of the list — no ordering between the lanes
-//            that decode different nodes), then out[row sample][column sample] += count over the cross product.
+//   emit     one wave per pattern pair: the full sample lists of both patterns as bit sets over blocks of 64 ids in LDS
+//            (lane d decodes the d-th node of the root path and ORs its local ids in), one BLOCK RECORD (row block,
+//            column block, row mask, column mask, count) per pair of non-empty blocks into a pool, in arrival order
+//   apply    kmdb_rect_sort_apply (a2a_blocks.hip): the all2all pipeline's counting sort by block pair and its matrix-core
+//            accumulation kernel, writing the dense rows x columns matrix.
 #include "kmdb_amd.h"
 #include "kmdb_internal.h"
 #include "engine_internal.h"

@@ -17,9 +17,11 @@
 //           Every node with H(r) > 0 is an ancestor-or-self of its first hit h_i and is larger than
 //           the previous hit h_{i-1}; so thread i climbs from h_i through the parent links while the
 //           node index stays above h_{i-1}: every such node is visited exactly once per query,
-//           decodes only its own gamma stream, gets H(r) from two reads of the scanned counts (one
-//           binary search over the query's sorted hits), and adds it to its local ids in an LDS
-//           histogram of the workgroup, flushed with one global atomic per touched sample.
+//           gets H(r) from two reads of the scanned counts (a doubling search from the previous
+//           subtree end over the query's sorted hits), and adds it to its local ids in an LDS
+//           histogram of the workgroup, flushed with one global atomic per touched sample.  A local
+//           list of up to 32 ids is decoded by the visiting thread, a longer one by the whole workgroup
+//           in pieces of 32 ids from the list index (checkpoints built with the node arrays).
 #include "kmdb_amd.h"
 #include "kmdb_internal.h"
 #include "engine_internal.h"
