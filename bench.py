@@ -51,6 +51,33 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def sources_sha16():
+    """hash of the engine's sources (kmer-db_amd/csrc): PMC traffic measured by profiles/collect_counters.sh is stamped with it
+    and only replayed into a bench line when the code is still the same (the GPU box has no .git to ask for a commit)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kmer-db_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode())
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def replayed_traffic(workload):
+    """(bytes per call, source text) from profiles/latest_traffic[_<workload>].json if it was measured on THIS code, else (None, why)"""
+    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json" if workload == "c2" else "latest_traffic_%s.json" % workload)
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as f:
+        tj = json.load(f)
+    if tj.get("sources_sha16") != sources_sha16():
+        return None, "profiles/%s was measured on other sources (%s, this code is %s): not replayed" % (os.path.basename(tpath), tj.get("sources_sha16"), sources_sha16())
+    return tj["traffic_bytes_per_pass"], "REPLAYED from profiles/%s (measured on these sources, sha16 %s, not in this run): %s" % (
+        os.path.basename(tpath), tj["sources_sha16"], tj["source"])
+
+
 def build_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, progress=None, with_items=False):
     """patterns of the k-mers whose prefix bucket is owned by `rank` (world == 1: all of them)"""
     g = S.CladeGenomes(n_samples, clade_size, length, seed=seed, device=device)
@@ -146,6 +173,66 @@ def cpu_baseline(K, S, O, args, device, arr, names, counts, nk, gpu_matrix):
                 "sample": "full %s database (%d patterns), reference SimilarityCalculator::all2all compute interval, -t %d -buffer %d "
                           "(best of a %d-point sweep on a 1/%d-length sample); the whole %d-cell GPU matrix compared equal"
                           % (args.workload, arr["num_kmers"].size, thr, buf, len(tried), max(1, args.length // L), m.size)}
+
+
+def extra_workload(K, S, args, device, name):
+    """The default run also times the 10 000-sample workload (BASELINE configs[2]'s sample count on one GPU) and embeds it in the one
+    JSON line: warm calls (HIP events around the whole call), the checksum identity, and — unless --no-cpu-baseline — the whole matrix
+    compared with the real reference's (oracle/_ref) on the same database written in the reference's format."""
+    wl = WORKLOADS[name]
+    dev_index = device.index or 0
+    arr, names, counts, nk, _ = build_db(K, S, wl["samples"], wl["clade_size"], wl["length"], args.k, args.seed, device, 0, 1)
+    release_generator_memory(0)
+    db, upload_s = upload(K, arr, wl["samples"], args.k, dev_index)
+    t0 = time.perf_counter()
+    first = db.all2all_dense()
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    st0 = db.stats()
+    cells = db.tri_size()
+    M = torch.zeros(max(cells, 1), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        db.all2all_dense_device(M.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    ms, parts = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        db.all2all_dense_device(M.data_ptr(), stream=stream)
+        _s = db.stats()
+        ms.append(_s["kernel_ms"])
+        parts.append((_s["k0_ms"], _s["k1n_ms"], _s["k1g_ms"], _s["k2_ms"]))
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    got = int(M[:cells].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+    assert got == int(st0["sum_pairs"]), "%s: matrix checksum mismatch" % name
+    assert np.array_equal(M[:cells].cpu().numpy().view(np.uint32), first), "%s: warm call differs from the first call" % name
+    stl = db.stats()
+    kern_ms = float(np.mean(ms))
+    pk = np.mean(np.array(parts), axis=0)
+    alg = st0["algorithmic_bytes"]
+    traffic, traffic_src = replayed_traffic(name)
+    out = {"workload": "%s: %d synthetic %g Mbp genomes (clades of %d), k=%d f=1.0, dense all2all" % (name, wl["samples"], wl["length"] / 1e6, wl["clade_size"], args.k),
+           "ms_per_step": wall_ms, "kernel_ms": kern_ms, "value": float(st0["sum_pairs"]) / (wall_ms * 1e-3), "unit": "kmer-pair-comparisons/s",
+           "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg},
+           "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3])},
+           "patterns": db.P, "records": stl["n_records"], "wide_nodes": stl["n_wide"], "record_chunks": stl["n_chunks"], "block_width": stl["width"],
+           "path": {1: "block-record pipeline", 2: "v1 tile kernel", 3: "v1 HBM-atomics kernel"}.get(stl["path"], "none"),
+           "upload_s": upload_s, "cold_call_ms": cold_ms, "checks": "sum of the matrix == sum_p w_p C(n_p, 2); warm == cold", "reference_match": None}
+    db.close()
+    del M
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        if O.have_ref():
+            with tempfile.TemporaryDirectory(dir=args.tmp) as td:
+                path = os.path.join(td, "full.db")
+                S.write_db_fast(path, args.k, 1.0, names, counts, arr, kmers_count=nk, device=device)
+                m, info = O.ref_all2all(path, os.path.join(td, "full.u32"), threads=min(os.cpu_count() or 1, 16), buffer_mb=8)
+                assert np.array_equal(m, first), "%s: GPU matrix differs from the reference's" % name
+                out["reference_match"] = True
+                out["reference_compute_s"] = info["seconds"]
+                out["checks"] += "; the whole %d-cell matrix == the real reference's (all2all, -t %d -buffer 8) on the same database" % (m.size, min(os.cpu_count() or 1, 16))
+    return out
 
 
 def measured_copy_gbs(device, gib=2):
@@ -338,6 +425,83 @@ def secondary_mode(args, K, S, device):
     print(json.dumps(out), flush=True)
 
 
+def sparse_multi(args, K, S, device, rank, world, dist, rccl):
+    """--mode all2all-sp --gpus N (BASELINE configs[3]): prefix-bucket shards, one per rank (weak scaling: genomes N x longer, rank r owns
+    the buckets congruent to r mod N); every step = dense accumulation of the rank's partial matrix on its GPU, one RCCL reduce-scatter
+    of the triangle in flat chunks (xGMI is point to point: every peer pair uses its own link), and the compaction of the rank's own
+    chunk into sparse rows (kmdb_sparse_from_dense_device).  The ranks' rows concatenate to the reference's all2all_sp output
+    (similarity_calculator.cpp:442-657, array.h:391-446); nothing but the sparse rows leaves the devices."""
+    dev_index = device.index or 0
+    N, cs, L, k, f = args.samples, args.clade_size, args.length * world, args.k, args.fraction
+    g = S.CladeGenomes(N, cs, L, seed=args.seed, device=device)
+    t0 = time.time()
+    pat = S.build_patterns(lambda i: S.kmers_of(g.sample(i), k, f, prefix_shard=(rank, world)), N, device, progress=None)
+    arr = S.to_view_arrays(pat)
+    log("[rank %d] synth shard: %d k-mers, %d patterns in %.1f s" % (rank, pat["dictionary"].numel(), arr["num_kmers"].size, time.time() - t0))
+    release_generator_memory(rank)
+    d, upload_s = upload(K, arr, N, k, dev_index)
+    cells = d.tri_size()
+    per = (cells + world - 1) // world
+    M = torch.zeros(per * world, dtype=torch.int32, device=device)          # the triangle, padded to equal chunks
+    mine = torch.zeros(max(per, 1), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    lo, hi = min(cells, rank * per), min(cells, (rank + 1) * per)
+
+    def step():
+        d.all2all_dense_device(M.data_ptr(), stream=stream)
+        dev_ms = d.stats()["kernel_ms"]
+        if args.backend == "nccl":
+            dist.reduce_scatter_tensor(mine, M, op=dist.ReduceOp.SUM)        # uint32 wrap-around sum == int32 sum bitwise
+        else:
+            torch.cuda.synchronize()
+            h = M.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            mine.copy_(h[rank * per: (rank + 1) * per])
+        sp = d.sparse_from_dense_device(mine.data_ptr(), lo, hi, stream=stream)
+        return sp, dev_ms + d.stats()["kernel_ms"]
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dev_ms = []
+    for _ in range(args.steps):
+        sp, ms = step()
+        dev_ms.append(ms)
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    cdev = device if args.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed, upload_s, float(np.mean(dev_ms))], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, upload_s, dev_mean = float(t[0]), float(t[1]), float(t[2])
+    st = d.stats()
+    tot = torch.tensor([float(st["sum_pairs"]), float(sp.nnz), float(sp.val.astype(np.uint64).sum()), float(pattern_bytes(arr))], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    sum_pairs, nnz, val_sum, bpat = (float(x) for x in tot)
+    # identity over the whole output: the ranks' non-zeros sum to sum over all shards of sum_p w_p C(n_p, 2)
+    assert val_sum == sum_pairs, "sharded sparse output checksum mismatch: %r vs %r" % (val_sum, sum_pairs)
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        alg = bpat + 8 * nnz
+        achieved = alg / (ms_per_step * 1e-3) / 1e9
+        out = {"metric": "all2all-sp k-mer pair-comparisons/sec", "value": sum_pairs / (elapsed / args.steps), "unit": "kmer-pair-comparisons/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u32", "data": "synthetic",
+               "config": {"workload": "%s: %d synthetic %g Mbp genomes (clades of %d), k=%d f=%g, all2all-sp, k-mer space sharded by prefix bucket over %d GPUs + "
+                                      "reduce-scatter of the partial matrices + per-rank compaction" % (args.workload, N, L / 1e6, cs, k, f, world),
+                          "samples": N, "genome_length_bp": L, "k": k, "fraction": f, "mode": "all2all-sp", "nnz": int(nnz), "patterns_rank0": int(d.P),
+                          "parallelism": "prefix-shard x%d" % world, "rccl": rccl, "collective": "reduce_scatter" if args.backend == "nccl" else "gloo all_reduce (functional test)"},
+               "wall": {"upload_s": upload_s, "device_ms_per_step_max_rank": dev_mean,
+                        "note": "ms_per_step: wall clock of one step on the slowest rank (dense accumulation + collective + compaction + D2H of the rank's sparse rows)"},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
+                            "kernel": "whole step on every rank", "kernel_ms": ms_per_step, "algorithmic_bytes_per_launch": alg}}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def respawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run"""
     port = 29500 + (os.getpid() % 2000)
@@ -367,6 +531,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample-length", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="default workload only: skip the 10 000-sample workload that rides along in the same JSON line")
     ap.add_argument("--tmp", default=None, help="directory for the reference's .db files (default: the system temp dir)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
@@ -406,6 +571,9 @@ def main():
     S = importlib.import_module("kmerdb_amd.synth")
 
     if args.mode != "all2all":
+        if world != 1 and args.mode == "all2all-sp":
+            sparse_multi(args, K, S, device, rank, world, dist, rccl)
+            return
         if world != 1:
             raise SystemExit("bench.py: --mode %s runs on one GPU" % args.mode)
         secondary_mode(args, K, S, device)
@@ -496,12 +664,8 @@ def main():
         # HBM bytes per call come from separate rocprofv3 --pmc runs of this same command (profiles/): they
         # cannot be collected from inside the timed process; quoted only for the default workload
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "c2" and args.length == 5_000_000 and args.samples == 1000:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("pipeline") == "r02":
-                traffic, traffic_src = tj["traffic_bytes_per_pass"], "REPLAYED from profiles/latest_traffic.json (not measured in this run): " + tj["source"]
+        if world == 1 and args.length == WORKLOADS[args.workload]["length"] and args.samples == WORKLOADS[args.workload]["samples"]:
+            traffic, traffic_src = replayed_traffic(args.workload)
         out = {
             "metric": "all2all k-mer pair-comparisons/sec",
             "value": sum_pairs / (elapsed / args.steps),
@@ -552,6 +716,12 @@ def main():
             cb = out["cpu_baseline"]
             if cb["kind"] == "reference":
                 out["wall"]["reference_compute_s"] = cb["seconds"]
+        if world == 1 and args.workload == "c2" and args.length == WORKLOADS["c2"]["length"] and args.samples == WORKLOADS["c2"]["samples"] and not args.no_extra:
+            # the 10 000-sample workload rides along in the same line (the configuration BASELINE's target is written for)
+            db.close()
+            del arr
+            torch.cuda.empty_cache()
+            out["extra"] = {"c3part": extra_workload(K, S, args, device, "c3part")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

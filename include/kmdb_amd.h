@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KMDB_ABI_VERSION 3
+#define KMDB_ABI_VERSION 4
 
 /* ---------------------------------------------------------------------------------------
  * Host-side view of a loaded database = what the reference hands to SimilarityCalculator:
@@ -181,6 +181,17 @@ void kmdb_sparse_free(kmdb_sparse_rows* rows);
  * arithmetic (incl. its libm log).  measure: KMDB_METRIC_* or -1. */
 int  kmdb_all2all_sparse_filtered(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers,
                                   int measure, kmdb_sparse_rows* out, const kmdb_opts* opts);
+/* Multi-GPU all2all-sp (BASELINE configs[3]; SURVEY 8e "reduce compacted tiles"): the compaction stage of the two calls above
+ * on cells the CALLER accumulated — typically the sum over prefix-bucket shards, after an RCCL reduce / reduce-scatter of the
+ * partial matrices of kmdb_all2all_dense_device.  cells_dev points at cell `cell_lo` of the lower triangle (row i at
+ * i (i - 1) / 2, array.h:136-140) and holds the flat range [cell_lo, cell_hi) — a rank's reduce-scatter chunk can be passed as
+ * it is; the whole triangle is {0, N (N - 1) / 2}.  out has all N rows; rows outside the range are empty and a row cut by a
+ * range end lists only its cells inside, so the ranks' outputs concatenate row by row (rank order = ascending columns) to
+ * exactly what SparseMatrix::compact2 + saveRowSparse produce (array.h:391-446, 625-637; console_all2all_sparse.cpp:44-96).
+ * Filters / measure as in kmdb_all2all_sparse_filtered (the cells are complete sums here, so prefix shards may use them). */
+int  kmdb_sparse_from_dense_device(kmdb_db* db, const void* cells_dev, uint64_t cell_lo, uint64_t cell_hi,
+                                   const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure,
+                                   kmdb_sparse_rows* out, const kmdb_opts* opts);
 /* the measure itself (params.cpp:14-42): uint32 wrap-around integer parts, double arithmetic */
 double kmdbh_metric(int metric, uint32_t common, uint32_t cnt_row, uint32_t cnt_col, int kmer_length);
 /* KMDB_METRIC_* of a criterion name ("jaccard", "min", ..., "num-kmers"), -1 if unknown */

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -68,7 +68,7 @@ PATH_NONE, PATH_RECORDS, PATH_TILE, PATH_GLOBAL = 0, 1, 2, 3
 # every symbol include/kmdb_amd.h declares
 EXPORTS = [
     "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_stats",
-    "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
+    "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdb_sparse_from_dense_device", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
     "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
     "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
     "kmdbh_db_start_fraction", "kmdbh_db_alphabet", "kmdbh_db_n_samples", "kmdbh_db_sample_name",
@@ -102,6 +102,8 @@ def lib():
     L.kmdb_all2all_dense_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_all2all_sparse.argtypes = [C.c_void_p, C.POINTER(_Sparse), C.POINTER(_Opts)]
     L.kmdb_all2all_sparse_filtered.argtypes = [C.c_void_p, C.POINTER(_CellFilter), C.c_size_t, C.c_void_p, C.c_int, C.POINTER(_Sparse), C.POINTER(_Opts)]
+    L.kmdb_sparse_from_dense_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(_CellFilter), C.c_size_t, C.c_void_p, C.c_int,
+                                                C.POINTER(_Sparse), C.POINTER(_Opts)]
     L.kmdbh_metric.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.kmdbh_metric.restype = C.c_double
     L.kmdbh_metric_id.argtypes = [C.c_char_p]
@@ -324,6 +326,25 @@ class DeviceDB:
         cnt = np.ascontiguousarray(sample_kmers, np.uint32)
         _check(lib().kmdb_all2all_sparse_filtered(self._d, fs, len(filters), cnt.ctypes.data, -1 if measure is None else METRICS.index(measure),
                                                   C.byref(raw), C.byref(o)))
+        try:
+            return SparseRows(raw)
+        finally:
+            lib().kmdb_sparse_free(C.byref(raw))
+
+    def sparse_from_dense_device(self, dev_ptr, cell_lo=0, cell_hi=None, filters=(), sample_kmers=None, measure=None, stream=None):
+        """Sparse rows of caller-accumulated cells [cell_lo, cell_hi) of the lower triangle, dev_ptr = device address of cell_lo
+        (kmdb_sparse_from_dense_device): the compaction stage of all2all-sp after a multi-GPU reduce of the partial matrices."""
+        raw = _Sparse()
+        o = _opts(self.device, stream=stream)
+        fs = (_CellFilter * max(1, len(filters)))()
+        for i, (name, lo, hi) in enumerate(filters):
+            fs[i].metric = METRICS.index(name)
+            fs[i].lo = -np.finfo(np.float64).max if lo is None else lo
+            fs[i].hi = np.finfo(np.float64).max if hi is None else hi
+        cnt = None if sample_kmers is None else np.ascontiguousarray(sample_kmers, np.uint32)
+        _check(lib().kmdb_sparse_from_dense_device(self._d, C.c_void_p(dev_ptr), int(cell_lo), self.tri_size() if cell_hi is None else int(cell_hi),
+                                                   fs, len(filters), None if cnt is None else cnt.ctypes.data,
+                                                   -1 if measure is None else METRICS.index(measure), C.byref(raw), C.byref(o)))
         try:
             return SparseRows(raw)
         finally:

@@ -661,17 +661,44 @@ __global__ void wide_expand_kernel(const unsigned long long* __restrict__ bits, 
 }
 
 // ------------------------------------------------------------------------------------------
-// K1g: nodes with more than two blocks
+// K1w: nodes with more than two blocks
 // ------------------------------------------------------------------------------------------
-struct GParams {
-    const uint32_t* widx;
+// Summary of a stretch of a root path as a list of (block, mask) entries: how many entries it has, its first and last block and
+// the mask of its last entry.  Ids ascend along a root path, so two stretches can only share the block at their seam; stretches
+// merge associatively (pointer doubling across lanes, scans along a path).
+constexpr uint32_t BLK_NONE = 0xFFFFu;
+struct LSum { unsigned long long lm; uint32_t c, fb, lb; };
+__device__ __forceinline__ LSum lsum_none() { return LSum{0ull, 0u, BLK_NONE, BLK_NONE}; }
+// A = the stretch closer to the root, B = the stretch below it
+__device__ __forceinline__ LSum lsum_merge(const LSum& A, const LSum& B) {
+    if (B.c == 0u) return A;
+    if (A.c == 0u) return B;
+    const bool seam = A.lb == B.fb;
+    return LSum{(B.c == 1u && seam) ? (A.lm | B.lm) : B.lm, A.c + B.c - (seam ? 1u : 0u), A.fb, B.lb};
+}
+__device__ __forceinline__ LSum lsum_shfl(const LSum& s, int src) {
+    return LSum{shfl64(s.lm, src), (uint32_t)__shfl((int)s.c, src, WAVE), (uint32_t)__shfl((int)s.fb, src, WAVE), (uint32_t)__shfl((int)s.lb, src, WAVE)};
+}
+__device__ __forceinline__ LSum lsum_shfl_up(const LSum& s, int d) {
+    return LSum{shfl_up64(s.lm, d), (uint32_t)__shfl_up((int)s.c, d, WAVE), (uint32_t)__shfl_up((int)s.fb, d, WAVE), (uint32_t)__shfl_up((int)s.lb, d, WAVE)};
+}
+// the (blocks, masks) the narrow kernel left for a wide node whose parent has at most two blocks
+__device__ __forceinline__ LSum lsum_of_fn(uint32_t fb, const ulonglong2& fm) {
+    const uint32_t b0 = fb & 0xFFFFu, b1 = fb >> 16;
+    if (b0 == BLK_NONE) return lsum_none();
+    if (b1 == BLK_NONE) return LSum{fm.x, 1u, b0, b0};
+    return LSum{fm.y, 2u, b0, b1};
+}
+
+struct WParams {
+    const uint32_t* widx;          // the wide nodes, DFS order
     uint32_t n_wide;
     const uint32_t* nl;
     const int32_t* parent;
     const uint32_t* w;
     const uint16_t* dflag;
     const unsigned long long* widebits;
-    const uint32_t* wide_base;     // wide nodes before every 64-node word of the DFS stream
+    const uint32_t* wide_base;     // [n_words + 1] wide nodes before every 64-node word of the DFS stream
     const unsigned long long* p0_mask;
     const uint32_t* p0_info;
     const uint32_t* pair_ofs;
@@ -679,79 +706,91 @@ struct GParams {
     const unsigned long long* pair_mask;
     const ulonglong2* fn_mask;
     const uint32_t* fn_blk;
+    const uint32_t* seg_anc;       // [n_runs][chain_cap] root path of the first node of every run's slice of the DFS stream, root first
+    const uint32_t* seg_anc_n;
+    uint32_t seg_words;            // 64-node words of the DFS stream per run
+    uint32_t n_words, n_runs, n_waves;
+    uint32_t chain_cap, arena_cap, e_cap;
     uint32_t emit_lo, emit_hi;
-    uint32_t run;                  // consecutive batches per run
-    uint32_t n_waves;              // waves of the launch, each with runs of consecutive batches of 64 wide nodes
-    uint32_t tbits, n_states;
     PoolView pool;
 };
-constexpr int K1G_WAVES = 2;
-constexpr uint32_t K1G_ROW = 8;            // entries of a lane's row (lists with more blocks take the climbing path); 12 cost a third of the occupancy
-constexpr uint32_t K1G_ENT = 64 * K1G_ROW; // the rows double as the entry pool of the climbing path
-constexpr uint32_t K1G_CH = 16;            // chain slots (by depth mod 16)
-constexpr uint32_t K1G_QCAP = 128;         // record descriptors queued per round
-constexpr uint32_t K1G_RUN = 4;            // consecutive batches per run of a wave
-struct K1GWave {
-    unsigned long long ent_mask[K1G_ENT];
-    unsigned long long ch_mask[K1G_CH * K1G_ROW];
-    uint32_t queue[K1G_QCAP];               // owner lane | a << 6 | b << 19
-    uint32_t st_w[64];
-    uint32_t ch_node[K1G_CH];
-    uint16_t ent_blk[K1G_ENT];
-    uint16_t ch_blk[K1G_CH * K1G_ROW];
-    uint16_t st_start[64];
-    uint16_t ch_len[K1G_CH];
-    unsigned long long co_mask[64];         // the list of the node the whole wave emits, contiguous (a lane's row is strided: one bank)
-    uint16_t co_blk[64];
+constexpr int K1W_WAVES = 2;
+constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
+constexpr uint32_t K1W_HEAVY = 11;         // a node with that many blocks (66 records and more) is emitted by the whole wave
+enum : uint32_t { WB_NONE = 0, WB_FN = 1, WB_LANE = 2, WB_CHAIN = 3 };
+// LDS of one wave, carved from the dynamic allocation (the sizes depend on the database: blocks, depth of the tree)
+struct K1WLds {
+    unsigned long long* ent_mask;  // [arena_cap] rows of the batch's nodes, one contiguous run of entries per lane
+    unsigned long long* e_mask;    // [e_cap] the chain list: the full list of the deepest node of the chain
+    unsigned long long* ch_last;   // [chain_cap] per depth: the mask of the node's last entry (the chain list may hold more ids there)
+    unsigned long long* own_m0;    // [64] first own pair of every lane's node
+    uint32_t* ch_node;             // [chain_cap] the wide node of that depth on the current root path (0xFFFFFFFF: none)
+    uint32_t* own_po;              // [64] further own pairs: first entry in the pair pool
+    uint32_t* own_node;            // [64]
+    uint32_t* st_w;                // [64]
+    uint32_t* queue;               // [K1W_QCAP] owner lane | a << 6 | b << 19
+    uint16_t* ent_blk;             // [arena_cap]
+    uint16_t* e_blk;               // [e_cap]
+    uint16_t* ch_len;              // [chain_cap] entries of the node's list = a prefix of the chain list
+    uint16_t* own_b0;              // [64]
+    uint16_t* own_np;              // [64]
+    uint16_t* own_link;            // [64] parent's lane (WB_LANE) or chain slot (WB_CHAIN)
+    uint16_t* st_start;            // [64] first arena entry of the lane's row
+    unsigned char* own_base;       // [64] WB_*
 };
+__host__ __device__ inline size_t k1w_wave_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
+    const size_t b = (size_t)8 * (arena_cap + e_cap + chain_cap + 64) + (size_t)4 * (chain_cap + 3 * 64 + K1W_QCAP) + (size_t)2 * (arena_cap + e_cap + chain_cap + 5 * 64) + 64;
+    return (b + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ K1WLds k1w_carve(unsigned char* p, uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
+    K1WLds L;
+    L.ent_mask = (unsigned long long*)p;  L.e_mask = L.ent_mask + arena_cap;  L.ch_last = L.e_mask + e_cap;  L.own_m0 = L.ch_last + chain_cap;
+    L.ch_node = (uint32_t*)(L.own_m0 + 64);  L.own_po = L.ch_node + chain_cap;  L.own_node = L.own_po + 64;  L.st_w = L.own_node + 64;  L.queue = L.st_w + 64;
+    L.ent_blk = (uint16_t*)(L.queue + K1W_QCAP);  L.e_blk = L.ent_blk + arena_cap;  L.ch_len = L.e_blk + e_cap;  L.own_b0 = L.ch_len + chain_cap;
+    L.own_np = L.own_b0 + 64;  L.own_link = L.own_np + 64;  L.st_start = L.own_link + 64;
+    L.own_base = (unsigned char*)(L.st_start + 64);
+    return L;
+}
 
-// One lane per wide node, batches of 64 consecutive nodes of the (DFS-ordered) wide list, a run of batches per wave.
+// One lane per wide node, batches of 64 consecutive nodes of the (DFS-ordered) wide list.  A run = the wide nodes of one slice of
+// the DFS stream; runs are dealt round-robin to the waves (the records per node differ by orders of magnitude — 3 blocks: 6
+// records, 200 blocks: 20 100 — and heavy nodes sit together in the DFS order).
 // A wide node's parent is wide as well or has at most two blocks.  Its list = the parent's list + its own pairs:
 //   parent with <= 2 blocks: the (blocks, masks) the narrow kernel left in HBM;
-//   wide parent inside the batch: that lane's row in LDS (lanes resolve in rounds, parents first);
-//   wide parent before the batch: the wave's chain table (the latest wide node of every depth, by depth mod 16);
-//   anything else (the parent belongs to another wave's run, a list longer than a row): the lane climbs the parent links
-//   up to the nearest ancestor with <= 2 blocks and gathers the pairs on the way (the slow path, a few lanes per wave).
-__global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) {
-    __shared__ K1GWave lds[K1G_WAVES];
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];       // open-chunk tables: [K1G_WAVES][2 << tbits]
+//   wide parent inside the batch: that lane (the lengths resolve by pointer doubling, the rows are filled by walking the in-batch
+//   parents);
+//   wide parent before the batch: the CHAIN — the wide nodes on the root path of the previous batch's last node.  Their lists are
+//   prefixes of one another (ids ascend along a root path), so the chain is ONE list, the deepest node's, plus per depth the
+//   number of entries and the mask of the node's own last entry.  At the start of a run the chain is built from the root path of
+//   the slice's first node (a table made at upload): the lists of all its wide ancestors in one scan.
+// No node climbs parent links, and a list may have as many entries as there are blocks.
+__global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    K1GWave& L = lds[wave];
-    const uint32_t wid = blockIdx.x * K1G_WAVES + wave;          // every wave takes a run of consecutive batches
+    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + wave;         // 1 or K1W_WAVES waves per workgroup, by the LDS a wave needs
     if (wid >= q.n_waves) return;
-    const uint32_t n_batches = (q.n_wide + WAVE - 1) / WAVE;
-    // runs of K1G_RUN consecutive batches, dealt round-robin: the records per node differ by orders of magnitude (3 blocks: 6
-    // records, 200 blocks: 20 100) and heavy nodes sit together in the DFS order — equal contiguous shares left a few waves
-    // with most of the work.  (A shared work counter is no alternative: same-address device atomics run at a few million per second.)
-    const uint32_t n_runs = (n_batches + q.run - 1u) / q.run;
+    const K1WLds L = k1w_carve(lds_raw + k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap) * wave, q.arena_cap, q.e_cap, q.chain_cap);
     auto iswide = [&](uint32_t y) -> bool { return (q.widebits[y >> 6] >> (y & 63u)) & 1ull; };
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     WaveArena A;
-    arena_init(A, (uint32_t*)(lds_raw + arena_table_bytes(q.tbits, q.n_states) * wave), q.tbits, q.n_states, wid + 64u, lane);
-    if (lane < K1G_CH) L.ch_node[lane] = 0xFFFFFFFFu;
-    lds_sync();
+    arena_init(A, nullptr, 0u, 0u, wid + 64u, lane);
+    uint32_t n_miss = 0;
 
     // record-parallel emission of the lanes in `on` (list of lane j: m entries from st_start[j]): a node with m blocks owns
     // m (m + 1) / 2 records (block pairs a >= b); the records are numbered by a prefix sum, every owner pushes one descriptor per
     // record into a queue, then the wave takes 64 descriptors at a time, one record per lane
-    auto emit = [&](bool on, uint32_t m, uint32_t wv, uint32_t stride) {
-        // a node with many blocks (66 records and more) is taken by the whole wave: lane t builds pair t of the node
+    auto emit = [&](bool on, uint32_t m, uint32_t wv) {
+        // a node with many blocks is taken by the whole wave: lane t builds pair t of the node
         {
-            unsigned long long hb = __ballot(on && m >= 11u);
+            unsigned long long hb = __ballot(on && m >= K1W_HEAVY);
             while (hb) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(hb);
                 hb &= hb - 1ull;
                 const uint32_t mj = bcast(m, j), wj = bcast(wv, j);
-                uint32_t stj = L.st_start[j];
+                const uint32_t stj = L.st_start[j];
                 const unsigned long long* cmask = L.ent_mask + stj;
                 const uint16_t* cblk = L.ent_blk + stj;
-                if (stride != 1u) {
-                    lds_sync();
-                    if (lane < mj) { L.co_mask[lane] = L.ent_mask[stj + lane * stride]; L.co_blk[lane] = L.ent_blk[stj + lane * stride]; }
-                    lds_sync();
-                    cmask = L.co_mask; cblk = L.co_blk;
-                }
                 const uint32_t Tj = mj * (mj + 1u) / 2u;
                 for (uint32_t t0 = 0; t0 < Tj; t0 += WAVE) {
                     const uint32_t t = t0 + lane;
@@ -772,7 +811,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                     wide_emit(A, q.pool, rec_on, FX, FY, wj, stream, lane, lt_mask);
                 }
             }
-            on = on && m < 11u;
+            on = on && m < K1W_HEAVY;
         }
         const uint32_t myrec = on ? m * (m + 1u) / 2u : 0u;
         const uint32_t rincl = wave_incl_scan(myrec, lane);
@@ -780,10 +819,10 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
         const uint32_t rexcl = rincl - myrec;
         L.st_w[lane] = wv;
         lds_sync();
-        for (uint32_t q0 = 0; q0 < T; q0 += K1G_QCAP) {
+        for (uint32_t q0 = 0; q0 < T; q0 += K1W_QCAP) {
             if (myrec) {
                 const uint32_t lo = rexcl > q0 ? rexcl : q0;
-                const uint32_t hi2 = rincl < q0 + K1G_QCAP ? rincl : q0 + K1G_QCAP;
+                const uint32_t hi2 = rincl < q0 + K1W_QCAP ? rincl : q0 + K1W_QCAP;
                 if (lo < hi2) {
                     const uint32_t r0 = lo - rexcl;
                     uint32_t a = (uint32_t)((__fsqrt_rn(8.0f * (float)r0 + 1.0f) - 1.0f) * 0.5f);
@@ -797,7 +836,7 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                 }
             }
             lds_sync();
-            const uint32_t tend = T < q0 + K1G_QCAP ? T : q0 + K1G_QCAP;
+            const uint32_t tend = T < q0 + K1W_QCAP ? T : q0 + K1W_QCAP;
             for (uint32_t t0 = q0; t0 < tend; t0 += WAVE) {
                 const uint32_t t = t0 + lane;
                 bool rec_on = false, diag = false;
@@ -807,8 +846,8 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
                     const uint32_t d = L.queue[t - q0];
                     const uint32_t own = d & 63u, a = (d >> 6) & 0x1FFFu, b = d >> 19;
                     const uint32_t st = L.st_start[own];
-                    FX = L.ent_mask[st + a * stride]; FY = L.ent_mask[st + b * stride];
-                    const uint32_t X = L.ent_blk[st + a * stride], Y = L.ent_blk[st + b * stride];
+                    FX = L.ent_mask[st + a]; FY = L.ent_mask[st + b];
+                    const uint32_t X = L.ent_blk[st + a], Y = L.ent_blk[st + b];
                     ww = L.st_w[own];
                     diag = a == b;
                     rec_on = !diag || __popcll(FX) >= 2;           // a diagonal record needs two ids to have a pair
@@ -821,171 +860,190 @@ __global__ __launch_bounds__(WAVE * K1G_WAVES) void k1g_kernel(const GParams q) 
         }
     };
 
-    uint32_t n_slow = 0;
-    for (uint32_t run = wid; run < n_runs; run += q.n_waves)
-    for (uint32_t batch = run * q.run; batch < (run + 1u) * q.run && batch < n_batches; ++batch) {
-        const uint32_t k = batch * WAVE + lane;
-        const bool valid = k < q.n_wide;
-        const uint32_t node = valid ? q.widx[k] : 0u;
-        const uint32_t nlv = valid ? q.nl[node] : 0u;
-        const uint32_t wv = valid ? q.w[node] : 0u;
-        const bool act = valid && wv != 0 && (nlv & 0xFFFFu) >= 2u && node >= q.emit_lo && node < q.emit_hi;
-        const int32_t par = valid ? q.parent[node] : -1;
-        const uint32_t dep = valid ? (uint32_t)(q.dflag[node] & 0x7FFFu) : 0x7FFFu;
-        const uint32_t info = valid ? q.p0_info[node] : 0u;
-        const uint32_t np = info >> 16;
-        const unsigned long long m0 = valid ? q.p0_mask[node] : 0ull;
-        const uint32_t po = np > 1 ? q.pair_ofs[node] : 0u;
-        // ---- where the parent's list comes from
-        enum : uint32_t { SRC_NOW = 0, SRC_LANE = 1, SRC_CHAIN = 2, SRC_SLOW = 3 };
-        uint32_t src = SRC_NOW, plane = 0;
-        bool par_narrow = false;
-        if (valid && par >= 0) {
-            if (!iswide((uint32_t)par)) par_narrow = true;
-            else {
-                const uint32_t pw = (uint32_t)par >> 6;
-                const uint32_t prank = q.wide_base[pw] + (uint32_t)__popcll(q.widebits[pw] & ((1ull << ((uint32_t)par & 63u)) - 1ull));
-                if (prank >= batch * WAVE) { src = SRC_LANE; plane = prank - batch * WAVE; }
-                else {
-                    const uint32_t cs = (dep - 1u) & (K1G_CH - 1u);
-                    src = (L.ch_node[cs] == (uint32_t)par && L.ch_len[cs] != 0xFFFFu) ? SRC_CHAIN : SRC_SLOW;
+    for (uint32_t run = wid; run < q.n_runs; run += q.n_waves) {
+        const uint32_t w0 = run * q.seg_words;
+        const uint32_t w1 = (q.n_words - w0) < q.seg_words ? q.n_words : w0 + q.seg_words;
+        const uint32_t kb = q.wide_base[w0], ke = q.wide_base[w1];
+        if (kb == ke) continue;
+        // ---- the chain at the start of the run: the wide nodes on the root path of the slice's first node.  Wide nodes are a
+        // suffix of a root path; the topmost one starts from its (narrow) parent's (blocks, masks).
+        {
+            for (uint32_t e = lane; e < q.chain_cap; e += WAVE) L.ch_node[e] = 0xFFFFFFFFu;
+            const uint32_t d = q.seg_anc_n[run];
+            LSum carry = lsum_none();
+            bool started = false;
+            for (uint32_t cb = 0; cb < d; cb += WAVE) {
+                const uint32_t j = cb + lane;
+                const bool on = j < d;
+                const uint32_t a = on ? q.seg_anc[(size_t)run * q.chain_cap + j] : 0u;
+                const unsigned long long wb = __ballot(on && iswide(a));
+                if (!started && !wb) continue;
+                const uint32_t t = started ? 0u : (uint32_t)__builtin_ctzll(wb);
+                if (!started) {
+                    const uint32_t at = bcast(a, t);
+                    if (q.parent[at] >= 0) {
+                        const uint32_t fb = q.fn_blk[at];
+                        const ulonglong2 fm = q.fn_mask[at];
+                        carry = lsum_of_fn(fb, fm);
+                        if (lane == 0) {
+                            if (carry.c >= 1u) { L.e_blk[0] = (uint16_t)(fb & 0xFFFFu); L.e_mask[0] = fm.x; }
+                            if (carry.c >= 2u) { L.e_blk[1] = (uint16_t)(fb >> 16); L.e_mask[1] = fm.y; }
+                        }
+                    }
+                    started = true;
                 }
-            }
-        }
-        // ---- rows: the parent's entries, then the node's own pairs (ascending; an equal block at the seam merges)
-        const uint32_t row = lane;                              // rows are entry-major: entry e of this lane at row + 64 e (no bank conflicts)
-        uint32_t len = 0;
-        bool slow = valid && src == SRC_SLOW, done = !valid || src == SRC_NOW || src == SRC_CHAIN || src == SRC_SLOW;
-        auto push = [&](uint32_t blk, unsigned long long mask) {
-            if (len && L.ent_blk[row + 64u * (len - 1u)] == blk) L.ent_mask[row + 64u * (len - 1u)] |= mask;
-            else if (len < K1G_ROW) { L.ent_blk[row + 64u * len] = (uint16_t)blk; L.ent_mask[row + 64u * len] = mask; ++len; }
-            else slow = true;                                   // longer than a row
-        };
-        auto push_own = [&]() {
-            if (np) push(info & 0xFFFFu, m0);
-            for (uint32_t t = 0; t + 1 < np && !slow; ++t) push(q.pair_blk[po + t], q.pair_mask[po + t]);
-        };
-        if (valid && !slow) {
-            if (src == SRC_NOW) {
-                if (par_narrow) {
-                    const uint32_t fb = q.fn_blk[node];
-                    const ulonglong2 fm = q.fn_mask[node];
-                    if ((fb & 0xFFFFu) != 0xFFFFu) push(fb & 0xFFFFu, fm.x);
-                    if ((fb >> 16) != 0xFFFFu) push(fb >> 16, fm.y);
+                const bool act = on && lane >= t;
+                const uint32_t info = act ? q.p0_info[a] : 0u;
+                const uint32_t np = info >> 16, b0 = info & 0xFFFFu;
+                const unsigned long long m0 = act ? q.p0_mask[a] : 0ull;
+                const uint32_t po = np > 1u ? q.pair_ofs[a] : 0u;
+                uint32_t lb = b0;
+                unsigned long long lm = m0;
+                if (np > 1u) { lb = q.pair_blk[po + np - 2u]; lm = q.pair_mask[po + np - 2u]; }
+                LSum S = np ? LSum{lm, np, b0, lb} : lsum_none();
+                if (lane == t) S = lsum_merge(carry, S);
+#pragma unroll
+                for (int s = 1; s < WAVE; s <<= 1) {
+                    const LSum o = lsum_shfl_up(S, s);
+                    if (lane >= (uint32_t)s) S = lsum_merge(o, S);
                 }
-                push_own();
-            } else if (src == SRC_CHAIN) {
-                const uint32_t cs = (dep - 1u) & (K1G_CH - 1u);
-                const uint32_t cl = L.ch_len[cs];
-                for (uint32_t e = 0; e < cl; ++e) { L.ent_blk[row + 64u * e] = L.ch_blk[cs * K1G_ROW + e]; L.ent_mask[row + 64u * e] = L.ch_mask[cs * K1G_ROW + e]; }
-                len = cl;
-                push_own();
-            }
-        }
-        // in-batch parents, parents first
-        while (__ballot(!done)) {
-            const uint32_t pstate = (uint32_t)__shfl((int)((done ? 1u : 0u) | (slow ? 2u : 0u) | (len << 2)), (int)plane, WAVE);
-            if (!done && (pstate & 1u)) {
-                if (pstate & 2u) slow = true;
-                else {
-                    const uint32_t pl = pstate >> 2, prow = plane;
-                    for (uint32_t e = 0; e < pl; ++e) { L.ent_blk[row + 64u * e] = L.ent_blk[prow + 64u * e]; L.ent_mask[row + 64u * e] = L.ent_mask[prow + 64u * e]; }
-                    len = pl;
-                    push_own();
+                LSum Pp = lsum_shfl_up(S, 1);
+                if (lane == t) Pp = carry;
+                const bool seam = act && np && Pp.c && Pp.lb == b0;
+                const uint32_t idx0 = Pp.c - (seam ? 1u : 0u);
+                if (act && np) {
+                    if (!seam) { L.e_blk[idx0] = (uint16_t)b0; L.e_mask[idx0] = m0; }
+                    for (uint32_t p = 1; p < np; ++p) { L.e_blk[idx0 + p] = q.pair_blk[po + p - 1u]; L.e_mask[idx0 + p] = q.pair_mask[po + p - 1u]; }
                 }
-                done = true;
+                lds_sync();
+                if (seam) atomicOr(&L.e_mask[idx0], m0);
+                if (act) { L.ch_node[j] = a; L.ch_len[j] = (uint16_t)S.c; L.ch_last[j] = S.lm; }
+                carry = lsum_shfl(S, WAVE - 1);
+                lds_sync();
             }
             lds_sync();
         }
-        // ---- chain slots for the next batches: the lanes on the root path of the batch's last node
-        {
-            uint32_t mdep = dep;
-#pragma unroll
-            for (int sft = 1; sft < WAVE; sft <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_down((int)mdep, sft, WAVE);
-                if (lane + (uint32_t)sft < (uint32_t)WAVE) mdep = o < mdep ? o : mdep;
-            }
-            uint32_t later = (uint32_t)__shfl_down((int)mdep, 1, WAVE);
-            if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
-            // two path nodes whose depths differ by a multiple of the table size share a slot: the deeper one keeps it
-            bool writer = valid && dep < later;
-            {
-                const uint32_t mycs = dep & (K1G_CH - 1u);
-#pragma unroll
-                for (uint32_t c2 = 0; c2 < K1G_CH; ++c2) {
-                    const unsigned long long wm = __ballot(writer && mycs == c2);
-                    if (writer && mycs == c2 && (wm >> lane) > 1ull) writer = false;      // a later (deeper) lane wants the slot
+        // ---- the batches of the run
+        for (uint32_t k0 = kb; k0 < ke; k0 += WAVE) {
+            const uint32_t nv = ke - k0 < (uint32_t)WAVE ? ke - k0 : (uint32_t)WAVE;
+            const bool valid = lane < nv;
+            const uint32_t node = valid ? q.widx[k0 + lane] : 0u;
+            const uint32_t nlv = valid ? q.nl[node] : 0u;
+            const uint32_t wv = valid ? q.w[node] : 0u;
+            const bool act = valid && wv != 0 && (nlv & 0xFFFFu) >= 2u && node >= q.emit_lo && node < q.emit_hi;
+            const int32_t par = valid ? q.parent[node] : -1;
+            const uint32_t dep = valid ? (uint32_t)(q.dflag[node] & 0x7FFFu) : 0x7FFFu;
+            const uint32_t info = valid ? q.p0_info[node] : 0u;
+            const uint32_t np = info >> 16, b0 = info & 0xFFFFu;
+            const unsigned long long m0 = valid ? q.p0_mask[node] : 0ull;
+            const uint32_t po = np > 1u ? q.pair_ofs[node] : 0u;
+            uint32_t lb = b0;
+            unsigned long long lm = m0;
+            if (np > 1u) { lb = q.pair_blk[po + np - 2u]; lm = q.pair_mask[po + np - 2u]; }
+            // ---- where the parent's list comes from
+            uint32_t base = WB_NONE, link = 0;
+            LSum Pb = lsum_none();
+            if (valid && par >= 0) {
+                if (!iswide((uint32_t)par)) {
+                    base = WB_FN;
+                    Pb = lsum_of_fn(q.fn_blk[node], q.fn_mask[node]);
+                } else {
+                    const uint32_t pw = (uint32_t)par >> 6;
+                    const uint32_t prank = q.wide_base[pw] + (uint32_t)__popcll(q.widebits[pw] & ((1ull << ((uint32_t)par & 63u)) - 1ull));
+                    if (prank >= k0) { base = WB_LANE; link = prank - k0; }
+                    else {
+                        base = WB_CHAIN; link = dep - 2u;
+                        if (link < q.chain_cap && L.ch_node[link] == (uint32_t)par) {
+                            const uint32_t cl = L.ch_len[link];
+                            Pb = LSum{L.ch_last[link], cl, 0u, cl ? (uint32_t)L.e_blk[cl - 1u] : BLK_NONE};
+                        } else { base = WB_NONE; ++n_miss; }         // cannot happen (the engine treats it as an internal error)
+                    }
                 }
             }
-            if (writer) {
-                const uint32_t cs = dep & (K1G_CH - 1u);
-                L.ch_node[cs] = node;
-                L.ch_len[cs] = slow ? (uint16_t)0xFFFFu : (uint16_t)len;
-                if (!slow) for (uint32_t e = 0; e < len; ++e) { L.ch_blk[cs * K1G_ROW + e] = L.ent_blk[row + 64u * e]; L.ch_mask[cs * K1G_ROW + e] = L.ent_mask[row + 64u * e]; }
+            // ---- entries of every node's list: own stretch below the base, in-batch parents by pointer doubling
+            LSum S = np ? LSum{lm, np, b0, lb} : lsum_none();
+            if (base != WB_LANE) S = lsum_merge(Pb, S);
+            {
+                int pl = base == WB_LANE ? (int)link : -1;
+                while (__ballot(pl >= 0)) {
+                    const int src = pl >= 0 ? pl : (int)lane;
+                    const LSum o = lsum_shfl(S, src);
+                    const int opl = __shfl(pl, src, WAVE);                // -1 once that lane's stretch reaches its base
+                    if (pl >= 0) { S = lsum_merge(o, S); pl = opl; }
+                }
             }
-        }
-        L.st_start[lane] = (uint16_t)row;
-        lds_sync();
-        emit(act && !slow, len, wv, 64u);
-        // ---- the slow path: climb to the nearest ancestor with at most two blocks, twice (count, then fill)
-        n_slow += (uint32_t)__popcll(__ballot(slow));
-        if (__ballot(slow)) {
-            uint32_t cnt = 0;
-            if (slow) {
-                cnt = np;
-                int32_t y = par;
-                while (y >= 0 && iswide((uint32_t)y)) { cnt += q.p0_info[y] >> 16; y = q.parent[y]; }
-                if (y >= 0) cnt += 2;
-                if (cnt > K1G_ENT) { atomicOr(&q.pool.counters[KCTR_LIST_OVERFLOW], 1u); cnt = 0; }      // the engine falls back
-            }
-            uint32_t fin = 0;                                      // lanes below `fin` are finished
-            while (fin < (uint32_t)WAVE) {
-                // the lanes [fin, hi) whose pairs fit the entry pool together
-                const uint32_t c = lane >= fin ? cnt : 0u;
+            const uint32_t len = valid ? S.c : 0u;
+            L.own_np[lane] = (uint16_t)np; L.own_b0[lane] = (uint16_t)b0; L.own_m0[lane] = m0; L.own_po[lane] = po;
+            L.own_base[lane] = (unsigned char)base; L.own_link[lane] = (uint16_t)link; L.own_node[lane] = node;
+            lds_sync();
+            // ---- rows, as many lanes at a time as the arena holds, and their records.  Only the lanes that emit need a row, and
+            // the last one (its list becomes the chain list).
+            const bool need = valid && (act || lane == nv - 1u);
+            uint32_t fin = 0, last_start = 0;
+            while (fin < nv) {
+                const uint32_t c = (lane >= fin && need) ? len : 0u;
                 const uint32_t incl = wave_incl_scan(c, lane);
-                const unsigned long long over = __ballot(incl > K1G_ENT);
-                const uint32_t hi = over ? (uint32_t)__builtin_ctzll(over) : (uint32_t)WAVE;      // > fin: a single list fits
-                const bool on = lane >= fin && lane < hi && cnt != 0;
-                const uint32_t off = incl - c;
-                uint32_t m = 0, start = 0;
+                const unsigned long long over = __ballot(incl > q.arena_cap);
+                uint32_t hi = over ? (uint32_t)__builtin_ctzll(over) : (uint32_t)WAVE;
+                if (hi <= fin) { if (lane == 0) atomicOr(&q.pool.counters[KCTR_LIST_OVERFLOW], 1u); hi = fin + 1u; }     // a single list longer than the arena: cannot happen
+                const bool on = need && lane >= fin && lane < hi && incl <= q.arena_cap;
+                const uint32_t start = incl - c;
                 if (on) {
-                    // fill the lane's region right to left (the climb meets the blocks in descending order)
-                    uint32_t pos = off + cnt, cur = 0xFFFFFFFFu;
+                    // fill the row right to left: own pairs, the in-batch parents' pairs, then the base
+                    uint32_t pos = start + len, cur = 0xFFFFFFFFu;
                     auto rpush = [&](uint32_t blk, unsigned long long mask) {
                         if (blk == cur) L.ent_mask[pos] |= mask;
                         else { --pos; L.ent_blk[pos] = (uint16_t)blk; L.ent_mask[pos] = mask; cur = blk; }
                     };
-                    int32_t y = (int32_t)node;
+                    uint32_t y = lane;
                     for (;;) {
-                        const uint32_t yi = q.p0_info[y];
-                        const uint32_t ynp = yi >> 16;
-                        if (ynp > 1) {
-                            const uint32_t ypo = q.pair_ofs[y];
-                            for (uint32_t t = ynp - 1; t-- > 0;) rpush(q.pair_blk[ypo + t], q.pair_mask[ypo + t]);
+                        const uint32_t ynp = L.own_np[y];
+                        if (ynp > 1u) {
+                            const uint32_t ypo = L.own_po[y];
+                            for (uint32_t t = ynp - 1u; t-- > 0u;) rpush(q.pair_blk[ypo + t], q.pair_mask[ypo + t]);
                         }
-                        if (ynp) rpush(yi & 0xFFFFu, q.p0_mask[y]);
-                        const int32_t z = y;                      // the wide node whose parent may be the end of the climb
-                        y = q.parent[y];
-                        if (y < 0) break;
-                        if (!iswide((uint32_t)y)) {
-                            const uint32_t fb = q.fn_blk[z];
-                            const ulonglong2 fm = q.fn_mask[z];
-                            if ((fb >> 16) != 0xFFFFu) rpush(fb >> 16, fm.y);
-                            if ((fb & 0xFFFFu) != 0xFFFFu) rpush(fb & 0xFFFFu, fm.x);
-                            break;
+                        if (ynp) rpush(L.own_b0[y], L.own_m0[y]);
+                        const uint32_t yb = L.own_base[y];
+                        if (yb == WB_LANE) { y = L.own_link[y]; continue; }
+                        if (yb == WB_FN) {
+                            const uint32_t ynode = L.own_node[y];
+                            const uint32_t fb = q.fn_blk[ynode];
+                            const ulonglong2 fm = q.fn_mask[ynode];
+                            if ((fb >> 16) != BLK_NONE) rpush(fb >> 16, fm.y);
+                            if ((fb & 0xFFFFu) != BLK_NONE) rpush(fb & 0xFFFFu, fm.x);
+                        } else if (yb == WB_CHAIN) {
+                            const uint32_t cs = L.own_link[y];
+                            const uint32_t cl = L.ch_len[cs];
+                            for (uint32_t e = cl; e-- > 0u;) rpush(L.e_blk[e], e + 1u == cl ? L.ch_last[cs] : L.e_mask[e]);
                         }
+                        break;
                     }
-                    m = off + cnt - pos; start = pos;
                 }
                 L.st_start[lane] = (uint16_t)start;
+                if (lane == nv - 1u && on) last_start = start;
                 lds_sync();
-                emit(on && act, m, wv, 1u);
+                emit(on && act, len, wv);
                 fin = hi;
+            }
+            // ---- the chain for the next batches: the lanes on the root path of the batch's last node, and that node's list
+            {
+                uint32_t mdep = dep;
+#pragma unroll
+                for (int sft = 1; sft < WAVE; sft <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_down((int)mdep, sft, WAVE);
+                    if (lane + (uint32_t)sft < (uint32_t)WAVE) mdep = o < mdep ? o : mdep;
+                }
+                uint32_t later = (uint32_t)__shfl_down((int)mdep, 1, WAVE);
+                if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
+                if (valid && dep < later && dep - 1u < q.chain_cap) { L.ch_node[dep - 1u] = node; L.ch_len[dep - 1u] = (uint16_t)len; L.ch_last[dep - 1u] = S.lm; }
+                const uint32_t ll = bcast(len, nv - 1u), ls = bcast(last_start, nv - 1u);
+                for (uint32_t e = lane; e < ll; e += WAVE) { L.e_blk[e] = L.ent_blk[ls + e]; L.e_mask[e] = L.ent_mask[ls + e]; }
+                lds_sync();
             }
         }
     }
     arena_finish(A, q.pool, lane);
-    if (lane == 0 && n_slow) atomicAdd(&q.pool.counters[KCTR_SLOW], n_slow);
+    if (lane == 0 && n_miss) atomicAdd(&q.pool.counters[KCTR_SLOW], n_miss);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1582,7 +1640,7 @@ PoolView pool_view(const kmdb_db* db, bool dense) {
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 #define FREE_NULL(x) free_and_null((void**)&(x))
 
-constexpr uint32_t K1G_MAX_WAVES = 8192;
+constexpr uint32_t K1W_MAX_WAVES = 8192;
 struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
 struct ValidKey { uint32_t n_states, kmask; __host__ __device__ uint32_t operator()(uint32_t k) const { return (k & kmask) < n_states ? 1u : 0u; } };
 
@@ -1821,6 +1879,11 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2;          // streams = block pairs
     if (n_states + 1 >= (1ull << 22)) { db->fallback_reason = "too many block pairs"; return 0; }          // 22 stream bits + 8-bit weight digits in a key word
     db->n_states = (uint32_t)n_states;
+    if (k1w_wave_bytes(std::max<uint32_t>(512u, (db->NB + 2u + 63u) & ~63u), (db->NB + 2u + 3u) & ~3u, db->chain_cap) > (size_t)(152u << 10)) {
+        db->fallback_reason = "the lists of the wide-node kernel do not fit the LDS (" + std::to_string(db->NB) + " blocks, root paths of up to " +
+                              std::to_string(db->max_depth) + " nodes)";
+        return 0;
+    }
     // ---- working set
     HIP_TRY(hipMalloc((void**)&db->p0_mask, P * 8));
     HIP_TRY(hipMalloc((void**)&db->p0_info, P * 4));
@@ -1865,7 +1928,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide pool: the wide estimate and a grab per wave
     if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
-    if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1G_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;
+    if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1W_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;
     return 0;
 }
 
@@ -1995,21 +2058,22 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     if (!db->widx) { HIP_TRY(hipMalloc((void**)&db->widx, 4)); db->wide_cap = std::max<uint64_t>(db->wide_cap, 1); }
     hipLaunchKernelGGL(wide_expand_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, db->widebits, db->wide_base, n_words, db->widx,
                        (uint32_t)db->wide_cap, db->counters);
-    // ---- K1g
+    // ---- K1w
     if (n_wide) {
-        GParams q{};
+        WParams q{};
         q.widx = db->widx; q.n_wide = n_wide; q.nl = db->nl; q.parent = db->parent; q.w = db->w; q.widebits = db->widebits;
         q.dflag = db->dflag; q.wide_base = db->wide_base;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
-        const uint32_t batches = (n_wide + WAVE - 1) / WAVE;
-        q.run = K1G_RUN;
-        if (const char* e = getenv("KMDB_K1G_RUN")) q.run = std::max(1, atoi(e));
-        q.n_waves = std::min<uint32_t>(K1G_MAX_WAVES, (batches + q.run - 1) / q.run);
-        q.tbits = 0u; q.n_states = db->n_states;              // the wide kernel always writes into the wide pool: no open-chunk table
-        const size_t lds = arena_table_bytes(q.tbits, q.n_states) * K1G_WAVES;
-        HIP_TRY(hipFuncSetAttribute((const void*)k1g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(K1GWave) * K1G_WAVES)));
-        hipLaunchKernelGGL(k1g_kernel, dim3((q.n_waves + K1G_WAVES - 1) / K1G_WAVES), dim3(WAVE * K1G_WAVES), lds, st, q);
+        q.seg_anc = db->wseg_anc; q.seg_anc_n = db->wseg_anc_n; q.seg_words = db->wseg_nodes / 64u; q.n_words = n_words; q.n_runs = db->n_wsegs;
+        q.n_waves = std::min<uint32_t>(K1W_MAX_WAVES, q.n_runs);
+        if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(q.n_runs, (uint32_t)atoi(e)));
+        // LDS of a wave: rows of a batch (at least one full list: as many entries as there are blocks), the chain list, the chain
+        q.chain_cap = db->chain_cap; q.e_cap = (db->NB + 2u + 3u) & ~3u; q.arena_cap = std::max<uint32_t>(512u, (db->NB + 2u + 63u) & ~63u);
+        const size_t wave_lds = k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap);
+        const uint32_t waves = wave_lds * K1W_WAVES <= (size_t)(64u << 10) ? (uint32_t)K1W_WAVES : 1u;
+        HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
+        hipLaunchKernelGGL(k1w_kernel, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
     }
     HIP_TRY(hipGetLastError());
     if (stage("wide emit")) return 1;

@@ -48,10 +48,11 @@ namespace {
 // (log-based measures are monotone in theirs) and widened by a safety margin on the host; a cell that misses a widened bound is
 // dropped here, the rest is decided on the host with the reference's own arithmetic.
 enum { RATIO_JACCARD = 0, RATIO_MIN, RATIO_MAX, RATIO_COSINE, RATIO_QUERY, RATIO_NUM };
+constexpr int DEV_FILTER_MAX = 12;      // one bound per criterion of Params::availableMetrics (9) and a few repeats
 struct DevFilter {
     int n;                          // bounds in use (0: keep every non-zero cell)
-    int kind[8];
-    double lo[8], hi[8];
+    int kind[DEV_FILTER_MAX];
+    double lo[DEV_FILTER_MAX], hi[DEV_FILTER_MAX];
     const uint32_t* counts;         // [N] k-mer counts of the samples
 };
 __device__ __forceinline__ bool dev_keep(const DevFilter& f, uint32_t c, uint32_t row, uint32_t col) {
@@ -72,11 +73,22 @@ __device__ __forceinline__ bool dev_keep(const DevFilter& f, uint32_t c, uint32_
     }
     return true;
 }
-__global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t N, unsigned long long* __restrict__ row_nnz, const DevFilter f) {
-    const uint64_t row = blockIdx.x;
-    const uint32_t* r = M + tri64(row);
+// The columns of row `row` inside the flat cell range [cell_lo, cell_hi) of the lower triangle (row i at i (i - 1) / 2,
+// reference src/array.h:136-140): [j0, j1).  M points at cell `cell_lo`.
+__device__ __forceinline__ void row_span(uint64_t row, uint64_t cell_lo, uint64_t cell_hi, uint64_t& j0, uint64_t& j1) {
+    const uint64_t b = tri64(row), e = b + row;
+    j0 = cell_lo > b ? cell_lo - b : 0;
+    j1 = cell_hi < e ? (cell_hi > b ? cell_hi - b : 0) : row;
+    if (j0 > j1) j0 = j1;
+}
+__global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t row_lo, uint64_t cell_lo, uint64_t cell_hi, unsigned long long* __restrict__ row_nnz,
+                               const DevFilter f) {
+    const uint64_t row = row_lo + blockIdx.x;
+    const uint32_t* r = M + ((int64_t)tri64(row) - (int64_t)cell_lo);      // only cells of the range are touched
+    uint64_t j0, j1;
+    row_span(row, cell_lo, cell_hi, j0, j1);
     uint32_t c = 0;
-    for (uint64_t j = threadIdx.x; j < row; j += blockDim.x) c += dev_keep(f, r[j], (uint32_t)row, (uint32_t)j) ? 1u : 0u;
+    for (uint64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) c += dev_keep(f, r[j], (uint32_t)row, (uint32_t)j) ? 1u : 0u;
     __shared__ uint32_t red[256];
     red[threadIdx.x] = c;
     __syncthreads();
@@ -88,18 +100,20 @@ __global__ void row_nnz_kernel(const uint32_t* __restrict__ M, uint64_t N, unsig
 }
 
 // one block per row, ordered compaction with a block-wide running offset
-__global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t N, const unsigned long long* __restrict__ row_ptr,
-                                   uint32_t* __restrict__ col, uint32_t* __restrict__ val, const DevFilter f) {
-    const uint64_t row = blockIdx.x;
-    const uint32_t* r = M + tri64(row);
+__global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t row_lo, uint64_t cell_lo, uint64_t cell_hi,
+                                   const unsigned long long* __restrict__ row_ptr, uint32_t* __restrict__ col, uint32_t* __restrict__ val, const DevFilter f) {
+    const uint64_t row = row_lo + blockIdx.x;
+    const uint32_t* r = M + ((int64_t)tri64(row) - (int64_t)cell_lo);
+    uint64_t jb, je;
+    row_span(row, cell_lo, cell_hi, jb, je);
     __shared__ uint32_t wave_cnt[4];
     __shared__ unsigned long long running;
     if (threadIdx.x == 0) running = row_ptr[row];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint64_t j0 = 0; j0 < row; j0 += blockDim.x) {
+    for (uint64_t j0 = jb; j0 < je; j0 += blockDim.x) {
         const uint64_t j = j0 + threadIdx.x;
-        uint32_t v = j < row ? r[j] : 0u;
+        uint32_t v = j < je ? r[j] : 0u;
         if (!dev_keep(f, v, (uint32_t)row, (uint32_t)j)) v = 0u;
         const unsigned long long bal = __ballot(v != 0);
         if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
@@ -177,7 +191,8 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     (void)hipSetDevice(db->device);
     kmdb_release_staging(db);
     kmdb_blocks_release(db);
-    void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
+    if (db->wseg_anc == db->nseg_anc) { db->wseg_anc = nullptr; db->wseg_anc_n = nullptr; }
+    void* ptrs[] = {db->wseg_anc, db->wseg_anc_n, db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
                     db->nseg_anc_n, db->meta, db->bitpos, db->ck_ofs, db->ck_bit, db->ck_id, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,
                     db->bucket_offset, db->slots, db->pid2dfs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -374,27 +389,44 @@ RatioBound ratio_bound(const kmdb_cell_filter& f, int k) {
 }
 }  // namespace
 
-static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure, kmdb_sparse_rows* out,
-                       const kmdb_opts* opts);
+static int sparse_impl(kmdb_db* db, bool from_cells, const void* dense_dev, uint64_t cell_lo, uint64_t cell_hi, const kmdb_cell_filter* filters, size_t n_filters,
+                       const uint32_t* sample_kmers, int measure, kmdb_sparse_rows* out, const kmdb_opts* opts);
+
+static int check_filters(const char* who, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure) {
+    if ((n_filters && !filters) || ((n_filters || measure >= 0) && !sample_kmers)) return kmdb_set_error(std::string(who) + ": null argument");
+    if (measure >= KMDB_METRIC_COUNT) return kmdb_set_error(std::string(who) + ": unknown measure");
+    if (n_filters > (size_t)DEV_FILTER_MAX) return kmdb_set_error(std::string(who) + ": more than " + std::to_string(DEV_FILTER_MAX) + " bounds");
+    for (size_t i = 0; i < n_filters; ++i)
+        if (filters[i].metric < 0 || filters[i].metric >= KMDB_METRIC_COUNT) return kmdb_set_error(std::string(who) + ": unknown metric in a filter");
+    return 0;
+}
 
 extern "C" int kmdb_all2all_sparse(kmdb_db* db, kmdb_sparse_rows* out, const kmdb_opts* opts) {
-    return sparse_impl(db, nullptr, 0, nullptr, -1, out, opts);
+    return sparse_impl(db, false, nullptr, 0, ~0ull, nullptr, 0, nullptr, -1, out, opts);
 }
 
 extern "C" int kmdb_all2all_sparse_filtered(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure,
                                             kmdb_sparse_rows* out, const kmdb_opts* opts) {
-    if ((n_filters && !filters) || ((n_filters || measure >= 0) && !sample_kmers)) return kmdb_set_error("kmdb_all2all_sparse_filtered: null argument");
-    if (measure >= KMDB_METRIC_COUNT) return kmdb_set_error("kmdb_all2all_sparse_filtered: unknown measure");
-    if (n_filters > 8) return kmdb_set_error("kmdb_all2all_sparse_filtered: more than 8 bounds");
-    for (size_t i = 0; i < n_filters; ++i)
-        if (filters[i].metric < 0 || filters[i].metric >= KMDB_METRIC_COUNT) return kmdb_set_error("kmdb_all2all_sparse_filtered: unknown metric in a filter");
+    if (check_filters("kmdb_all2all_sparse_filtered", filters, n_filters, sample_kmers, measure)) return 1;
     // bounds are conditions on the whole cell: a slice of the pattern stream (opts->shard_*) holds partial sums only
     if ((n_filters || measure >= 0) && opts && opts->shard_count > 1) return kmdb_set_error("kmdb_all2all_sparse_filtered: filters need the whole database (shard_count must be 1)");
-    return sparse_impl(db, filters, n_filters, sample_kmers, measure, out, opts);
+    return sparse_impl(db, false, nullptr, 0, ~0ull, filters, n_filters, sample_kmers, measure, out, opts);
 }
 
-static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure, kmdb_sparse_rows* out,
-                       const kmdb_opts* opts) {
+extern "C" int kmdb_sparse_from_dense_device(kmdb_db* db, const void* cells_dev, uint64_t cell_lo, uint64_t cell_hi, const kmdb_cell_filter* filters,
+                                             size_t n_filters, const uint32_t* sample_kmers, int measure, kmdb_sparse_rows* out, const kmdb_opts* opts) {
+    if (!db || !out) return kmdb_set_error("kmdb_sparse_from_dense_device: null argument");
+    if (check_filters("kmdb_sparse_from_dense_device", filters, n_filters, sample_kmers, measure)) return 1;
+    const uint64_t cells = db->N ? db->N * (db->N - 1) / 2 : 0;
+    if (cell_hi > cells) cell_hi = cells;
+    if (cell_lo > cell_hi) return kmdb_set_error("kmdb_sparse_from_dense_device: cell_lo > cell_hi");
+    if (!cells_dev && cell_hi > cell_lo) return kmdb_set_error("kmdb_sparse_from_dense_device: null matrix");
+    return sparse_impl(db, true, cells_dev, cell_lo, cell_hi, filters, n_filters, sample_kmers, measure, out, opts);
+}
+
+// from_cells: compact the caller's cells [cell_lo, cell_hi) (dense_dev points at cell_lo); else accumulate the whole triangle first
+static int sparse_impl(kmdb_db* db, bool from_cells, const void* dense_dev, uint64_t cell_lo, uint64_t cell_hi, const kmdb_cell_filter* filters, size_t n_filters,
+                       const uint32_t* sample_kmers, int measure, kmdb_sparse_rows* out, const kmdb_opts* opts) {
     if (!db || !out) return kmdb_set_error("kmdb_all2all_sparse: null argument");
     std::memset(out, 0, sizeof *out);
     HIP_TRY(hipSetDevice(db->device));
@@ -410,8 +442,8 @@ static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_fi
         for (void* p : {(void*)M, (void*)row_nnz, (void*)row_ptr, (void*)col, (void*)val, (void*)d_counts, tmp}) if (p) (void)hipFree(p);
     };
     DevFilter df{};
-#define SP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    SP_TRY(hipMalloc((void**)&M, std::max<uint64_t>(cells, 1) * 4));
+#define SP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); kmdb_sparse_free(out); return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    if (!from_cells) SP_TRY(hipMalloc((void**)&M, std::max<uint64_t>(cells, 1) * 4));
     SP_TRY(hipMalloc((void**)&row_nnz, (N + 1) * 8));
     SP_TRY(hipMalloc((void**)&row_ptr, (N + 1) * 8));
     if (n_filters) {
@@ -423,12 +455,25 @@ static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_fi
             df.kind[i] = rb.kind; df.lo[i] = rb.lo; df.hi[i] = rb.hi;
         }
     }
-    rc = run_dense(db, M, opts, st);
-    if (rc) { cleanup(); return rc; }
+    const uint32_t* cellsp = (const uint32_t*)dense_dev;
+    if (!from_cells) {
+        rc = run_dense(db, M, opts, st);
+        if (rc) { cleanup(); return rc; }
+        cellsp = M; cell_lo = 0; cell_hi = cells;
+    } else {
+        SP_TRY(hipEventRecord(db->ev[0], st)); SP_TRY(hipEventRecord(db->ev[1], st)); SP_TRY(hipEventRecord(db->ev[2], st));
+        db->stats.path = KMDB_PATH_NONE;
+    }
+    // rows that meet the range: row r holds the cells [r (r - 1) / 2, r (r + 1) / 2)
+    uint64_t row_lo = 0, row_hi = 0;
+    if (cell_hi > cell_lo) {
+        auto row_of = [](uint64_t c) { uint64_t r = (uint64_t)((1.0 + std::sqrt(1.0 + 8.0 * (double)c)) / 2.0); while (r * (r - 1) / 2 > c) --r; while ((r + 1) * r / 2 <= c) ++r; return r; };
+        row_lo = row_of(cell_lo); row_hi = row_of(cell_hi - 1) + 1;
+    }
     SP_TRY(hipMemsetAsync(row_nnz, 0, (N + 1) * 8, st));
-    if (N) hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_nnz, df);
+    if (row_hi > row_lo) hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)(row_hi - row_lo)), dim3(256), 0, st, cellsp, row_lo, cell_lo, cell_hi, row_nnz, df);
     size_t tmp_bytes = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st);
+    SP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
     SP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
     SP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
     std::vector<unsigned long long> h_ptr(N + 1, 0);
@@ -437,7 +482,7 @@ static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_fi
     const uint64_t nnz = h_ptr[N];
     SP_TRY(hipMalloc((void**)&col, std::max<uint64_t>(nnz, 1) * 4));
     SP_TRY(hipMalloc((void**)&val, std::max<uint64_t>(nnz, 1) * 4));
-    if (N) hipLaunchKernelGGL(row_compact_kernel, dim3((unsigned)N), dim3(256), 0, st, M, N, row_ptr, col, val, df);
+    if (row_hi > row_lo) hipLaunchKernelGGL(row_compact_kernel, dim3((unsigned)(row_hi - row_lo)), dim3(256), 0, st, cellsp, row_lo, cell_lo, cell_hi, row_ptr, col, val, df);
     rc = finish_stats(db, st);
     if (rc) { cleanup(); return rc; }
     out->n_rows = N;
@@ -445,6 +490,7 @@ static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_fi
     out->row_ptr = (uint64_t*)std::malloc((N + 1) * 8);
     out->col = (uint32_t*)std::malloc(std::max<uint64_t>(nnz, 1) * 4);
     out->val = (uint32_t*)std::malloc(std::max<uint64_t>(nnz, 1) * 4);
+    if (!out->row_ptr || !out->col || !out->val) { cleanup(); kmdb_sparse_free(out); return kmdb_set_error("kmdb_all2all_sparse: out of host memory for the result"); }
     for (uint64_t i = 0; i <= N; ++i) out->row_ptr[i] = h_ptr[i];
     if (nnz) {
         SP_TRY(hipMemcpy(out->col, col, nnz * 4, hipMemcpyDeviceToHost));
@@ -489,6 +535,7 @@ static int sparse_impl(kmdb_db* db, const kmdb_cell_filter* filters, size_t n_fi
         out->nnz = new_ptr[N];
         if (measure >= 0) {
             out->measure = (double*)std::malloc(std::max<uint64_t>(out->nnz, 1) * 8);
+            if (!out->measure) { kmdb_sparse_free(out); return kmdb_set_error("kmdb_all2all_sparse: out of host memory for the measures"); }
             parallel([&](uint64_t i) {
                 for (uint64_t e = out->row_ptr[i]; e < out->row_ptr[i + 1]; ++e)
                     out->measure[e] = kmdbh_metric(measure, out->val[e], sample_kmers[i], sample_kmers[out->col[e]], k);

@@ -60,6 +60,10 @@ struct kmdb_db {
     uint32_t n_nsegs = 0;
     uint32_t* nseg_anc = nullptr;   // [n_nsegs][chain_cap] root path of every slice's first node
     uint32_t* nseg_anc_n = nullptr;
+    uint32_t wseg_nodes = 512;      // nodes per slice of the DFS stream for the wide-node kernel (a run of its wide nodes per wave)
+    uint32_t n_wsegs = 0;
+    uint32_t* wseg_anc = nullptr;   // [n_wsegs][chain_cap] root path of every such slice's first node (== nseg_anc when the slices are the same)
+    uint32_t* wseg_anc_n = nullptr;
     uint32_t chain_cap = 8;         // chain slots per wave = longest root path, rounded up
     uint32_t max_depth = 0, max_n = 0;
     bool chain_ok = false;          // root paths fit the chain table of the emit kernel

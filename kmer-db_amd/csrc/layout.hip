@@ -535,6 +535,18 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     if (db->n_nsegs)
         hipLaunchKernelGGL(lay_seg_anc_kernel, dim3((db->n_nsegs + 63) / 64), dim3(64), 0, st, db->parent, db->dflag, (uint32_t)P, db->nseg_nodes, db->n_nsegs,
                            db->chain_cap, db->nseg_anc, db->nseg_anc_n);
+    // the wide-node kernel takes shorter slices (its work per node varies by orders of magnitude); a very deep tree shares the table
+    db->wseg_nodes = db->chain_cap > 256 ? db->nseg_nodes : 512;
+    if (const char* e = getenv("KMDB_WSEG")) if (*e) db->wseg_nodes = (uint32_t)std::max<uint64_t>(64, strtoull(e, nullptr, 10) / 64 * 64);
+    if (db->wseg_nodes == db->nseg_nodes) { db->n_wsegs = db->n_nsegs; db->wseg_anc = db->nseg_anc; db->wseg_anc_n = db->nseg_anc_n; }
+    else {
+        db->n_wsegs = (uint32_t)((P + db->wseg_nodes - 1) / db->wseg_nodes);
+        HIP_TRY(hipMalloc((void**)&db->wseg_anc, std::max<size_t>((size_t)db->n_wsegs * db->chain_cap, 1) * 4));
+        HIP_TRY(hipMalloc((void**)&db->wseg_anc_n, std::max<size_t>(db->n_wsegs, 1) * 4));
+        if (db->n_wsegs)
+            hipLaunchKernelGGL(lay_seg_anc_kernel, dim3((db->n_wsegs + 63) / 64), dim3(64), 0, st, db->parent, db->dflag, (uint32_t)P, db->wseg_nodes, db->n_wsegs,
+                               db->chain_cap, db->wseg_anc, db->wseg_anc_n);
+    }
     db->n_long = hs.n_long;
     if (hs.n_long) {
         DevTmp<uint32_t> sel, lk, lk2, nsel;
@@ -562,6 +574,6 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     db->stats.tree_updates = hs.upd;
     db->stats.sum_pairs = hs.pairs;
     db->stats.n_segments = db->n_nsegs;
-    db->stats.device_bytes = P * (8 + 4 + 4 + 4 + 4 + 2 + 4) + n_bit_words * 8 + (uint64_t)db->n_nsegs * db->chain_cap * 4 + dev_ht_bytes;
+    db->stats.device_bytes = P * (8 + 4 + 4 + 4 + 4 + 2 + 4) + n_bit_words * 8 + (uint64_t)(db->n_nsegs + (db->wseg_anc != db->nseg_anc ? db->n_wsegs : 0)) * db->chain_cap * 4 + dev_ht_bytes;
     return 0;
 }

@@ -430,6 +430,58 @@ def test_upload_shards_of_a_real_db_sum_to_full_matrix(K, golden_dir, dev, stem,
         K.DeviceDB(K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True), device=dev, prefix_shard=(0, 2))
 
 
+@pytest.mark.parametrize("stem,shards", [("clade64_k25_f01", 2), ("virus_k18", 3), ("clade64", 8)])
+def test_sharded_all2all_sp_from_the_reduced_matrix(K, golden_dir, dev, stem, shards):
+    """BASELINE configs[3] on several GPUs, emulated on one: every prefix-bucket shard (kmdb_db_upload_shard) accumulates its partial
+    matrix on the device, the partial matrices are summed (the RCCL reduce-scatter of bench.py --mode all2all-sp --gpus N), and every
+    rank compacts ITS flat chunk of the triangle with kmdb_sparse_from_dense_device.  The ranks' rows, concatenated, are the reference's
+    all2all_sp output (similarity_calculator.cpp:442-657 + array.h:391-446, console_all2all_sparse.cpp:44-96)."""
+    import torch
+    h = K.HostDB(os.path.join(golden_dir, stem + ".db"))
+    N = h.N
+    cells = N * (N - 1) // 2
+    acc = torch.zeros(cells, dtype=torch.int32, device="cuda:%d" % dev)
+    part = torch.empty_like(acc)
+    d = None
+    for s in range(shards):
+        if d is not None:
+            d.close()
+        d = K.DeviceDB(h, device=dev, prefix_shard=(s, shards))
+        d.all2all_dense_device(part.data_ptr())
+        torch.cuda.synchronize()
+        acc += part
+    lines = open(os.path.join(golden_dir, stem + ".a2a_sp.ref.txt"), "rb").read().split(b"\n")
+    per = (cells + shards - 1) // shards                              # reduce_scatter chunks: equal flat ranges of the triangle
+    got = [b""] * N
+    nnz = 0
+    for r in range(shards):
+        lo, hi = min(cells, r * per), min(cells, (r + 1) * per)
+        chunk = acc[lo:hi].clone() if hi > lo else torch.zeros(1, dtype=torch.int32, device=acc.device)      # the rank's own buffer
+        sp = d.sparse_from_dense_device(chunk.data_ptr(), lo, hi)
+        assert sp.n_rows == N
+        nnz += sp.nnz
+        for i in range(N):
+            c, v = sp.row(i)
+            assert c.size == 0 or (lo <= i * (i - 1) // 2 + int(c[0]) and i * (i - 1) // 2 + int(c[-1]) < hi)
+            got[i] += "".join("%d:%d," % (a + 1, b) for a, b in zip(c, v)).encode()
+    for i in range(N):
+        assert got[i] == lines[i], i
+    full = d.sparse_from_dense_device(acc.data_ptr())
+    assert full.nnz == nnz == int((acc != 0).sum().item())
+    # bounds + measure on the reduced matrix == the single-GPU filtered call
+    cnt = h.sample_kmers.astype(np.uint32)
+    d1 = K.DeviceDB(h, device=dev)
+    flt = [("jaccard", 0.02, None), ("num-kmers", None, 5000.0)]
+    a = d1.all2all_sparse_filtered(flt, cnt, measure="mash")
+    b = d.sparse_from_dense_device(acc.data_ptr(), filters=flt, sample_kmers=cnt, measure="mash")
+    assert a.nnz == b.nnz and np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.col, b.col) and np.array_equal(a.val, b.val)
+    assert np.array_equal(a.measure, b.measure, equal_nan=True)
+    with pytest.raises(K.KmdbError, match="cell_lo > cell_hi"):
+        d.sparse_from_dense_device(acc.data_ptr(), 10, 5)
+    d.close()
+    d1.close()
+
+
 @pytest.mark.parametrize("N,cs,L,k,f,check", [(10000, 50, 400, 18, 1.0, "oracle"), (20000, 50, 1500, 25, 0.1, "oracle"),
                                                (50000, 50, 2000, 25, 0.1, "checksum")])
 def test_baseline_sample_counts_on_the_block_record_pipeline(K, O, dev, tmp_path, N, cs, L, k, f, check):
@@ -666,6 +718,27 @@ def test_bench_secondary_modes(dev, mode):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_driver")):
         assert d["cpu_baseline"]["kind"] == "reference" and "compared equal" in d["cpu_baseline"]["sample"]
+
+
+def test_bench_all2all_sp_two_ranks(dev):
+    """BASELINE configs[3] shape: `bench.py --mode all2all-sp --gpus 2` (two self-started ranks sharing this GPU over gloo): per-rank
+    prefix-bucket shards, reduce of the partial matrices, per-rank compaction of its chunk of the triangle.  Same non-zeros and the same
+    k-mer pair comparisons as the one-rank line on the same genomes (which compares every row with the real reference)."""
+    import json
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "all2all-sp", "--samples", "600", "--steps", "2", "--warmup", "1"]
+    r1 = subprocess.run(base + ["--length", "20000"], capture_output=True, text=True, env=env, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.strip().startswith("{")][0])
+    r2 = subprocess.run(base + ["--length", "10000", "--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    lines = [ln for ln in r2.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["mode"] == "all2all-sp" and d2["config"]["genome_length_bp"] == 20000
+    assert d2["config"]["nnz"] == d1["config"]["nnz"]
+    assert abs(d2["value"] * d2["ms_per_step"] - d1["value"] * d1["ms_per_step"]) / (d1["value"] * d1["ms_per_step"]) < 1e-9
 
 
 def test_new2all_synthetic_scale(K, O, dev, tmp_path):

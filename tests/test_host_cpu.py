@@ -265,10 +265,19 @@ def test_filtered_sparse_call_validates_its_arguments(K):
     cnt = np.ones(4, np.uint32)
     one = (F * 1)(); one[0].metric = 0; one[0].lo = 0.0; one[0].hi = 1.0
     bad = (F * 1)(); bad[0].metric = 99
-    nine = (F * 9)()
+    many = (F * 13)()
     cases = [((None, 1, cnt.ctypes.data, -1), "null argument"), ((one, 1, None, -1), "null argument"), ((None, 0, None, 3), "null argument"),
-             ((one, 1, cnt.ctypes.data, 99), "unknown measure"), ((nine, 9, cnt.ctypes.data, -1), "more than 8"),
+             ((one, 1, cnt.ctypes.data, 99), "unknown measure"), ((many, 13, cnt.ctypes.data, -1), "more than 12"),
              ((bad, 1, cnt.ctypes.data, -1), "unknown metric")]
     for (fl, n, counts, measure), msg in cases:
         rc = L.kmdb_all2all_sparse_filtered(None, fl, n, counts, measure, C.byref(raw), None)
         assert rc != 0 and msg in L.kmdb_last_error().decode(), (msg, L.kmdb_last_error())
+    # every criterion of the reference plus num-kmers (ten bounds) is accepted by the argument check (the call then fails on the null handle)
+    ten = (F * 10)()
+    for i in range(10):
+        ten[i].metric = i % 9; ten[i].lo = 0.0; ten[i].hi = 1.0
+    rc = L.kmdb_all2all_sparse_filtered(None, ten, 10, cnt.ctypes.data, -1, C.byref(raw), None)
+    assert rc != 0 and "null argument" in L.kmdb_last_error().decode()
+    # the compaction of caller-accumulated cells validates the same way, before it touches a device
+    rc = L.kmdb_sparse_from_dense_device(None, None, 0, 0, None, 0, None, -1, C.byref(raw), None)
+    assert rc != 0 and "null argument" in L.kmdb_last_error().decode()
