@@ -82,6 +82,8 @@ struct PoolView {
     uint32_t wsub_cap;             // chunks per sub-pool of the wide pool
     uint32_t dense;
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
+    uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool (key n_states + row) instead
+    uint32_t n_states;             // of the arrival-order pool, so that only the sort inside the rows remains
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
@@ -232,6 +234,78 @@ __device__ __forceinline__ uint32_t wide_weight(uint32_t key, uint32_t kbits, ui
     const uint32_t f = key >> kbits, dig = f & ((1u << dbits) - 1u), j = f >> dbits;
     const uint32_t sh = j * dbits;
     return sh < 32u ? dig << sh : 0u;
+}
+// ---- many streams (row mode): the wide records of block row X go to chunks of their own (CH_REC records, key n_states + X), so they
+// arrive grouped by row and only the sort inside the rows is left.  A wave keeps, per row, the next free slot of its open chunk and
+// the chunk's end in LDS; every lane reserves its slot with ONE LDS atomic (lanes that follow one another with the same row share
+// one): no loop over the rows of a step.  A reservation that runs past the chunk's end is the rare case (once per CH_REC records
+// and row): the row gets fresh chunks and the lanes beyond the end are renumbered.
+struct RowTab { uint32_t* pos; uint32_t* end; uint32_t n; };
+__host__ __device__ inline size_t rowtab_bytes(uint32_t n_rows) { return ((size_t)8 * n_rows + 15) & ~(size_t)15; }
+__device__ __forceinline__ void rowtab_init(RowTab& R, uint32_t* lds, uint32_t n, uint32_t lane) {
+    R.pos = lds; R.end = lds + n; R.n = n;
+    for (uint32_t e = lane; e < 2u * n; e += WAVE) lds[e] = 0u;         // end == 0: no open chunk
+    lds_sync();
+}
+__device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const RowTab& R, bool on, uint32_t X, unsigned long long rows, unsigned long long cols,
+                                         uint32_t w, uint32_t stream, uint32_t lane, unsigned long long lt_mask) {
+    const uint32_t dmask = (1u << pv.dbits) - 1u;
+    uint32_t j = 0;
+    for (;;) {
+        const unsigned long long onm = __ballot(on);
+        if (!onm) break;
+        // runs of consecutive lanes with the same row: the first lane of a run reserves for all of it
+        const uint32_t pX = (uint32_t)__shfl_up((int)X, 1, WAVE);
+        const bool lead = on && (lane == 0u || !((onm >> (lane - 1u)) & 1ull) || pX != X);
+        const unsigned long long leaders = __ballot(lead);
+        uint32_t ll = lane, cnt = 0;
+        if (on) {
+            ll = 63u - (uint32_t)__builtin_clzll(leaders & (lt_mask | (1ull << lane)));
+            const unsigned long long above = ll == 63u ? 0ull : ~((2ull << ll) - 1ull);
+            const unsigned long long after = (leaders | ~onm) & above;
+            cnt = (after ? (uint32_t)__builtin_ctzll(after) : 64u) - ll;
+        }
+        uint32_t old = 0, end = 0;
+        if (lead) { end = R.end[X]; old = atomicAdd(&R.pos[X], cnt); }
+        uint32_t p = (uint32_t)__shfl((int)old, (int)ll, WAVE) + (lane - ll);
+        const uint32_t e = (uint32_t)__shfl((int)end, (int)ll, WAVE);
+        bool ovf = on && p >= e;
+        unsigned long long pend = __ballot(ovf);
+        while (pend) {
+            const uint32_t l0 = (uint32_t)__builtin_ctzll(pend);
+            const uint32_t X0 = bcast(X, l0), e0 = bcast(e, l0);
+            lds_sync();
+            const uint32_t tot = R.pos[X0];                        // after every lane's reservation
+            const uint32_t over = tot - e0;                        // slots needed beyond the open chunk (no open chunk: e0 == 0, positions count from 0)
+            const uint32_t nnew = (over + CH_REC - 1u) >> CH_SHIFT;
+            if (lane == 0 && e0) pv.chunk_fill[(e0 - 1u) >> CH_SHIFT] = CH_REC;
+            const bool mine = ovf && X == X0;
+            const uint32_t qv = p - e0;
+            uint32_t cl = 0;
+            for (uint32_t i = 0; i < nnew; ++i) {
+                cl = arena_take(A, pv, pv.n_states + X0, lane);
+                if (lane == 0 && i + 1u < nnew) pv.chunk_fill[cl] = CH_REC;
+                if (mine && (qv >> CH_SHIFT) == i) p = (cl << CH_SHIFT) | (qv & (CH_REC - 1u));
+            }
+            if (lane == 0) { R.pos[X0] = (cl << CH_SHIFT) + (over - ((nnew - 1u) << CH_SHIFT)); R.end[X0] = (cl << CH_SHIFT) + CH_REC; }
+            lds_sync();
+            ovf = ovf && !mine;
+            pend = __ballot(ovf);
+        }
+        if (on) {
+            ((WideRec*)pv.rec)[p] = WideRec{rows, cols};
+            pv.recw[p] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
+        }
+        w >>= pv.dbits; ++j;
+        on = on && w != 0;
+    }
+}
+__device__ __forceinline__ void rowtab_finish(const RowTab& R, const PoolView& pv, uint32_t lane) {
+    lds_sync();
+    for (uint32_t X = lane; X < R.n; X += WAVE) {
+        const uint32_t e = R.end[X];
+        if (e) pv.chunk_fill[(e - 1u) >> CH_SHIFT] = CH_REC - (e - R.pos[X]);
+    }
 }
 // stream chunks hold the records (X, X, rows) of one block X: 8-byte rows in the first half of the chunk, weights beside
 __device__ __forceinline__ void rec_store_diag(const PoolView& pv, uint32_t slot, unsigned long long rows, uint32_t w) {
@@ -481,7 +555,9 @@ struct NParams {
     PoolView pool;
 };
 constexpr int K1N_WAVES = 4;
-__host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tbits, uint32_t n_states) { return (((size_t)chain_cap * 20 + 15) & ~(size_t)15) + arena_table_bytes(tbits, n_states); }
+__host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tbits, uint32_t n_states, uint32_t n_rows) {
+    return (((size_t)chain_cap * 20 + 15) & ~(size_t)15) + arena_table_bytes(tbits, n_states) + rowtab_bytes(n_rows);          // n_rows: 0 unless row mode
+}
 
 __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -489,11 +565,14 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + wave;            // 1 .. K1N_WAVES waves per workgroup, by the LDS a wave needs
     if (seg >= q.n_segs) return;
-    unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys) * wave;
+    const uint32_t n_rows = q.pool.row_mode ? q.n_keys : 0u;
+    unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys, n_rows) * wave;
     uint32_t* table = (uint32_t*)wbase;                                                      // open chunks
     ulonglong2* chain_m = (ulonglong2*)(wbase + arena_table_bytes(q.tbits, q.n_keys));      // [chain_cap] one slot per depth:
     uint32_t* chain_b = (uint32_t*)(chain_m + q.chain_cap);                                  // the latest node of that depth on the current root path
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    RowTab RT{nullptr, nullptr, 0u};
+    if (n_rows) rowtab_init(RT, (uint32_t*)(wbase + (((size_t)q.chain_cap * 20 + 15) & ~(size_t)15) + arena_table_bytes(q.tbits, q.n_keys)), n_rows, lane);
     const uint32_t first = seg * q.nseg_nodes;
     const uint32_t end = (q.P - first) < q.nseg_nodes ? q.P : first + q.nseg_nodes;
 
@@ -607,6 +686,8 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
                 if (mine) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, w);
                 pend &= ~bc;
             }
+        } else if (n_rows) {
+            row_emit(A, q.pool, RT, d0, w0, F0, F0, w, tri32(w0) + w0, lane, lt_mask);
         } else {
             wide_emit(A, q.pool, d0, F0, F0, w, tri32(w0) + w0, lane, lt_mask);
         }
@@ -615,8 +696,13 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         {
             const bool act2 = act && F1 != 0;
             if (__ballot(act2)) {
-                wide_emit(A, q.pool, act2, F1, F0, w, tri32(w1) + w0, lane, lt_mask);
-                wide_emit(A, q.pool, act2 && __popcll(F1) >= 2, F1, F1, w, tri32(w1) + w1, lane, lt_mask);
+                if (n_rows) {
+                    row_emit(A, q.pool, RT, act2, w1, F1, F0, w, tri32(w1) + w0, lane, lt_mask);
+                    row_emit(A, q.pool, RT, act2 && __popcll(F1) >= 2, w1, F1, F1, w, tri32(w1) + w1, lane, lt_mask);
+                } else {
+                    wide_emit(A, q.pool, act2, F1, F0, w, tri32(w1) + w0, lane, lt_mask);
+                    wide_emit(A, q.pool, act2 && __popcll(F1) >= 2, F1, F1, w, tri32(w1) + w1, lane, lt_mask);
+                }
             }
         }
         // ---- chain slots for the next batch: the nodes on the root path of this batch's last node, i.e. the
@@ -635,6 +721,7 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         }
     }
     arena_finish(A, q.pool, lane);
+    if (n_rows) rowtab_finish(RT, q.pool, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -711,6 +798,7 @@ struct WParams {
     uint32_t seg_words;            // 64-node words of the DFS stream per run
     uint32_t n_words, n_runs, n_waves;
     uint32_t chain_cap, arena_cap, e_cap;
+    uint32_t n_rows;               // row mode: block rows (0 otherwise)
     uint32_t emit_lo, emit_hi;
     PoolView pool;
 };
@@ -738,9 +826,12 @@ struct K1WLds {
     uint16_t* st_start;            // [64] first arena entry of the lane's row
     unsigned char* own_base;       // [64] WB_*
 };
-__host__ __device__ inline size_t k1w_wave_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
+__host__ __device__ inline size_t k1w_core_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
     const size_t b = (size_t)8 * (arena_cap + e_cap + chain_cap + 64) + (size_t)4 * (chain_cap + 3 * 64 + K1W_QCAP) + (size_t)2 * (arena_cap + e_cap + chain_cap + 5 * 64) + 64;
     return (b + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t k1w_wave_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap, uint32_t n_rows) {
+    return k1w_core_bytes(arena_cap, e_cap, chain_cap) + rowtab_bytes(n_rows);
 }
 __device__ __forceinline__ K1WLds k1w_carve(unsigned char* p, uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
     K1WLds L;
@@ -770,7 +861,10 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + wave;         // 1 or K1W_WAVES waves per workgroup, by the LDS a wave needs
     if (wid >= q.n_waves) return;
-    const K1WLds L = k1w_carve(lds_raw + k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap) * wave, q.arena_cap, q.e_cap, q.chain_cap);
+    unsigned char* wbase = lds_raw + k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap, q.n_rows) * wave;
+    const K1WLds L = k1w_carve(wbase, q.arena_cap, q.e_cap, q.chain_cap);
+    RowTab RT{nullptr, nullptr, 0u};
+    if (q.n_rows) rowtab_init(RT, (uint32_t*)(wbase + k1w_core_bytes(q.arena_cap, q.e_cap, q.chain_cap)), q.n_rows, lane);
     auto iswide = [&](uint32_t y) -> bool { return (q.widebits[y >> 6] >> (y & 63u)) & 1ull; };
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     WaveArena A;
@@ -795,7 +889,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 for (uint32_t t0 = 0; t0 < Tj; t0 += WAVE) {
                     const uint32_t t = t0 + lane;
                     bool rec_on = false;
-                    uint32_t stream = 0;
+                    uint32_t stream = 0, X = 0;
                     unsigned long long FX = 0, FY = 0;
                     if (t < Tj) {
                         uint32_t a = (uint32_t)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -803,12 +897,14 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                         while (tri32(a + 1u) <= t) ++a;
                         const uint32_t b = t - tri32(a);
                         FX = cmask[a]; FY = cmask[b];
-                        const uint32_t X = cblk[a], Y = cblk[b];
+                        X = cblk[a];
+                        const uint32_t Y = cblk[b];
                         rec_on = a != b || __popcll(FX) >= 2;
                         if (a == b) FY = FX;
                         stream = tri32(X) + Y;
                     }
-                    wide_emit(A, q.pool, rec_on, FX, FY, wj, stream, lane, lt_mask);
+                    if (q.n_rows) row_emit(A, q.pool, RT, rec_on, X, FX, FY, wj, stream, lane, lt_mask);
+                    else wide_emit(A, q.pool, rec_on, FX, FY, wj, stream, lane, lt_mask);
                 }
             }
             on = on && m < K1W_HEAVY;
@@ -840,21 +936,24 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             for (uint32_t t0 = q0; t0 < tend; t0 += WAVE) {
                 const uint32_t t = t0 + lane;
                 bool rec_on = false, diag = false;
-                uint32_t stream = 0, ww = 0;
+                uint32_t stream = 0, ww = 0, X = 0;
                 unsigned long long FX = 0, FY = 0;
                 if (t < tend) {
                     const uint32_t d = L.queue[t - q0];
                     const uint32_t own = d & 63u, a = (d >> 6) & 0x1FFFu, b = d >> 19;
                     const uint32_t st = L.st_start[own];
                     FX = L.ent_mask[st + a]; FY = L.ent_mask[st + b];
-                    const uint32_t X = L.ent_blk[st + a], Y = L.ent_blk[st + b];
+                    X = L.ent_blk[st + a];
+                    const uint32_t Y = L.ent_blk[st + b];
                     ww = L.st_w[own];
                     diag = a == b;
                     rec_on = !diag || __popcll(FX) >= 2;           // a diagonal record needs two ids to have a pair
                     stream = tri32(X) + Y;
                 }
-                // the step's records go to the wide pool in arrival order: one reservation for all lanes
-                wide_emit(A, q.pool, rec_on, FX, diag ? FX : FY, ww, stream, lane, lt_mask);
+                // few streams: the step's records go to the wide pool in arrival order (one reservation for all lanes); many: to
+                // the chunks of their block rows
+                if (q.n_rows) row_emit(A, q.pool, RT, rec_on, X, FX, diag ? FX : FY, ww, stream, lane, lt_mask);
+                else wide_emit(A, q.pool, rec_on, FX, diag ? FX : FY, ww, stream, lane, lt_mask);
             }
             lds_sync();
         }
@@ -1043,6 +1142,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
         }
     }
     arena_finish(A, q.pool, lane);
+    if (q.n_rows) rowtab_finish(RT, q.pool, lane);
     if (lane == 0 && n_miss) atomicAdd(&q.pool.counters[KCTR_SLOW], n_miss);
 }
 
@@ -1449,6 +1549,164 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
     }
 }
 
+// ---- the chunk table grouped by key (stream chunks [0, n_states), row chunks n_states + row; n_keys = never opened) without a general
+// sort: histogram with device atomics (hundreds of thousands of chunks spread over thousands of counters: no hot address), scan,
+// scatter.  The order of the chunks inside a key is arbitrary (uint32 adds commute).
+__global__ void ct_hist_kernel(const uint32_t* __restrict__ chunk_key, uint32_t n, uint32_t n_keys, uint32_t* __restrict__ hist) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = chunk_key[i];
+    if (k < n_keys) atomicAdd(&hist[k], 1u);
+}
+__global__ void ct_scatter_kernel(const uint32_t* __restrict__ chunk_key, uint32_t n, uint32_t n_keys, uint32_t* __restrict__ cursor,
+                                  uint32_t* __restrict__ sorted_key, uint32_t* __restrict__ sorted_id) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = chunk_key[i];
+    if (k >= n_keys) return;
+    const uint32_t o = atomicAdd(&cursor[k], 1u);
+    sorted_key[o] = k; sorted_id[o] = i;
+}
+// stream chunks in use, slots of the sorted chunk table in use
+__global__ void ct_count_kernel(const uint32_t* __restrict__ ct_offs, uint32_t n_states, uint32_t n_keys, uint32_t* __restrict__ counters) {
+    counters[KCTR_CHUNKS] = ct_offs[n_states];
+    counters[KCTR_RAW] = ct_offs[n_keys] - ct_offs[n_states];          // row chunks
+}
+
+// ---- many streams: the sort inside the block rows.  Row X's records sit in the chunks [ct_offs[n_states + X], ct_offs[n_states + X + 1])
+// of the grouped chunk table, cut into jobs of RS_JOB_CHUNKS chunks, one workgroup each; bins = the row's X + 1 streams.  Counting sort
+// as above (LDS histograms per job, one scan over [row][stream][job], LDS-staged scatter), reading through the chunk table, writing
+// the dense sorted arrays k2_sorted_kernel walks.
+constexpr uint32_t RS_JOB_CHUNKS = 64;
+__global__ void rs_rows_kernel(const uint32_t* __restrict__ ct_offs, uint32_t n_states, uint32_t NB, uint32_t* __restrict__ row_job, uint32_t* __restrict__ row_tab,
+                               uint32_t* __restrict__ counters) {
+    __shared__ uint32_t s_job[1024], s_tab[1024];
+    // jobs and table entries of every row, then two block-wide exclusive scans (NB may be a few thousand)
+    uint32_t cj = 0, ct = 0;
+    for (uint32_t base = 0; base < NB; base += 1024) {
+        const uint32_t X = base + threadIdx.x;
+        uint32_t nj = 0;
+        if (X < NB) nj = (ct_offs[n_states + X + 1] - ct_offs[n_states + X] + RS_JOB_CHUNKS - 1u) / RS_JOB_CHUNKS;
+        s_job[threadIdx.x] = nj; s_tab[threadIdx.x] = X < NB ? nj * (X + 1u) : 0u;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t a = threadIdx.x >= d ? s_job[threadIdx.x - d] : 0u, b = threadIdx.x >= d ? s_tab[threadIdx.x - d] : 0u;
+            __syncthreads();
+            s_job[threadIdx.x] += a; s_tab[threadIdx.x] += b;
+            __syncthreads();
+        }
+        if (X < NB) { row_job[X] = cj + s_job[threadIdx.x] - nj; row_tab[X] = ct + s_tab[threadIdx.x] - nj * (X + 1u); }
+        cj += s_job[1023]; ct += s_tab[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { row_job[NB] = cj; row_tab[NB] = ct; counters[KCTR_ROWJOBS] = cj; }
+}
+struct RsJob { uint32_t X, c, nj, cb, ce, tab; };
+__device__ __forceinline__ bool rs_job(const uint32_t* __restrict__ ct_offs, uint32_t n_states, uint32_t NB, const uint32_t* __restrict__ row_job,
+                                       const uint32_t* __restrict__ row_tab, RsJob& j) {
+    if (blockIdx.x >= row_job[NB]) return false;
+    uint32_t a = 0, b = NB;                                  // last row whose first job is <= this one (rows without jobs share their successor's first job)
+    while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if (row_job[mid] <= blockIdx.x) a = mid; else b = mid; }
+    j.X = a; j.c = blockIdx.x - row_job[a]; j.nj = row_job[a + 1] - row_job[a];
+    j.cb = ct_offs[n_states + a] + j.c * RS_JOB_CHUNKS;
+    const uint32_t re = ct_offs[n_states + a + 1];
+    j.ce = re - j.cb > RS_JOB_CHUNKS ? j.cb + RS_JOB_CHUNKS : re;
+    j.tab = row_tab[a] + j.c;
+    return true;
+}
+__global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ ct_offs, uint32_t n_states, uint32_t NB, const uint32_t* __restrict__ row_job,
+                                                     const uint32_t* __restrict__ row_tab, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ chunk_fill,
+                                                     const uint32_t* __restrict__ recw, uint32_t kmask, uint32_t* __restrict__ H) {
+    extern __shared__ uint32_t cs_lds[];
+    RsJob j;
+    if (!rs_job(ct_offs, n_states, NB, row_job, row_tab, j)) return;
+    const uint32_t nb = j.X + 1u, sub = tri32(j.X);
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) cs_lds[k] = 0;
+    __syncthreads();
+    for (uint32_t ch = j.cb; ch < j.ce; ++ch) {
+        const uint32_t id = sorted_id[ch];
+        if (threadIdx.x < chunk_fill[id]) {
+            const uint32_t bin = (recw[((size_t)id << CH_SHIFT) + threadIdx.x] & kmask) - sub;
+            if (bin < nb) atomicAdd(&cs_lds[bin], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) H[(size_t)j.tab + (size_t)k * j.nj] = cs_lds[k];
+}
+__global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ ct_offs, uint32_t n_states, uint32_t NB, const uint32_t* __restrict__ row_job,
+                                                         const uint32_t* __restrict__ row_tab, const uint32_t* __restrict__ sorted_id,
+                                                         const uint32_t* __restrict__ chunk_fill, const uint32_t* __restrict__ recw, const WideRec* __restrict__ rec,
+                                                         uint32_t kmask, const uint32_t* __restrict__ O, uint32_t cap, uint32_t* __restrict__ swkey,
+                                                         WideRec* __restrict__ swrec, uint32_t* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
+    RsJob job;
+    if (!rs_job(ct_offs, n_states, NB, row_job, row_tab, job)) return;
+    const uint32_t nb = job.X + 1u, sub = tri32(job.X);
+    WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
+    uint32_t* st_dst = (uint32_t*)(st_rec + CS_TILE);                     // [CS_TILE] global destination
+    uint32_t* st_key = st_dst + CS_TILE;                                  // [CS_TILE]
+    uint32_t* hist = st_key + CS_TILE;                                    // [nb] records of the tile per bin
+    uint32_t* toff = hist + NB;                                           // [nb] first staging position of the bin
+    uint32_t* cursor = toff + NB;                                         // [nb] next global position of the bin for this workgroup
+    uint32_t* part = cursor + NB;                                         // [CS_THREADS] scan scratch
+    for (uint32_t k = threadIdx.x; k < nb; k += CS_THREADS) cursor[k] = O[(size_t)job.tab + (size_t)k * job.nj];
+    constexpr uint32_t PER = CS_TILE / CH_REC;                            // chunks per tile: thread t takes slot t of each
+    static_assert(CH_REC == CS_THREADS, "a chunk per pass of the workgroup");
+    const uint32_t kper = (nb + CS_THREADS - 1u) / CS_THREADS;
+    for (uint32_t t0 = job.cb; t0 < job.ce; t0 += PER) {
+        for (uint32_t k = threadIdx.x; k < nb; k += CS_THREADS) hist[k] = 0;
+        __syncthreads();
+        uint32_t key[PER], kw[PER], rank[PER], slot[PER];
+#pragma unroll
+        for (uint32_t jj = 0; jj < PER; ++jj) {
+            const uint32_t ch = t0 + jj;
+            key[jj] = 0xFFFFFFFFu; kw[jj] = 0xFFFFFFFFu; rank[jj] = 0; slot[jj] = 0;
+            if (ch < job.ce) {
+                const uint32_t id = sorted_id[ch];
+                if (threadIdx.x < chunk_fill[id]) {
+                    slot[jj] = (id << CH_SHIFT) + threadIdx.x;
+                    kw[jj] = recw[slot[jj]];
+                    key[jj] = (kw[jj] & kmask) - sub;
+                    if (key[jj] < nb) rank[jj] = atomicAdd(&hist[key[jj]], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t sum = 0;
+        for (uint32_t k = threadIdx.x * kper; k < nb && k < (threadIdx.x + 1u) * kper; ++k) sum += hist[k];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t d = 1; d < CS_THREADS; d <<= 1) {
+            const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = part[threadIdx.x] - sum;
+        for (uint32_t k = threadIdx.x * kper; k < nb && k < (threadIdx.x + 1u) * kper; ++k) { toff[k] = run; run += hist[k]; }
+        __syncthreads();
+        const uint32_t tile_n = part[CS_THREADS - 1];
+#pragma unroll
+        for (uint32_t jj = 0; jj < PER; ++jj) {
+            if (key[jj] < nb) {
+                const uint32_t pp = toff[key[jj]] + rank[jj];
+                st_rec[pp] = rec[slot[jj]];
+                st_dst[pp] = cursor[key[jj]] + rank[jj];
+                st_key[pp] = kw[jj];
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nb; k += CS_THREADS) cursor[k] += hist[k];
+        for (uint32_t pp = threadIdx.x; pp < tile_n; pp += CS_THREADS) {
+            const uint32_t d = st_dst[pp];
+            if (d < cap) { swrec[d] = st_rec[pp]; swkey[d] = st_key[pp]; }
+            else atomicOr(&counters[KCTR_WIDE_OVERFLOW], 1u);            // the sorted arrays are too small: the call is repeated with larger ones
+        }
+        __syncthreads();
+    }
+}
+__host__ __device__ inline size_t rs_scatter_lds(uint32_t NB) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)NB * 12 + CS_THREADS * 4 + 64; }
+
 // K2 over records sorted by stream (dense mode): a window of K2S_WIN sorted positions, one 64 x 64 tile per run of equal streams
 constexpr uint32_t K2S_WIN = 4096;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
@@ -1634,7 +1892,7 @@ inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits)};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -1645,8 +1903,8 @@ struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) 
 struct ValidKey { uint32_t n_states, kmask; __host__ __device__ uint32_t operator()(uint32_t k) const { return (k & kmask) < n_states ? 1u : 0u; } };
 
 int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
-    FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota);
-    FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->sort_tmp);
+    FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id);
+    FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->sort_tmp); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs); FREE_NULL(db->rs_tmp);
     db->pool_cap = 0;
     chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB);
     if (chunks >= (1ull << 31) >> CH_SHIFT) return kmdb_set_error("kmdb: record pool would exceed 2^31 record slots");
@@ -1654,44 +1912,44 @@ int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipMalloc((void**)&db->chunk_fill, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->sorted_key, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->sorted_id, chunks * 4));
-    HIP_TRY(hipMalloc((void**)&db->chunk_iota, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->rec, (chunks << CH_SHIFT) * 16));
     HIP_TRY(hipMalloc((void**)&db->recw, (chunks << CH_SHIFT) * 4));
-    hipLaunchKernelGGL(iota_u32_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, db->stream, db->chunk_iota, (uint32_t)chunks);
-    int key_bits = 1;
-    while ((1ull << key_bits) <= (uint64_t)db->n_states + 1) ++key_bits;          // streams; n_states = never opened; all-ones = never written
-    db->key_bits = key_bits;
-    size_t tb = 0, tb2 = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id, (int)chunks, 0, key_bits, db->stream));
     {
         hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
-        HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, tb2, it, (unsigned long long*)nullptr, (int)chunks, db->stream));
+        HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, db->sort_tmp_bytes, it, (unsigned long long*)nullptr, (int)chunks, db->stream));
     }
-    db->sort_tmp_bytes = std::max(tb, tb2);
     HIP_TRY(hipMalloc(&db->sort_tmp, std::max<size_t>(db->sort_tmp_bytes, 16)));
+    if (db->row_mode) {
+        // the sort inside the rows: at most chunks / RS_JOB_CHUNKS + NB jobs, every one with at most NB bins
+        db->rs_entries = (chunks / RS_JOB_CHUNKS + db->NB + 1) * (uint64_t)db->NB + 1;
+        if (db->rs_entries >= (1ull << 31)) return kmdb_set_error("kmdb: the table of the sort inside the block rows would exceed 2^31 entries");
+        HIP_TRY(hipMalloc((void**)&db->rs_hist, db->rs_entries * 4));
+        HIP_TRY(hipMalloc((void**)&db->rs_offs, db->rs_entries * 4));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->rs_tmp_bytes, db->rs_hist, db->rs_offs, (int)db->rs_entries, db->stream));
+        HIP_TRY(hipMalloc(&db->rs_tmp, std::max<size_t>(db->rs_tmp_bytes, 16)));
+    }
     db->pool_cap = chunks;
     return 0;
 }
-// the wide pool: records in arrival order + their stream keys, and the sorted copies
+// few streams: the wide pool (records in arrival order + their stream keys) and the sorted copies; many streams (row mode): the
+// sorted arrays only — the wide records travel through row chunks of the chunk pool
 int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp);
-    db->wide_pool_cap = 0;
+    db->wide_pool_cap = 0; db->sorted_cap = 0;
     chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * WIDE_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * WIDE_GRAB) * ((uint64_t)KMDB_SUBPOOLS * WIDE_GRAB);
     const uint64_t slots = chunks << WCH_SHIFT;
     if (slots >= (1ull << 31)) return kmdb_set_error("kmdb: wide record pool would exceed 2^31 record slots");
-    HIP_TRY(hipMalloc((void**)&db->wkey, slots * 4));
-    HIP_TRY(hipMalloc(&db->wrec, slots * sizeof(WideRec)));
     HIP_TRY(hipMalloc((void**)&db->swkey, slots * 4));
     HIP_TRY(hipMalloc(&db->swrec, slots * sizeof(WideRec)));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, db->sort2_tmp_bytes, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)slots, 0, db->key_bits,
-                                               db->stream));
-    HIP_TRY(hipMalloc(&db->sort2_tmp, std::max<size_t>(db->sort2_tmp_bytes, 16)));
-    if ((db->n_states <= CS_MAX_KEYS || db->NB <= CS_MAX_ROWS) && !db->cs_hist) {
-        // one pass: [stream][workgroup]; two passes: [row][workgroup], then per row [stream of the row][chunk of the row]
-        const size_t ne = db->n_states <= CS_MAX_KEYS ? (size_t)db->n_states * CS_BLOCKS_ONE + 1 : (size_t)(2 * CS_BLOCKS + db->NB + 2) * db->NB + 1;
+    db->sorted_cap = slots;
+    if (db->row_mode) { db->wide_pool_cap = chunks; return 0; }
+    HIP_TRY(hipMalloc((void**)&db->wkey, slots * 4));
+    HIP_TRY(hipMalloc(&db->wrec, slots * sizeof(WideRec)));
+    if (!db->cs_hist) {
+        // one pass: [stream][workgroup]
+        const size_t ne = (size_t)db->n_states * CS_BLOCKS_ONE + 1;
         HIP_TRY(hipMalloc((void**)&db->cs_hist, ne * 4));
         HIP_TRY(hipMalloc((void**)&db->cs_offs, ne * 4));
-        HIP_TRY(hipMalloc((void**)&db->cs_rows, (size_t)3 * (db->NB + 1) * 4));
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->cs_tmp_bytes, db->cs_hist, db->cs_offs, (int)ne, db->stream));
         HIP_TRY(hipMalloc(&db->cs_tmp, std::max<size_t>(db->cs_tmp_bytes, 16)));
     }
@@ -1879,7 +2137,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2;          // streams = block pairs
     if (n_states + 1 >= (1ull << 22)) { db->fallback_reason = "too many block pairs"; return 0; }          // 22 stream bits + 8-bit weight digits in a key word
     db->n_states = (uint32_t)n_states;
-    if (k1w_wave_bytes(std::max<uint32_t>(512u, (db->NB + 2u + 63u) & ~63u), (db->NB + 2u + 3u) & ~3u, db->chain_cap) > (size_t)(152u << 10)) {
+    if (k1w_wave_bytes(std::max<uint32_t>(512u, (db->NB + 2u + 63u) & ~63u), (db->NB + 2u + 3u) & ~3u, db->chain_cap, db->NB) > (size_t)(152u << 10)) {
         db->fallback_reason = "the lists of the wide-node kernel do not fit the LDS (" + std::to_string(db->NB) + " blocks, root paths of up to " +
                               std::to_string(db->max_depth) + " nodes)";
         return 0;
@@ -1918,17 +2176,48 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     }
     HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->wsub_cursor, KMDB_SUBPOOLS * 16 * 4));
-    // The nodes with many blocks scatter their records over many streams, a few per stream and wave: the wide kernel writes them
-    // in arrival order into its own pool and a device-wide sort groups them (measured: 5 x faster than per-stream reservations).
-    // The narrow kernel keeps per-stream chunks: its records follow the clustering of the DFS stream.  With more streams than its
-    // open-chunk table holds it switches to the wide pool too, if its chunks turn out to be evicted nearly empty.
+    // Where the records go.  The narrow kernel's first-block diagonal records follow the clustering of the DFS stream: per-stream
+    // chunks (an open chunk per block and wave), applied straight from the grouped chunk table.  The other records spread over
+    // many streams, a few per stream and wave:
+    //   few streams (<= CS_MAX_KEYS):  arrival order into the wide pool, ONE counting-sort pass by stream (measured: 5 x faster than
+    //                                  per-stream reservations);
+    //   many streams ("row mode"):     per-BLOCK-ROW chunks (an open chunk per row and wave, slots by LDS atomics), so the records
+    //                                  arrive grouped by row and only the counting sort inside the rows remains (a scatter straight
+    //                                  to 20 100 streams is bound by the number of write requests: measured 25.8 ms for 495 M records;
+    //                                  grouping by row in a pass of its own cost another 7.5 ms).
+    // With more streams than the narrow kernel's open-chunk table holds it sends its diagonal records the same way, if its chunks turn
+    // out to be evicted nearly empty.
     db->dense_wide = true;
     db->dense_narrow = false;
     if (const char* e = getenv("KMDB_DENSE")) db->dense_narrow = atoi(e) >= 2;
+    db->row_mode = db->n_states > CS_MAX_KEYS;
+    if (const char* e = getenv("KMDB_ROW_MODE")) if (*e) db->row_mode = atoi(e) != 0;          // (tests: small databases through the many-streams path)
+    db->n_ckeys = db->n_states + (db->row_mode ? db->NB : 0u);
+    {
+        int key_bits = 1;
+        while ((1ull << key_bits) <= (uint64_t)db->n_states + 1) ++key_bits;          // streams; all-ones = never written
+        db->key_bits = key_bits;
+    }
+    HIP_TRY(hipMalloc((void**)&db->ct_hist, ((size_t)db->n_ckeys + 2) * 4));
+    HIP_TRY(hipMalloc((void**)&db->ct_offs, ((size_t)db->n_ckeys + 2) * 4));
+    HIP_TRY(hipMalloc((void**)&db->ct_cursor, ((size_t)db->n_ckeys + 2) * 4));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->ct_tmp_bytes, db->ct_hist, db->ct_offs, (int)(db->n_ckeys + 1), db->stream));
+    HIP_TRY(hipMalloc(&db->ct_tmp, std::max<size_t>(db->ct_tmp_bytes, 16)));
+    // waves of the wide-node kernel: in row mode every wave may end with an open chunk per block row
+    db->k1w_waves = std::min<uint32_t>(K1W_MAX_WAVES, std::max<uint32_t>(1u, db->n_wsegs));
+    if (db->row_mode) {
+        db->k1w_waves = std::min<uint32_t>(db->k1w_waves, std::max<uint32_t>(256u, std::min<uint32_t>(4096u, (1u << 21) / std::max<uint32_t>(db->NB, 1u))));
+        HIP_TRY(hipMalloc((void**)&db->rs_rows, (size_t)2 * (db->NB + 1) * 4));
+    }
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
-    // unfinished grab); wide pool: the wide estimate and a grab per wave
-    if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
-    if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1W_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;
+    // unfinished grab); wide records: the wide estimate at two thirds (+ a grab / the open row chunks per wave)
+    if (db->row_mode) {
+        if (alloc_record_pool(db, (est_n + est_g) * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
+        if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + 4096)) return 1;
+    } else {
+        if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
+        if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1W_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;
+    }
     return 0;
 }
 
@@ -1939,14 +2228,16 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->sorted_id); FREE_NULL(db->chunk_iota); FREE_NULL(db->sort_tmp);
     FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_rows); FREE_NULL(db->cs_tmp);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
+    FREE_NULL(db->ct_hist); FREE_NULL(db->ct_offs); FREE_NULL(db->ct_cursor); FREE_NULL(db->ct_tmp); FREE_NULL(db->rs_rows); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs);
+    FREE_NULL(db->rs_tmp);
     if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
     db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
 }
 
 uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
     if (!db->counters) return 0;
-    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 20 + db->wide_cap * 4 + (db->P / 64) * 16 +
-           (db->wide_pool_cap << WCH_SHIFT) * 40;
+    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 16 + db->wide_cap * 4 + (db->P / 64) * 16 +
+           (db->wide_pool_cap << WCH_SHIFT) * (db->row_mode ? 20 : 40) + db->rs_entries * 8 + (uint64_t)db->n_ckeys * 12;
 }
 
 namespace {
@@ -1966,17 +2257,20 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     const BlockMap bm{db->width, (uint32_t)((1ull << 32) / db->width) + 1u};
     const uint32_t n_words = (P + 63) / 64;
     const uint32_t pool_cap = (uint32_t)db->pool_cap;
+    const bool row_mode = db->row_mode;
+    const uint32_t n_ckeys = db->n_ckeys;
     HIP_TRY(hipMemsetAsync(db->counters, 0, KCTR_COUNT * 4, st));
     HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, (KMDB_PAIR_REGIONS + 1) * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->sub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->wsub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
-    {
+    if (!row_mode) {
         // never-written slots of the wide pool sort last; only the part the previous call used has to be reset
         const uint64_t wslots = db->have_counts ? std::min<uint64_t>((uint64_t)db->last_n_raw << WCH_SHIFT, db->wide_pool_cap << WCH_SHIFT) : db->wide_pool_cap << WCH_SHIFT;
         HIP_TRY(hipMemsetAsync(db->wkey, 0xFF, wslots * 4, st));
     }
     HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, st));
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, st, db->chunk_key, pool_cap, db->n_states);
+    HIP_TRY(hipMemsetAsync(db->ct_hist, 0, ((size_t)n_ckeys + 2) * 4, st));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, st, db->chunk_key, pool_cap, n_ckeys);
     if (stage("init")) return 1;
     // ---- K0
     {
@@ -2009,7 +2303,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.all_wide = db->dense_narrow ? 1u : 0u;
         q.pool = pool_view(db, db->dense_narrow);
         // a wave's chain table grows with the depth of the tree: as many waves per workgroup as 144 KB of LDS hold
-        const size_t wave_lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys);
+        const size_t wave_lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys, row_mode ? db->NB : 0u);
         const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(K1N_WAVES, (144u << 10) / wave_lds));
         const size_t lds = wave_lds * waves;
         HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2018,18 +2312,22 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     }
     if (stage("narrow emit")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[1], st));
-    // ---- on the side stream, next to the wide kernel: the stream chunks (all written by now) sorted by stream and applied
     hipStream_t s2 = db->stream2;
-    HIP_TRY(hipEventRecord(db->ev_side[0], st));
-    HIP_TRY(hipStreamWaitEvent(s2, db->ev_side[0], 0));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort_tmp, db->sort_tmp_bytes, db->chunk_key, db->sorted_key, db->chunk_iota, db->sorted_id,
-                                               (int)pool_cap, 0, db->key_bits, s2));
-    hipLaunchKernelGGL(count_chunks_kernel, dim3(1), dim3(1), 0, s2, db->sorted_key, pool_cap, db->n_states, db->counters);
-    {
-        hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
-        HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
-    }
-    {
+    // The chunk table grouped by key (on stream `cs`), then on the side stream the stream chunks applied.  Few streams: right here,
+    // next to the wide kernel (which writes no chunks).  Many streams: after the wide kernel (it writes the row chunks), next to
+    // the sort inside the rows.
+    auto group_and_apply_chunks = [&](hipStream_t cs) -> int {
+        hipLaunchKernelGGL(ct_hist_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, cs, db->chunk_key, pool_cap, n_ckeys, db->ct_hist);
+        size_t tb = db->ct_tmp_bytes;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->ct_tmp, tb, db->ct_hist, db->ct_offs, (int)(n_ckeys + 1), cs));
+        HIP_TRY(hipMemcpyAsync(db->ct_cursor, db->ct_offs, ((size_t)n_ckeys + 1) * 4, hipMemcpyDeviceToDevice, cs));
+        hipLaunchKernelGGL(ct_scatter_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, cs, db->chunk_key, pool_cap, n_ckeys, db->ct_cursor, db->sorted_key, db->sorted_id);
+        hipLaunchKernelGGL(ct_count_kernel, dim3(1), dim3(1), 0, cs, db->ct_offs, db->n_states, n_ckeys, db->counters);
+        if (cs != s2) { HIP_TRY(hipEventRecord(db->ev_side[0], cs)); HIP_TRY(hipStreamWaitEvent(s2, db->ev_side[0], 0)); }
+        {
+            hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
+            HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
+        }
         const uint32_t win = db->n_states <= CS_MAX_KEYS ? K2_WIN / 2 : K2_WIN;
         uint32_t grid = (pool_cap + win - 1) / win;
         if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + win - 1) / win);
@@ -2037,9 +2335,15 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, s2, db->rec, db->recw, db->sorted_key, db->sorted_id, db->chunk_fill, db->n_states,
                                pool_cap, M, (uint32_t)db->N, db->width, win);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(db->ev_side[1], s2));
+        if (sync_debug) { const hipError_t e = hipStreamSynchronize(s2); fprintf(stderr, "[kmdb] stage %-14s %s\n", "chunk apply", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
+        return 0;
+    };
+    if (!row_mode) {
+        HIP_TRY(hipEventRecord(db->ev_side[0], st));
+        HIP_TRY(hipStreamWaitEvent(s2, db->ev_side[0], 0));
+        if (group_and_apply_chunks(s2)) return 1;
     }
-    HIP_TRY(hipEventRecord(db->ev_side[1], s2));
-    if (sync_debug) { const hipError_t e = hipStreamSynchronize(s2); fprintf(stderr, "[kmdb] stage %-14s %s\n", "chunk apply", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
     // ---- wide list
     hipLaunchKernelGGL(wide_count_kernel, dim3((n_words + 1 + 255) / 256), dim3(256), 0, st, db->widebits, n_words, db->wide_cnt);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->scan_tmp, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1), st));
@@ -2066,11 +2370,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
         q.seg_anc = db->wseg_anc; q.seg_anc_n = db->wseg_anc_n; q.seg_words = db->wseg_nodes / 64u; q.n_words = n_words; q.n_runs = db->n_wsegs;
-        q.n_waves = std::min<uint32_t>(K1W_MAX_WAVES, q.n_runs);
-        if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(q.n_runs, (uint32_t)atoi(e)));
+        q.n_waves = db->k1w_waves;
+        if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(q.n_waves, (uint32_t)atoi(e)));
         // LDS of a wave: rows of a batch (at least one full list: as many entries as there are blocks), the chain list, the chain
         q.chain_cap = db->chain_cap; q.e_cap = (db->NB + 2u + 3u) & ~3u; q.arena_cap = std::max<uint32_t>(512u, (db->NB + 2u + 63u) & ~63u);
-        const size_t wave_lds = k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap);
+        q.n_rows = row_mode ? db->NB : 0u;
+        const size_t wave_lds = k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap, q.n_rows);
         const uint32_t waves = wave_lds * K1W_WAVES <= (size_t)(64u << 10) ? (uint32_t)K1W_WAVES : 1u;
         HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
         hipLaunchKernelGGL(k1w_kernel, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
@@ -2078,8 +2383,35 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     HIP_TRY(hipGetLastError());
     if (stage("wide emit")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[2], st));
-    hipLaunchKernelGGL(count_raw_kernel, dim3(1), dim3(1), 0, st, db->wsub_cursor, db->counters);
-    {
+    const uint32_t kmask = (1u << db->key_bits) - 1u;
+    if (row_mode) {
+        // ---- many streams: chunk table grouped (stream chunks -> side stream), then the sort inside the block rows and its apply
+        if (group_and_apply_chunks(st)) return 1;
+        const uint32_t NB = db->NB;
+        uint32_t* row_job = db->rs_rows, *row_tab = db->rs_rows + (NB + 1);
+        hipLaunchKernelGGL(rs_rows_kernel, dim3(1), dim3(1024), 0, st, db->ct_offs, db->n_states, NB, row_job, row_tab, db->counters);
+        // jobs and table entries: measured by the previous call, else their upper bounds (workgroups beyond the last job leave at once)
+        const uint32_t jobs = db->have_counts ? std::max<uint32_t>(db->last_n_rowjobs, 1u) : (uint32_t)(pool_cap / RS_JOB_CHUNKS + NB + 1);
+        const size_t ne = std::min<size_t>(db->rs_entries, (size_t)jobs * NB + 1);
+        HIP_TRY(hipMemsetAsync(db->rs_hist, 0, ne * 4, st));
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(jobs), dim3(256), NB * 4, st, db->ct_offs, db->n_states, NB, row_job, row_tab, db->sorted_id, db->chunk_fill, db->recw, kmask,
+                           db->rs_hist);
+        size_t tb = db->rs_tmp_bytes;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->rs_tmp, tb, db->rs_hist, db->rs_offs, (int)ne, st));
+        const uint32_t* total_ptr = db->rs_offs + (ne - 1);
+        HIP_TRY(hipFuncSetAttribute((const void*)rs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds(NB)));
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(jobs), dim3(CS_THREADS), rs_scatter_lds(NB), st, db->ct_offs, db->n_states, NB, row_job, row_tab, db->sorted_id, db->chunk_fill,
+                           db->recw, (const WideRec*)db->rec, kmask, db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters);
+        HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
+        const uint32_t nsorted = db->have_counts ? db->last_n_sorted : (uint32_t)db->sorted_cap;
+        const uint32_t g2 = (nsorted + K2S_WIN - 1) / K2S_WIN;
+        if (g2)
+            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, (uint32_t)db->sorted_cap, total_ptr,
+                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u);
+        HIP_TRY(hipGetLastError());
+        if (stage("row sort+apply")) return 1;
+    } else {
+        hipLaunchKernelGGL(count_raw_kernel, dim3(1), dim3(1), 0, st, db->wsub_cursor, db->counters);
         // the wide pool: records sorted by stream (the sort moves the 16-byte records with their key words), one tile per run
         uint32_t n_raw;
         if (db->have_counts) n_raw = db->last_n_raw;
@@ -2090,62 +2422,19 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         }
         if (n_raw) {
             const uint32_t nslots = (uint32_t)((uint64_t)n_raw << WCH_SHIFT);
-            const uint32_t* total_ptr = nullptr;
-            const uint32_t kmask = (1u << db->key_bits) - 1u;
-            const uint32_t* sorted_key = db->swkey;
-            const WideRec* sorted_rec = (const WideRec*)db->swrec;
-            if (db->cs_hist) {
-                const bool large = db->n_states > CS_MAX_KEYS;
-                const CsRows no_rows{};
-                size_t ne;
-                if (large) {
-                    // many streams: the records grouped by block row first (bins = rows), then every row by itself (bins = its streams)
-                    const uint32_t NB = db->NB;
-                    const size_t ne1 = (size_t)NB * CS_BLOCKS + 1;
-                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS), dim3(256), NB * 4, st, db->wkey, nslots, db->n_states, NB, (int)CS_BY_ROW, no_rows, kmask, db->cs_hist);
-                    size_t tb = db->cs_tmp_bytes;
-                    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne1, st));
-                    HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(NB)));
-                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), cs_scatter_lds(NB), st, db->wkey, (const WideRec*)db->wrec, nslots,
-                                       db->n_states, NB, (int)CS_BY_ROW, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
-                    // second pass: rows cut into chunks of whole tiles, about CS_BLOCKS workgroups in all
-                    const uint32_t chunk = std::max<uint32_t>(16u * CS_TILE, ((nslots + CS_BLOCKS - 1) / CS_BLOCKS + CS_TILE - 1) / CS_TILE * CS_TILE);
-                    const uint32_t blocks2 = nslots / chunk + NB + 1;                            // >= sum over the rows of ceil(n_row / chunk)
-                    const CsRows rows{db->cs_rows, db->cs_rows + (NB + 1), db->cs_rows + 2 * (NB + 1), NB, chunk};
-                    hipLaunchKernelGGL(cs_rows_kernel, dim3(1), dim3(256), 0, st, db->cs_offs, NB, chunk, db->cs_rows, db->cs_rows + (NB + 1), db->cs_rows + 2 * (NB + 1));
-                    ne = (size_t)blocks2 * NB + 1;                                                // >= table entries in use; the rest stays zero
-                    HIP_TRY(hipMemsetAsync(db->cs_hist, 0, ne * 4, st));
-                    hipLaunchKernelGGL(cs_hist_kernel, dim3(blocks2), dim3(256), NB * 4, st, db->swkey, nslots, db->n_states, NB, (int)CS_IN_ROW, rows, kmask, db->cs_hist);
-                    tb = db->cs_tmp_bytes;
-                    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
-                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(blocks2), dim3(CS_THREADS), cs_scatter_lds(NB), st, db->swkey, (const WideRec*)db->swrec, nslots,
-                                       db->n_states, NB, (int)CS_IN_ROW, rows, kmask, db->cs_offs, db->wkey, (WideRec*)db->wrec);
-                    sorted_key = db->wkey; sorted_rec = (const WideRec*)db->wrec;
-                } else {
-                    ne = (size_t)db->n_states * CS_BLOCKS_ONE + 1;
-                    hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS_ONE), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, db->n_states, (int)CS_BY_STREAM,
-                                       no_rows, kmask, db->cs_hist);
-                    size_t tb = db->cs_tmp_bytes;
-                    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
-                    HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
-                    hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
-                                       db->n_states, db->n_states, (int)CS_BY_STREAM, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
-                }
-                total_ptr = db->cs_offs + (ne - 1);
-                HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
-            } else {
-                {
-                    // records in the wide pool (statistics): the slots whose key is a stream
-                    hipcub::TransformInputIterator<uint32_t, ValidKey, uint32_t*> it(db->wkey, ValidKey{db->n_states, (1u << db->key_bits) - 1u});
-                    size_t tbv = db->sort2_tmp_bytes;
-                    HIP_TRY(hipcub::DeviceReduce::Sum(db->sort2_tmp, tbv, it, db->counters + KCTR_WIDE_RECORDS, (int)nslots, st));
-                }
-                size_t tb = db->sort2_tmp_bytes;
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort2_tmp, tb, db->wkey, db->swkey, (WideRec*)db->wrec, (WideRec*)db->swrec, (int)nslots, 0,
-                                                           db->key_bits, st));
-            }
+            const CsRows no_rows{};
+            const size_t ne = (size_t)db->n_states * CS_BLOCKS_ONE + 1;
+            hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS_ONE), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, db->n_states, (int)CS_BY_STREAM,
+                               no_rows, kmask, db->cs_hist);
+            size_t tb = db->cs_tmp_bytes;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
+            HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
+            hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                               db->n_states, db->n_states, (int)CS_BY_STREAM, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+            const uint32_t* total_ptr = db->cs_offs + (ne - 1);
+            HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
             const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
-            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, sorted_key, sorted_rec, nslots, total_ptr,
+            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, nslots, total_ptr,
                                db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u);
             HIP_TRY(hipGetLastError());
         }
@@ -2157,8 +2446,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t* c = db->h_counters;
-    if (c[KCTR_LIST_OVERFLOW]) {
-        db->fallback_reason = "a chain of more-than-two-block nodes does not fit the entry pool of the wide-node kernel";
+    if (c[KCTR_LIST_OVERFLOW] || c[KCTR_SLOW]) {
+        db->fallback_reason = "internal: the wide-node kernel lost a list (chain miss " + std::to_string(c[KCTR_SLOW]) + ", arena overflow " + std::to_string(c[KCTR_LIST_OVERFLOW]) + ")";
         return 0;
     }
     if (c[KCTR_PAIR_OVERFLOW] || c[KCTR_POOL_OVERFLOW] || c[KCTR_WIDE_OVERFLOW]) {
@@ -2178,15 +2467,20 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         }
         if (c[KCTR_POOL_OVERFLOW]) {
             uint64_t want = db->pool_cap * 2;
-            if (!db->dense_narrow && db->n_states > (1u << ST_MAX_BITS) && (db->pool_cap << CH_SHIFT) > 8 * (db->est_records + (1u << 22))) {
+            if (!row_mode && !db->dense_narrow && db->n_states > (1u << ST_MAX_BITS) && (db->pool_cap << CH_SHIFT) > 8 * (db->est_records + (1u << 22))) {
                 // the estimate is long covered: the narrow kernel's chunks are being evicted nearly empty.  Wide pool for it as well.
                 db->dense_narrow = true;
                 if (verbose) fprintf(stderr, "[kmdb] record chunks of the narrow kernel are evicted nearly empty: its records go through the sort too\n");
                 if (alloc_wide_pool(db, db->wide_pool_cap + db->est_records * 5 / 4 / WCH_REC + (uint64_t)db->n_nsegs * (WIDE_GRAB + 2))) return 1;
                 want = 0;
+            } else if (row_mode && !db->dense_narrow && db->NB > (1u << ST_MAX_BITS) && (db->pool_cap << CH_SHIFT) > 8 * (db->est_records + (1u << 22))) {
+                // the same with row chunks: the diagonal records join the rows
+                db->dense_narrow = true;
+                if (verbose) fprintf(stderr, "[kmdb] record chunks of the narrow kernel are evicted nearly empty: its records go through the row chunks too\n");
+                if (alloc_wide_pool(db, db->wide_pool_cap + db->est_records * 5 / 4 / WCH_REC)) return 1;
+                want = 0;
             } else if ((want << CH_SHIFT) >= (1ull << 31)) {
-                db->fallback_reason = "the record pool does not converge (" + std::to_string(db->n_states) + " streams, " +
-                                      std::to_string(db->pool_cap) + " chunks were not enough)";
+                db->fallback_reason = "more than 2^31 block records (" + std::to_string(db->n_states) + " streams, " + std::to_string(db->pool_cap) + " chunks were not enough)";
                 return 0;
             }
             if (want) {
@@ -2197,13 +2491,15 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         db->have_counts = false; *retry = true;
         return 0;
     }
-    if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks || c[KCTR_RAW] != db->last_n_raw)) {
+    if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks || c[KCTR_RAW] != db->last_n_raw ||
+                            (row_mode && (c[KCTR_ROWJOBS] != db->last_n_rowjobs || c[KCTR_WIDE_RECORDS] != db->last_n_sorted)))) {
         // cannot happen for an unchanged database and emit range; redo the call with measured sizes
         db->have_counts = false; *retry = true;
         return 0;
     }
     db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW]; db->last_n_slow = c[KCTR_SLOW];
-    db->last_records = ((uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32)) + c[KCTR_WIDE_RECORDS];
+    db->last_n_rowjobs = c[KCTR_ROWJOBS]; db->last_n_sorted = c[KCTR_WIDE_RECORDS];
+    db->last_records = ((uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32)) + (row_mode ? 0u : c[KCTR_WIDE_RECORDS]);
     return 0;
 }
 

@@ -33,6 +33,7 @@ enum : uint32_t {
     KCTR_SLOW = 8,          // wide nodes that took the climbing path
     KCTR_WIDE_OVERFLOW = 9, // != 0: the wide record pool was too small
     KCTR_WIDE_RECORDS = 10, // records written to the wide pool
+    KCTR_ROWJOBS = 11,      // row mode: workgroups of the sort inside the block rows
     KCTR_COUNT = 16
 };
 constexpr uint32_t KMDB_PAIR_REGIONS = 4096;
@@ -103,6 +104,20 @@ struct kmdb_db {
     void *wrec = nullptr, *swrec = nullptr;         // wide pool: 16-byte records {rows, cols} (weight digit in the key word), and sorted by stream
     uint64_t wide_pool_cap = 0;     // chunks of 64 records
     uint32_t* wsub_cursor = nullptr;
+    // many streams ("row mode"): the wide records go to per-block-row chunks of the chunk pool; the chunk table grouped by key, then a
+    // counting sort inside every row
+    bool row_mode = false;
+    uint32_t n_ckeys = 0;                              // keys of the chunk table: streams (+ block rows in row mode); n_ckeys = never opened
+    uint32_t *ct_hist = nullptr, *ct_offs = nullptr, *ct_cursor = nullptr;   // [n_ckeys + 2]
+    void* ct_tmp = nullptr;
+    size_t ct_tmp_bytes = 0;
+    uint32_t* rs_rows = nullptr;                       // [2][NB + 1] first job / first table entry of every row
+    uint32_t *rs_hist = nullptr, *rs_offs = nullptr;   // [rs_entries] per row [stream][job] counts / offsets
+    uint64_t rs_entries = 0;
+    void* rs_tmp = nullptr;
+    size_t rs_tmp_bytes = 0;
+    uint64_t sorted_cap = 0;                           // records the sorted arrays (swkey / swrec) hold
+    uint32_t last_n_rowjobs = 0, last_n_sorted = 0, k1w_waves = 0;
     uint32_t* cs_rows = nullptr;                       // two-pass sort: row starts / first workgroup / first table entry, [3][NB + 1]
     uint32_t *cs_hist = nullptr, *cs_offs = nullptr;   // counting sort of the wide pool: [stream][block] counts / offsets (+ total)
     void* cs_tmp = nullptr;

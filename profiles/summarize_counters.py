@@ -91,8 +91,9 @@ for k in sorted(res):
     d = res[k]
     waves = g(d, "SQ_WAVES")
     wc = g(d, "SQ_WAVE_CYCLES")
-    lanes = 100.0 * g(d, "SQ_THREAD_CYCLES_VALU") / (64.0 * g(d, "SQ_ACTIVE_INST_VALU") * 4.0) if d.get("SQ_ACTIVE_INST_VALU") else float("nan")
-    # SQ_THREAD_CYCLES_VALU counts thread-cycles of VALU work; SQ_ACTIVE_INST_VALU quad-cycles of waves issuing VALU: lanes/64 of the cycles VALU was active
+    lanes = 100.0 * g(d, "SQ_THREAD_CYCLES_VALU") / (64.0 * g(d, "SQ_ACTIVE_INST_VALU")) if d.get("SQ_ACTIVE_INST_VALU") else float("nan")
+    # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = active lanes per VALU instruction (a full-wave copy kernel measures 62 of 64);
+    # SQ_ACTIVE_INST_VALU counts one quad-cycle per wave64 VALU instruction (it equals SQ_INSTS_VALU within 1 %)
     valu_busy = 100.0 * g(d, "SQ_ACTIVE_INST_VALU") / wc if wc == wc and wc else float("nan")
     wait = 100.0 * g(d, "SQ_WAIT_ANY") / (g(d, "SQ_WAIT_ANY") + g(d, "SQ_WAIT_INST_ANY") + g(d, "SQ_ACTIVE_INST_ANY")) if d.get("SQ_ACTIVE_INST_ANY") else float("nan")
     stall = 100.0 * g(d, "SQ_WAIT_INST_ANY") / (g(d, "SQ_WAIT_ANY") + g(d, "SQ_WAIT_INST_ANY") + g(d, "SQ_ACTIVE_INST_ANY")) if d.get("SQ_ACTIVE_INST_ANY") else float("nan")

@@ -629,6 +629,61 @@ def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local, ch
         assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
 
 
+def test_patterns_that_touch_every_block_of_many(K, O, dev):
+    """One conserved k-mer shared by most samples is a pattern whose full list touches EVERY block: at more than 32 768 samples
+    that is more than 512 (block, mask) entries — the limit at which round 2's wide-node kernel gave the whole database up (ADVICE
+    round 2).  Lists are now as long as there are blocks: a forest of such patterns (a root with one id in every block and a chain of
+    children that fill the blocks in) stays on the block-record pipeline and equals the flat-form definition computed here on the
+    host (reference similarity_calculator.cpp:596-638: every pattern adds its weight to all pairs of its full list)."""
+    import torch
+    N, step = 36000, 40
+    ids0 = np.arange(0, N, step, dtype=np.int64)                 # 900 ids: one in every block of any width >= 40, two in most
+    locs = [np.zeros(0, dtype=np.int64), ids0]
+    parent, w = [-1, -1], [0, 3]
+    # children: ids above the root's last id cannot exist (ids ascend along a path), so the chain grows at the top end only; siblings
+    # of the root pattern cover other residues
+    for r in (1, 7, 13):
+        locs.append(np.arange(r, N, step, dtype=np.int64)); parent.append(-1); w.append(1 + r)
+    top = int(ids0[-1])
+    chain_par = 1
+    for j in range(1, 30):
+        if top + j >= N:
+            break
+        locs.append(np.array([top + j], dtype=np.int64)); parent.append(chain_par); w.append(j % 3); chain_par = len(locs) - 1
+    P = len(locs)
+    nloc = np.array([len(x) for x in locs], dtype=np.int64)
+    nsam = np.zeros(P, dtype=np.int64)
+    for p in range(1, P):
+        nsam[p] = nloc[p] + (nsam[parent[p]] if parent[p] >= 0 else 0)
+    lp = np.zeros(P + 1, dtype=np.int64); lp[1:] = np.cumsum(nloc)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int64)))      # noqa: E731
+    pat = {"num_kmers": t(w), "parent": t(parent), "num_samples": t(nsam), "num_local": t(nloc), "local_ptr": t(lp), "local_ids": t(np.concatenate(locs))}
+    import importlib
+    S = importlib.import_module("kmerdb_amd.synth")
+    arr = S.to_view_arrays(pat)
+    view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                       arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+    st = d.stats()
+    assert st["path"] == K.capi.PATH_RECORDS and st["n_wide"] >= 4
+    # flat form on the host: full lists by walking the parents
+    exp = np.zeros(N * (N - 1) // 2, dtype=np.uint32)
+    for p in range(1, P):
+        if w[p] == 0:
+            continue
+        full, q = [], p
+        while q >= 0:
+            full.append(locs[q]); q = parent[q]
+        full = np.sort(np.concatenate(full))
+        for a in range(1, full.size):
+            i = int(full[a])
+            exp[i * (i - 1) // 2 + full[:a]] += np.uint32(w[p])
+    assert np.array_equal(got, exp)
+    assert st["sum_pairs"] == int(exp.astype(np.uint64).sum())
+    d.close()
+
+
 def test_degenerate_databases(K, O, dev, tmp_path):
     import importlib
     import torch
