@@ -163,6 +163,8 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     for (auto& e : db->ev_k) if (hipEventCreate(&e) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
     if (hipStreamCreate(&db->stream2) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
     for (auto& e : db->ev_side) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
+    if (hipStreamCreate(&db->stream3) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
+    for (auto& e : db->ev_band) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
     if (kmdb_layout_upload(db, v, with_hashtables, shard_index, shard_count)) return fail();
     // the working set of all2all: now for an all2all upload, on the first all2all call for a new2all / db2db upload
     if (!with_hashtables && kmdb_blocks_prepare(db)) return fail();
@@ -191,14 +193,15 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     (void)hipSetDevice(db->device);
     kmdb_release_staging(db);
     kmdb_blocks_release(db);
-    if (db->wseg_anc == db->nseg_anc) { db->wseg_anc = nullptr; db->wseg_anc_n = nullptr; }
-    void* ptrs[] = {db->wseg_anc, db->wseg_anc_n, db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
+    void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
                     db->nseg_anc_n, db->meta, db->bitpos, db->ck_ofs, db->ck_bit, db->ck_id, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,
                     db->bucket_offset, db->slots, db->pid2dfs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_k) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_side) if (e) (void)hipEventDestroy(e);
+    for (auto& e : db->ev_band) if (e) (void)hipEventDestroy(e);
+    if (db->stream3) (void)hipStreamDestroy(db->stream3);
     if (db->stream2) (void)hipStreamDestroy(db->stream2);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;

@@ -61,10 +61,6 @@ struct kmdb_db {
     uint32_t n_nsegs = 0;
     uint32_t* nseg_anc = nullptr;   // [n_nsegs][chain_cap] root path of every slice's first node
     uint32_t* nseg_anc_n = nullptr;
-    uint32_t wseg_nodes = 512;      // nodes per slice of the DFS stream for the wide-node kernel (a run of its wide nodes per wave)
-    uint32_t n_wsegs = 0;
-    uint32_t* wseg_anc = nullptr;   // [n_wsegs][chain_cap] root path of every such slice's first node (== nseg_anc when the slices are the same)
-    uint32_t* wseg_anc_n = nullptr;
     uint32_t chain_cap = 8;         // chain slots per wave = longest root path, rounded up
     uint32_t max_depth = 0, max_n = 0;
     bool chain_ok = false;          // root paths fit the chain table of the emit kernel
@@ -84,6 +80,8 @@ struct kmdb_db {
     uint32_t* wide_cnt = nullptr;   // [words + 1] popcounts / their exclusive scan
     uint32_t* wide_base = nullptr;
     uint32_t* widx = nullptr;       // [wide_cap] the wide nodes, DFS order
+    uint32_t* wrun_anc = nullptr;   // [runs][chain_cap] root path of the first node of every run of the wide-node kernel (built by every call)
+    uint32_t* wrun_anc_n = nullptr;
     uint64_t wide_cap = 0;
     uint32_t* chunk_key = nullptr;  // [pool_cap] stream of every chunk (n_states: never opened)
     uint32_t* chunk_fill = nullptr; // [pool_cap] records in the chunk
@@ -111,13 +109,18 @@ struct kmdb_db {
     uint32_t *ct_hist = nullptr, *ct_offs = nullptr, *ct_cursor = nullptr;   // [n_ckeys + 2]
     void* ct_tmp = nullptr;
     size_t ct_tmp_bytes = 0;
+    uint32_t *rg_hist = nullptr, *rg_offs = nullptr;   // row chunks grouped by row: [NB][rg_blocks] counts / offsets (+ total)
+    uint32_t* row_ids = nullptr;                       // the row chunks' ids, grouped by row
+    uint32_t rg_blocks = 0;
+    void* rg_tmp = nullptr;
+    size_t rg_tmp_bytes = 0;
     uint32_t* rs_rows = nullptr;                       // [2][NB + 1] first job / first table entry of every row
     uint32_t *rs_hist = nullptr, *rs_offs = nullptr;   // [rs_entries] per row [stream][job] counts / offsets
     uint64_t rs_entries = 0;
     void* rs_tmp = nullptr;
     size_t rs_tmp_bytes = 0;
     uint64_t sorted_cap = 0;                           // records the sorted arrays (swkey / swrec) hold
-    uint32_t last_n_rowjobs = 0, last_n_sorted = 0, k1w_waves = 0;
+    uint32_t last_n_rowjobs = 0, last_n_sorted = 0, k1w_waves = 0, k1w_slots = 0;   // (k1w_waves: most the pools are sized for; k1w_slots: waves the chip holds at once)
     uint32_t* cs_rows = nullptr;                       // two-pass sort: row starts / first workgroup / first table entry, [3][NB + 1]
     uint32_t *cs_hist = nullptr, *cs_offs = nullptr;   // counting sort of the wide pool: [stream][block] counts / offsets (+ total)
     void* cs_tmp = nullptr;
@@ -161,6 +164,9 @@ struct kmdb_db {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the stream chunks are sorted and applied next to the wide kernel
     hipEvent_t ev_side[2] = {nullptr, nullptr};
+    hipStream_t stream3 = nullptr;  // many streams: the sorted bands of block rows applied next to the sort of the following band
+    hipEvent_t ev_band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // band b sorted (0..7), stream3 done (8)
+    uint32_t* rs_bands = nullptr;   // [2][9] first job / first sorted record of every band (+ end)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // after decode / narrow / wide / apply
     kmdb_stats stats{};

@@ -205,6 +205,31 @@ __global__ void lay_shard_weights_kernel(const uint64_t* __restrict__ slots, con
     }
 }
 
+// A prefix shard keeps only the part of the tree it needs (north_star: near-linear scaling): a node stays when its
+// subtree holds a k-mer of the shard — a dropped node emits no record and no kept node needs its ids (a kept node's ancestors are
+// kept).  Flags climb the parent links until nothing changes (at most as many rounds as the tree is deep).
+__global__ void lay_keep_init_kernel(const uint32_t* __restrict__ w, uint32_t P, uint32_t* __restrict__ keep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) keep[i] = w[i] != 0u ? 1u : 0u;
+}
+__global__ void lay_keep_up_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* __restrict__ keep, uint32_t* __restrict__ changed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P || !keep[i]) return;
+    const int32_t par = parent[i];
+    if (par >= 0 && !keep[par]) { keep[par] = 1u; *changed = 1u; }
+}
+__global__ void lay_compact_kernel(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ newidx, const int32_t* __restrict__ parent,
+                                   const uint32_t* __restrict__ ll, const uint32_t* __restrict__ n, const uint32_t* __restrict__ nbits, const uint32_t* __restrict__ w,
+                                   const uint64_t* __restrict__ spos, uint32_t P, int32_t* __restrict__ parent2, uint32_t* __restrict__ ll2, uint32_t* __restrict__ n2,
+                                   uint32_t* __restrict__ nbits2, uint32_t* __restrict__ w2, uint64_t* __restrict__ spos2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P || !keep[i]) return;
+    const uint32_t o = newidx[i];
+    const int32_t par = parent[i];
+    parent2[o] = par < 0 ? -1 : (int32_t)newidx[par];
+    ll2[o] = ll[i]; n2[o] = n[i]; nbits2[o] = nbits[i]; w2[o] = w[i]; spos2[o] = spos[i];
+}
+
 // Host staging buffers of the upload: anonymous mappings, handed to the database handle and given back piece by piece by a helper
 // thread after the first call (kmdb_release_staging).  Unmapping them right after the copies took 0.31 s of a 0.63 s upload
 // (the HIP runtime has the ranges registered for its DMA), and a thread that does it meanwhile blocks every hipMalloc of the
@@ -251,7 +276,8 @@ void kmdb_release_staging(kmdb_db* db) {
 }
 
 int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count) {
-    const uint64_t P = v->n_patterns, N = v->n_samples;
+    uint64_t P = v->n_patterns;                                // (a prefix shard may shrink it: only the nodes the shard needs are laid out)
+    const uint64_t N = v->n_samples;
     const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
     auto tphase0 = std::chrono::steady_clock::now();
     auto phase = [&](const char* what) {
@@ -263,7 +289,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     };
     hipStream_t st = db->stream;
     const unsigned B = 256;
-    const unsigned G = (unsigned)((P + B - 1) / B), G1 = (unsigned)((P + 1 + B - 1) / B);
+    unsigned G = (unsigned)((P + B - 1) / B), G1 = (unsigned)((P + 1 + B - 1) / B);
 
     // ---- host: narrow + validate the header fields, pack the streams in pid order
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -365,6 +391,48 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     }
     HIP_TRY(hipStreamSynchronize(st));
     phase("H2D");
+    DevTmp<uint64_t> d_spos;                                  // pruned shard: where every kept node's stream starts in the uploaded bit array
+    if (shard_count > 1 && !with_hashtables && P > 1 && !getenv("KMDB_SHARD_WHOLE_TREE")) {
+        // (an upload that carries the hashtables keeps the whole tree: new2all's pattern ids must all resolve)
+        DevTmp<uint32_t> keep, newidx, flag;
+        DevTmp<uint64_t> spos;
+        if (keep.alloc(P + 1) || newidx.alloc(P + 1) || flag.alloc(1) || spos.alloc(P + 1)) return 1;
+        hipLaunchKernelGGL(lay_keep_init_kernel, dim3(G), dim3(B), 0, st, d_w.p, (uint32_t)P, keep.p);
+        HIP_TRY(hipMemsetAsync(keep.p + P, 0, 4, st));
+        for (int round = 0; round < 1 << 16; round += 8) {
+            HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
+            for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(lay_keep_up_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, keep.p, flag.p);
+            uint32_t changed = 0;
+            HIP_TRY(hipMemcpyAsync(&changed, flag.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (!changed) break;
+        }
+        size_t tb = 0, tb2 = 0;
+        hipcub::TransformInputIterator<uint64_t, U32toU64, uint32_t*> it_nb(d_nbits.p, U32toU64());
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, keep.p, newidx.p, (int)(P + 1), st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, it_nb, spos.p, (int)P, st));
+        DevTmp<unsigned char> tmp;
+        if (tmp.alloc(std::max(tb, tb2))) return 1;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, keep.p, newidx.p, (int)(P + 1), st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, it_nb, spos.p, (int)P, st));
+        uint32_t P2 = 0;
+        HIP_TRY(hipMemcpyAsync(&P2, newidx.p + P, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (P2 && P2 < P) {
+            DevTmp<int32_t> parent2;
+            DevTmp<uint32_t> ll2, n2, nbits2, w2;
+            if (parent2.alloc(P2) || ll2.alloc(P2) || n2.alloc(P2) || nbits2.alloc(P2) || w2.alloc(P2) || d_spos.alloc(P2 + 1)) return 1;
+            hipLaunchKernelGGL(lay_compact_kernel, dim3(G), dim3(B), 0, st, keep.p, newidx.p, d_parent.p, d_ll.p, d_n.p, d_nbits.p, d_w.p, spos.p, (uint32_t)P,
+                               parent2.p, ll2.p, n2.p, nbits2.p, w2.p, d_spos.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+            std::swap(d_parent.p, parent2.p); std::swap(d_ll.p, ll2.p); std::swap(d_n.p, n2.p); std::swap(d_nbits.p, nbits2.p); std::swap(d_w.p, w2.p);
+            if (verbose) fprintf(stderr, "[kmdb] upload: prefix shard %u / %u keeps %u of %llu patterns\n", shard_index, shard_count, P2, (unsigned long long)P);
+            P = P2; db->P = P2;
+            G = (unsigned)((P + B - 1) / B); G1 = (unsigned)((P + 1 + B - 1) / B);
+        }
+        phase("shard: nodes the shard needs");
+    }
     for (HostRegion r : {h_parent.release(), h_ll.release(), h_n.release(), h_nbits.release(), h_w.release(), h_bits.release()})
         if (r.p) db->staging.emplace_back(r.p, r.bytes);
 
@@ -503,7 +571,8 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it_src, srcpos.p, (int)P, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, it_src, srcpos.p, (int)P, st));
+        if (d_spos.p) HIP_TRY(hipMemcpyAsync(srcpos.p, d_spos.p, P * 8, hipMemcpyDeviceToDevice, st));          // pruned shard: the streams keep their uploaded places
+        else HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, it_src, srcpos.p, (int)P, st));
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, it_dst, dstpos.p, (int)P, st));
         HIP_TRY(hipMalloc((void**)&db->bits, n_bit_words * 8));
         HIP_TRY(hipMemsetAsync(db->bits, 0, n_bit_words * 8, st));
@@ -535,18 +604,6 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     if (db->n_nsegs)
         hipLaunchKernelGGL(lay_seg_anc_kernel, dim3((db->n_nsegs + 63) / 64), dim3(64), 0, st, db->parent, db->dflag, (uint32_t)P, db->nseg_nodes, db->n_nsegs,
                            db->chain_cap, db->nseg_anc, db->nseg_anc_n);
-    // the wide-node kernel takes shorter slices (its work per node varies by orders of magnitude); a very deep tree shares the table
-    db->wseg_nodes = db->chain_cap > 256 ? db->nseg_nodes : 512;
-    if (const char* e = getenv("KMDB_WSEG")) if (*e) db->wseg_nodes = (uint32_t)std::max<uint64_t>(64, strtoull(e, nullptr, 10) / 64 * 64);
-    if (db->wseg_nodes == db->nseg_nodes) { db->n_wsegs = db->n_nsegs; db->wseg_anc = db->nseg_anc; db->wseg_anc_n = db->nseg_anc_n; }
-    else {
-        db->n_wsegs = (uint32_t)((P + db->wseg_nodes - 1) / db->wseg_nodes);
-        HIP_TRY(hipMalloc((void**)&db->wseg_anc, std::max<size_t>((size_t)db->n_wsegs * db->chain_cap, 1) * 4));
-        HIP_TRY(hipMalloc((void**)&db->wseg_anc_n, std::max<size_t>(db->n_wsegs, 1) * 4));
-        if (db->n_wsegs)
-            hipLaunchKernelGGL(lay_seg_anc_kernel, dim3((db->n_wsegs + 63) / 64), dim3(64), 0, st, db->parent, db->dflag, (uint32_t)P, db->wseg_nodes, db->n_wsegs,
-                               db->chain_cap, db->wseg_anc, db->wseg_anc_n);
-    }
     db->n_long = hs.n_long;
     if (hs.n_long) {
         DevTmp<uint32_t> sel, lk, lk2, nsel;
@@ -574,6 +631,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     db->stats.tree_updates = hs.upd;
     db->stats.sum_pairs = hs.pairs;
     db->stats.n_segments = db->n_nsegs;
-    db->stats.device_bytes = P * (8 + 4 + 4 + 4 + 4 + 2 + 4) + n_bit_words * 8 + (uint64_t)(db->n_nsegs + (db->wseg_anc != db->nseg_anc ? db->n_wsegs : 0)) * db->chain_cap * 4 + dev_ht_bytes;
+    db->stats.n_patterns = P;
+    db->stats.device_bytes = P * (8 + 4 + 4 + 4 + 4 + 2 + 4) + n_bit_words * 8 + (uint64_t)db->n_nsegs * db->chain_cap * 4 + dev_ht_bytes;
     return 0;
 }

@@ -13,6 +13,8 @@ R=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
 BA=${BENCH_ARGS:-}
+# counters only for the engine's kernels (the synthetic generator's thousands of torch kernels would be serialised too)
+KRE=${KERNEL_REGEX:-"k0_|k1n_|k1w_|k2_|cs_|rs_|rg_|ct_|wide_|wrun_|n2a_|d2_|row_nnz|row_compact|lay_|width_estimate|pair_estimate|iota_u32"}
 declare -A G
 G[sq1]="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
 G[sq2]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM"
@@ -24,7 +26,7 @@ FILES=""
 for g in $GROUPS_WANTED; do
   C=${G[$g]}
   rm -rf /tmp/pmc_$g
-  ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$g -- python $R/bench.py $BA --no-cpu-baseline --steps 2 --warmup 1 > /tmp/pmc_$g.json 2> /tmp/pmc_$g.err )
+  ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$KRE" --output-format csv -d /tmp/pmc_$g -- python $R/bench.py $BA --no-cpu-baseline --steps 2 --warmup 1 > /tmp/pmc_$g.json 2> /tmp/pmc_$g.err )
   f=$(find /tmp/pmc_$g -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then cp $f /tmp/pmc_$g.csv; FILES="$FILES /tmp/pmc_$g.csv"; else echo "group $g: no counter file"; tail -5 /tmp/pmc_$g.err; fi
 done

@@ -15,11 +15,13 @@ if [ "$WHAT" = "all" ]; then
 python bench.py $BA 2> $OUT/${TAG}_bench.err | tee $OUT/${TAG}_bench.json
 fi
 if [ "$WHAT" != "pmc" ]; then
+rm -rf /tmp/prof_stats
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py $BA --no-cpu-baseline --steps 5 --warmup 2 > $OUT/${TAG}_bench_profiled.json 2> /tmp/prof_stats.err )
 find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_all.csv \;
 fi
 if [ "$WHAT" != "stats" ]; then
 for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_$C
   ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- python $R/bench.py $BA --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> /tmp/prof_$C.err )
   find /tmp/prof_$C -name '*counter_collection.csv' -exec cp {} /tmp/${C}.csv \;
 done

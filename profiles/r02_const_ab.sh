@@ -11,7 +11,7 @@ for v in "" "$@"; do
   done
   make -C kmer-db_amd -j8 > /dev/null 2>&1
   for w in c2 ${C3:+c3part}; do
-    python bench.py --workload $w --no-cpu-baseline --steps 5 > /tmp/ab.json 2> /dev/null
+    python bench.py --workload $w --no-cpu-baseline --no-extra --steps 5 > /tmp/ab.json 2> /dev/null
     python3 -c "
 import json
 c=json.load(open('/tmp/ab.json')); print('%-28s %-6s' % ('${v:-(as committed)}', '$w'), round(c['ms_per_step'],3), {k:round(v,2) for k,v in c['roofline']['per_kernel_ms'].items()})"

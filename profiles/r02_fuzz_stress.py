@@ -28,13 +28,13 @@ for c in range(cases):
     nseg = int(rng.choice([0, 64, 192]))
     chain = float(rng.choice([0.0, 0.0, 0.6, 0.9]))
     rowmode = int(rng.choice([0, 0, 1]))                   # 1: the many-streams path (per-block-row chunks + sort inside the rows) whatever the size
-    wseg = int(rng.choice([0, 64, 128]))                   # slices of the wide-node kernel (a chain seeded from the root path per slice)
+    wseg = int(rng.choice([0, 64, 128]))                   # wide nodes per run of the wide-node kernel (a chain seeded from the root path per run)
     k1w = int(rng.choice([0, 1, 3]))                       # waves of the wide-node kernel (few: every wave takes many runs)
     pat = _random_forest(rng, N, P, max_local, heavy_frac=float(rng.random()) * 0.5, zero_frac=float(rng.random()) * 0.5, chain_frac=chain)
     arr = S.to_view_arrays(pat)
     view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
                        arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
-    for name, val in (("KMDB_BLOCK_WIDTH", width), ("KMDB_NSEG", nseg), ("KMDB_ROW_MODE", rowmode), ("KMDB_WSEG", wseg), ("KMDB_K1W_WAVES", k1w)):
+    for name, val in (("KMDB_BLOCK_WIDTH", width), ("KMDB_NSEG", nseg), ("KMDB_ROW_MODE", rowmode), ("KMDB_K1W_RUN", wseg), ("KMDB_K1W_WAVES", k1w)):
         if val:
             os.environ[name] = str(val)
         else:
@@ -55,7 +55,7 @@ for c in range(cases):
         bad += 1
         print("MISMATCH case", c, "N", N, "P", P, "max_local", max_local, "width", width, "nseg", nseg, "chain", chain, "rowmode", rowmode, "wseg", wseg, "k1w", k1w,
               "diff cells", int((got != ref).sum()), flush=True)
-for name in ("KMDB_BLOCK_WIDTH", "KMDB_NSEG", "KMDB_ROW_MODE", "KMDB_WSEG", "KMDB_K1W_WAVES"):
+for name in ("KMDB_BLOCK_WIDTH", "KMDB_NSEG", "KMDB_ROW_MODE", "KMDB_K1W_RUN", "KMDB_K1W_WAVES"):
     os.environ.pop(name, None)
 print("fuzz: %d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)

@@ -13,8 +13,9 @@ from collections import defaultdict
 tag, out = sys.argv[1:3]
 files = sys.argv[3:]
 KERNELS = ("k0_decode_kernel", "k1n_kernel", "k1g_kernel", "k1w_kernel", "k2_apply_kernel", "k2_sorted_kernel", "cs_hist_kernel", "cs_scatter_kernel",
-           "wide_count_kernel", "wide_expand_kernel", "n2a_walk_kernel", "n2a_probe_kernel", "d2_emit_kernel", "d2_probe_kernel", "row_nnz_kernel",
-           "row_compact_kernel", "rc_", "ct_")
+           "rs_hist_kernel", "rs_scatter_kernel", "rs_rows_kernel", "rg_hist_kernel", "rg_scatter_kernel", "ct_hist_kernel", "ct_scatter_kernel", "wrun_anc_kernel",
+           "wide_count_kernel", "wide_expand_kernel", "n2a_walk_kernel", "n2a_probe_kernel", "n2a_extract_kernel", "d2_emit_kernel", "d2_probe_kernel", "row_nnz_kernel",
+           "row_compact_kernel")
 
 
 def short(name):
@@ -22,7 +23,7 @@ def short(name):
         if k in name:
             if k == "k0_decode_kernel":
                 return "k0_decode_kernel<long>" if "<true>" in name or "true" in name.split("k0_decode_kernel")[1][:12] else "k0_decode_kernel<short>"
-            return k if not k.endswith("_") else name.split("(")[0].split("::")[-1][:40]
+            return k
     if "rocprim" in name and ("radix" in name or "onesweep" in name):
         return "rocprim radix sort"
     if "rocprim" in name and "scan" in name:

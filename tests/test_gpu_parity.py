@@ -416,16 +416,22 @@ def test_upload_shards_of_a_real_db_sum_to_full_matrix(K, golden_dir, dev, stem,
         K.DeviceDB(h, device=dev).all2all_dense()
     acc = np.zeros_like(ref)
     total_pairs = 0
+    kept = []
     for s in range(shards):
         d = K.DeviceDB(h, device=dev, prefix_shard=(s, shards))
         part = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
         st = d.stats()
         assert st["path"] == K.capi.PATH_RECORDS and (st["n_records"] > 0 or st["sum_pairs"] == 0)
+        # the shard's tree: only the nodes whose subtree holds one of its k-mers (every k-mer sits in one shard, so the shards' trees
+        # are proper parts of the whole one)
+        assert 0 < st["n_patterns"] < d.P
+        kept.append(st["n_patterns"])
         assert st["sum_pairs"] == int(part.astype(np.uint64).sum())          # the shard's own checksum identity
         total_pairs += st["sum_pairs"]
         acc += part
         d.close()
     assert np.array_equal(acc, ref) and total_pairs == int(ref.astype(np.uint64).sum())
+    assert sum(kept) < shards * d.P                               # the front half of the pipeline is sharded too, not only the weights
     with pytest.raises(K.KmdbError, match="no hashtables"):
         K.DeviceDB(K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True), device=dev, prefix_shard=(0, 2))
 
