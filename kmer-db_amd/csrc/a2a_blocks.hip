@@ -799,6 +799,7 @@ struct WParams {
     const uint32_t* seg_anc_n;
     uint32_t run_nodes;            // wide nodes per run (a multiple of 64)
     uint32_t n_runs, n_waves;
+    uint32_t* run_ctr;             // [K1W_CTRS * 16] next run of every class (run r belongs to class r % K1W_CTRS), a cache line apart
     uint32_t chain_cap, arena_cap, e_cap;
     uint32_t n_rows;               // row mode: block rows (0 otherwise)
     uint32_t emit_lo, emit_hi;
@@ -808,6 +809,7 @@ constexpr int K1W_WAVES = 2;
 constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
 constexpr uint32_t K1W_HEAVY = 11;         // a node with that many blocks (66 records and more) is emitted by the whole wave
 constexpr uint32_t K1W_OXCAP = 256;        // further own pairs of a batch's nodes kept in LDS
+constexpr uint32_t K1W_CTRS = 16;          // run counters: a wave takes its next run from the counter of its class
 enum : uint32_t { WB_NONE = 0, WB_FN = 1, WB_LANE = 2, WB_CHAIN = 3 };
 // LDS of one wave, carved from the dynamic allocation (the sizes depend on the database: blocks, depth of the tree)
 struct K1WLds {
@@ -865,7 +867,7 @@ __global__ void wrun_anc_kernel(const uint32_t* __restrict__ widx, uint32_t n_wi
 }
 
 // One lane per wide node, batches of 64 consecutive nodes of the (DFS-ordered) wide list.  A run = a few consecutive batches;
-// runs are dealt round-robin to the waves (the records per node differ by orders of magnitude — 3 blocks: 6
+// the waves take runs as they go (the records per node differ by orders of magnitude — 3 blocks: 6
 // records, 200 blocks: 20 100 — and heavy nodes sit together in the DFS order).
 // A wide node's parent is wide as well or has at most two blocks.  Its list = the parent's list + its own pairs:
 //   parent with <= 2 blocks: the (blocks, masks) the narrow kernel left in HBM;
@@ -970,7 +972,16 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
         lds_sync();
     };
 
-    for (uint32_t run = wid; run < q.n_runs; run += q.n_waves) {
+    // The records per node differ by orders of magnitude (3 blocks: 6 records, 200 blocks: 20 100) and heavy nodes sit together
+    // in the DFS order: runs dealt round-robin left some waves with several heavy runs (the kernel ended when the slowest wave did,
+    // the average wave at half that time).  A wave takes its next run when it is done with one — from one of K1W_CTRS counters (a
+    // single counter would be a hot address: same-address device atomics run at some ten million per second).
+    for (;;) {
+        uint32_t run = 0;
+        const uint32_t n_cls = q.n_waves < K1W_CTRS ? q.n_waves : K1W_CTRS;       // classes of runs = counters in use (every class needs a wave)
+        if (lane == 0) run = atomicAdd(&q.run_ctr[(wid % n_cls) * 16u], 1u);
+        run = bcast(run, 0) * n_cls + wid % n_cls;
+        if (run >= q.n_runs) break;
         const uint32_t kb = run * q.run_nodes;
         const uint32_t ke = q.n_wide - kb < q.run_nodes ? q.n_wide : kb + q.run_nodes;
         // ---- the chain at the start of the run: the wide nodes on the root path of the run's first node.  Wide nodes are a
@@ -2121,8 +2132,19 @@ __global__ void ck_fill_kernel(const uint2* __restrict__ k0in, const uint32_t* _
     }
 }
 
+static int ensure_v1_impl(kmdb_db* db);
 int kmdb_ensure_v1_arrays(kmdb_db* db) {
-    if (db->meta) return 0;
+    if (db->v1_ready) return 0;
+    if (ensure_v1_impl(db)) {
+        // nothing half made is left behind: the next call starts over
+        for (void** p : {(void**)&db->meta, (void**)&db->bitpos, (void**)&db->wprefix, (void**)&db->v1_counters, (void**)&db->segs, (void**)&db->v1_scan_tmp,
+                         (void**)&db->ck_ofs, (void**)&db->ck_bit, (void**)&db->ck_id}) free_and_null(p);
+        return 1;
+    }
+    db->v1_ready = true;
+    return 0;
+}
+static int ensure_v1_impl(kmdb_db* db) {
     const uint64_t P = db->P;
     HIP_TRY(hipMalloc((void**)&db->meta, std::max<uint64_t>(P, 1) * sizeof(uint4)));
     HIP_TRY(hipMalloc((void**)&db->bitpos, std::max<uint64_t>(P, 1) * 8));
@@ -2210,10 +2232,16 @@ int kmdb_rect_sort_apply(hipStream_t st, uint32_t* wkey, void* wrec, uint32_t ns
     return 0;
 }
 
+static int blocks_prepare_impl(kmdb_db* db);
+// (the flag is set only when every allocation succeeded: a failed lazy preparation inside a call leaves nothing half made behind)
 int kmdb_blocks_prepare(kmdb_db* db) {
+    if (blocks_prepare_impl(db)) { kmdb_blocks_release(db); return 1; }
+    db->blocks_prepared = true;
+    return 0;
+}
+static int blocks_prepare_impl(kmdb_db* db) {
     const uint64_t N = db->N, P = db->P;
     db->fallback_reason.clear();
-    db->blocks_prepared = true;
     if (N < 2 || P == 0) { db->fallback_reason = "fewer than two samples"; return 0; }
     if (!db->chain_ok) {
         db->fallback_reason = "a root path of " + std::to_string(db->max_depth) + " nodes exceeds the chain table (" + std::to_string(KMDB_CHAIN_MAX) + ")";
@@ -2300,6 +2328,7 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     }
     HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->wsub_cursor, KMDB_SUBPOOLS * 16 * 4));
+    HIP_TRY(hipMalloc((void**)&db->run_ctr, K1W_CTRS * 16 * 4));
     // Where the records go.  The narrow kernel's first-block diagonal records follow the clustering of the DFS stream: per-stream
     // chunks (an open chunk per block and wave), applied straight from the grouped chunk table.  The other records spread over
     // many streams, a few per stream and wave:
@@ -2327,6 +2356,22 @@ int kmdb_blocks_prepare(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->ct_cursor, ((size_t)db->n_ckeys + 2) * 4));
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->ct_tmp_bytes, db->ct_hist, db->ct_offs, (int)(db->n_ckeys + 1), db->stream));
     HIP_TRY(hipMalloc(&db->ct_tmp, std::max<size_t>(db->ct_tmp_bytes, 16)));
+    // A database whose records do not fit one pass (2^31 record slots, or the memory left) is taken in SLICES of the pattern stream:
+    // every slice emits the records of its own patterns only, the partial matrices add up in place (the engine's own version of
+    // kmdb_opts.shard_index / shard_count; the reference blocks by `-buffer` the same way, similarity_calculator.cpp:290-325).
+    {
+        uint64_t slices = 1;
+        const uint64_t slots = (est_n + est_g) * 3 / 2;
+        slices = std::max<uint64_t>(slices, (slots + (3ull << 29) - 1) / (3ull << 29));                 // 1.6 G slots of the 2^31 a pool can index
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
+            slices = std::max<uint64_t>(slices, (slots * 44 + free_b / 2) / std::max<size_t>(free_b * 6 / 10, 1));     // pool + sorted copy: 44 B per slot, 60 % of what is free
+        if (const char* e = getenv("KMDB_SLICES")) if (*e) slices = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        db->n_slices = (uint32_t)std::min<uint64_t>(slices, 1u << 16);
+        if (verbose && db->n_slices > 1) fprintf(stderr, "[kmdb] %llu block records estimated: %u slices of the pattern stream per call\n",
+                                                 (unsigned long long)(est_n + est_g), db->n_slices);
+        est_n = est_n / db->n_slices + 1; est_g = est_g / db->n_slices + 1;
+    }
     // waves of the wide-node kernel: in row mode every wave may end with an open chunk per block row
     db->k1w_waves = K1W_MAX_WAVES;
     if (db->row_mode) {
@@ -2354,7 +2399,7 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_rows); FREE_NULL(db->cs_tmp);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     FREE_NULL(db->ct_hist); FREE_NULL(db->ct_offs); FREE_NULL(db->ct_cursor); FREE_NULL(db->ct_tmp); FREE_NULL(db->rs_rows); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs);
-    FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->rs_bands);
+    FREE_NULL(db->run_ctr); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->rs_bands);
     if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
     db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
 }
@@ -2388,9 +2433,16 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, (KMDB_PAIR_REGIONS + 1) * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->sub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->wsub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
+    HIP_TRY(hipMemsetAsync(db->run_ctr, 0, K1W_CTRS * 16 * 4, st));
+    // Sizes of the launches: measured by the previous call on this handle.  What the narrow kernel produces repeats exactly; where
+    // the wide kernel's records land depends on which wave took which run, so the chunk counts behind it vary a little from call
+    // to call: those launches get some slack, every kernel takes the true counts from device memory, and the call is repeated with
+    // upper bounds if a true count exceeded its launch (checked at the end).
+    auto with_slack = [](uint32_t v) -> uint32_t { return v + v / 8u + 1024u; };
+    const uint32_t raw_launch = db->have_counts ? (uint32_t)std::min<uint64_t>(with_slack(db->last_n_raw), row_mode ? 0xFFFFFFFFull : db->wide_pool_cap) : 0u;
     if (!row_mode) {
         // never-written slots of the wide pool sort last; only the part the previous call used has to be reset
-        const uint64_t wslots = db->have_counts ? std::min<uint64_t>((uint64_t)db->last_n_raw << WCH_SHIFT, db->wide_pool_cap << WCH_SHIFT) : db->wide_pool_cap << WCH_SHIFT;
+        const uint64_t wslots = db->have_counts ? (uint64_t)raw_launch << WCH_SHIFT : db->wide_pool_cap << WCH_SHIFT;
         HIP_TRY(hipMemsetAsync(db->wkey, 0xFF, wslots * 4, st));
     }
     HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, st));
@@ -2522,6 +2574,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             db->k1w_slots = (uint32_t)std::max(1, per_cu) * waves * (uint32_t)std::max(1, prop.multiProcessorCount);
         }
         q.n_waves = std::min<uint32_t>(std::min<uint32_t>(db->k1w_slots, db->k1w_waves), q.n_runs);
+        q.run_ctr = db->run_ctr;
         if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(db->k1w_waves, q.n_runs), (uint32_t)atoi(e)));
         hipLaunchKernelGGL(k1w_kernel, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
     }
@@ -2529,6 +2582,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     if (stage("wide emit")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[2], st));
     const uint32_t kmask = (1u << db->key_bits) - 1u;
+    uint32_t jobs_launched = 0;
     if (row_mode) {
         // ---- many streams: chunk table grouped (stream chunks -> side stream), then the sort inside the block rows and its apply
         if (group_and_apply_chunks(st)) return 1;
@@ -2545,7 +2599,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         hipLaunchKernelGGL(rs_rows_kernel, dim3(1), dim3(1024), 0, st, db->rg_offs, db->rg_blocks, NB, row_job, row_tab, db->counters);
         const RsRows R{db->rg_offs, db->row_ids, db->rg_blocks, NB, row_job, row_tab};
         // jobs and table entries: measured by the previous call, else their upper bounds (workgroups beyond the last job leave at once)
-        const uint32_t jobs = db->have_counts ? std::max<uint32_t>(db->last_n_rowjobs, 1u) : (uint32_t)(pool_cap / RS_JOB_CHUNKS + NB + 1);
+        const uint32_t jobs_bound = (uint32_t)(pool_cap / RS_JOB_CHUNKS + NB + 1);
+        const uint32_t jobs = db->have_counts ? std::min<uint32_t>(jobs_bound, with_slack(db->last_n_rowjobs)) : jobs_bound;
+        jobs_launched = jobs;
         const size_t ne = std::min<size_t>(db->rs_entries, (size_t)jobs * NB + 1);
         HIP_TRY(hipMemsetAsync(db->rs_hist, 0, ne * 4, st));
         hipLaunchKernelGGL(rs_hist_kernel, dim3(jobs), dim3(256), NB * 4, st, R, db->chunk_fill, db->recw, kmask, db->rs_hist);
@@ -2582,7 +2638,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         hipLaunchKernelGGL(count_raw_kernel, dim3(1), dim3(1), 0, st, db->wsub_cursor, db->counters);
         // the wide pool: records sorted by stream (the sort moves the 16-byte records with their key words), one tile per run
         uint32_t n_raw;
-        if (db->have_counts) n_raw = db->last_n_raw;
+        if (db->have_counts) n_raw = raw_launch;
         else {
             HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -2627,7 +2683,10 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         if (c[KCTR_WIDE_OVERFLOW]) {
             const uint64_t want = db->wide_pool_cap * 2;
             if ((want << WCH_SHIFT) >= (1ull << 31)) {
-                db->fallback_reason = "more than 2^31 block records from the nodes with many blocks";
+                if (db->n_slices >= (1u << 16)) { db->fallback_reason = "more than 2^31 block records from the nodes with many blocks in a 65536th of the patterns"; return 0; }
+                db->n_slices *= 2;                                  // the pools stay as they are: half as many patterns per pass
+                if (verbose) fprintf(stderr, "[kmdb] wide record pool at its limit: %u slices of the pattern stream per call\n", db->n_slices);
+                db->have_counts = false; *retry = true;
                 return 0;
             }
             if (verbose) fprintf(stderr, "[kmdb] wide record pool too small (%llu chunks): doubling\n", (unsigned long long)db->wide_pool_cap);
@@ -2648,7 +2707,13 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                 if (alloc_wide_pool(db, db->wide_pool_cap + db->est_records * 5 / 4 / WCH_REC)) return 1;
                 want = 0;
             } else if ((want << CH_SHIFT) >= (1ull << 31)) {
-                db->fallback_reason = "more than 2^31 block records (" + std::to_string(db->n_states) + " streams, " + std::to_string(db->pool_cap) + " chunks were not enough)";
+                if (db->n_slices >= (1u << 16)) {
+                    db->fallback_reason = "more than 2^31 block records in a 65536th of the patterns (" + std::to_string(db->n_states) + " streams, " + std::to_string(db->pool_cap) + " chunks were not enough)";
+                    return 0;
+                }
+                db->n_slices *= 2;
+                if (verbose) fprintf(stderr, "[kmdb] record pool at its limit: %u slices of the pattern stream per call\n", db->n_slices);
+                db->have_counts = false; *retry = true;
                 return 0;
             }
             if (want) {
@@ -2659,9 +2724,10 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         db->have_counts = false; *retry = true;
         return 0;
     }
-    if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks || c[KCTR_RAW] != db->last_n_raw ||
-                            (row_mode && (c[KCTR_ROWJOBS] != db->last_n_rowjobs || c[KCTR_WIDE_RECORDS] != db->last_n_sorted)))) {
-        // cannot happen for an unchanged database and emit range; redo the call with measured sizes
+    if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks ||
+                            (row_mode ? (c[KCTR_ROWJOBS] > jobs_launched || c[KCTR_WIDE_RECORDS] != db->last_n_sorted) : c[KCTR_RAW] > raw_launch))) {
+        // the exact counts cannot differ for an unchanged database and emit range, and the varying ones stay inside their slack in
+        // practice; if not: redo the call with upper bounds
         db->have_counts = false; *retry = true;
         return 0;
     }
@@ -2674,15 +2740,26 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
 }  // namespace
 
 int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, hipStream_t st) {
-    if (db->last_emit_lo != emit_lo || db->last_emit_hi != emit_hi) db->have_counts = false;   // grid sizes belong to one emit range
-    db->last_emit_lo = emit_lo; db->last_emit_hi = emit_hi;
     const uint64_t cells = db->N * (db->N - 1) / 2;
-    for (int attempt = 0; attempt < 24; ++attempt) {
-        bool retry = false;
-        if (attempt) HIP_TRY(hipMemsetAsync(M, 0, cells * 4, st));
-        if (blocks_attempt(db, M, emit_lo, emit_hi, st, &retry)) return 1;
-        if (!db->fallback_reason.empty()) return 0;
-        if (!retry) { db->have_counts = true; return 0; }
+    for (int round = 0; round < 64; ++round) {
+        // the slices of [emit_lo, emit_hi) one after the other, adding into the same matrix; a pass that had to enlarge a pool (or
+        // asked for more slices) leaves a partial sum behind: everything again from a zeroed matrix
+        const uint32_t S = std::max<uint32_t>(1u, db->n_slices);
+        bool again = false;
+        uint64_t records = 0;
+        for (uint32_t k = 0; k < S && !again; ++k) {
+            const uint32_t lo = emit_lo + (uint32_t)((uint64_t)(emit_hi - emit_lo) * k / S), hi = emit_lo + (uint32_t)((uint64_t)(emit_hi - emit_lo) * (k + 1) / S);
+            if (lo == hi) continue;
+            if (db->last_emit_lo != lo || db->last_emit_hi != hi) db->have_counts = false;   // launch sizes belong to one emit range
+            db->last_emit_lo = lo; db->last_emit_hi = hi;
+            bool retry = false;
+            if (blocks_attempt(db, M, lo, hi, st, &retry)) return 1;
+            if (!db->fallback_reason.empty()) return 0;
+            if (retry) again = true;
+            else { db->have_counts = true; records += db->last_records; }
+        }
+        if (!again) { db->last_records = records; return 0; }
+        HIP_TRY(hipMemsetAsync(M, 0, cells * 4, st));
     }
     return kmdb_set_error("kmdb_blocks_run: the record pools did not converge");
 }

@@ -281,6 +281,9 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
                             "expect it to be far slower\n", db->fallback_reason.c_str());
         }
         if (flags & KMDB_FLAG_NO_FALLBACK) return kmdb_set_error("kmdb_all2all: block-record pipeline unavailable: " + db->fallback_reason);
+        // a slice of the pattern stream means something else to the two paths (pattern ranges here, 2048-node segments there): partial
+        // matrices of slices that took different paths would not add up to the whole
+        if (shard_count > 1) return kmdb_set_error("kmdb_all2all: slices of the pattern stream (kmdb_opts.shard_count > 1) need the block-record pipeline: " + db->fallback_reason);
     }
     // v1 kernels: tree form, subtree weights (reference similarity_calculator.cpp:64-72) = exclusive scan of w in DFS order
     if (kmdb_ensure_v1_arrays(db)) return 1;

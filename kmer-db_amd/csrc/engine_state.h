@@ -102,6 +102,7 @@ struct kmdb_db {
     void *wrec = nullptr, *swrec = nullptr;         // wide pool: 16-byte records {rows, cols} (weight digit in the key word), and sorted by stream
     uint64_t wide_pool_cap = 0;     // chunks of 64 records
     uint32_t* wsub_cursor = nullptr;
+    uint32_t* run_ctr = nullptr;    // wide-node kernel: next run of every class
     // many streams ("row mode"): the wide records go to per-block-row chunks of the chunk pool; the chunk table grouped by key, then a
     // counting sort inside every row
     bool row_mode = false;
@@ -135,12 +136,14 @@ struct kmdb_db {
     uint32_t last_n_wide = 0, last_n_chunks = 0, last_n_raw = 0, last_n_slow = 0;
     uint64_t last_records = 0;
     uint32_t last_emit_lo = 0, last_emit_hi = 0;
+    uint32_t n_slices = 1;          // passes over the pattern stream per call (a database whose records do not fit one)
     void* scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     // ---- v1 kernels (A/B reference, fallback) and new2all: built lazily on the device from the arrays above
     // host staging buffers of the upload, given back by a helper thread after the first call (or when the handle is freed):
     // unmapping them costs 0.3 s (the HIP runtime had them registered for the copies) and blocks every hipMalloc meanwhile
     std::vector<std::pair<void*, size_t>> staging;
+    bool v1_ready = false;          // the arrays below exist (all of them)
     uint4* meta = nullptr;          // {n, l, last_id, nbits} per node, DFS order
     uint64_t* bitpos = nullptr;     // absolute bit offset of the node's gamma stream
     // new2all: index into the gamma streams of the nodes with more than KMDB_CK_IDS local ids — every KMDB_CK_IDS-th id and
