@@ -11,8 +11,8 @@ Reported:
   wall.cold_call_ms     first call after upload, host matrix out (H2D/D2H inclusive)
   wall.cold_total_s     upload + first call = what one `all2all` run costs end to end, next to cpu_baseline.seconds
 Workloads (--workload): c2 = BASELINE.json configs[1], 1000 x 5 Mbp; c3part = the sample count of configs[2] on one GPU,
-10 000 samples x 300 kbp (about half of one GPU's 625 kbp share of configs[2]: the synthetic generator's torch sorts stop at
-2^31 local ids, which 10 000 x 625 kbp exceeds).  With --gpus N the k-mer space is sharded by prefix bucket (kmer >> 32, reference
+10 000 samples x 300 kbp (rides along in the default line); c3gpu = one GPU's share of configs[2], 10 000 samples x 625 kbp
+(5 Mbp / 8 GPUs; more than 2^31 local ids in the pattern tree: the generator places them without a global sort).  With --gpus N the k-mer space is sharded by prefix bucket (kmer >> 32, reference
 src/types.h:25-27): --scaling weak (default) keeps per-GPU work fixed (genomes N x longer, rank r owns the buckets
 congruent to r mod N); --scaling strong shards ONE database of the workload's size (kmdb_db_upload_shard).  The
 partial matrices are summed with one RCCL reduce.  `python bench.py --gpus N` starts its own N ranks.
@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E p
 WORKLOADS = {
     "c2": dict(samples=1000, clade_size=50, length=5_000_000),
     "c3part": dict(samples=10000, clade_size=50, length=300_000),
+    "c3gpu": dict(samples=10000, clade_size=50, length=625_000),           # configs[2] / 8 GPUs
     # secondary modes (--mode), sized so that the synthetic generator and the reference finish in minutes
     "c4part": dict(samples=20000, clade_size=50, length=100_000, k=25, fraction=0.1),      # configs[3] is 50 000 samples: --samples 50000
     "c5part": dict(samples=10000, clade_size=50, length=100_000, queries=1000),            # configs[4]: 1000 queries vs a 10 000-sample database
@@ -533,6 +534,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="default workload only: skip the 10 000-sample workload that rides along in the same JSON line")
     ap.add_argument("--tmp", default=None, help="directory for the reference's .db files (default: the system temp dir)")
+    ap.add_argument("--collective", default="reduce", choices=["reduce", "reduce_scatter"],
+                    help="how the partial matrices of --gpus N meet: one reduce to rank 0 (north_star), or a reduce-scatter in flat chunks of the "
+                         "triangle after which every rank brings its own chunk to the host (SURVEY 8e: direct, every peer pair over its own xGMI link)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the matrix reduce goes through host memory); never used for reported numbers")
@@ -603,13 +607,28 @@ def main():
     stc = db.stats()
     log("[rank %d] cold call %.1f ms (device pipeline %.2f ms, path %d)" % (rank, cold_ms, stc["kernel_ms"], stc["path"]))
 
-    M = torch.zeros(max(cells, 1), dtype=torch.int32, device=device)
+    scatter = world > 1 and args.collective == "reduce_scatter"
+    per = (cells + world - 1) // world if scatter else 0
+    M = torch.zeros(max(per * world if scatter else cells, 1), dtype=torch.int32, device=device)      # (reduce_scatter: the triangle padded to equal chunks)
+    mine = torch.zeros(max(per, 1), dtype=torch.int32, device=device) if scatter else None
+    hband = torch.zeros(max(per, 1), dtype=torch.int32).pin_memory() if scatter else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         db.all2all_dense_device(M.data_ptr(), stream=stream)
         if world > 1:
-            if args.backend == "nccl":
+            if scatter:
+                # direct reduce-scatter in flat chunks of the triangle: xGMI is point to point, every peer pair sums its chunk over its own
+                # link; every rank then brings ITS chunk to the host (the front-end writes the rows of its chunk)
+                if args.backend == "nccl":
+                    dist.reduce_scatter_tensor(mine, M, op=dist.ReduceOp.SUM)
+                else:
+                    torch.cuda.synchronize()
+                    h = M.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    mine.copy_(h[rank * per: (rank + 1) * per])
+                hband.copy_(mine)
+            elif args.backend == "nccl":
                 dist.reduce(M, dst=0, op=dist.ReduceOp.SUM)      # uint32 wrap-around sum == int32 sum bitwise
             else:
                 torch.cuda.synchronize()
@@ -647,7 +666,12 @@ def main():
         sum_pairs, tree_updates = float(st0["sum_pairs"]), float(st0["tree_updates"])
 
     # size-independent check of the timed result: sum of the matrix == sum_p w_p C(n_p,2); and warm == cold
-    if rank == 0:
+    if scatter:
+        lo_c, hi_c = min(cells, rank * per), min(cells, (rank + 1) * per)
+        part_sum = torch.tensor([float(hband[: hi_c - lo_c].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())], dtype=torch.float64, device=cdev)
+        dist.all_reduce(part_sum, op=dist.ReduceOp.SUM)
+        assert float(part_sum[0]) == sum_pairs, "matrix checksum mismatch over the ranks' chunks: %r vs %r" % (float(part_sum[0]), sum_pairs)
+    elif rank == 0:
         got = int(M[:cells].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) if cells else 0
         assert got == int(sum_pairs), "matrix checksum mismatch: %d vs %d" % (got, int(sum_pairs))
         if world == 1:
@@ -680,8 +704,9 @@ def main():
             "config": {
                 "workload": "%s: %d synthetic %g Mbp genomes (clade-mutation model, clades of %d, r1=0.10 r2=0.01), k=%d f=1.0, "
                             "dense all2all%s" % (args.workload, args.samples, total_len / 1e6, args.clade_size, args.k,
-                                                 "" if world == 1 else ", k-mer space sharded by prefix bucket over %d GPUs (%s) + RCCL reduce"
-                                                 % (world, "one database, kmdb_db_upload_shard" if strong else "per-rank databases")),
+                                                 "" if world == 1 else ", k-mer space sharded by prefix bucket over %d GPUs (%s) + RCCL %s"
+                                                 % (world, "one database, kmdb_db_upload_shard" if strong else "per-rank databases",
+                                                    "reduce-scatter by flat chunks + D2H of every rank's chunk" if scatter else "reduce")),
                 "samples": args.samples, "genome_length_bp": total_len, "k": args.k, "fraction": 1.0,
                 "patterns_rank0": db.P, "distinct_kmers_rank0": nk, "parallelism": "prefix-shard x%d" % world, "rccl": rccl,
                 "sample_pairs_per_s": args.samples * (args.samples - 1) / 2 / (elapsed / args.steps),

@@ -35,7 +35,7 @@
 #include "device_common.h"
 #include "engine_internal.h"
 
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 #include <algorithm>
 #include <cmath>
@@ -2041,8 +2041,8 @@ int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipMalloc((void**)&db->rec, (chunks << CH_SHIFT) * 16));
     HIP_TRY(hipMalloc((void**)&db->recw, (chunks << CH_SHIFT) * 4));
     {
-        hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
-        HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, db->sort_tmp_bytes, it, (unsigned long long*)nullptr, (int)chunks, db->stream));
+        rocprim::transform_iterator<uint32_t*, U32toU64, unsigned long long> it(db->chunk_fill, U32toU64());
+        HIP_TRY(prim::sum(nullptr, db->sort_tmp_bytes, it, (unsigned long long*)nullptr, (int)chunks, db->stream));
     }
     HIP_TRY(hipMalloc(&db->sort_tmp, std::max<size_t>(db->sort_tmp_bytes, 16)));
     if (db->row_mode) {
@@ -2053,14 +2053,14 @@ int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
         HIP_TRY(hipMalloc((void**)&db->rg_hist, rg_ne * 4));
         HIP_TRY(hipMalloc((void**)&db->rg_offs, rg_ne * 4));
         HIP_TRY(hipMalloc((void**)&db->row_ids, chunks * 4));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->rg_tmp_bytes, db->rg_hist, db->rg_offs, (int)rg_ne, db->stream));
+        HIP_TRY(prim::exclusive_sum(nullptr, db->rg_tmp_bytes, db->rg_hist, db->rg_offs, (int)rg_ne, db->stream));
         HIP_TRY(hipMalloc(&db->rg_tmp, std::max<size_t>(db->rg_tmp_bytes, 16)));
         // the sort inside the rows: at most chunks / RS_JOB_CHUNKS + NB jobs, every one with at most NB bins
         db->rs_entries = (chunks / RS_JOB_CHUNKS + db->NB + 1) * (uint64_t)db->NB + 1;
         if (db->rs_entries >= (1ull << 31)) return kmdb_set_error("kmdb: the table of the sort inside the block rows would exceed 2^31 entries");
         HIP_TRY(hipMalloc((void**)&db->rs_hist, db->rs_entries * 4));
         HIP_TRY(hipMalloc((void**)&db->rs_offs, db->rs_entries * 4));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->rs_tmp_bytes, db->rs_hist, db->rs_offs, (int)db->rs_entries, db->stream));
+        HIP_TRY(prim::exclusive_sum(nullptr, db->rs_tmp_bytes, db->rs_hist, db->rs_offs, (int)db->rs_entries, db->stream));
         HIP_TRY(hipMalloc(&db->rs_tmp, std::max<size_t>(db->rs_tmp_bytes, 16)));
     }
     db->pool_cap = chunks;
@@ -2085,7 +2085,7 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
         const size_t ne = (size_t)db->n_states * CS_BLOCKS_ONE + 1;
         HIP_TRY(hipMalloc((void**)&db->cs_hist, ne * 4));
         HIP_TRY(hipMalloc((void**)&db->cs_offs, ne * 4));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->cs_tmp_bytes, db->cs_hist, db->cs_offs, (int)ne, db->stream));
+        HIP_TRY(prim::exclusive_sum(nullptr, db->cs_tmp_bytes, db->cs_hist, db->cs_offs, (int)ne, db->stream));
         HIP_TRY(hipMalloc(&db->cs_tmp, std::max<size_t>(db->cs_tmp_bytes, 16)));
     }
     db->wide_pool_cap = chunks;
@@ -2161,7 +2161,7 @@ static int ensure_v1_impl(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->segs, std::max<size_t>(segs.size(), 1) * sizeof(Segment)));
     if (!segs.empty()) HIP_TRY(hipMemcpy(db->segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
     db->n_segs = (uint32_t)segs.size();
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1)));
+    HIP_TRY(prim::exclusive_sum(nullptr, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1)));
     HIP_TRY(hipMalloc(&db->v1_scan_tmp, std::max<size_t>(db->v1_scan_tmp_bytes, 16)));
     {
         const uint64_t P1 = P + 1;
@@ -2171,9 +2171,9 @@ static int ensure_v1_impl(kmdb_db* db) {
         HIP_TRY(hipMalloc((void**)&cnt, P1 * 4));
         HIP_TRY(hipMalloc((void**)&db->ck_ofs, P1 * 4));
         hipLaunchKernelGGL(ck_count_kernel, dim3((unsigned)((P1 + 255) / 256)), dim3(256), 0, db->stream, db->k0in, (uint32_t)P, cnt);
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, db->ck_ofs, (int)P1, db->stream));
+        HIP_TRY(prim::exclusive_sum(nullptr, tb, cnt, db->ck_ofs, (int)P1, db->stream));
         HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, db->ck_ofs, (int)P1, db->stream));
+        HIP_TRY(prim::exclusive_sum(tmp, tb, cnt, db->ck_ofs, (int)P1, db->stream));
         uint32_t n_ck = 0;
         HIP_TRY(hipMemcpyAsync(&n_ck, db->ck_ofs + P, 4, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
@@ -2208,20 +2208,20 @@ int kmdb_rect_sort_apply(hipStream_t st, uint32_t* wkey, void* wrec, uint32_t ns
         size_t tb = 0;
         RS_TRY(hipMalloc((void**)&hist, ne * 4));
         RS_TRY(hipMalloc((void**)&offs, ne * 4));
-        RS_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hist, offs, (int)ne, st));
+        RS_TRY(prim::exclusive_sum(nullptr, tb, hist, offs, (int)ne, st));
         RS_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
         const CsRows no_rows{};
         hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS_ONE), dim3(256), n_states * 4, st, wkey, nslots, n_states, n_states, (int)CS_BY_STREAM, no_rows, kmask, hist);
-        RS_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, hist, offs, (int)ne, st));
+        RS_TRY(prim::exclusive_sum(tmp, tb, hist, offs, (int)ne, st));
         RS_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(n_states)));
         hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(n_states), st, wkey, (const WideRec*)wrec, nslots, n_states, n_states,
                            (int)CS_BY_STREAM, no_rows, kmask, offs, swkey, swrec);
         total_ptr = offs + (ne - 1);
     } else {
         size_t tb = 0;
-        RS_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, wkey, swkey, (WideRec*)wrec, swrec, (int)nslots, 0, key_bits, st));
+        RS_TRY(prim::sort_pairs(nullptr, tb, wkey, swkey, (WideRec*)wrec, swrec, (int)nslots, 0, key_bits, st));
         RS_TRY(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
-        RS_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, wkey, swkey, (WideRec*)wrec, swrec, (int)nslots, 0, key_bits, st));
+        RS_TRY(prim::sort_pairs(tmp, tb, wkey, swkey, (WideRec*)wrec, swrec, (int)nslots, 0, key_bits, st));
     }
     hipLaunchKernelGGL(k2_sorted_kernel, dim3((nslots + K2S_WIN - 1) / K2S_WIN), dim3(256), 0, st, swkey, (const WideRec*)swrec, nslots, total_ptr, (const uint32_t*)nullptr,
                        n_states, (uint32_t)key_bits, wide_digit_bits(key_bits), M, n_rows, 64u, nbc, n_cols);
@@ -2305,7 +2305,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->widebits, n_words * 8));
     HIP_TRY(hipMalloc((void**)&db->wide_cnt, (n_words + 1) * 4));
     HIP_TRY(hipMalloc((void**)&db->wide_base, (n_words + 1) * 4));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1)));
+    HIP_TRY(prim::exclusive_sum(nullptr, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1)));
     HIP_TRY(hipMalloc(&db->scan_tmp, std::max<size_t>(db->scan_tmp_bytes, 16)));
     HIP_TRY(hipMalloc((void**)&db->counters, KCTR_COUNT * 4));
     HIP_TRY(hipHostMalloc((void**)&db->h_counters, KCTR_COUNT * 4));
@@ -2354,7 +2354,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->ct_hist, ((size_t)db->n_ckeys + 2) * 4));
     HIP_TRY(hipMalloc((void**)&db->ct_offs, ((size_t)db->n_ckeys + 2) * 4));
     HIP_TRY(hipMalloc((void**)&db->ct_cursor, ((size_t)db->n_ckeys + 2) * 4));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, db->ct_tmp_bytes, db->ct_hist, db->ct_offs, (int)(db->n_ckeys + 1), db->stream));
+    HIP_TRY(prim::exclusive_sum(nullptr, db->ct_tmp_bytes, db->ct_hist, db->ct_offs, (int)(db->n_ckeys + 1), db->stream));
     HIP_TRY(hipMalloc(&db->ct_tmp, std::max<size_t>(db->ct_tmp_bytes, 16)));
     // A database whose records do not fit one pass (2^31 record slots, or the memory left) is taken in SLICES of the pattern stream:
     // every slice emits the records of its own patterns only, the partial matrices add up in place (the engine's own version of
@@ -2371,6 +2371,11 @@ static int blocks_prepare_impl(kmdb_db* db) {
         if (verbose && db->n_slices > 1) fprintf(stderr, "[kmdb] %llu block records estimated: %u slices of the pattern stream per call\n",
                                                  (unsigned long long)(est_n + est_g), db->n_slices);
         est_n = est_n / db->n_slices + 1; est_g = est_g / db->n_slices + 1;
+    }
+    if (const char* e = getenv("KMDB_POOL_PERCENT")) if (*e) {
+        // (tests: pools far too small, so that the first call takes the enlarge-and-repeat path on every one of them)
+        const uint64_t pct = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        est_n = est_n * pct / 100 + 1; est_g = est_g * pct / 100 + 1;
     }
     // waves of the wide-node kernel: in row mode every wave may end with an open chunk per block row
     db->k1w_waves = K1W_MAX_WAVES;
@@ -2496,14 +2501,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     auto group_and_apply_chunks = [&](hipStream_t cs) -> int {
         hipLaunchKernelGGL(ct_hist_kernel, dim3((pool_cap + CT_THREADS - 1) / CT_THREADS), dim3(CT_THREADS), 0, cs, db->chunk_key, pool_cap, n_ckeys, db->ct_hist);
         size_t tb = db->ct_tmp_bytes;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->ct_tmp, tb, db->ct_hist, db->ct_offs, (int)(n_ckeys + 1), cs));
+        HIP_TRY(prim::exclusive_sum(db->ct_tmp, tb, db->ct_hist, db->ct_offs, (int)(n_ckeys + 1), cs));
         HIP_TRY(hipMemcpyAsync(db->ct_cursor, db->ct_offs, ((size_t)n_ckeys + 1) * 4, hipMemcpyDeviceToDevice, cs));
         hipLaunchKernelGGL(ct_scatter_kernel, dim3((pool_cap + CT_THREADS - 1) / CT_THREADS), dim3(CT_THREADS), 0, cs, db->chunk_key, pool_cap, n_ckeys, db->ct_cursor, db->sorted_key, db->sorted_id);
         hipLaunchKernelGGL(ct_count_kernel, dim3(1), dim3(1), 0, cs, db->ct_offs, db->n_states, db->counters);
         if (cs != s2) { HIP_TRY(hipEventRecord(db->ev_side[0], cs)); HIP_TRY(hipStreamWaitEvent(s2, db->ev_side[0], 0)); }
         {
-            hipcub::TransformInputIterator<unsigned long long, U32toU64, uint32_t*> it(db->chunk_fill, U32toU64());
-            HIP_TRY(hipcub::DeviceReduce::Sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
+            rocprim::transform_iterator<uint32_t*, U32toU64, unsigned long long> it(db->chunk_fill, U32toU64());
+            HIP_TRY(prim::sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
         }
         const uint32_t win = db->n_states <= CS_MAX_KEYS ? K2_WIN / 2 : K2_WIN;
         uint32_t grid = (pool_cap + win - 1) / win;
@@ -2523,7 +2528,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     }
     // ---- wide list
     hipLaunchKernelGGL(wide_count_kernel, dim3((n_words + 1 + 255) / 256), dim3(256), 0, st, db->widebits, n_words, db->wide_cnt);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->scan_tmp, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1), st));
+    HIP_TRY(prim::exclusive_sum(db->scan_tmp, db->scan_tmp_bytes, db->wide_cnt, db->wide_base, (int)(n_words + 1), st));
     uint32_t n_wide;
     if (db->have_counts && db->wide_cap >= db->last_n_wide) n_wide = db->last_n_wide;     // deterministic per database; checked at the end of the call
     else {
@@ -2593,7 +2598,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             const size_t rg_ne = (size_t)NB * db->rg_blocks + 1;
             hipLaunchKernelGGL(rg_hist_kernel, dim3(db->rg_blocks), dim3(RG_THREADS), NB * 4, st, db->chunk_key, pool_cap, db->n_states, NB, db->rg_hist);
             size_t tbg = db->rg_tmp_bytes;
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->rg_tmp, tbg, db->rg_hist, db->rg_offs, (int)rg_ne, st));
+            HIP_TRY(prim::exclusive_sum(db->rg_tmp, tbg, db->rg_hist, db->rg_offs, (int)rg_ne, st));
             hipLaunchKernelGGL(rg_scatter_kernel, dim3(db->rg_blocks), dim3(RG_THREADS), NB * 4, st, db->chunk_key, pool_cap, db->n_states, NB, db->rg_offs, db->row_ids);
         }
         hipLaunchKernelGGL(rs_rows_kernel, dim3(1), dim3(1024), 0, st, db->rg_offs, db->rg_blocks, NB, row_job, row_tab, db->counters);
@@ -2606,7 +2611,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         HIP_TRY(hipMemsetAsync(db->rs_hist, 0, ne * 4, st));
         hipLaunchKernelGGL(rs_hist_kernel, dim3(jobs), dim3(256), NB * 4, st, R, db->chunk_fill, db->recw, kmask, db->rs_hist);
         size_t tb = db->rs_tmp_bytes;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->rs_tmp, tb, db->rs_hist, db->rs_offs, (int)ne, st));
+        HIP_TRY(prim::exclusive_sum(db->rs_tmp, tb, db->rs_hist, db->rs_offs, (int)ne, st));
         const uint32_t* total_ptr = db->rs_offs + (ne - 1);
         HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
         // Bands of block rows with about equal record counts (a row's share grows with its index): band b is sorted on this stream,
@@ -2651,7 +2656,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS_ONE), dim3(256), db->n_states * 4, st, db->wkey, nslots, db->n_states, db->n_states, (int)CS_BY_STREAM,
                                no_rows, kmask, db->cs_hist);
             size_t tb = db->cs_tmp_bytes;
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
+            HIP_TRY(prim::exclusive_sum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
             HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
             hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
                                db->n_states, db->n_states, (int)CS_BY_STREAM, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);

@@ -18,7 +18,7 @@
 #include "engine_internal.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -255,18 +255,18 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
     D2_TRY(hipEventRecord(ev0, st));
     if (n_slots && nr && nc) {
         size_t tb_sort = 0, tb_rle = 0;
-        D2_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
+        D2_TRY(prim::sort_keys(nullptr, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
                                                  (int)n_slots, 0, 64, st));
-        D2_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
+        D2_TRY(prim::run_length_encode(nullptr, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                      d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)n_slots, st));
         D2_TRY(d_tmp.alloc(std::max(tb_sort, tb_rle)));
         const D2Db vr = view_of(er), vc = view_of(ec);
         hipLaunchKernelGGL(d2_probe_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, vr, vc, n_slots,
                            d_keys.as<unsigned long long>());
         D2_TRY(hipGetLastError());
-        D2_TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
+        D2_TRY(prim::sort_keys(d_tmp.p, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
                                                  (int)n_slots, 0, 64, st));
-        D2_TRY(hipcub::DeviceRunLengthEncode::Encode(d_tmp.p, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
+        D2_TRY(prim::run_length_encode(d_tmp.p, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                      d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)n_slots, st));
         uint32_t nruns = 0;
         D2_TRY(hipMemcpyAsync(&nruns, d_nruns.p, 4, hipMemcpyDeviceToHost, st));

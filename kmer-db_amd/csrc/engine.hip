@@ -9,7 +9,7 @@
 #include "device_common.h"
 #include "engine_internal.h"
 
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 #include <algorithm>
 #include <cmath>
@@ -288,7 +288,7 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
     // v1 kernels: tree form, subtree weights (reference similarity_calculator.cpp:64-72) = exclusive scan of w in DFS order
     if (kmdb_ensure_v1_arrays(db)) return 1;
     HIP_TRY(hipMemsetAsync(db->v1_counters, 0, 8 * sizeof(unsigned long long), st));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db->v1_scan_tmp, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1), st));
+    HIP_TRY(prim::exclusive_sum(db->v1_scan_tmp, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1), st));
     HIP_TRY(hipEventRecord(db->ev[1], st));
     const uint32_t seg_begin = (uint32_t)((uint64_t)db->n_segs * shard_index / shard_count) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
     const uint32_t seg_end = shard_index + 1 == shard_count ? db->n_segs : (uint32_t)((uint64_t)db->n_segs * (shard_index + 1) / shard_count) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
@@ -479,9 +479,9 @@ static int sparse_impl(kmdb_db* db, bool from_cells, const void* dense_dev, uint
     SP_TRY(hipMemsetAsync(row_nnz, 0, (N + 1) * 8, st));
     if (row_hi > row_lo) hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)(row_hi - row_lo)), dim3(256), 0, st, cellsp, row_lo, cell_lo, cell_hi, row_nnz, df);
     size_t tmp_bytes = 0;
-    SP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
+    SP_TRY(prim::exclusive_sum(nullptr, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
     SP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-    SP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
+    SP_TRY(prim::exclusive_sum(tmp, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
     std::vector<unsigned long long> h_ptr(N + 1, 0);
     SP_TRY(hipMemcpyAsync(h_ptr.data(), row_ptr, (N + 1) * 8, hipMemcpyDeviceToHost, st));
     SP_TRY(hipStreamSynchronize(st));

@@ -11,7 +11,7 @@
 #include "device_common.h"
 #include "engine_internal.h"
 
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 #include <algorithm>
 #include <atomic>
@@ -408,13 +408,13 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
             if (!changed) break;
         }
         size_t tb = 0, tb2 = 0;
-        hipcub::TransformInputIterator<uint64_t, U32toU64, uint32_t*> it_nb(d_nbits.p, U32toU64());
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, keep.p, newidx.p, (int)(P + 1), st));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, it_nb, spos.p, (int)P, st));
+        rocprim::transform_iterator<uint32_t*, U32toU64, uint64_t> it_nb(d_nbits.p, U32toU64());
+        HIP_TRY(prim::exclusive_sum(nullptr, tb, keep.p, newidx.p, (int)(P + 1), st));
+        HIP_TRY(prim::exclusive_sum(nullptr, tb2, it_nb, spos.p, (int)P, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(std::max(tb, tb2))) return 1;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, keep.p, newidx.p, (int)(P + 1), st));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, it_nb, spos.p, (int)P, st));
+        HIP_TRY(prim::exclusive_sum(tmp.p, tb, keep.p, newidx.p, (int)(P + 1), st));
+        HIP_TRY(prim::exclusive_sum(tmp.p, tb2, it_nb, spos.p, (int)P, st));
         uint32_t P2 = 0;
         HIP_TRY(hipMemcpyAsync(&P2, newidx.p + P, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -453,12 +453,12 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         int end_bit = 1;
         while ((1ull << end_bit) <= P) ++end_bit;
         size_t tb = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
+        HIP_TRY(prim::sort_pairs(nullptr, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
         HIP_TRY(hipStreamSynchronize(st));
         phase("  keys + sort temporaries");
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
+        HIP_TRY(prim::sort_pairs(tmp.p, tb, keys.p, skeys.p, vals.p, schild.p, (int)P, 0, end_bit, st));
         HIP_TRY(hipStreamSynchronize(st));
         phase("  radix sort");
     }
@@ -492,10 +492,10 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         DevTmp<uint32_t> dmax;
         if (dmax.alloc(1)) return 1;
         size_t tb = 0;
-        HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, dep[dcur].p, dmax.p, (int)P, st));
+        HIP_TRY(prim::max(nullptr, tb, dep[dcur].p, dmax.p, (int)P, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
-        HIP_TRY(hipcub::DeviceReduce::Max(tmp.p, tb, dep[dcur].p, dmax.p, (int)P, st));
+        HIP_TRY(prim::max(tmp.p, tb, dep[dcur].p, dmax.p, (int)P, st));
         HIP_TRY(hipMemcpyAsync(&max_depth, dmax.p, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -509,10 +509,10 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     hipLaunchKernelGGL(lay_gather_u32_kernel, dim3(G), dim3(B), 0, st, size.p, schild.p, (uint32_t)P, ssz.p);
     {
         size_t tb1 = 0;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, ssz.p, S.p, (int)P, st));
+        HIP_TRY(prim::exclusive_sum(nullptr, tb1, ssz.p, S.p, (int)P, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb1)) return 1;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb1, ssz.p, S.p, (int)P, st));
+        HIP_TRY(prim::exclusive_sum(tmp.p, tb1, ssz.p, S.p, (int)P, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     ssz.reset();
@@ -566,14 +566,14 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         DevTmp<uint64_t> srcpos, dstpos;
         if (nb_dfs.alloc(P) || srcpos.alloc(P + 1) || dstpos.alloc(P + 1)) return 1;
         hipLaunchKernelGGL(lay_nbits_dfs_kernel, dim3(G), dim3(B), 0, st, db->k0in, (uint32_t)P, nb_dfs.p);
-        hipcub::TransformInputIterator<uint64_t, U32toU64, uint32_t*> it_src(d_nbits.p, U32toU64()), it_dst(nb_dfs.p, U32toU64());
+        rocprim::transform_iterator<uint32_t*, U32toU64, uint64_t> it_src(d_nbits.p, U32toU64()), it_dst(nb_dfs.p, U32toU64());
         size_t tb = 0;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it_src, srcpos.p, (int)P, st));
+        HIP_TRY(prim::exclusive_sum(nullptr, tb, it_src, srcpos.p, (int)P, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
         if (d_spos.p) HIP_TRY(hipMemcpyAsync(srcpos.p, d_spos.p, P * 8, hipMemcpyDeviceToDevice, st));          // pruned shard: the streams keep their uploaded places
-        else HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, it_src, srcpos.p, (int)P, st));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, it_dst, dstpos.p, (int)P, st));
+        else HIP_TRY(prim::exclusive_sum(tmp.p, tb, it_src, srcpos.p, (int)P, st));
+        HIP_TRY(prim::exclusive_sum(tmp.p, tb, it_dst, dstpos.p, (int)P, st));
         HIP_TRY(hipMalloc((void**)&db->bits, n_bit_words * 8));
         HIP_TRY(hipMemsetAsync(db->bits, 0, n_bit_words * 8, st));
         db->n_bit_words = n_bit_words;
@@ -609,19 +609,19 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         DevTmp<uint32_t> sel, lk, lk2, nsel;
         if (sel.alloc(hs.n_long + 1) || lk.alloc(hs.n_long) || lk2.alloc(hs.n_long) || nsel.alloc(1)) return 1;
         HIP_TRY(hipMalloc((void**)&db->long_nodes, (size_t)hs.n_long * 4));
-        hipcub::CountingInputIterator<uint32_t> first(0u);
+        rocprim::counting_iterator<uint32_t> first(0u);
         size_t tb = 0;
-        HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
+        HIP_TRY(prim::select_if(nullptr, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
-        HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
+        HIP_TRY(prim::select_if(tmp.p, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
         hipLaunchKernelGGL(lay_long_keys_kernel, dim3((hs.n_long + 255) / 256), dim3(256), 0, st, db->k0in, sel.p, hs.n_long, lk.p);
         // most work first; the sort is stable, so equal work keeps ascending DFS order
         size_t tb2 = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb2, lk.p, lk2.p, sel.p, db->long_nodes, (int)hs.n_long, 0, 32, st));
+        HIP_TRY(prim::sort_pairs_desc(nullptr, tb2, lk.p, lk2.p, sel.p, db->long_nodes, (int)hs.n_long, 0, 32, st));
         DevTmp<unsigned char> tmp2;
         if (tmp2.alloc(tb2)) return 1;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2.p, tb2, lk.p, lk2.p, sel.p, db->long_nodes, (int)hs.n_long, 0, 32, st));
+        HIP_TRY(prim::sort_pairs_desc(tmp2.p, tb2, lk.p, lk2.p, sel.p, db->long_nodes, (int)hs.n_long, 0, 32, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     HIP_TRY(hipStreamSynchronize(st));

@@ -27,7 +27,7 @@
 #include "engine_internal.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 #include <algorithm>
 #include <cmath>
@@ -261,11 +261,11 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
     N2_TRY(d_qstart.alloc((nq + 2) * 4));
     N2_TRY(d_sim.alloc(nq * N * 4));
     size_t tb_sort = 0, tb_rle = 0, tb_scan = 0;
-    N2_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
+    N2_TRY(prim::sort_keys(nullptr, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
                                              (int)total, 0, 64, st));
-    N2_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
+    N2_TRY(prim::run_length_encode(nullptr, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                  d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)total, st));
-    N2_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb_scan, d_cnt.as<uint32_t>(), d_csum.as<uint32_t>(), (int)(total + 1), st));
+    N2_TRY(prim::exclusive_sum(nullptr, tb_scan, d_cnt.as<uint32_t>(), d_csum.as<uint32_t>(), (int)(total + 1), st));
     N2_TRY(d_tmp.alloc(std::max(tb_sort, std::max(tb_rle, tb_scan))));
     N2_TRY(hipMemsetAsync(d_sim.p, 0, std::max<uint64_t>(nq * N * 4, 4), st));
 
@@ -278,14 +278,14 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
                            total, e.n_buckets, e.bucket_offset, e.slots, e.pid2dfs, e.w, d_keys.as<unsigned long long>());
         N2_TRY(hipGetLastError());
         // queries need 32 - clz(nq) high bits; sorting all 64 is simplest and the key count is small
-        N2_TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
+        N2_TRY(prim::sort_keys(d_tmp.p, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
                                                  (int)total, 0, 64, st));
         N2_TRY(hipMemsetAsync(d_cnt.p, 0, (total + 2) * 4, st));
-        N2_TRY(hipcub::DeviceRunLengthEncode::Encode(d_tmp.p, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
+        N2_TRY(prim::run_length_encode(d_tmp.p, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                      d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)total, st));
         N2_TRY(hipMemcpyAsync(&nruns, d_nruns.p, 4, hipMemcpyDeviceToHost, st));
         N2_TRY(hipStreamSynchronize(st));
-        N2_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb_scan, d_cnt.as<uint32_t>(), d_csum.as<uint32_t>(), (int)(nruns + 1), st));
+        N2_TRY(prim::exclusive_sum(d_tmp.p, tb_scan, d_cnt.as<uint32_t>(), d_csum.as<uint32_t>(), (int)(nruns + 1), st));
         hipLaunchKernelGGL(n2a_query_ranges_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st,
                            d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
         if (nruns) {
@@ -525,22 +525,22 @@ static int new2all_seq_once(kmdb_db* dbh, const char* const* seqs, const size_t*
         int qbits = 1;
         while ((1ull << qbits) < nq) ++qbits;
         size_t tb1 = 0, tb2 = 0, tb3 = 0;
-        N2_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_kmer.as<unsigned long long>(), d_kmer2.as<unsigned long long>(),
+        N2_TRY(prim::sort_pairs(nullptr, tb1, d_kmer.as<unsigned long long>(), d_kmer2.as<unsigned long long>(),
                                                   d_qid.as<uint32_t>(), d_qid2.as<uint32_t>(), (int)L, 0, kbits, st));
-        N2_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, d_qid2.as<uint32_t>(), d_qid.as<uint32_t>(),
+        N2_TRY(prim::sort_pairs(nullptr, tb2, d_qid2.as<uint32_t>(), d_qid.as<uint32_t>(),
                                                   d_kmer2.as<unsigned long long>(), d_kmer.as<unsigned long long>(), (int)L, 0, 32, st));
-        N2_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, d_head.as<uint32_t>(), d_hscan.as<uint32_t>(), (int)(L + 1), st));
+        N2_TRY(prim::exclusive_sum(nullptr, tb3, d_head.as<uint32_t>(), d_hscan.as<uint32_t>(), (int)(L + 1), st));
         N2_TRY(d_tmp.alloc(std::max(tb1, std::max(tb2, tb3))));
-        N2_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tb1, d_kmer.as<unsigned long long>(), d_kmer2.as<unsigned long long>(),
+        N2_TRY(prim::sort_pairs(d_tmp.p, tb1, d_kmer.as<unsigned long long>(), d_kmer2.as<unsigned long long>(),
                                                   d_qid.as<uint32_t>(), d_qid2.as<uint32_t>(), (int)L, 0, kbits, st));
         // dropped positions carry query ~0: all 32 bits take part so that they sort behind every query
         (void)qbits;
-        N2_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tb2, d_qid2.as<uint32_t>(), d_qid.as<uint32_t>(),
+        N2_TRY(prim::sort_pairs(d_tmp.p, tb2, d_qid2.as<uint32_t>(), d_qid.as<uint32_t>(),
                                                   d_kmer2.as<unsigned long long>(), d_kmer.as<unsigned long long>(), (int)L, 0, 32, st));
         N2_TRY(hipMemsetAsync(d_head.p, 0, (L + 1) * 4, st));
         hipLaunchKernelGGL(n2a_heads_kernel, dim3(blocks), dim3(256), 0, st, d_kmer.as<unsigned long long>(), d_qid.as<uint32_t>(), L,
                            d_head.as<uint32_t>());
-        N2_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb3, d_head.as<uint32_t>(), d_hscan.as<uint32_t>(), (int)(L + 1), st));
+        N2_TRY(prim::exclusive_sum(d_tmp.p, tb3, d_head.as<uint32_t>(), d_hscan.as<uint32_t>(), (int)(L + 1), st));
         uint32_t n_unique = 0;
         N2_TRY(hipMemcpyAsync(&n_unique, d_hscan.as<uint32_t>() + L, 4, hipMemcpyDeviceToHost, st));
         hipLaunchKernelGGL(n2a_query_offsets_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st, d_qid.as<uint32_t>(),

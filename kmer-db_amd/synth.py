@@ -192,7 +192,7 @@ def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progre
     isp = _Grow(torch.bool, dev, fill=False)
     for g in (here, nsam, par, isp):
         g.extend_to(1)                  # pattern 0 = the empty pattern (prefix_kmer_db.cpp:24)
-    ev_pid, ev_sid = [], []             # (pattern, sample) "sample appended to the pattern's local list"
+    ev_pid, ev_sid = [], []             # chunks of patterns / their sample: "sample appended to the pattern's local list"
     sample_counts = []
 
     for s in range(n_samples):
@@ -214,7 +214,7 @@ def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progre
         if uq_ext.numel():
             nsam.t[uq_ext] += 1
             ev_pid.append(uq_ext.to(torch.int32))
-            ev_sid.append(torch.full((uq_ext.numel(),), s, dtype=torch.int32, device=dev))
+            ev_sid.append(s)
         # new child patterns (:206-222, pattern.h:104-113)
         if n_new:
             uq_new, cnt_new = uq[new], cnt[new]
@@ -230,7 +230,7 @@ def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progre
             nz = uq_new != 0
             here.t[uq_new[nz]] -= cnt_new[nz]
             ev_pid.append(ids.to(torch.int32))
-            ev_sid.append(torch.full((n_new,), s, dtype=torch.int32, device=dev))
+            ev_sid.append(s)
             # k-mers of the new groups now point at the new pattern
             target = uq.clone()
             target[new] = ids
@@ -239,67 +239,105 @@ def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progre
             print("  synth build: %d/%d samples, %d patterns" % (s + 1, n_samples, here.n), file=sys.stderr, flush=True)
 
     P = here.n
-    ev_pid = torch.cat(ev_pid) if ev_pid else torch.zeros(0, dtype=torch.int32, device=dev)
-    ev_sid = torch.cat(ev_sid) if ev_sid else torch.zeros(0, dtype=torch.int32, device=dev)
-    # events were appended in sample order; a stable sort by pattern gives ascending local ids
-    order = torch.sort(ev_pid.to(torch.int64), stable=True)[1]
-    ev_pid, ev_sid = ev_pid[order], ev_sid[order]
-    num_local = torch.bincount(ev_pid.to(torch.int64), minlength=P)
+    # The events were appended in sample order, one chunk per sample and at most one event per pattern in a chunk: every pattern's ids
+    # are placed in ascending order by a running fill count — no sort over all events (a collection of 10 000 genomes of 625 kbp has
+    # more than 2^31 of them, beyond what the device sorts take).
+    num_local = torch.zeros(P, dtype=torch.int64, device=dev)
+    one = None
+    for ch in ev_pid:
+        if one is None or one.numel() < ch.numel():
+            one = torch.ones(ch.numel(), dtype=torch.int64, device=dev)
+        num_local.index_add_(0, ch.to(torch.int64), one[: ch.numel()])
     local_ptr = torch.zeros(P + 1, dtype=torch.int64, device=dev)
     local_ptr[1:] = torch.cumsum(num_local, 0)
+    E = int(local_ptr[-1])
+    local_ids = torch.zeros(E, dtype=torch.int64, device=dev)
+    fill = local_ptr[:-1].clone()
+    for ch, sid in zip(ev_pid, ev_sid):
+        idx = ch.to(torch.int64)
+        pos = fill[idx]
+        local_ids[pos] = sid
+        fill[idx] = pos + 1
+    del fill
     return {
         "num_kmers": here.t[:P].clone(), "parent": par.t[:P].to(torch.int64), "num_samples": nsam.t[:P].to(torch.int64),
-        "num_local": num_local, "local_ptr": local_ptr, "local_ids": ev_sid.to(torch.int64),
+        "num_local": num_local, "local_ptr": local_ptr, "local_ids": local_ids,
         "dictionary": D, "kmer_pid": cur, "sample_counts": sample_counts,
     }
 
 
-def gamma_encode_patterns(pat):
+def gamma_encode_patterns(pat, max_events=1 << 27):
     """-> (last_sample_id, num_bits, data_offset (uint64 words), data words) in the on-disk layout:
-    l-1 gamma-coded deltas per pattern, stream padded to 128 bits (pattern.h:79-81)."""
+    l-1 gamma-coded deltas per pattern, stream padded to 128 bits (pattern.h:79-81).  Worked through in ranges of patterns
+    with at most `max_events` local ids each (every tensor stays far below 2^31 elements, whatever the collection)."""
     dev = pat["num_local"].device
     P = pat["num_local"].numel()
     lp, ids, l = pat["local_ptr"], pat["local_ids"], pat["num_local"]
     last = torch.zeros(P, dtype=torch.int64, device=dev)
     has = l > 0
     last[has] = ids[lp[1:][has] - 1]
-    # deltas: every local id except the first of its pattern
-    E = ids.numel()
-    first_mask = torch.zeros(E, dtype=torch.bool, device=dev)
-    first_mask[lp[:-1][has]] = True
-    delta = torch.zeros(E, dtype=torch.int64, device=dev)
-    delta[1:] = ids[1:] - ids[:-1]
-    dmask = ~first_mask
-    d = delta[dmask]
-    owner = torch.repeat_interleave(torch.arange(P, device=dev), l)[dmask]
-    Lb = torch.frexp(d.to(torch.float64))[1].to(torch.int64)             # bit length
-    clen = 2 * Lb - 1
-    code = (((1 << (Lb - 1)) - 1) << Lb) | (d - (1 << (Lb - 1)))
-    nbits = torch.zeros(P, dtype=torch.int64, device=dev).index_add_(0, owner, clen)
+    nbits = torch.zeros(P, dtype=torch.int64, device=dev)
+    # ranges of patterns: cut where the running number of events passes a multiple of max_events
+    cuts = [0]
+    if P:
+        marks = torch.searchsorted(lp, torch.arange(max_events, int(lp[-1]) + max_events, max_events, dtype=torch.int64, device=dev), right=True) - 1
+        for m in marks.tolist():
+            m = min(max(m, cuts[-1] + 1), P)
+            if m > cuts[-1]:
+                cuts.append(m)
+        if cuts[-1] != P:
+            cuts.append(P)
+
+    def codes(p0, p1):
+        """(owner pattern, code length, code) of every delta of the patterns [p0, p1)"""
+        e0, e1 = int(lp[p0]), int(lp[p1])
+        seg = ids[e0:e1]
+        ll = l[p0:p1]
+        first_mask = torch.zeros(e1 - e0, dtype=torch.bool, device=dev)
+        hh = ll > 0
+        first_mask[(lp[p0:p1][hh] - e0)] = True
+        delta = torch.zeros(e1 - e0, dtype=torch.int64, device=dev)
+        if e1 - e0 > 1:
+            delta[1:] = seg[1:] - seg[:-1]
+        dmask = ~first_mask
+        d = delta[dmask]
+        owner = torch.repeat_interleave(torch.arange(p0, p1, device=dev), ll)[dmask]
+        Lb = torch.frexp(d.to(torch.float64))[1].to(torch.int64)             # bit length
+        clen = 2 * Lb - 1
+        code = (((1 << (Lb - 1)) - 1) << Lb) | (d - (1 << (Lb - 1)))
+        return owner, clen, code
+
+    for p0, p1 in zip(cuts[:-1], cuts[1:]):
+        owner, clen, _ = codes(p0, p1)
+        nbits.index_add_(0, owner, clen)
     words = ((nbits + 127) // 128) * 2
     data_off = torch.zeros(P + 1, dtype=torch.int64, device=dev)
     data_off[1:] = torch.cumsum(words, 0)
     total_words = int(data_off[-1])
-    # bit offset of every code inside its pattern's stream
-    csum = torch.cumsum(clen, 0) - clen
-    pat_first = torch.zeros(P, dtype=torch.int64, device=dev)
-    cnt_codes = torch.bincount(owner, minlength=P)
-    code_ptr = torch.cumsum(cnt_codes, 0) - cnt_codes
-    nz = cnt_codes > 0
-    pat_first[nz] = csum[code_ptr[nz]]
-    boff = csum - pat_first[owner] + data_off[owner] * 64
     data = torch.zeros(total_words + 2, dtype=torch.int64, device=dev)
-    w = boff >> 6
-    s = boff & 63
-    room = 64 - s
-    fits = clen <= room
-    hi_part = torch.where(fits, code << (room - clen).clamp(min=0), code >> (clen - room).clamp(min=0))
-    data.index_add_(0, w, hi_part)
-    spill = ~fits
-    if bool(spill.any()):
-        rem = (clen - room)[spill]
-        lo_part = (code[spill] & ((1 << rem) - 1)) << (64 - rem)
-        data.index_add_(0, w[spill] + 1, lo_part)
+    for p0, p1 in zip(cuts[:-1], cuts[1:]):
+        owner, clen, code = codes(p0, p1)
+        if owner.numel() == 0:
+            continue
+        # bit offset of every code inside its pattern's stream
+        csum = torch.cumsum(clen, 0) - clen
+        cnt_codes = torch.bincount(owner - p0, minlength=p1 - p0)
+        code_ptr = torch.cumsum(cnt_codes, 0) - cnt_codes
+        pat_first = torch.zeros(p1 - p0, dtype=torch.int64, device=dev)
+        nz = cnt_codes > 0
+        pat_first[nz] = csum[code_ptr[nz]]
+        boff = csum - pat_first[owner - p0] + data_off[owner] * 64
+        w = boff >> 6
+        sft = boff & 63
+        room = 64 - sft
+        fits = clen <= room
+        hi_part = torch.where(fits, code << (room - clen).clamp(min=0), code >> (clen - room).clamp(min=0))
+        data.index_add_(0, w, hi_part)
+        spill = ~fits
+        if bool(spill.any()):
+            rem = (clen - room)[spill]
+            lo_part = (code[spill] & ((1 << rem) - 1)) << (64 - rem)
+            data.index_add_(0, w[spill] + 1, lo_part)
     return last, nbits, data_off[:-1], data[: max(total_words, 0) + 2]
 
 

@@ -252,6 +252,12 @@ def test_db2db_large_parts(K, O, dev, tmp_path, N, L, near):
         na = len(ids_a)
         for r in range(0, len(ids_b), 97):
             assert np.array_equal(got[r], O.tri_row(full, na + r)[:na]), r
+        # and straight from the definition: shared k-mers of the two samples' k-mer sets (no pattern, no tree involved)
+        ka = [S.kmers_of(g.sample(i), k) for i in ids_a[:: max(1, len(ids_a) // 11)]]
+        for r in (0, 1, len(ids_b) // 2, len(ids_b) - 1):
+            kb = S.kmers_of(g.sample(ids_b[r]), k)
+            want = [int(torch.isin(kb, x).sum()) for x in ka]
+            assert got[r][:: max(1, len(ids_a) // 11)][: len(want)].tolist() == want, r
     else:
         assert np.array_equal(got, O.OracleDB(pb).db2db(O.OracleDB(pa))) and got.any()
     assert np.array_equal(da.db2db(db_), got.T)
@@ -529,6 +535,15 @@ def test_baseline_sample_counts_on_the_block_record_pipeline(K, O, dev, tmp_path
             row = O.tri_row(Mh, i)
             nz = np.nonzero(row)[0]
             assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
+    # rows of the matrix straight from the definition, independent of patterns, trees and records: M[i][j] = |K_i ∩ K_j| over the
+    # samples' k-mer SETS (first rows, both sides of a clade boundary, the middle, the last clade, the last row)
+    allk = torch.cat([S.kmers_of(g.sample(j), k, f) for j in range(N)])
+    sid = torch.repeat_interleave(torch.arange(N, device=device), torch.tensor(pat["sample_counts"], device=device))
+    Mrows = d.all2all_dense() if check == "oracle" else Mh
+    for i in (1, 2, cs - 1, cs, cs + 1, N // 2, N - cs, N - 1):
+        hit = torch.isin(allk, allk[sid == i])
+        want = torch.bincount(sid[hit], minlength=N)[:i].cpu().numpy().astype(np.uint32)
+        assert np.array_equal(O.tri_row(Mrows, i), want), i
 
 
 def test_prefix_sharded_ranks_on_one_gpu(K, O, dev, tmp_path):
@@ -633,6 +648,41 @@ def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local, ch
         row = O.tri_row(exp, i)
         nz = np.nonzero(row)[0]
         assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
+
+
+@pytest.mark.parametrize("rowmode", ["0", "1"])
+def test_pools_too_small_are_enlarged_and_the_call_repeated(K, O, dev, tmp_path, rowmode):
+    """The record pools are sized from a 1-in-1024 sample; a pool that turns out too small is enlarged and the call repeated
+    (no test forced that path).  Pools of 1 % of the estimate, few streams and many (the per-block-row chunks):
+    the first call overflows every pool several times over and still returns the oracle's matrix; so does the sliced call."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    N, cs, L, k = 1200, 50, 4000, 18
+    device = torch.device("cuda", dev)
+    g, pat = S.synth_database(N, cs, L, k=k, seed=5, device=device)
+    arr = S.to_view_arrays(pat)
+    path = str(tmp_path / "s.db")
+    S.write_db_fast(path, k, 1.0, [g.name(i) for i in range(N)], pat["sample_counts"], arr, device=device)
+    exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+    view = K.make_view(k, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                       arr["data_offset"], arr["data"])
+    env = {"KMDB_POOL_PERCENT": "1", "KMDB_ROW_MODE": rowmode, "KMDB_BLOCK_WIDTH": "32"}
+    try:
+        os.environ.update(env)
+        d = K.DeviceDB(view, device=dev)
+        got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+        assert np.array_equal(got, exp) and d.stats()["path"] == K.capi.PATH_RECORDS
+        assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp) and d.stats()["sized_call"] == 0
+        d.close()
+        os.environ["KMDB_SLICES"] = "5"                      # the call takes the pattern stream in five passes
+        d = K.DeviceDB(view, device=dev)
+        assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp) and d.stats()["path"] == K.capi.PATH_RECORDS
+        assert d.stats()["n_records"] > 0
+        d.close()
+    finally:
+        for name in list(env) + ["KMDB_SLICES"]:
+            os.environ.pop(name, None)
 
 
 def test_patterns_that_touch_every_block_of_many(K, O, dev):
@@ -746,8 +796,8 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
     if d["cpu_baseline"]["kind"] == "reference":
         assert "full" in d["cpu_baseline"]["sample"]           # the reference timed on the whole database of the timed workload
     # `--gpus 2` with NO launcher: bench.py starts its own two ranks (weak scaling: per-rank databases)
-    for scaling in ("weak", "strong"):
-        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling,
+    for scaling, collective in (("weak", "reduce"), ("strong", "reduce"), ("strong", "reduce_scatter")):
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling, "--collective", collective,
                              "--length", "30000" if scaling == "weak" else "60000", "--steps", "2", "--warmup", "1"],
                             capture_output=True, text=True, env=env, timeout=900)
         assert r2.returncode == 0, r2.stderr[-3000:]
