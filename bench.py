@@ -52,17 +52,20 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+ALL2ALL_SOURCES = ("a2a_blocks.hip", "a2a_v1.hip", "device_common.h", "engine.hip", "engine_internal.h", "engine_state.h", "layout.hip", "prim.h")
+
+
 def sources_sha16():
-    """hash of the engine's sources (kmer-db_amd/csrc): PMC traffic measured by profiles/collect_counters.sh is stamped with it
-    and only replayed into a bench line when the code is still the same (the GPU box has no .git to ask for a commit)"""
+    """hash of the sources of the all2all call (kmer-db_amd/csrc: pipeline, layout, entry points, shared headers): PMC traffic measured by
+    profiles/collect_counters.sh is stamped with it and only replayed into a bench line when that code is still the same (the GPU box
+    has no .git to ask for a commit)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "kmer-db_amd", "csrc")
-    for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".h", ".cpp")):
-            h.update(fn.encode())
-            with open(os.path.join(d, fn), "rb") as f:
-                h.update(f.read())
+    for fn in ALL2ALL_SOURCES:
+        h.update(fn.encode())
+        with open(os.path.join(d, fn), "rb") as f:
+            h.update(f.read())
     return h.hexdigest()[:16]
 
 

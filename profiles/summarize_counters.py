@@ -66,10 +66,9 @@ if any("FETCH_SIZE" in d and "WRITE_SIZE" in d for d in res.values()):
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmer-db_amd", "csrc")
-    for fn in sorted(os.listdir(csrc)):
-        if fn.endswith((".hip", ".h", ".cpp")):
-            h.update(fn.encode())
-            h.update(open(os.path.join(csrc, fn), "rb").read())
+    for fn in ("a2a_blocks.hip", "a2a_v1.hip", "device_common.h", "engine.hip", "engine_internal.h", "engine_state.h", "layout.hip", "prim.h"):   # = bench.py ALL2ALL_SOURCES
+        h.update(fn.encode())
+        h.update(open(os.path.join(csrc, fn), "rb").read())
     # per call: a kernel's mean per launch x its launches per call (launches counted / 4 calls: cold, warm-up, two timed)
     fb = {k: d["FETCH_SIZE"] * 1024.0 * cnts[k]["FETCH_SIZE"] / 4.0 for k, d in res.items() if "FETCH_SIZE" in d}
     wb = {k: d["WRITE_SIZE"] * 1024.0 * cnts[k]["WRITE_SIZE"] / 4.0 for k, d in res.items() if "WRITE_SIZE" in d}
