@@ -314,11 +314,18 @@ int run_all2all_parts(std::vector<std::string>& args, Common& c) {
             std::cerr << "Processing cell (" << i + 1 << "," << j + 1 << ")" << std::endl;
             Db& dcol = get(j, i);
             cross[j].resize(nr * part_n[j] + 1);
-            check(kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &o));
+            if (kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &o)) {
+                // out of HBM inside the call (its scratch, lazily made working sets): the other resident parts go, one more try
+                for (size_t q = 0; q < resident.size(); ++q) if (q != i && q != j) resident[q].reset();
+                check(kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &o));
+            }
         }
         std::cerr << "Processing cell (" << i + 1 << "," << i + 1 << ")" << std::endl;
         kmdb_sparse_rows sp{};
-        check(kmdb_all2all_sparse(drow.d, &sp, &o));
+        if (kmdb_all2all_sparse(drow.d, &sp, &o)) {
+            for (size_t q = 0; q < resident.size(); ++q) if (q != i) resident[q].reset();
+            check(kmdb_all2all_sparse(drow.d, &sp, &o));
+        }
         for (uint64_t r = 0; r < nr; ++r) {
             cols.clear(); vals.clear();
             const uint32_t cr = (uint32_t)counts[row_shift + r];
