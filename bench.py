@@ -82,12 +82,12 @@ def replayed_traffic(workload):
         os.path.basename(tpath), tj["sources_sha16"], tj["source"])
 
 
-def build_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, progress=None, with_items=False):
+def build_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, progress=None, with_items=False, fraction=1.0):
     """patterns of the k-mers whose prefix bucket is owned by `rank` (world == 1: all of them)"""
     g = S.CladeGenomes(n_samples, clade_size, length, seed=seed, device=device)
 
     def kmers(i):
-        return S.kmers_of(g.sample(i), k, prefix_shard=(rank, world))
+        return S.kmers_of(g.sample(i), k, fraction, prefix_shard=(rank, world))
     t0 = time.time()
     pat = S.build_patterns(kmers, n_samples, device, progress=progress)
     arr = S.to_view_arrays(pat)
@@ -98,16 +98,64 @@ def build_db(K, S, n_samples, clade_size, length, k, seed, device, rank, world, 
     return arr, names, pat["sample_counts"], int(pat["dictionary"].numel()), items
 
 
+def generate_in_child(dev_index, tmp=None, **spec):
+    """build_db(**spec) in a process of its own; the arrays come back through files in shared memory.  The synthetic generator
+    works through ~100 GB of torch allocations on the GPU; a process that has just handed that much VRAM back to the driver
+    twice saw its next kmdb_db_upload take 5.8 s instead of 0.45 s (rounds 1-2, about 2 of 27 runs).  That is the generator's
+    cost, and a user's process (the front-end reading a .db) never has it: the timed process now starts its upload on a device
+    it has not churned, the way the front-end does, instead of sleeping after torch.cuda.empty_cache()."""
+    import shutil
+    base = tmp
+    if base is None:
+        base = tempfile.gettempdir()
+        try:
+            if shutil.disk_usage("/dev/shm").free > (32 << 30):
+                base = "/dev/shm"
+        except OSError:
+            pass
+    td = tempfile.mkdtemp(prefix="kmdb_gen_", dir=base)
+    try:
+        spec = dict(spec, out=td, dev_index=dev_index)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                "TORCHELASTIC_RUN_ID", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE")}
+        t0 = time.time()
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--generate-spec", json.dumps(spec)], env=env)
+        arr = {nm[:-4]: np.load(os.path.join(td, nm)) for nm in sorted(os.listdir(td)) if nm.endswith(".npy") and not nm.startswith("_")}
+        with open(os.path.join(td, "meta.json")) as f:
+            meta = json.load(f)
+        items = None
+        if meta["with_items"]:
+            items = (np.load(os.path.join(td, "_bucket_offset.npy")), np.load(os.path.join(td, "_items.npy")))
+        log("[rank %d] generator process done, arrays read back in %.1f s total" % (spec["rank"], time.time() - t0))
+        return arr, meta["names"], meta["sample_counts"], meta["n_kmers"], items
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def generator_child(spec):
+    """the other side of generate_in_child()"""
+    torch.cuda.set_device(spec["dev_index"])
+    device = torch.device("cuda", spec["dev_index"])
+    K = import_kmerdb_amd()
+    import importlib
+    S = importlib.import_module("kmerdb_amd.synth")
+    arr, names, counts, nk, items = build_db(K, S, spec["n_samples"], spec["clade_size"], spec["length"], spec["k"], spec["seed"], device, spec["rank"], spec["world"],
+                                             progress=spec.get("progress"), with_items=spec.get("with_items", False), fraction=spec.get("fraction", 1.0))
+    for nm, a in arr.items():
+        np.save(os.path.join(spec["out"], nm + ".npy"), a)
+    if items is not None:
+        np.save(os.path.join(spec["out"], "_bucket_offset.npy"), items[0])
+        np.save(os.path.join(spec["out"], "_items.npy"), items[1])
+    with open(os.path.join(spec["out"], "meta.json"), "w") as f:
+        json.dump({"names": names, "sample_counts": [int(c) for c in counts], "n_kmers": int(nk), "with_items": items is not None}, f)
+
+
 def release_generator_memory(rank):
-    """The synthetic generator is done: its cached VRAM goes back to the driver, and the driver gets a moment before the timed
-    upload starts.  Twice in about 27 first-in-process uploads on this pool kmdb_db_upload took 5.8 s instead of 0.45 s right after
-    torch.cuda.empty_cache() had handed back the generator's memory (a constant 5.4 s extra, phase unknown: the breakdown was
-    not being printed) — apparently the driver's clean-up of freed VRAM, which is the generator's cost, not the upload's.
-    (Keeping torch's cache instead made every phase of the upload that allocates 2-10 x slower: 1.27 s.)"""
+    """torch's cached VRAM goes back to the driver before an upload (the big generator runs in a process of its own, see
+    generate_in_child(); what is left in this process are the small tensors of earlier steps)"""
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
-    time.sleep(3.0)
     free, total = torch.cuda.mem_get_info()
     log("[rank %d] device memory before the upload: %.0f of %.0f GB free" % (rank, free / 1e9, total / 1e9))
 
@@ -185,7 +233,8 @@ def extra_workload(K, S, args, device, name):
     compared with the real reference's (oracle/_ref) on the same database written in the reference's format."""
     wl = WORKLOADS[name]
     dev_index = device.index or 0
-    arr, names, counts, nk, _ = build_db(K, S, wl["samples"], wl["clade_size"], wl["length"], args.k, args.seed, device, 0, 1)
+    arr, names, counts, nk, _ = generate_in_child(dev_index, n_samples=wl["samples"], clade_size=wl["clade_size"], length=wl["length"], k=args.k, seed=args.seed,
+                                                  rank=0, world=1)
     release_generator_memory(0)
     db, upload_s = upload(K, arr, wl["samples"], args.k, dev_index)
     t0 = time.perf_counter()
@@ -437,11 +486,7 @@ def sparse_multi(args, K, S, device, rank, world, dist, rccl):
     (similarity_calculator.cpp:442-657, array.h:391-446); nothing but the sparse rows leaves the devices."""
     dev_index = device.index or 0
     N, cs, L, k, f = args.samples, args.clade_size, args.length * world, args.k, args.fraction
-    g = S.CladeGenomes(N, cs, L, seed=args.seed, device=device)
-    t0 = time.time()
-    pat = S.build_patterns(lambda i: S.kmers_of(g.sample(i), k, f, prefix_shard=(rank, world)), N, device, progress=None)
-    arr = S.to_view_arrays(pat)
-    log("[rank %d] synth shard: %d k-mers, %d patterns in %.1f s" % (rank, pat["dictionary"].numel(), arr["num_kmers"].size, time.time() - t0))
+    arr, _, _, _, _ = generate_in_child(dev_index, n_samples=N, clade_size=cs, length=L, k=k, seed=args.seed, rank=rank, world=world, fraction=f)
     release_generator_memory(rank)
     d, upload_s = upload(K, arr, N, k, dev_index)
     cells = d.tri_size()
@@ -536,6 +581,7 @@ def main():
     ap.add_argument("--cpu-sample-length", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="default workload only: skip the 10 000-sample workload that rides along in the same JSON line")
+    ap.add_argument("--generate-spec", default=None, help=argparse.SUPPRESS)       # generate_in_child()'s other side
     ap.add_argument("--tmp", default=None, help="directory for the reference's .db files (default: the system temp dir)")
     ap.add_argument("--collective", default="reduce", choices=["reduce", "reduce_scatter"],
                     help="how the partial matrices of --gpus N meet: one reduce to rank 0 (north_star), or a reduce-scatter in flat chunks of the "
@@ -544,6 +590,9 @@ def main():
                     help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the matrix reduce goes through host memory); never used for reported numbers")
     args = ap.parse_args()
+    if args.generate_spec is not None:
+        generator_child(json.loads(args.generate_spec))
+        return
     if args.workload is None:
         args.workload = MODE_WORKLOAD[args.mode]
     for key, val in dict(dict(k=18, fraction=1.0, queries=0), **WORKLOADS[args.workload]).items():
@@ -591,13 +640,13 @@ def main():
     total_len = args.length if (world == 1 or strong) else args.length * world
     if strong:
         # every rank derives the same database and keeps its prefix shard of it
-        arr, names, counts, nk, items = build_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device, rank, 1,
-                                                 progress=100 if rank == 0 else None, with_items=True)
+        arr, names, counts, nk, items = generate_in_child(dev_index, n_samples=args.samples, clade_size=args.clade_size, length=total_len, k=args.k, seed=args.seed,
+                                                          rank=rank, world=1, progress=100 if rank == 0 else None, with_items=True)
         release_generator_memory(rank)
         db, upload_s = upload(K, arr, args.samples, args.k, dev_index, items=items, prefix_shard=(rank, world))
     else:
-        arr, names, counts, nk, items = build_db(K, S, args.samples, args.clade_size, total_len, args.k, args.seed, device, rank, world,
-                                                 progress=100 if rank == 0 else None)
+        arr, names, counts, nk, items = generate_in_child(dev_index, n_samples=args.samples, clade_size=args.clade_size, length=total_len, k=args.k, seed=args.seed,
+                                                          rank=rank, world=world, progress=100 if rank == 0 else None)
         release_generator_memory(rank)
         db, upload_s = upload(K, arr, args.samples, args.k, dev_index)
     st0 = db.stats()

@@ -38,6 +38,7 @@
 #include "prim.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2248,6 +2249,14 @@ static int blocks_prepare_impl(kmdb_db* db) {
         return 0;
     }
     const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
+    auto t_mark = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {                        // where the preparation's time goes (hipMalloc of tens of GB is not free)
+        if (!verbose) return;
+        (void)hipStreamSynchronize(db->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kmdb] prepare: %-36s %.3f s\n", what, std::chrono::duration<double>(now - t_mark).count());
+        t_mark = now;
+    };
     // ---- block width: fewer sample ids per block than 64 pay off when the samples cluster (clades, species) in id
     // ranges that a 64-id grid would cut in two.  One node in `stride` is decoded along its whole root path and its
     // blocks are counted for every candidate at once; the candidate with the fewest records wins.
@@ -2294,6 +2303,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
                               std::to_string(db->max_depth) + " nodes)";
         return 0;
     }
+    phase("block width estimate");
     // ---- working set
     HIP_TRY(hipMalloc((void**)&db->p0_mask, P * 8));
     HIP_TRY(hipMalloc((void**)&db->p0_info, P * 4));
@@ -2309,6 +2319,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     HIP_TRY(hipMalloc(&db->scan_tmp, std::max<size_t>(db->scan_tmp_bytes, 16)));
     HIP_TRY(hipMalloc((void**)&db->counters, KCTR_COUNT * 4));
     HIP_TRY(hipHostMalloc((void**)&db->h_counters, KCTR_COUNT * 4));
+    phase("per-node arrays (hipMalloc)");
     {
         // extra pairs: sampled with the chosen width (K0 reserves min(l - 1, blocks spanned) per list that is not a single short run)
         unsigned long long* d_need = nullptr;
@@ -2326,6 +2337,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
         if (verbose) fprintf(stderr, "[kmdb] extra (block, mask) pairs, sampled: %llu\n", (unsigned long long)est_pairs);
         if (alloc_pair_pool(db, std::max<uint64_t>(est_pairs * 2 + P / 4, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
     }
+    phase("pair estimate + pair pool");
     HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->wsub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->run_ctr, K1W_CTRS * 16 * 4));
@@ -2393,6 +2405,8 @@ static int blocks_prepare_impl(kmdb_db* db) {
         if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
         if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1W_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;
     }
+    if (verbose) fprintf(stderr, "[kmdb] prepare: record pools %.2f GB\n", kmdb_blocks_device_bytes(db) / 1e9);
+    phase("record pools (hipMalloc)");
     return 0;
 }
 
@@ -2445,14 +2459,26 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     // upper bounds if a true count exceeded its launch (checked at the end).
     auto with_slack = [](uint32_t v) -> uint32_t { return v + v / 8u + 1024u; };
     const uint32_t raw_launch = db->have_counts ? (uint32_t)std::min<uint64_t>(with_slack(db->last_n_raw), row_mode ? 0xFFFFFFFFull : db->wide_pool_cap) : 0u;
+    // The pools' resets and the long streams' decode run beside the decode of the short streams (which waits on memory most of the
+    // time, while the long streams' kernel is bound by instruction issue): side streams, joined before the narrow kernel.
+    // KMDB_K0_SIDE=0: everything on the call's stream, one after the other.
+    static const bool k0_side = !(getenv("KMDB_K0_SIDE") && atoi(getenv("KMDB_K0_SIDE")) == 0);
+    hipStream_t s_long = st, s_init = st;
+    if (k0_side) {
+        s_long = db->stream2; s_init = db->stream3;
+        HIP_TRY(hipEventRecord(db->ev_side[2], st));
+        HIP_TRY(hipStreamWaitEvent(s_long, db->ev_side[2], 0));
+        HIP_TRY(hipStreamWaitEvent(s_init, db->ev_side[2], 0));
+    }
     if (!row_mode) {
         // never-written slots of the wide pool sort last; only the part the previous call used has to be reset
         const uint64_t wslots = db->have_counts ? (uint64_t)raw_launch << WCH_SHIFT : db->wide_pool_cap << WCH_SHIFT;
-        HIP_TRY(hipMemsetAsync(db->wkey, 0xFF, wslots * 4, st));
+        HIP_TRY(hipMemsetAsync(db->wkey, 0xFF, wslots * 4, s_init));
     }
-    HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, st));
-    HIP_TRY(hipMemsetAsync(db->ct_hist, 0, ((size_t)n_ckeys + 2) * 4, st));
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, st, db->chunk_key, pool_cap, 0xFFFFFFFFu);      // never opened
+    HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, s_init));
+    HIP_TRY(hipMemsetAsync(db->ct_hist, 0, ((size_t)n_ckeys + 2) * 4, s_init));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, s_init, db->chunk_key, pool_cap, 0xFFFFFFFFu);      // never opened
+    if (k0_side) HIP_TRY(hipEventRecord(db->ev_side[3], s_init));
     if (stage("init")) return 1;
     // ---- K0
     {
@@ -2465,12 +2491,19 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         // three quarters of the pool in sub-pools, the rest shared
         q.pair_cursor = db->pair_cursor; q.n_regions = nreg; q.region_cap = (uint32_t)(db->pair_cap * 3 / 4 / nreg);
         q.spill_cap = (uint32_t)(db->pair_cap - (uint64_t)q.region_cap * nreg); q.counters = db->counters;
-        hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
         if (db->n_long) {
-            q.perm = db->long_nodes; q.P = db->n_long;
-            hipLaunchKernelGGL((k0_decode_kernel<true>), dim3((db->n_long + 255) / 256), dim3(256), 0, st, q);
+            // the long streams first: few workgroups, most work first
+            K0Params ql = q;
+            ql.perm = db->long_nodes; ql.P = db->n_long;
+            hipLaunchKernelGGL((k0_decode_kernel<true>), dim3((db->n_long + 255) / 256), dim3(256), 0, s_long, ql);
         }
+        hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
         HIP_TRY(hipGetLastError());
+        if (k0_side) {
+            HIP_TRY(hipEventRecord(db->ev_side[4], s_long));
+            HIP_TRY(hipStreamWaitEvent(st, db->ev_side[4], 0));
+            HIP_TRY(hipStreamWaitEvent(st, db->ev_side[3], 0));
+        }
     }
     if (stage("decode")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[0], st));

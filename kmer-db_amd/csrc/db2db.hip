@@ -8,9 +8,12 @@
 //            table of the same prefix (murmur3 fmix32 probe, src/hashmap_lp.h:53-64,308-333);
 //            key = DFS index of the row pattern << 32 | DFS index of the column pattern, or ~0
 //   count    radix sort + run-length encode of the keys: (pattern pair, number of shared k-mers)
-//   emit     one wave per pattern pair: the full sample lists of both patterns as bit sets over blocks of 64 ids in LDS
-//            (lane d decodes the d-th node of the root path and ORs its local ids in), one BLOCK RECORD (row block,
-//            column block, row mask, column mask, count) per pair of non-empty blocks into a pool, in arrival order
+//   lists    once per handle (kept with it: every cell of an all2all-parts grid uses a part many times): the FULL sample list of
+//            every pattern as a bit set over blocks of 64 ids, filled top-down — list(node) = list(parent) | local ids — one
+//            launch per tree level.  Parts with more than 4096 samples or a store beyond 8 GB do without it: their waves
+//            climb the root path of each pattern of a pair instead (lane d decodes the d-th node of the path)
+//   emit     one wave per pattern pair: both lists from the store into LDS, one BLOCK RECORD (row block, column block, row
+//            mask, column mask, count) per pair of non-empty blocks into a pool, in arrival order
 //   apply    kmdb_rect_sort_apply (a2a_blocks.hip): the all2all pipeline's counting sort by block pair and its matrix-core
 //            accumulation kernel, writing the dense rows x columns matrix.
 #include "kmdb_amd.h"
@@ -120,6 +123,53 @@ __device__ __forceinline__ void d2_list_bits(const D2Db& db, uint32_t node, unsi
     }
 }
 
+// ---- the list store
+// One launch per level of the tree: a node is filled in the first round that finds its parent filled by an EARLIER round
+// (done[] holds round + 1; a parent filled in this very round reads as either 0 or round + 1, both mean "not yet").
+constexpr uint32_t D2_SETS_MAX_NB = 64;                       // parts of up to 4096 samples
+constexpr uint64_t D2_SETS_MAX_BYTES = 8ull << 30;
+__global__ __launch_bounds__(256) void d2_sets_round_kernel(D2Db db, uint32_t P, uint32_t nb, uint32_t round, uint32_t* __restrict__ done,
+                                                            unsigned long long* __restrict__ sets, uint32_t* __restrict__ n_done) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool fill = i < P && done[i] == 0;
+    int32_t par = -1;
+    if (fill) {
+        par = db.parent[i];
+        if (par >= 0) { const uint32_t dr = done[par]; fill = dr != 0 && dr != round + 1u; }
+    }
+    if (fill) {
+        unsigned long long* s = sets + (size_t)i * nb;
+        if (par >= 0) { const unsigned long long* ps = sets + (size_t)par * nb; for (uint32_t k = 0; k < nb; ++k) s[k] = ps[k]; }
+        else for (uint32_t k = 0; k < nb; ++k) s[k] = 0;
+        const uint4 m = db.meta[i];
+        const uint32_t l = m.y;
+        if (l) {
+            uint32_t id = m.z;
+            if (l > 1) {
+                D2Cursor c1(db.bits, db.bitpos[i]);
+                uint32_t sum = 0;
+                for (uint32_t t = 0; t + 1 < l; ++t) sum += c1.next();
+                id = m.z - sum;
+                D2Cursor c2(db.bits, db.bitpos[i]);
+                uint32_t cw = id >> 6;
+                unsigned long long acc = 0;
+                for (uint32_t t = 0; t + 1 < l; ++t) {                    // ids ascend: one read-modify-write per word
+                    const uint32_t wd = id >> 6;
+                    if (wd != cw) { s[cw] |= acc; acc = 0; cw = wd; }
+                    acc |= 1ull << (id & 63u);
+                    id += c2.next();
+                }
+                if ((id >> 6) != cw) { s[cw] |= acc; acc = 0; cw = id >> 6; }
+                acc |= 1ull << (id & 63u);
+                s[cw] |= acc;
+            } else s[id >> 6] |= 1ull << (id & 63u);
+        }
+        done[i] = round + 1u;
+    }
+    const unsigned long long bal = __ballot(fill);
+    if (bal && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)bal) - 1u) atomicAdd(n_done, (uint32_t)__popcll(bal));
+}
+
 // Pattern pairs -> block records.  A pair (row pattern, column pattern, c shared k-mers) adds c to every cell (sample of the
 // row pattern, sample of the column pattern): with both lists as bit sets over blocks of 64 ids that is one record
 // (row block, column block, row mask, column mask, c) per pair of non-empty blocks — the record form of the all2all pipeline
@@ -129,8 +179,9 @@ __device__ __forceinline__ void d2_list_bits(const D2Db& db, uint32_t node, unsi
 // arrival order, slots taken GRAB at a time from one of 256 cursors (a shared cursor would serialise: same-address atomics).
 constexpr uint32_t D2_GRAB = 512, D2_CURSORS = 256;
 struct D2Pool { uint32_t* wkey; ulonglong2* wrec; uint32_t* cursor; uint32_t region; uint32_t kbits, dbits; uint32_t* overflow; };
-template <bool COUNT>
-__global__ __launch_bounds__(256) void d2_emit_kernel(D2Db row, D2Db col, const unsigned long long* __restrict__ pairs, const uint32_t* __restrict__ counts,
+template <bool COUNT, bool STORE>
+__global__ __launch_bounds__(256) void d2_emit_kernel(D2Db row, D2Db col, const unsigned long long* __restrict__ rsets, const unsigned long long* __restrict__ csets,
+                                                      const unsigned long long* __restrict__ pairs, const uint32_t* __restrict__ counts,
                                                       uint32_t npairs, uint32_t nbr, uint32_t nbc, D2Pool pool, unsigned long long* __restrict__ n_records) {
     extern __shared__ unsigned long long d2_lds[];          // per wave: row set [nbr], column set [nbc], then the non-empty blocks of each
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -155,10 +206,16 @@ __global__ __launch_bounds__(256) void d2_emit_kernel(D2Db row, D2Db col, const 
         const uint32_t pr = (uint32_t)(key >> 32), pc = (uint32_t)key;
         uint32_t c = counts[i];
         const bool new_row = pr != cached_pr;
-        for (uint32_t k = lane + (new_row ? 0u : nbr); k < nbr + nbc; k += 64u) rset[k] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (new_row) d2_list_bits(row, pr, rset, lane);
-        d2_list_bits(col, pc, cset, lane);
+        if (STORE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the previous pair's reads)
+            if (new_row) for (uint32_t k = lane; k < nbr; k += 64u) rset[k] = rsets[(size_t)pr * nbr + k];
+            for (uint32_t k = lane; k < nbc; k += 64u) cset[k] = csets[(size_t)pc * nbc + k];
+        } else {
+            for (uint32_t k = lane + (new_row ? 0u : nbr); k < nbr + nbc; k += 64u) rset[k] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (new_row) d2_list_bits(row, pr, rset, lane);
+            d2_list_bits(col, pc, cset, lane);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // the non-empty blocks of both lists, compacted in order
         uint32_t nb = 0;
@@ -221,6 +278,36 @@ D2Db view_of(const kmdb_engine_view& e) {
     return D2Db{e.n_buckets, e.bucket_offset, e.slots, e.pid2dfs, e.meta, e.bitpos, e.parent, e.bits};
 }
 
+// the handle's list store (nullptr: this part does without one)
+const unsigned long long* d2_list_store(const kmdb_engine_view& e, hipStream_t st) {
+    if (*e.list_sets) return *e.list_sets;
+    if (*e.list_sets_tried || !e.P) return nullptr;
+    *e.list_sets_tried = true;
+    if (getenv("KMDB_D2_NO_STORE")) return nullptr;
+    const uint32_t nb = (uint32_t)((e.N + 63) / 64);
+    const uint64_t bytes = e.P * nb * 8;
+    if (nb > D2_SETS_MAX_NB || bytes > D2_SETS_MAX_BYTES || e.P >= (1ull << 31)) return nullptr;
+    unsigned long long* sets = nullptr;
+    uint32_t* done = nullptr;
+    if (hipMalloc((void**)&sets, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMalloc((void**)&done, (e.P + 1) * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sets); return nullptr; }
+    bool ok = hipMemsetAsync(done, 0, (e.P + 1) * 4, st) == hipSuccess;
+    const D2Db v = view_of(e);
+    uint32_t filled = 0, round = 0;
+    while (ok && filled < e.P && round < e.P + 1) {
+        // max_depth rounds fill everything; the count is read back after them (and every 32 rounds after, if that was not so)
+        const uint32_t upto = round ? round + 32u : std::max<uint32_t>(e.max_depth, 1u);
+        for (; round < upto; ++round)
+            hipLaunchKernelGGL(d2_sets_round_kernel, dim3((unsigned)((e.P + 255) / 256)), dim3(256), 0, st, v, (uint32_t)e.P, nb, round, done, sets, done + e.P);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&filled, done + e.P, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    }
+    (void)hipFree(done);
+    if (!ok || filled != e.P) { (void)hipGetLastError(); (void)hipFree(sets); return nullptr; }
+    if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] db2db: list store of %llu patterns x %u words (%.2f GB) filled in %u rounds\n", (unsigned long long)e.P, nb, bytes / 1e9, round);
+    *e.list_sets = sets; *e.list_sets_nb = nb; *e.device_bytes += bytes;
+    return sets;
+}
+
 }  // namespace
 
 #define D2_TRY(expr)                                                                            \
@@ -279,13 +366,19 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
             const uint32_t dbits = (uint32_t)(32 - key_bits - 2);
             const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nruns + 3) / 4, 256 * 8);
             const size_t lds = (size_t)4 * 2 * (nbr + nbc) * 8;
+            // both parts' list stores, or neither (a wave that climbs one side's root paths gains nothing from the other's store)
+            const unsigned long long* rsets = d2_list_store(er, st);
+            const unsigned long long* csets = rsets ? (db_col == db_row ? rsets : d2_list_store(ec, st)) : nullptr;
+            const bool store = rsets && csets;
             DevBuf d_nrec, d_cursor;
             D2_TRY(d_nrec.alloc(64 * 8 * 8)); D2_TRY(d_cursor.alloc(D2_CURSORS * 16 * 4));
             D2_TRY(hipMemsetAsync(d_nrec.p, 0, 64 * 8 * 8, st));
             D2_TRY(hipMemsetAsync(d_cursor.p, 0, D2_CURSORS * 16 * 4, st));
             D2Pool pool{nullptr, nullptr, d_cursor.as<uint32_t>(), 0u, (uint32_t)key_bits, dbits, d_flag.as<uint32_t>() + 1};
-            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            D2_TRY(hipFuncSetAttribute((const void*)d2_emit_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             // the pool: sized for six records per pair first; if that overflows, the
             // records are counted and the pool is made to measure
             DevBuf d_wkey, d_wrec;
@@ -294,8 +387,12 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
                 unsigned long long total = 6ull * nruns;
                 if (attempt) {
                     D2_TRY(hipMemsetAsync(d_nrec.p, 0, 64 * 8 * 8, st));
-                    hipLaunchKernelGGL(d2_emit_kernel<true>, dim3(grid), dim3(256), lds, st, vr, vc, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(), nruns, nbr,
-                                       nbc, pool, d_nrec.as<unsigned long long>());
+                    if (store)
+                        hipLaunchKernelGGL((d2_emit_kernel<true, true>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                                           nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
+                    else
+                        hipLaunchKernelGGL((d2_emit_kernel<true, false>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                                           nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
                     D2_TRY(hipGetLastError());
                     unsigned long long h_nrec[64 * 8];
                     D2_TRY(hipMemcpyAsync(h_nrec, d_nrec.p, sizeof h_nrec, hipMemcpyDeviceToHost, st));
@@ -315,8 +412,12 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
                 D2_TRY(hipMemsetAsync(d_cursor.p, 0, D2_CURSORS * 16 * 4, st));
                 D2_TRY(hipMemsetAsync(d_flag.as<uint32_t>() + 1, 0, 4, st));
                 pool.wkey = d_wkey.as<uint32_t>(); pool.wrec = d_wrec.as<ulonglong2>(); pool.region = (uint32_t)region;
-                hipLaunchKernelGGL(d2_emit_kernel<false>, dim3(grid), dim3(256), lds, st, vr, vc, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(), nruns, nbr, nbc,
-                                   pool, d_nrec.as<unsigned long long>());
+                if (store)
+                    hipLaunchKernelGGL((d2_emit_kernel<false, true>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                                       nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
+                else
+                    hipLaunchKernelGGL((d2_emit_kernel<false, false>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                                       nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
                 D2_TRY(hipGetLastError());
                 uint32_t ovf = 0;
                 D2_TRY(hipMemcpyAsync(&ovf, d_flag.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, st));

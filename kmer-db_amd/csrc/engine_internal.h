@@ -25,6 +25,13 @@ struct kmdb_engine_view {
     const uint64_t* bucket_offset;
     const uint64_t* slots;
     const uint32_t* pid2dfs;
+    uint32_t max_depth;            // nodes on the longest root path
+    // list store of db2db.hip, kept with the handle: the full sample list of every pattern as a bit set of list_sets_nb words
+    // (built on the first db2db call that can afford it, freed by kmdb_db_free)
+    unsigned long long** list_sets;
+    uint32_t* list_sets_nb;
+    bool* list_sets_tried;
+    uint64_t* device_bytes;
     void* stream;
     void* ev[4];
 };

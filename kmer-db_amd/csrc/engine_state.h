@@ -63,6 +63,10 @@ struct kmdb_db {
     uint32_t* nseg_anc_n = nullptr;
     uint32_t chain_cap = 8;         // chain slots per wave = longest root path, rounded up
     uint32_t max_depth = 0, max_n = 0;
+    // db2db's list store (db2db.hip): full sample list of every pattern as a bit set, list_sets_nb words per pattern
+    unsigned long long* list_sets = nullptr;
+    uint32_t list_sets_nb = 0;
+    bool list_sets_tried = false;
     bool chain_ok = false;          // root paths fit the chain table of the emit kernel
     // ---- per-call working set of the block-record pipeline (contents rebuilt by every call)
     uint32_t width = 64;            // sample ids per block, picked at upload from a sampled estimate
@@ -166,7 +170,7 @@ struct kmdb_db {
     uint32_t* pid2dfs = nullptr;    // original pattern id -> DFS index
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the stream chunks are sorted and applied next to the wide kernel
-    hipEvent_t ev_side[2] = {nullptr, nullptr};
+    hipEvent_t ev_side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..1] chunk apply; [2] call start, [3] pools reset, [4] long streams decoded
     hipStream_t stream3 = nullptr;  // many streams: the sorted bands of block rows applied next to the sort of the following band
     hipEvent_t ev_band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // band b sorted (0..7), stream3 done (8)
     uint32_t* rs_bands = nullptr;   // [2][9] first job / first sorted record of every band (+ end)

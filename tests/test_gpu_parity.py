@@ -272,7 +272,7 @@ def _synth_part(S, g, ids, k, path, device):
 
 
 @pytest.mark.parametrize("split", ["halves", "interleaved"])
-def test_db2db_synthetic_parts(K, O, dev, tmp_path, split):
+def test_db2db_synthetic_parts(K, O, dev, tmp_path, split, monkeypatch):
     """db2db on two parts of one clade-structured collection: GPU == oracle == the real reference's db2db_sp, and the
     cell equals the corresponding block of the all2all matrix of the whole collection."""
     import importlib
@@ -289,9 +289,20 @@ def test_db2db_synthetic_parts(K, O, dev, tmp_path, split):
     _synth_part(S, g, ids_a + ids_b, k, pall, device)
     da = K.DeviceDB(K.HostDB(pa), device=dev, with_hashtables=True)
     db_ = K.DeviceDB(K.HostDB(pb), device=dev, with_hashtables=True)
+    bytes0 = da.stats()["device_bytes"]
     got = db_.db2db(da)
     exp = O.OracleDB(pb).db2db(O.OracleDB(pa))
     assert np.array_equal(got, exp) and got.any()
+    # the call left the patterns' full lists with both handles (db2db.hip, list store); handles that do without it
+    # (as parts of more than 4096 samples do) climb the root paths and give the same cell
+    assert da.stats()["device_bytes"] > bytes0
+    assert np.array_equal(db_.db2db(da), got)
+    monkeypatch.setenv("KMDB_D2_NO_STORE", "1")
+    da2 = K.DeviceDB(K.HostDB(pa), device=dev, with_hashtables=True)
+    db2 = K.DeviceDB(K.HostDB(pb), device=dev, with_hashtables=True)
+    bytes2 = da2.stats()["device_bytes"]
+    assert np.array_equal(db2.db2db(da2), got) and da2.stats()["device_bytes"] == bytes2
+    monkeypatch.delenv("KMDB_D2_NO_STORE")
     full = K.DeviceDB(K.HostDB(pall, skip_hashtables=True), device=dev).all2all_dense()
     na = len(ids_a)
     for r in (0, 7, len(ids_b) - 1):
