@@ -2459,28 +2459,17 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     // upper bounds if a true count exceeded its launch (checked at the end).
     auto with_slack = [](uint32_t v) -> uint32_t { return v + v / 8u + 1024u; };
     const uint32_t raw_launch = db->have_counts ? (uint32_t)std::min<uint64_t>(with_slack(db->last_n_raw), row_mode ? 0xFFFFFFFFull : db->wide_pool_cap) : 0u;
-    // The pools' resets and the long streams' decode run beside the decode of the short streams (which waits on memory most of the
-    // time, while the long streams' kernel is bound by instruction issue): side streams, joined before the narrow kernel.
-    // KMDB_K0_SIDE=0: everything on the call's stream, one after the other.
-    static const bool k0_side = !(getenv("KMDB_K0_SIDE") && atoi(getenv("KMDB_K0_SIDE")) == 0);
-    hipStream_t s_long = st, s_init = st;
-    if (k0_side) {
-        s_long = db->stream2; s_init = db->stream3;
-        HIP_TRY(hipEventRecord(db->ev_side[2], st));
-        HIP_TRY(hipStreamWaitEvent(s_long, db->ev_side[2], 0));
-        HIP_TRY(hipStreamWaitEvent(s_init, db->ev_side[2], 0));
-    }
     if (!row_mode) {
         // never-written slots of the wide pool sort last; only the part the previous call used has to be reset
         const uint64_t wslots = db->have_counts ? (uint64_t)raw_launch << WCH_SHIFT : db->wide_pool_cap << WCH_SHIFT;
-        HIP_TRY(hipMemsetAsync(db->wkey, 0xFF, wslots * 4, s_init));
+        HIP_TRY(hipMemsetAsync(db->wkey, 0xFF, wslots * 4, st));
     }
-    HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, s_init));
-    HIP_TRY(hipMemsetAsync(db->ct_hist, 0, ((size_t)n_ckeys + 2) * 4, s_init));
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, s_init, db->chunk_key, pool_cap, 0xFFFFFFFFu);      // never opened
-    if (k0_side) HIP_TRY(hipEventRecord(db->ev_side[3], s_init));
+    HIP_TRY(hipMemsetAsync(db->chunk_fill, 0, (size_t)pool_cap * 4, st));
+    HIP_TRY(hipMemsetAsync(db->ct_hist, 0, ((size_t)n_ckeys + 2) * 4, st));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((pool_cap + 255) / 256), dim3(256), 0, st, db->chunk_key, pool_cap, 0xFFFFFFFFu);      // never opened
     if (stage("init")) return 1;
-    // ---- K0
+    // ---- K0  (the two launches one after the other: both are bound by instruction issue, side by side on two streams they take
+    // exactly as long — measured, profiles/r03_k0side_ab.sh)
     {
         K0Params q{};
         q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.perm = nullptr; q.P = P; q.bm = bm;
@@ -2491,19 +2480,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         // three quarters of the pool in sub-pools, the rest shared
         q.pair_cursor = db->pair_cursor; q.n_regions = nreg; q.region_cap = (uint32_t)(db->pair_cap * 3 / 4 / nreg);
         q.spill_cap = (uint32_t)(db->pair_cap - (uint64_t)q.region_cap * nreg); q.counters = db->counters;
-        if (db->n_long) {
-            // the long streams first: few workgroups, most work first
-            K0Params ql = q;
-            ql.perm = db->long_nodes; ql.P = db->n_long;
-            hipLaunchKernelGGL((k0_decode_kernel<true>), dim3((db->n_long + 255) / 256), dim3(256), 0, s_long, ql);
-        }
         hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
-        HIP_TRY(hipGetLastError());
-        if (k0_side) {
-            HIP_TRY(hipEventRecord(db->ev_side[4], s_long));
-            HIP_TRY(hipStreamWaitEvent(st, db->ev_side[4], 0));
-            HIP_TRY(hipStreamWaitEvent(st, db->ev_side[3], 0));
+        if (db->n_long) {
+            q.perm = db->long_nodes; q.P = db->n_long;
+            hipLaunchKernelGGL((k0_decode_kernel<true>), dim3((db->n_long + 255) / 256), dim3(256), 0, st, q);
         }
+        HIP_TRY(hipGetLastError());
     }
     if (stage("decode")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[0], st));

@@ -153,8 +153,8 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
         return kmdb_set_error("kmdb_db_upload: no HIP device available (the engine has no CPU fallback)");
     }
     const int device = opts ? opts->device : 0;
-    HIP_TRY(hipSetDevice(device));
     const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(device));
     auto* db = new kmdb_db();
     db->device = device; db->N = N; db->P = P; db->kmer_length = v->kmer_length;
     auto fail = [&]() { kmdb_db_free(db); return 1; };
@@ -165,10 +165,24 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     for (auto& e : db->ev_side) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
     if (hipStreamCreate(&db->stream3) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
     for (auto& e : db->ev_band) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
+    // KMDB_VERBOSE: the four parts of the upload as wholes (the layout and the preparation print their own phases; what those
+    // leave out — the release of their temporaries, the first use of the device by the process — shows up here)
+    const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
+    auto t_mark = t0;
+    auto part = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kmdb] upload part: %-40s %.3f s\n", what, std::chrono::duration<double>(now - t_mark).count());
+        t_mark = now;
+    };
+    part("streams + events (first use of the device)");
     if (kmdb_layout_upload(db, v, with_hashtables, shard_index, shard_count)) return fail();
+    part("layout incl. release of its temporaries");
     // the working set of all2all: now for an all2all upload, on the first all2all call for a new2all / db2db upload
     if (!with_hashtables && kmdb_blocks_prepare(db)) return fail();
+    part("preparation of the all2all working set");
     if (hipStreamSynchronize(db->stream) != hipSuccess) { kmdb_set_error("kmdb_db_upload: device error"); return fail(); }
+    part("final wait");
     db->stats.device_bytes += kmdb_blocks_device_bytes(db);
     db->stats.width = db->width;
     db->stats.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

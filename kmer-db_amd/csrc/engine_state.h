@@ -170,7 +170,7 @@ struct kmdb_db {
     uint32_t* pid2dfs = nullptr;    // original pattern id -> DFS index
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the stream chunks are sorted and applied next to the wide kernel
-    hipEvent_t ev_side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..1] chunk apply; [2] call start, [3] pools reset, [4] long streams decoded
+    hipEvent_t ev_side[2] = {nullptr, nullptr};
     hipStream_t stream3 = nullptr;  // many streams: the sorted bands of block rows applied next to the sort of the following band
     hipEvent_t ev_band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // band b sorted (0..7), stream3 done (8)
     uint32_t* rs_bands = nullptr;   // [2][9] first job / first sorted record of every band (+ end)

@@ -11,7 +11,7 @@ import csv, json, os, sys
 from collections import defaultdict
 
 tag, out = sys.argv[1:3]
-files = sys.argv[3:]
+files = sys.argv[3:]          # per-dispatch CSVs; none: the table is re-made from <out>/<tag>_counters.json
 KERNELS = ("k0_decode_kernel", "k1n_kernel", "k1g_kernel", "k1w_kernel", "k2_apply_kernel", "k2_sorted_kernel", "cs_hist_kernel", "cs_scatter_kernel",
            "rs_hist_kernel", "rs_scatter_kernel", "rs_rows_kernel", "rg_hist_kernel", "rg_scatter_kernel", "ct_hist_kernel", "ct_scatter_kernel", "wrun_anc_kernel",
            "wide_count_kernel", "wide_expand_kernel", "n2a_walk_kernel", "n2a_probe_kernel", "n2a_extract_kernel", "d2_emit_kernel", "d2_probe_kernel", "row_nnz_kernel",
@@ -59,10 +59,13 @@ for k in vals:
     res[k] = {c: vals[k][c] / max(1, cnts[k][c]) for c in vals[k]}
     res[k]["_launches_counted"] = max(cnts[k].values())
     res[k]["_meta"] = meta.get(k, {})
-json.dump(res, open(os.path.join(out, tag + "_counters.json"), "w"), indent=1)
+if files:
+    json.dump(res, open(os.path.join(out, tag + "_counters.json"), "w"), indent=1)
+else:
+    res = json.load(open(os.path.join(out, tag + "_counters.json")))
 # HBM traffic of one call (every kernel of the call that has both counters), stamped with the hash of the sources it was measured on:
 # bench.py replays it into its line only when the code is unchanged
-if any("FETCH_SIZE" in d and "WRITE_SIZE" in d for d in res.values()):
+if files and any("FETCH_SIZE" in d and "WRITE_SIZE" in d for d in res.values()):
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmer-db_amd", "csrc")
@@ -101,7 +104,10 @@ for k in sorted(res):
     conf = 100.0 * g(d, "SQ_LDS_BANK_CONFLICT") / g(d, "SQ_LDS_IDX_ACTIVE") if d.get("SQ_LDS_IDX_ACTIVE") else float("nan")
     mix = "%.0f : %.0f : %.0f : %.0f : %.0f" % tuple(g(d, c) / waves if waves == waves and waves else float("nan")
                                                     for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM"))
-    mfma = 100.0 * g(d, "SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * g(d, "SQ_BUSY_CYCLES")) if d.get("SQ_BUSY_CYCLES") and d.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None else float("nan")
+    # SQ_VALU_MFMA_BUSY_CYCLES: cycles, summed over the SIMDs (32 per v_mfma_i32_32x32x32_i8); SQ_BUSY_CYCLES: summed over the 32 shader
+    # engines, each with 32 SIMDs.  Cross-check at 10 000 samples: 515 M records / 32 per MFMA step x 4 MFMAs x 32 cycles = 2.06 G
+    # SIMD-cycles = 0.84 ms of the 1024 SIMDs at 2.4 GHz = 14.7 % of k2_sorted_kernel's 5.7 ms; this column says 14.8 %.
+    mfma = 100.0 * g(d, "SQ_VALU_MFMA_BUSY_CYCLES") / (32.0 * g(d, "SQ_BUSY_CYCLES")) if d.get("SQ_BUSY_CYCLES") and d.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None else float("nan")
     m = d["_meta"]
     lines.append("| `%s` | %.0f | %s+%s / %s / %s | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %s | %.1f | %.1f | %.1f |" % (
         k, waves, m.get("vgpr"), m.get("accum_vgpr"), m.get("lds_bytes"), m.get("scratch_bytes"), lanes, valu_busy, wait, stall, ldsst, conf, mix, mfma,
