@@ -6,8 +6,9 @@
 // pattern_col) pairs and adds the count to every pair of samples of the two patterns.  Here:
 //   probe    one thread per hashtable slot of the COLUMN database: its k-mer is looked up in the row database's
 //            table of the same prefix (murmur3 fmix32 probe, src/hashmap_lp.h:53-64,308-333);
-//            key = DFS index of the row pattern << 32 | DFS index of the column pattern, or ~0
-//   count    radix sort + run-length encode of the keys: (pattern pair, number of shared k-mers)
+//            key = DFS index of the row pattern << cbits | DFS index of the column pattern (cbits: as many as the column
+//            database's patterns need), or ~0
+//   count    radix sort (of the bits in use only) + run-length encode of the keys: (pattern pair, number of shared k-mers)
 //   lists    once per handle (kept with it: every cell of an all2all-parts grid uses a part many times): the FULL sample list of
 //            every pattern as a bit set over blocks of 64 ids, filled top-down — list(node) = list(parent) | local ids — one
 //            launch per tree level.  Parts with more than 4096 samples or a store beyond 8 GB do without it: their waves
@@ -24,6 +25,7 @@
 #include "prim.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -48,7 +50,7 @@ struct D2Db {                                   // device pointers of one reside
     const uint64_t* bits;
 };
 
-__global__ void d2_probe_kernel(D2Db row, D2Db col, uint64_t n_col_slots, unsigned long long* __restrict__ keys) {
+__global__ void d2_probe_kernel(D2Db row, D2Db col, uint64_t n_col_slots, uint32_t cbits, unsigned long long* __restrict__ keys) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_col_slots) return;
     unsigned long long key = D2_INVALID;
@@ -69,7 +71,7 @@ __global__ void d2_probe_kernel(D2Db row, D2Db col, uint64_t n_col_slots, unsign
                     const uint64_t r = row.slots[off + h];
                     const int32_t pr = (int32_t)(r >> 32);
                     if (pr == 0x7fffffff) break;
-                    if ((uint32_t)r == kk) { key = ((unsigned long long)row.pid2dfs[pr] << 32) | col.pid2dfs[pc]; break; }
+                    if ((uint32_t)r == kk) { key = ((unsigned long long)row.pid2dfs[pr] << cbits) | col.pid2dfs[pc]; break; }
                     h = (h + 1) & mask;
                 }
             }
@@ -182,7 +184,8 @@ struct D2Pool { uint32_t* wkey; ulonglong2* wrec; uint32_t* cursor; uint32_t reg
 template <bool COUNT, bool STORE>
 __global__ __launch_bounds__(256) void d2_emit_kernel(D2Db row, D2Db col, const unsigned long long* __restrict__ rsets, const unsigned long long* __restrict__ csets,
                                                       const unsigned long long* __restrict__ pairs, const uint32_t* __restrict__ counts,
-                                                      uint32_t npairs, uint32_t nbr, uint32_t nbc, D2Pool pool, unsigned long long* __restrict__ n_records) {
+                                                      uint32_t npairs, uint32_t nbr, uint32_t nbc, uint32_t cbits, D2Pool pool,
+                                                      unsigned long long* __restrict__ n_records) {
     extern __shared__ unsigned long long d2_lds[];          // per wave: row set [nbr], column set [nbc], then the non-empty blocks of each
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per_wave = 2u * (nbr + nbc);
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void d2_emit_kernel(D2Db row, D2Db col, const 
     for (uint32_t i = i_lo; i < i_hi; ++i) {
         const unsigned long long key = pairs[i];
         if (key == D2_INVALID) continue;
-        const uint32_t pr = (uint32_t)(key >> 32), pc = (uint32_t)key;
+        const uint32_t pr = (uint32_t)(key >> cbits), pc = (uint32_t)(key & ((1ull << cbits) - 1ull));
         uint32_t c = counts[i];
         const bool new_row = pr != cached_pr;
         if (STORE) {
@@ -340,24 +343,40 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
     D2_TRY(hipMemsetAsync(d_flag.p, 0, 16, st));
     hipEvent_t ev0 = (hipEvent_t)er.ev[0], ev3 = (hipEvent_t)er.ev[3];
     D2_TRY(hipEventRecord(ev0, st));
+    const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
+    auto t_mark = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {                          // KMDB_VERBOSE: host-side wall time of the call's steps (each one waited for)
+        if (!verbose) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kmdb] db2db: %-34s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+        t_mark = now;
+    };
+    // bits of a key: 2^cbits > patterns of the column database, 2^rbits > patterns of the row database (so no key in use is all ones
+    // in the sorted bits: the unused slots' ~0 sorts last)
+    uint32_t cbits = 1, rbits = 1;
+    while ((1ull << cbits) <= ec.P) ++cbits;
+    while ((1ull << rbits) <= er.P) ++rbits;
+    const unsigned key_end = std::min<unsigned>(64u, cbits + rbits);
     if (n_slots && nr && nc) {
         size_t tb_sort = 0, tb_rle = 0;
         D2_TRY(prim::sort_keys(nullptr, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
-                                                 (int)n_slots, 0, 64, st));
+                                                 (int)n_slots, 0, key_end, st));
         D2_TRY(prim::run_length_encode(nullptr, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                      d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)n_slots, st));
         D2_TRY(d_tmp.alloc(std::max(tb_sort, tb_rle)));
         const D2Db vr = view_of(er), vc = view_of(ec);
-        hipLaunchKernelGGL(d2_probe_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, vr, vc, n_slots,
+        hipLaunchKernelGGL(d2_probe_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, vr, vc, n_slots, cbits,
                            d_keys.as<unsigned long long>());
         D2_TRY(hipGetLastError());
         D2_TRY(prim::sort_keys(d_tmp.p, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
-                                                 (int)n_slots, 0, 64, st));
+                                                 (int)n_slots, 0, key_end, st));
         D2_TRY(prim::run_length_encode(d_tmp.p, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                      d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)n_slots, st));
         uint32_t nruns = 0;
         D2_TRY(hipMemcpyAsync(&nruns, d_nruns.p, 4, hipMemcpyDeviceToHost, st));
         D2_TRY(hipStreamSynchronize(st));
+        phase("probe + sort + run lengths");
         if (nruns) {
             // pairs -> block records -> sorted by block pair -> accumulated on the matrix cores (a2a_blocks.hip)
             const uint32_t nbr = (uint32_t)((nr + 63) / 64), nbc = (uint32_t)((nc + 63) / 64);
@@ -370,6 +389,7 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
             const unsigned long long* rsets = d2_list_store(er, st);
             const unsigned long long* csets = rsets ? (db_col == db_row ? rsets : d2_list_store(ec, st)) : nullptr;
             const bool store = rsets && csets;
+            phase("list stores");
             DevBuf d_nrec, d_cursor;
             D2_TRY(d_nrec.alloc(64 * 8 * 8)); D2_TRY(d_cursor.alloc(D2_CURSORS * 16 * 4));
             D2_TRY(hipMemsetAsync(d_nrec.p, 0, 64 * 8 * 8, st));
@@ -389,10 +409,10 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
                     D2_TRY(hipMemsetAsync(d_nrec.p, 0, 64 * 8 * 8, st));
                     if (store)
                         hipLaunchKernelGGL((d2_emit_kernel<true, true>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
-                                           nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
+                                           nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                     else
                         hipLaunchKernelGGL((d2_emit_kernel<true, false>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
-                                           nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
+                                           nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                     D2_TRY(hipGetLastError());
                     unsigned long long h_nrec[64 * 8];
                     D2_TRY(hipMemcpyAsync(h_nrec, d_nrec.p, sizeof h_nrec, hipMemcpyDeviceToHost, st));
@@ -414,10 +434,10 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
                 pool.wkey = d_wkey.as<uint32_t>(); pool.wrec = d_wrec.as<ulonglong2>(); pool.region = (uint32_t)region;
                 if (store)
                     hipLaunchKernelGGL((d2_emit_kernel<false, true>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
-                                       nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
+                                       nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                 else
                     hipLaunchKernelGGL((d2_emit_kernel<false, false>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
-                                       nruns, nbr, nbc, pool, d_nrec.as<unsigned long long>());
+                                       nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                 D2_TRY(hipGetLastError());
                 uint32_t ovf = 0;
                 D2_TRY(hipMemcpyAsync(&ovf, d_flag.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, st));
@@ -426,7 +446,9 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
                 if (!ovf) break;
                 if (attempt) return kmdb_set_error("kmdb_db2db_dense: internal error (record pool overflow)");
             }
+            phase("pool + emit");
             if (kmdb_rect_sort_apply(st, d_wkey.as<uint32_t>(), d_wrec.p, (uint32_t)slots, nbr, nbc, key_bits, d_out.as<uint32_t>(), (uint32_t)nr, (uint32_t)nc)) return 1;
+            phase("sort + apply");
         }
     }
     D2_TRY(hipEventRecord(ev3, st));

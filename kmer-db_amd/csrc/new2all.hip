@@ -119,8 +119,11 @@ struct N2Cursor {                                                 // gamma strea
 // (a few nodes near the root carry thousands of ids) go to a queue in LDS and are decoded afterwards by ALL threads of the
 // workgroup in pieces of KMDB_CK_IDS ids, each piece starting from a checkpoint of the list index (engine_state.h) —
 // measured before that: 8 % of the lanes active, the others waiting for a neighbour's long list.
-constexpr uint32_t N2_QCAP = 1024, N2_THREADS = 512;      // 512 threads share one per-query histogram: twice the waves per byte of LDS
-template <bool LDS_HIST>
+// The threads of a workgroup share one per-query histogram in LDS (4 B per sample).  512 threads: with 10 000 samples two
+// workgroups fit a CU (4 waves per SIMD).  1024 threads would fill the SIMDs, and were measured slower (71.4 against 59.0 ms per
+// 1000 queries: twice the threads behind every workgroup barrier and on the same histogram); KMDB_N2A_THREADS=1024 runs them.
+constexpr uint32_t N2_QCAP = 1024;
+template <bool LDS_HIST, uint32_t N2_THREADS>
 __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned long long* __restrict__ uniq, const uint32_t* __restrict__ csum,
                                                        const uint32_t* __restrict__ qstart, uint32_t nruns, uint32_t nq,
                                                        const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
@@ -289,15 +292,19 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
         hipLaunchKernelGGL(n2a_query_ranges_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st,
                            d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
         if (nruns) {
-            const unsigned wblocks = (nruns + N2_THREADS - 1) / N2_THREADS;
-            if (N * 4 + 20 * 1024 <= 64 * 1024)                     // the per-query histogram next to the kernel's 19 KB of static LDS
-                hipLaunchKernelGGL(n2a_walk_kernel<true>, dim3(wblocks), dim3(N2_THREADS), N * 4, st, d_uniq.as<unsigned long long>(),
-                                   d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent,
-                                   e.sub_end, e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>());
-            else
-                hipLaunchKernelGGL(n2a_walk_kernel<false>, dim3(wblocks), dim3(N2_THREADS), 0, st, d_uniq.as<unsigned long long>(),
-                                   d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent,
-                                   e.sub_end, e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>());
+            const bool lds_hist = N * 4 + 24 * 1024 <= 64 * 1024;   // the per-query histogram next to the kernel's 20-odd KB of static LDS
+            uint32_t threads = 512;
+            if (const char* ev = getenv("KMDB_N2A_THREADS")) if (atoi(ev) == 1024) threads = 1024;
+            const unsigned wblocks = (nruns + threads - 1) / threads;
+#define N2A_WALK(H, T)                                                                                                                   \
+    hipLaunchKernelGGL((n2a_walk_kernel<H, T>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),            \
+                       d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent, e.sub_end,       \
+                       e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>())
+            if (lds_hist && threads == 1024) N2A_WALK(true, 1024);
+            else if (lds_hist) N2A_WALK(true, 512);
+            else if (threads == 1024) N2A_WALK(false, 1024);
+            else N2A_WALK(false, 512);
+#undef N2A_WALK
         }
         N2_TRY(hipGetLastError());
     }

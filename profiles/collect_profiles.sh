@@ -17,13 +17,16 @@ fi
 if [ "$WHAT" != "pmc" ]; then
 rm -rf /tmp/prof_stats
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py $BA --no-cpu-baseline --steps 5 --warmup 2 > $OUT/${TAG}_bench_profiled.json 2> /tmp/prof_stats.err )
-find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_all.csv \;
+# one stats file per traced process (bench.py runs its synthetic generator in a child): keep the one with the engine's kernels
+for f in $(find /tmp/prof_stats -name '*kernel_stats.csv'); do
+  if grep -q -E "k0_decode_kernel|n2a_|d2_|row_nnz_kernel" $f; then cp $f $OUT/${TAG}_kernel_stats_all.csv; fi
+done
 fi
 if [ "$WHAT" != "stats" ]; then
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$C
   ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- python $R/bench.py $BA --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> /tmp/prof_$C.err )
-  find /tmp/prof_$C -name '*counter_collection.csv' -exec cp {} /tmp/${C}.csv \;
+  cp $(find /tmp/prof_$C -name '*counter_collection.csv' -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2) /tmp/${C}.csv
 done
 fi
 python profiles/summarize_profiles.py $TAG /tmp/FETCH_SIZE.csv /tmp/WRITE_SIZE.csv $OUT
