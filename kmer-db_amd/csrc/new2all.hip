@@ -122,8 +122,7 @@ struct N2Cursor {                                                 // gamma strea
 // The threads of a workgroup share one per-query histogram in LDS (4 B per sample).  512 threads: with 10 000 samples two
 // workgroups fit a CU (4 waves per SIMD).  1024 threads would fill the SIMDs, and were measured slower (71.4 against 59.0 ms per
 // 1000 queries: twice the threads behind every workgroup barrier and on the same histogram); KMDB_N2A_THREADS=1024 runs them.
-constexpr uint32_t N2_QCAP = 1024;
-template <bool LDS_HIST, uint32_t N2_THREADS>
+template <bool LDS_HIST, uint32_t N2_THREADS, uint32_t N2_QCAP>
 __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned long long* __restrict__ uniq, const uint32_t* __restrict__ csum,
                                                        const uint32_t* __restrict__ qstart, uint32_t nruns, uint32_t nq,
                                                        const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
@@ -157,17 +156,28 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
             const uint32_t cbase = csum[i];
             int64_t r = h;
             uint32_t ub = i + 1;                               // grows while climbing: an ancestor's subtree contains the node's
+            // A step's loads depend on each other (subtree end -> search over the hits -> count; list header -> stream -> ids; parent):
+            // the records of the NEXT node of the path are fetched at the top of a step, before the current node's search and decode,
+            // so the dependent round trips of consecutive steps overlap.
+            uint32_t se = sub_end[r];
+            uint4 m = meta[r];
+            int32_t par = parent[r];
+            uint64_t bp = bitpos[r];
             while (r > prev) {
+                const int64_t rn = par;
+                uint32_t se_n = 0;
+                uint4 m_n = make_uint4(0u, 0u, 0u, 0u);
+                int32_t par_n = -1;
+                uint64_t bp_n = 0;
+                if (rn > prev) { se_n = sub_end[rn]; m_n = meta[rn]; par_n = parent[rn]; bp_n = bitpos[rn]; }
                 // hits below r: indices [i, ub), ub = first run of this query whose pattern is >= sub_end[r].  Searched from the
                 // previous ub in doubling steps: near the leaves a subtree holds a handful of hits, one or two probes find its end
-                const uint32_t se = sub_end[r];
                 uint32_t lo = ub, hi = ub, step = 1;
                 while (hi < qe && (uint32_t)uniq[hi] < se) { lo = hi + 1; hi += step; step <<= 1; }
                 if (hi > qe) hi = qe;
                 while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)uniq[mid] < se) lo = mid + 1; else hi = mid; }
                 ub = lo;
                 const uint32_t H = csum[lo] - cbase;
-                const uint4 m = meta[r];
                 const uint32_t l = m.y;
                 bool inl = l != 0;
                 if (l > KMDB_CK_IDS) {
@@ -178,23 +188,23 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                     uint32_t id = m.z;
                     if (l > 1) {
                         // pattern_t::decodeSamples (src/pattern.cpp:99-109): first id = last - sum of the deltas
-                        N2Cursor c1(bits, bitpos[r]);
+                        N2Cursor c1(bits, bp);
                         uint32_t sum = 0;
                         for (uint32_t t = 0; t + 1 < l; ++t) sum += c1.next();
                         id = m.z - sum;
-                        N2Cursor c2(bits, bitpos[r]);
+                        N2Cursor c2(bits, bp);
                         for (uint32_t t = 0; t + 1 < l; ++t) { atomicAdd(&acc[id], H); id += c2.next(); }
                     }
                     atomicAdd(&acc[id], H);
                 }
-                r = parent[r];
+                r = rn; se = se_n; m = m_n; par = par_n; bp = bp_n;
             }
         }
         __syncthreads();
         // ---- the queued long lists, KMDB_CK_IDS ids per thread and step
         const uint32_t nt = q_n < N2_QCAP ? q_n : N2_QCAP;
         if (nt) {
-            constexpr uint32_t PER = N2_QCAP / N2_THREADS;
+            constexpr uint32_t PER = N2_QCAP / N2_THREADS ? N2_QCAP / N2_THREADS : 1u;
             uint32_t sum = 0;
             for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) sum += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS;
             part[threadIdx.x] = sum;
@@ -292,18 +302,20 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
         hipLaunchKernelGGL(n2a_query_ranges_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st,
                            d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
         if (nruns) {
-            const bool lds_hist = N * 4 + 24 * 1024 <= 64 * 1024;   // the per-query histogram next to the kernel's 20-odd KB of static LDS
+            // LDS of a workgroup: the per-query histogram (4 B per sample) + the queue of long lists (16 B per entry) + 2-4 KB
+            // (a queue of 256 entries would let a third workgroup onto a CU and was measured 1.5 x slower: every second hit visits
+            // a node with more than 32 local ids, a full queue leaves those to single threads)
             uint32_t threads = 512;
+            const uint32_t qcap = 1024;
             if (const char* ev = getenv("KMDB_N2A_THREADS")) if (atoi(ev) == 1024) threads = 1024;
+            const bool lds_hist = N * 4 + qcap * 16 + 8 * 1024 <= 64 * 1024;
             const unsigned wblocks = (nruns + threads - 1) / threads;
-#define N2A_WALK(H, T)                                                                                                                   \
-    hipLaunchKernelGGL((n2a_walk_kernel<H, T>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),            \
+#define N2A_WALK(H, T, Q)                                                                                                                \
+    hipLaunchKernelGGL((n2a_walk_kernel<H, T, Q>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),         \
                        d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent, e.sub_end,       \
                        e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>())
-            if (lds_hist && threads == 1024) N2A_WALK(true, 1024);
-            else if (lds_hist) N2A_WALK(true, 512);
-            else if (threads == 1024) N2A_WALK(false, 1024);
-            else N2A_WALK(false, 512);
+            if (threads == 1024) { if (lds_hist) N2A_WALK(true, 1024, 1024); else N2A_WALK(false, 1024, 1024); }
+            else { if (lds_hist) N2A_WALK(true, 512, 1024); else N2A_WALK(false, 512, 1024); }
 #undef N2A_WALK
         }
         N2_TRY(hipGetLastError());
