@@ -111,6 +111,15 @@ struct N2Cursor {                                                 // gamma strea
         if (s >= 64u) { s -= 64u; ++wi; c0 = c1; c1 = bits[wi + 1]; }
         return low | (1u << ones);
     }
+    // the "0" codes (deltas of 1) at the cursor, at most `limit` of them: taken in one step
+    __device__ __forceinline__ uint32_t zeros(uint32_t limit) {
+        const uint64_t win = s ? ((c0 << s) | (c1 >> (64u - s))) : c0;
+        uint32_t z = win ? (uint32_t)__clzll((long long)win) : 64u;
+        z = z < limit ? z : limit;
+        s += z;
+        if (s >= 64u) { s -= 64u; ++wi; c0 = c1; c1 = bits[wi + 1]; }
+        return z;
+    }
 };
 
 // (4) walk: one thread per distinct (query, hit pattern).  A thread climbs from its hit towards the root until it meets the
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                 bool inl = l != 0;
                 if (l > KMDB_CK_IDS) {
                     const uint32_t slot = atomicAdd(&q_n, 1u);
-                    if (slot < N2_QCAP) { q_node[slot] = (uint32_t)r; q_h[slot] = H; q_l[slot] = l; inl = false; }      // a full queue: decoded here
+                    if (slot < N2_QCAP) { q_node[slot] = ck_ofs[r]; q_h[slot] = H; q_l[slot] = l; inl = false; }      // (the node's first checkpoint)      // a full queue: decoded here
                 }
                 if (inl) {
                     uint32_t id = m.z;
@@ -190,10 +199,19 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                         // pattern_t::decodeSamples (src/pattern.cpp:99-109): first id = last - sum of the deltas
                         N2Cursor c1(bits, bp);
                         uint32_t sum = 0;
-                        for (uint32_t t = 0; t + 1 < l; ++t) sum += c1.next();
+                        for (uint32_t rem = l - 1u; rem;) {                 // runs of deltas of 1 in one step each
+                            const uint32_t z = c1.zeros(rem);
+                            sum += z; rem -= z;
+                            if (rem) { sum += c1.next(); --rem; }
+                        }
                         id = m.z - sum;
                         N2Cursor c2(bits, bp);
-                        for (uint32_t t = 0; t + 1 < l; ++t) { atomicAdd(&acc[id], H); id += c2.next(); }
+                        for (uint32_t rem = l - 1u; rem;) {
+                            const uint32_t z = c2.zeros(rem);
+                            for (uint32_t t = 0; t < z; ++t) { atomicAdd(&acc[id], H); ++id; }
+                            rem -= z;
+                            if (rem) { atomicAdd(&acc[id], H); id += c2.next(); --rem; }
+                        }
                     }
                     atomicAdd(&acc[id], H);
                 }
@@ -207,29 +225,83 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
             constexpr uint32_t PER = N2_QCAP / N2_THREADS ? N2_QCAP / N2_THREADS : 1u;
             uint32_t sum = 0;
             for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) sum += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS;
-            part[threadIdx.x] = sum;
-            __syncthreads();
-            for (uint32_t d = 1; d < N2_THREADS; d <<= 1) {
-                const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-                __syncthreads();
-                part[threadIdx.x] += v;
-                __syncthreads();
+            // exclusive scan of the threads' piece counts: inside the waves by shuffles, the wave totals through LDS
+            const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t o2 = (uint32_t)__shfl_up((int)incl, dd, 64);
+                if (lane >= (uint32_t)dd) incl += o2;
             }
-            uint32_t run = part[threadIdx.x] - sum;
+            if (lane == 63u) part[wv] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum, all = 0;
+            for (uint32_t w2 = 0; w2 < N2_THREADS / 64u; ++w2) { const uint32_t pw = part[w2]; if (w2 < wv) run += pw; all += pw; }
             for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) { q_pre[t] = run; run += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS; }
-            if (threadIdx.x == N2_THREADS - 1u) q_pre[nt] = part[N2_THREADS - 1u];
+            if (threadIdx.x == 0) q_pre[nt] = all;
             __syncthreads();
             const uint32_t S = q_pre[nt];
+            // The long lists are mostly RUNS of consecutive ids (a clade's samples), many of them the same runs, and adding H to
+            // every id of every run is what this kernel waited for (same-address LDS atomics).  With the histogram in LDS the
+            // queued lists go in as differences instead: +H at the first id of a run, -H behind its last — two atomics per run —
+            // and one prefix sum over the histogram turns them back into counts.  The short lists of the climb were added
+            // directly: the histogram is brought to difference form first (d[s] = h[s] - h[s-1]), in place, every thread its own
+            // contiguous range.
+            const uint32_t per = ((N + N2_THREADS - 1u) / N2_THREADS) | 1u;          // odd: the threads' ranges start in different LDS banks
+            const uint32_t ra = threadIdx.x * per < N ? threadIdx.x * per : N, rb = ra + per < N ? ra + per : N;
+            if (LDS_HIST) {
+                uint32_t prev = (ra && ra < N) ? hist[ra - 1u] : 0u;
+                __syncthreads();
+                for (uint32_t s2 = ra; s2 < rb; ++s2) { const uint32_t v = hist[s2]; hist[s2] = v - prev; prev = v; }
+                __syncthreads();
+            }
             for (uint32_t g = threadIdx.x; g < S; g += N2_THREADS) {
                 uint32_t lo = 0, hi = nt;                       // the task whose pieces contain g: last t with q_pre[t] <= g
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (q_pre[mid] <= g) lo = mid; else hi = mid; }
-                const uint32_t piece = g - q_pre[lo], r = q_node[lo], H = q_h[lo], l = q_l[lo];
-                const uint32_t o = ck_ofs[r] + piece;
+                const uint32_t piece = g - q_pre[lo], H = q_h[lo], l = q_l[lo];
+                const uint32_t o = q_node[lo] + piece;
                 uint32_t id = ck_id[o];
                 const uint32_t left = l - piece * KMDB_CK_IDS, cnt = left < KMDB_CK_IDS ? left : KMDB_CK_IDS;
-                atomicAdd(&acc[id], H);
                 N2Cursor c(bits, ck_bit[o]);
-                for (uint32_t t = 1; t < cnt; ++t) { id += c.next(); atomicAdd(&acc[id], H); }
+                if (LDS_HIST) {
+                    uint32_t start = id, len = 1, rem = cnt - 1u;          // the run [start, start + len) under construction
+                    while (rem) {
+                        const uint32_t z = c.zeros(rem);
+                        len += z; rem -= z;
+                        if (rem) {
+                            const uint32_t d = c.next();
+                            --rem;
+                            if (d == 1u) ++len;
+                            else {
+                                atomicAdd(&hist[start], H);
+                                if (start + len < N) atomicAdd(&hist[start + len], 0u - H);
+                                start += len - 1u + d; len = 1;
+                            }
+                        }
+                    }
+                    atomicAdd(&hist[start], H);
+                    if (start + len < N) atomicAdd(&hist[start + len], 0u - H);
+                } else {
+                    atomicAdd(&acc[id], H);
+                    for (uint32_t t = 1; t < cnt; ++t) { id += c.next(); atomicAdd(&acc[id], H); }
+                }
+            }
+            if (LDS_HIST) {
+                // back to counts: prefix sum over the histogram (range sums, scan of the 512 range sums by waves, ranges rewritten)
+                __syncthreads();
+                uint32_t sum2 = 0;
+                for (uint32_t s2 = ra; s2 < rb; ++s2) sum2 += hist[s2];
+                uint32_t incl2 = sum2;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const uint32_t o2 = (uint32_t)__shfl_up((int)incl2, dd, 64);
+                    if (lane >= (uint32_t)dd) incl2 += o2;
+                }
+                if (lane == 63u) part[wv] = incl2;
+                __syncthreads();
+                uint32_t run2 = incl2 - sum2;
+                for (uint32_t w2 = 0; w2 < wv; ++w2) run2 += part[w2];
+                for (uint32_t s2 = ra; s2 < rb; ++s2) { run2 += hist[s2]; hist[s2] = run2; }
             }
         }
         if (LDS_HIST) {
