@@ -105,31 +105,36 @@ def generate_in_child(dev_index, tmp=None, **spec):
     cost, and a user's process (the front-end reading a .db) never has it: the timed process now starts its upload on a device
     it has not churned, the way the front-end does, instead of sleeping after torch.cuda.empty_cache()."""
     import shutil
-    base = tmp
-    if base is None:
-        base = tempfile.gettempdir()
+    bases = [tmp] if tmp is not None else []
+    if tmp is None:
         try:
             if shutil.disk_usage("/dev/shm").free > (32 << 30):
-                base = "/dev/shm"
+                bases.append("/dev/shm")
         except OSError:
             pass
-    td = tempfile.mkdtemp(prefix="kmdb_gen_", dir=base)
-    try:
-        spec = dict(spec, out=td, dev_index=dev_index)
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
-                                                                "TORCHELASTIC_RUN_ID", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE")}
-        t0 = time.time()
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--generate-spec", json.dumps(spec)], env=env)
-        arr = {nm[:-4]: np.load(os.path.join(td, nm)) for nm in sorted(os.listdir(td)) if nm.endswith(".npy") and not nm.startswith("_")}
-        with open(os.path.join(td, "meta.json")) as f:
-            meta = json.load(f)
-        items = None
-        if meta["with_items"]:
-            items = (np.load(os.path.join(td, "_bucket_offset.npy")), np.load(os.path.join(td, "_items.npy")))
-        log("[rank %d] generator process done, arrays read back in %.1f s total" % (spec["rank"], time.time() - t0))
-        return arr, meta["names"], meta["sample_counts"], meta["n_kmers"], items
-    finally:
-        shutil.rmtree(td, ignore_errors=True)
+        bases.append(tempfile.gettempdir())          # (also the second try when shared memory fills up: several ranks write at once)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                            "TORCHELASTIC_RUN_ID", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE")}
+    last = None
+    for base in bases:
+        td = tempfile.mkdtemp(prefix="kmdb_gen_", dir=base)
+        try:
+            t0 = time.time()
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--generate-spec", json.dumps(dict(spec, out=td, dev_index=dev_index))], env=env)
+            arr = {nm[:-4]: np.load(os.path.join(td, nm)) for nm in sorted(os.listdir(td)) if nm.endswith(".npy") and not nm.startswith("_")}
+            with open(os.path.join(td, "meta.json")) as f:
+                meta = json.load(f)
+            items = None
+            if meta["with_items"]:
+                items = (np.load(os.path.join(td, "_bucket_offset.npy")), np.load(os.path.join(td, "_items.npy")))
+            log("[rank %d] generator process done, arrays read back in %.1f s total" % (spec["rank"], time.time() - t0))
+            return arr, meta["names"], meta["sample_counts"], meta["n_kmers"], items
+        except (subprocess.CalledProcessError, OSError) as e:
+            last = e
+            log("[rank %d] generator process with its files under %s failed (%s)" % (spec["rank"], base, e))
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    raise SystemExit("bench.py: the synthetic generator failed: %s" % last)
 
 
 def generator_child(spec):
