@@ -142,9 +142,23 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[N2_THREADS];
     __shared__ uint32_t q_n;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < nruns && uniq[i] != N2_INVALID;
-    const uint32_t myq = live ? (uint32_t)(uniq[i] >> 32) : 0xFFFFFFFFu;
+    // The workgroup's own stretch of the sorted hit list (patterns, scanned counts; one entry beyond) stays in LDS: near the leaves a
+    // subtree ends a few hits further on, so the searches of the climb mostly stay inside it instead of going to memory step by step.
+    __shared__ uint32_t w_pat[N2_THREADS + 1], w_cs[N2_THREADS + 1];
+    const uint32_t blk0 = blockIdx.x * blockDim.x;
+    const uint32_t i = blk0 + threadIdx.x;
+    const unsigned long long my_key = i < nruns ? uniq[i] : N2_INVALID;
+    const bool live = my_key != N2_INVALID;
+    const uint32_t myq = live ? (uint32_t)(my_key >> 32) : 0xFFFFFFFFu;
+    w_pat[threadIdx.x] = (uint32_t)my_key;
+    w_cs[threadIdx.x] = i <= nruns ? csum[i] : 0u;
+    if (threadIdx.x == 0) {
+        const uint32_t j = blk0 + N2_THREADS;
+        w_pat[N2_THREADS] = j < nruns ? (uint32_t)uniq[j] : 0xFFFFFFFFu;
+        w_cs[N2_THREADS] = j <= nruns ? csum[j] : 0u;
+    }
+    auto pat_at = [&](uint32_t x) -> uint32_t { const uint32_t o = x - blk0; return o <= N2_THREADS ? w_pat[o] : (uint32_t)uniq[x]; };      // x >= blk0
+    auto cs_at = [&](uint32_t x) -> uint32_t { const uint32_t o = x - blk0; return o <= N2_THREADS ? w_cs[o] : csum[x]; };
     // the block's runs are sorted by query: loop over the (few) queries it spans
     __shared__ uint32_t q_lo, q_hi;
     if (threadIdx.x == 0) { q_lo = 0xFFFFFFFFu; q_hi = 0; }
@@ -160,9 +174,9 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
         uint32_t* acc = LDS_HIST ? hist : (sim + (size_t)q * N);
         if (live && myq == q) {
             const uint32_t qs = qstart[q], qe = qstart[q + 1];
-            const uint32_t h = (uint32_t)uniq[i];
-            const int64_t prev = i > qs ? (int64_t)(uint32_t)uniq[i - 1] : -1;
-            const uint32_t cbase = csum[i];
+            const uint32_t h = (uint32_t)my_key;
+            const int64_t prev = i > qs ? (int64_t)(threadIdx.x ? w_pat[threadIdx.x - 1u] : (uint32_t)uniq[i - 1]) : -1;
+            const uint32_t cbase = w_cs[threadIdx.x];
             int64_t r = h;
             uint32_t ub = i + 1;                               // grows while climbing: an ancestor's subtree contains the node's
             // A step's loads depend on each other (subtree end -> search over the hits -> count; list header -> stream -> ids; parent):
@@ -182,11 +196,11 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                 // hits below r: indices [i, ub), ub = first run of this query whose pattern is >= sub_end[r].  Searched from the
                 // previous ub in doubling steps: near the leaves a subtree holds a handful of hits, one or two probes find its end
                 uint32_t lo = ub, hi = ub, step = 1;
-                while (hi < qe && (uint32_t)uniq[hi] < se) { lo = hi + 1; hi += step; step <<= 1; }
+                while (hi < qe && pat_at(hi) < se) { lo = hi + 1; hi += step; step <<= 1; }
                 if (hi > qe) hi = qe;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)uniq[mid] < se) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pat_at(mid) < se) lo = mid + 1; else hi = mid; }
                 ub = lo;
-                const uint32_t H = csum[lo] - cbase;
+                const uint32_t H = cs_at(lo) - cbase;
                 const uint32_t l = m.y;
                 bool inl = l != 0;
                 if (l > KMDB_CK_IDS) {
@@ -362,9 +376,12 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
         hipLaunchKernelGGL(n2a_probe_kernel, dim3(blocks), dim3(256), 0, st, d_kmers, d_qoff_p, (uint32_t)nq,
                            total, e.n_buckets, e.bucket_offset, e.slots, e.pid2dfs, e.w, d_keys.as<unsigned long long>());
         N2_TRY(hipGetLastError());
-        // queries need 32 - clz(nq) high bits; sorting all 64 is simplest and the key count is small
+        // only the bits in use are sorted: 32 of the pattern, and as many as the queries need (the unused slots' ~0 is all ones in
+        // those too, and no key in use is)
+        unsigned qbits = 1;
+        while ((1ull << qbits) < nq) ++qbits;
         N2_TRY(prim::sort_keys(d_tmp.p, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
-                                                 (int)total, 0, 64, st));
+                                                 (int)total, 0, std::min(64u, 32u + qbits), st));
         N2_TRY(hipMemsetAsync(d_cnt.p, 0, (total + 2) * 4, st));
         N2_TRY(prim::run_length_encode(d_tmp.p, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                      d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)total, st));
@@ -374,13 +391,14 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
         hipLaunchKernelGGL(n2a_query_ranges_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st,
                            d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
         if (nruns) {
-            // LDS of a workgroup: the per-query histogram (4 B per sample) + the queue of long lists (16 B per entry) + 2-4 KB
+            // LDS of a workgroup: the per-query histogram (4 B per sample) + the queue of long lists (16 B per entry) + 12 B per thread
+            // (scan scratch, the workgroup's stretch of the hit list)
             // (a queue of 256 entries would let a third workgroup onto a CU and was measured 1.5 x slower: every second hit visits
             // a node with more than 32 local ids, a full queue leaves those to single threads)
             uint32_t threads = 512;
             const uint32_t qcap = 1024;
             if (const char* ev = getenv("KMDB_N2A_THREADS")) if (atoi(ev) == 1024) threads = 1024;
-            const bool lds_hist = N * 4 + qcap * 16 + 8 * 1024 <= 64 * 1024;
+            const bool lds_hist = N * 4 + qcap * 16 + threads * 12 + 1024 <= 64 * 1024;
             const unsigned wblocks = (nruns + threads - 1) / threads;
 #define N2A_WALK(H, T, Q)                                                                                                                \
     hipLaunchKernelGGL((n2a_walk_kernel<H, T, Q>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),         \
