@@ -222,7 +222,10 @@ int  kmdb_new2all_batch_seq(kmdb_db* db, const char* const* seqs, const size_t* 
 /* Replaces SimilarityCalculator::db2db_sp(db_row, db_col, SparseMatrix&, bubbles) (similarity_calculator.cpp:1225-1540),
  * the off-diagonal cell of the all2all-parts grid (call sites console_all2all_parts.cpp:180,226): both databases
  * resident with hashtables on the same device.  out: n_samples(db_row) x n_samples(db_col) uint32, row-major, host
- * memory: out[r][c] = number of k-mers shared by sample r of db_row and sample c of db_col. */
+ * memory: out[r][c] = number of k-mers shared by sample r of db_row and sample c of db_col.
+ * The first call on a handle of up to 4096 samples leaves the full sample lists of its patterns with the handle (n_samples / 8
+ * bytes per pattern, at most 8 GB; counted in kmdb_stats.device_bytes, freed by kmdb_db_free): the other cells of the grid that
+ * use the part read them instead of rebuilding them. */
 int  kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmdb_opts* opts);
 
 /* ---------------------------------------------------------------------------------------
