@@ -140,7 +140,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                                                        const uint64_t* __restrict__ ck_bit, const uint32_t* __restrict__ ck_id, uint32_t N,
                                                        uint32_t* __restrict__ sim) {
     extern __shared__ uint32_t hist[];
-    __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[N2_THREADS];
+    __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[N2_THREADS / 64];      // part: wave totals of the scans
     __shared__ uint32_t q_n;
     // The workgroup's own stretch of the sorted hit list (patterns, scanned counts; one entry beyond) stays in LDS: near the leaves a
     // subtree ends a few hits further on, so the searches of the climb mostly stay inside it instead of going to memory step by step.
@@ -396,9 +396,9 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
             // (a queue of 256 entries would let a third workgroup onto a CU and was measured 1.5 x slower: every second hit visits
             // a node with more than 32 local ids, a full queue leaves those to single threads)
             uint32_t threads = 512;
-            const uint32_t qcap = 1024;
+            const uint32_t qcap = 1024;          // (512 entries: a third workgroup per CU, and 47.1 against 45.9 ms — the queue fills up)
             if (const char* ev = getenv("KMDB_N2A_THREADS")) if (atoi(ev) == 1024) threads = 1024;
-            const bool lds_hist = N * 4 + qcap * 16 + threads * 12 + 1024 <= 64 * 1024;
+            const bool lds_hist = N * 4 + qcap * 16 + threads * 8 + 1024 <= 64 * 1024;
             const unsigned wblocks = (nruns + threads - 1) / threads;
 #define N2A_WALK(H, T, Q)                                                                                                                \
     hipLaunchKernelGGL((n2a_walk_kernel<H, T, Q>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),         \
