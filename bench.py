@@ -224,12 +224,48 @@ def cpu_baseline(K, S, O, args, device, arr, names, counts, nk, gpu_matrix):
         m, info = O.ref_all2all(path, os.path.join(td, "full.u32"), threads=thr, buffer_mb=buf)
         log("  reference on the full database: compute %.2f s (whole process incl. deserialize %.1f s)" % (info["seconds"], time.time() - t0))
         assert np.array_equal(m, gpu_matrix), "GPU matrix differs from the reference's on the full database"
+        ref_process_s = time.time() - t0
         sum_pairs = float(m.astype(np.uint64).sum())
+        fe = frontend_run(K, path, td, m, names, counts, args.k)
+        log("  front-end on the same .db: %.2f s whole process (compute %.3f s, CSV %.3f s), CSV == the reference matrix's" % (
+            fe["frontend_s"], fe["frontend_compute_s"] or -1, fe["frontend_csv_s"] or -1))
         return {"value": sum_pairs / info["seconds"], "unit": "kmer-pair-comparisons/s", "cores": thr, "host_cores": cores, "kind": "reference",
-                "seconds": info["seconds"], "process_seconds": time.time() - t0, "buffer_mb": buf,
+                "seconds": info["seconds"], "process_seconds": ref_process_s, "buffer_mb": buf, "frontend": fe,
                 "sample": "full %s database (%d patterns), reference SimilarityCalculator::all2all compute interval, -t %d -buffer %d "
                           "(best of a %d-point sweep on a 1/%d-length sample); the whole %d-cell GPU matrix compared equal"
                           % (args.workload, arr["num_kmers"].size, thr, buf, len(tried), max(1, args.length // L), m.size)}
+
+
+def frontend_run(K, db_path, td, ref_matrix, names, counts, k):
+    """`kmer-db-amd all2all <db> <csv>` — the product's front-end as a user runs it: .db read from disk, upload, the call, CSV written —
+    timed as a whole process next to the reference's (console_all2all.cpp:25-78); the CSV compared byte for byte with one formatted
+    from the REFERENCE's raw matrix (same row format: array.h:254-257, conversion.h:99-165)."""
+    exe = os.path.join(ROOT, "kmer-db_amd", "bin", "kmer-db-amd")
+    out_csv = os.path.join(td, "frontend.csv")
+    t0 = time.time()
+    r = subprocess.run([exe, "all2all", db_path, out_csv], capture_output=True, text=True)
+    wall = time.time() - t0
+    if r.returncode != 0:
+        raise SystemExit("bench.py: the front-end failed: %s" % r.stderr[-2000:])
+    import re
+    secs = [float(x) for x in re.findall(r"OK \(([0-9.eE+-]+) seconds\)", r.stderr)]
+    res = {"frontend_s": wall, "frontend_compute_s": secs[0] if secs else None, "frontend_csv_s": secs[1] if len(secs) > 1 else None,
+           "frontend_csv_bytes": os.path.getsize(out_csv)}
+    # expected text: header lines + one row per sample from the reference's matrix
+    n = len(names)
+    h = K.HostDB(db_path, skip_hashtables=True)
+    exp = [K.format_header(h)]
+    h.close()
+    m = np.ascontiguousarray(ref_matrix, np.uint32)
+    for i in range(n):
+        exp.append(K.format_dense_row(names[i], int(counts[i]), m[i * (i - 1) // 2: i * (i - 1) // 2 + i]))
+    exp = b"".join(exp)
+    with open(out_csv, "rb") as f:
+        got = f.read()
+    assert got == exp, "front-end CSV differs from the CSV of the reference's matrix"
+    res["frontend_csv_matches_reference_matrix"] = True
+    os.unlink(out_csv)
+    return res
 
 
 def extra_workload(K, S, args, device, name):
@@ -289,6 +325,7 @@ def extra_workload(K, S, args, device, name):
                 assert np.array_equal(m, first), "%s: GPU matrix differs from the reference's" % name
                 out["reference_match"] = True
                 out["reference_compute_s"] = info["seconds"]
+                out.update(frontend_run(K, path, td, m, names, counts, args.k))
                 out["checks"] += "; the whole %d-cell matrix == the real reference's (all2all, -t %d -buffer 8) on the same database" % (m.size, min(os.cpu_count() or 1, 16))
     return out
 
@@ -599,7 +636,9 @@ def main():
         generator_child(json.loads(args.generate_spec))
         return
     if args.workload is None:
-        args.workload = MODE_WORKLOAD[args.mode]
+        # one GPU: BASELINE configs[1]; several: configs[2] — 10 000 samples, every rank one GPU's share of the 5 Mbp genomes (c3gpu =
+        # 5 Mbp / 8: at --gpus 8 with the default --scaling weak the job IS configs[2])
+        args.workload = "c3gpu" if (args.mode == "all2all" and args.gpus > 1) else MODE_WORKLOAD[args.mode]
     for key, val in dict(dict(k=18, fraction=1.0, queries=0), **WORKLOADS[args.workload]).items():
         if getattr(args, key) is None:
             setattr(args, key, val)
@@ -671,9 +710,13 @@ def main():
     hband = torch.zeros(max(per, 1), dtype=torch.int32).pin_memory() if scatter else None
     stream = torch.cuda.current_stream().cuda_stream
 
+    coll_ev = []                                             # (before, after) events around the collective of every timed step
+
     def step():
         db.all2all_dense_device(M.data_ptr(), stream=stream)
         if world > 1:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
             if scatter:
                 # direct reduce-scatter in flat chunks of the triangle: xGMI is point to point, every peer pair sums its chunk over its own
                 # link; every rank then brings ITS chunk to the host (the front-end writes the rows of its chunk)
@@ -693,6 +736,8 @@ def main():
                 dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
                 if rank == 0:
                     M.copy_(h)
+            ev[1].record()
+            coll_ev.append(ev)
 
     def fence():
         if world > 1:
@@ -702,6 +747,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    coll_ev.clear()
     call_ms, parts = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -719,8 +765,15 @@ def main():
         tot = torch.tensor([st0["sum_pairs"], st0["tree_updates"], st0["algorithmic_bytes"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         sum_pairs, tree_updates = float(tot[0]), float(tot[1])
+        # every rank's own figures: device time of its calls (HIP events around the whole call) and of the collective (events around the
+        # RCCL op on the stream it runs on; with --collective reduce_scatter the D2H of the rank's chunk is inside)
+        mine_t = torch.tensor([float(np.mean(call_ms)), float(np.mean([a.elapsed_time(b) for a, b in coll_ev])), float(db.P), 1.0], dtype=torch.float64, device=cdev)
+        per_rank = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(per_rank, mine_t)
+        per_rank = [[float(x) for x in t.tolist()] for t in per_rank]
     else:
         sum_pairs, tree_updates = float(st0["sum_pairs"]), float(st0["tree_updates"])
+        per_rank = None
 
     # size-independent check of the timed result: sum of the matrix == sum_p w_p C(n_p,2); and warm == cold
     if scatter:
@@ -766,6 +819,10 @@ def main():
                                                     "reduce-scatter by flat chunks + D2H of every rank's chunk" if scatter else "reduce")),
                 "samples": args.samples, "genome_length_bp": total_len, "k": args.k, "fraction": 1.0,
                 "patterns_rank0": db.P, "distinct_kmers_rank0": nk, "parallelism": "prefix-shard x%d" % world, "rccl": rccl,
+                "n_ranks_seen": world if per_rank is None else int(sum(r[3] for r in per_rank)),
+                "per_rank": None if per_rank is None else {"call_ms": [r[0] for r in per_rank], "collective_ms": [r[1] for r in per_rank],
+                                                           "patterns": [int(r[2]) for r in per_rank], "backend": args.backend,
+                                                           "collective": "reduce_scatter + D2H of the rank's chunk" if scatter else "reduce to rank 0"},
                 "sample_pairs_per_s": args.samples * (args.samples - 1) / 2 / (elapsed / args.steps),
                 "cell_updates_per_s": tree_updates / (elapsed / args.steps),
                 "path": path_name, "block_width": stl["width"],
@@ -798,6 +855,10 @@ def main():
             cb = out["cpu_baseline"]
             if cb["kind"] == "reference":
                 out["wall"]["reference_compute_s"] = cb["seconds"]
+                # end to end, both as whole processes on the same .db file: the reference's compute-only run (it writes no CSV here) and the
+                # front-end's read + upload + call + CSV
+                out["wall"]["reference_process_s"] = cb["process_seconds"]
+                out["wall"].update(cb.pop("frontend"))
         if world == 1 and args.workload == "c2" and args.length == WORKLOADS["c2"]["length"] and args.samples == WORKLOADS["c2"]["samples"] and not args.no_extra:
             # the 10 000-sample workload rides along in the same line (the configuration BASELINE's target is written for)
             db.close()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KMDB_ABI_VERSION 4
+#define KMDB_ABI_VERSION 5
 
 /* ---------------------------------------------------------------------------------------
  * Host-side view of a loaded database = what the reference hands to SimilarityCalculator:
@@ -118,7 +118,6 @@ typedef struct kmdb_cell_filter {
 
 typedef struct kmdb_stats {        /* measurements of the LAST call on this db handle */
     double   kernel_ms;            /* HIP-event time of the whole device pipeline of the call */
-    double   dominant_kernel_ms;   /* HIP-event time of the dominant kernel alone */
     uint64_t algorithmic_bytes;    /* B_pat + 4*N(N-1)/2 (dense) */
     uint64_t tree_updates;         /* cell updates performed (tree form) */
     uint64_t sum_pairs;            /* sum_p w_p*C(n_p,2) = sum of the matrix = k-mer pair comparisons */
@@ -160,6 +159,10 @@ int  kmdb_db_upload_shard(const kmdb_db_view* view, const kmdb_opts* opts, int w
                           uint32_t shard_count, kmdb_db** out);
 void kmdb_db_free(kmdb_db* db);
 int  kmdb_db_stats(const kmdb_db* db, kmdb_stats* out);
+/* Why the last all2all call on this handle could not take the block-record pipeline ("" when it did, or before any call): the
+ * note the engine prints once on stderr when it falls back to the HBM-atomics kernel (kmdb_stats.path == KMDB_PATH_GLOBAL), e.g.
+ * a root path of more than 4096 nodes.  The pointer stays valid until the next call on the handle. */
+const char* kmdb_db_fallback_reason(const kmdb_db* db);
 
 /* Replaces SimilarityCalculator::all2all(db, LowerTriangularMatrix&)
  * (similarity_calculator.cpp:42-438; call site console_all2all.cpp:34).
@@ -194,6 +197,9 @@ int  kmdb_all2all_sparse_filtered(kmdb_db* db, const kmdb_cell_filter* filters, 
 int  kmdb_sparse_from_dense_device(kmdb_db* db, const void* cells_dev, uint64_t cell_lo, uint64_t cell_hi,
                                    const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure,
                                    kmdb_sparse_rows* out, const kmdb_opts* opts);
+/* NOTE on streams: the call reads cells_dev on opts->stream (the handle's own stream when NULL) and does NOT order itself after
+ * the caller's producer: the cells must be complete on that stream (or the device idle) before the call — after an RCCL collective
+ * on another stream, wait for it first (hipStreamWaitEvent / hipStreamSynchronize). */
 /* the measure itself (params.cpp:14-42): uint32 wrap-around integer parts, double arithmetic */
 double kmdbh_metric(int metric, uint32_t common, uint32_t cnt_row, uint32_t cnt_col, int kmer_length);
 /* KMDB_METRIC_* of a criterion name ("jaccard", "min", ..., "num-kmers"), -1 if unknown */
@@ -227,6 +233,37 @@ int  kmdb_new2all_batch_seq(kmdb_db* db, const char* const* seqs, const size_t* 
  * bytes per pattern, at most 8 GB; counted in kmdb_stats.device_bytes, freed by kmdb_db_free): the other cells of the grid that
  * use the part read them instead of rebuilding them. */
 int  kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmdb_opts* opts);
+
+/* ---------------------------------------------------------------------------------------
+ * One database over the GPUs of a node (north_star: prefix buckets sharded across the GPUs, one RCCL reduce of the
+ * partial matrices over xGMI).  Makes the reference's single call sites multi-GPU: SimilarityCalculator::all2all at
+ * console_all2all.cpp:31-36 and all2all_sp + compact2 at console_all2all_sparse.cpp:44,79.
+ * kmdb_node_upload: shard s of n_shards (kmdb_db_upload_shard: the k-mers of the prefix buckets b with b % n_shards == s) goes to
+ * devices[s % D], D = min(n_shards, n_devices); the view must carry the hashtables when n_shards > 1.  One host thread per
+ * device inside every call; several shards of one device run one after the other and are summed on the device (a one-GPU box
+ * takes any n_shards that way).  With D > 1 the partial matrices meet in ONE ncclReduceScatter (uint32 sum) over flat chunks of the
+ * lower triangle — xGMI is point to point, every peer pair sums its chunk over its own link — and every device brings its own
+ * chunk to the host (dense) or compacts it where it is (sparse); librccl.so is loaded with dlopen only then.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kmdb_node kmdb_node;
+typedef struct kmdb_node_stats {   /* the LAST call on the node handle; maxima over the devices */
+    uint32_t n_shards, n_devices;
+    int32_t  rccl_version;         /* ncclGetVersion, 0 when RCCL was not needed */
+    uint32_t reserved;
+    double   upload_s;             /* kmdb_node_upload, wall clock */
+    double   call_ms;              /* wall clock of the slowest device's kmdb_all2all_dense_device calls (all its shards) */
+    double   collective_ms;        /* HIP events around ncclReduceScatter on the slowest device */
+    double   d2h_ms;               /* dense: copy of the device's chunk to the host; sparse: compaction + copy of its CSR */
+} kmdb_node_stats;
+int  kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, const int32_t* devices, uint32_t n_devices, kmdb_node** out);
+void kmdb_node_free(kmdb_node* node);
+int  kmdb_node_stats_get(const kmdb_node* node, kmdb_node_stats* out);
+/* = kmdb_all2all_dense over all shards: out_lower_tri N(N-1)/2 uint32 in host memory */
+int  kmdb_node_all2all_dense(kmdb_node* node, uint32_t* out_lower_tri, const kmdb_opts* opts);
+/* = kmdb_all2all_sparse_filtered over all shards (filters / measure on the complete sums; n_filters 0 and measure -1: plain
+ * kmdb_all2all_sparse); rows concatenate over the devices' chunks in ascending column order */
+int  kmdb_node_all2all_sparse(kmdb_node* node, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure,
+                              kmdb_sparse_rows* out, const kmdb_opts* opts);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side helpers of the front-end (no GPU needed).  They mirror the reference's loader

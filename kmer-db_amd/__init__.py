@@ -13,6 +13,7 @@ from .capi import (  # noqa: F401
     DeviceDB,
     HostDB,
     KmdbError,
+    NodeDB,
     SparseRows,
     device_count,
     extract_kmers,

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -50,13 +50,18 @@ METRICS = ["jaccard", "min", "max", "cosine", "mash", "ani", "ani-shorter", "mas
 
 
 class _Stats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
+    _fields_ = [("kernel_ms", C.c_double),
                 ("algorithmic_bytes", C.c_uint64), ("tree_updates", C.c_uint64), ("sum_pairs", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("n_segments", C.c_uint64), ("tile_flushes", C.c_uint64),
                 ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64), ("k0_ms", C.c_double),
                 ("k1n_ms", C.c_double), ("k1g_ms", C.c_double), ("upload_ms", C.c_double), ("n_wide", C.c_uint64),
                 ("n_chunks", C.c_uint64), ("path", C.c_uint32), ("width", C.c_uint32), ("sized_call", C.c_uint32),
                 ("n_slow_wide", C.c_uint32), ("n_patterns", C.c_uint64)]
+
+
+class _NodeStats(C.Structure):
+    _fields_ = [("n_shards", C.c_uint32), ("n_devices", C.c_uint32), ("rccl_version", C.c_int32), ("reserved", C.c_uint32),
+                ("upload_s", C.c_double), ("call_ms", C.c_double), ("collective_ms", C.c_double), ("d2h_ms", C.c_double)]
 
 
 FLAG_FORCE_GLOBAL_ATOMICS = 1
@@ -67,7 +72,8 @@ PATH_NONE, PATH_RECORDS, PATH_TILE, PATH_GLOBAL = 0, 1, 2, 3
 
 # every symbol include/kmdb_amd.h declares
 EXPORTS = [
-    "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_stats",
+    "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_stats", "kmdb_db_fallback_reason",
+    "kmdb_node_upload", "kmdb_node_free", "kmdb_node_stats_get", "kmdb_node_all2all_dense", "kmdb_node_all2all_sparse",
     "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdb_sparse_from_dense_device", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
     "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
     "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
@@ -98,6 +104,13 @@ def lib():
     L.kmdb_db_upload_shard.argtypes = [C.POINTER(_View), C.POINTER(_Opts), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.kmdb_db_free.argtypes = [C.c_void_p]
     L.kmdb_db_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    L.kmdb_db_fallback_reason.argtypes = [C.c_void_p]
+    L.kmdb_db_fallback_reason.restype = C.c_char_p
+    L.kmdb_node_upload.argtypes = [C.POINTER(_View), C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.kmdb_node_free.argtypes = [C.c_void_p]
+    L.kmdb_node_stats_get.argtypes = [C.c_void_p, C.POINTER(_NodeStats)]
+    L.kmdb_node_all2all_dense.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
+    L.kmdb_node_all2all_sparse.argtypes = [C.c_void_p, C.POINTER(_CellFilter), C.c_size_t, C.c_void_p, C.c_int, C.POINTER(_Sparse), C.POINTER(_Opts)]
     L.kmdb_all2all_dense.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_all2all_dense_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_all2all_sparse.argtypes = [C.c_void_p, C.POINTER(_Sparse), C.POINTER(_Opts)]
@@ -400,10 +413,65 @@ class DeviceDB:
         _check(lib().kmdb_db_stats(self._d, C.byref(s)))
         return {f: getattr(s, f) for f, _ in _Stats._fields_}
 
+    def fallback_reason(self):
+        """why the last all2all call could not take the block-record pipeline ("" when it did)"""
+        return lib().kmdb_db_fallback_reason(self._d).decode(errors="replace")
+
     def close(self):
         if self._d:
             lib().kmdb_db_free(self._d)
             self._d = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NodeDB:
+    """One database prefix-sharded over the devices of the node (kmdb_node_upload): n_shards shards, shard s on devices[s % D]."""
+
+    def __init__(self, src, n_shards, devices=(0,)):
+        self._keep = src
+        view = src.view if isinstance(src, HostDB) else C.pointer(src[0])
+        self._n = C.c_void_p()
+        devs = (C.c_int32 * len(devices))(*devices)
+        _check(lib().kmdb_node_upload(view, int(n_shards), devs, len(devices), C.byref(self._n)))
+        self.N = int(view.contents.n_samples)
+
+    def tri_size(self):
+        return self.N * (self.N - 1) // 2 if self.N else 0
+
+    def all2all_dense(self):
+        out = np.zeros(max(1, self.tri_size()), dtype=np.uint32)
+        _check(lib().kmdb_node_all2all_dense(self._n, out.ctypes.data, None))
+        return out[: self.tri_size()]
+
+    def all2all_sparse(self, filters=(), sample_kmers=None, measure=None):
+        raw = _Sparse()
+        fs = (_CellFilter * max(1, len(filters)))()
+        for i, (name, lo, hi) in enumerate(filters):
+            fs[i].metric = METRICS.index(name)
+            fs[i].lo = -np.finfo(np.float64).max if lo is None else lo
+            fs[i].hi = np.finfo(np.float64).max if hi is None else hi
+        cnt = None if sample_kmers is None else np.ascontiguousarray(sample_kmers, np.uint32)
+        _check(lib().kmdb_node_all2all_sparse(self._n, fs, len(filters), None if cnt is None else cnt.ctypes.data,
+                                              -1 if measure is None else METRICS.index(measure), C.byref(raw), None))
+        try:
+            return SparseRows(raw)
+        finally:
+            lib().kmdb_sparse_free(C.byref(raw))
+
+    def stats(self):
+        s = _NodeStats()
+        _check(lib().kmdb_node_stats_get(self._n, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in _NodeStats._fields_}
+
+    def close(self):
+        if self._n:
+            lib().kmdb_node_free(self._n)
+            self._n = C.c_void_p()
 
     def __del__(self):
         try:

@@ -2029,12 +2029,17 @@ constexpr uint32_t K1W_RUN_NODES = 256;     // wide nodes per run of a wave (rou
 struct U32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
 struct ValidKey { uint32_t n_states, kmask; __host__ __device__ uint32_t operator()(uint32_t k) const { return (k & kmask) < n_states ? 1u : 0u; } };
 
+// Record slots a pool can index.  Slot numbers are 32-bit; the few-streams path hands slot counts to rocPRIM as int (2^31).  The many-streams
+// path (row mode) is the engine's own kernels throughout: 2^32 minus a margin (the slot after the last chunk must not wrap to the
+// "no open chunk" value 0 of the row tables, and the windows of the apply kernel round the record count up).
+inline uint64_t pool_slot_limit(const kmdb_db* db) { return db->row_mode ? (1ull << 32) - (1ull << 20) : (1ull << 31); }
+
 int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->sort_tmp); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs); FREE_NULL(db->rs_tmp);
     db->pool_cap = 0;
     chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB);
-    if (chunks >= (1ull << 31) >> CH_SHIFT) return kmdb_set_error("kmdb: record pool would exceed 2^31 record slots");
+    if (chunks >= pool_slot_limit(db) >> CH_SHIFT) return kmdb_set_error("kmdb: record pool would exceed its " + std::to_string(pool_slot_limit(db)) + " record slots");
     HIP_TRY(hipMalloc((void**)&db->chunk_key, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->chunk_fill, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->sorted_key, chunks * 4));
@@ -2074,7 +2079,7 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     db->wide_pool_cap = 0; db->sorted_cap = 0;
     chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * WIDE_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * WIDE_GRAB) * ((uint64_t)KMDB_SUBPOOLS * WIDE_GRAB);
     const uint64_t slots = chunks << WCH_SHIFT;
-    if (slots >= (1ull << 31)) return kmdb_set_error("kmdb: wide record pool would exceed 2^31 record slots");
+    if (slots >= pool_slot_limit(db)) return kmdb_set_error("kmdb: wide record pool would exceed its " + std::to_string(pool_slot_limit(db)) + " record slots");
     HIP_TRY(hipMalloc((void**)&db->swkey, slots * 4));
     HIP_TRY(hipMalloc(&db->swrec, slots * sizeof(WideRec)));
     db->sorted_cap = slots;
@@ -2374,7 +2379,8 @@ static int blocks_prepare_impl(kmdb_db* db) {
     {
         uint64_t slices = 1;
         const uint64_t slots = (est_n + est_g) * 3 / 2;
-        slices = std::max<uint64_t>(slices, (slots + (3ull << 29) - 1) / (3ull << 29));                 // 1.6 G slots of the 2^31 a pool can index
+        const uint64_t usable = pool_slot_limit(db) / 4 * 3;                                            // three quarters of the slots a pool can index
+        slices = std::max<uint64_t>(slices, (slots + usable - 1) / usable);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
             slices = std::max<uint64_t>(slices, (slots * 44 + free_b / 2) / std::max<size_t>(free_b * 6 / 10, 1));     // pool + sorted copy: 44 B per slot, 60 % of what is free
@@ -2432,7 +2438,8 @@ uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
 namespace {
 
 // one attempt of the whole pipeline; *retry is set when a pool was too small (it has been enlarged)
-int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, hipStream_t st, bool* retry) {
+// decode: run K0 (the first slice of a call does; what it leaves — the local (block, mask) pairs of every node — serves all slices)
+int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, bool decode, hipStream_t st, bool* retry) {
     *retry = false;
     // KMDB_SYNC_DEBUG: wait after every stage and name the one that failed (debugging aid, no effect on results)
     static const bool sync_debug = getenv("KMDB_SYNC_DEBUG") != nullptr;
@@ -2449,7 +2456,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     const bool row_mode = db->row_mode;
     const uint32_t n_ckeys = db->n_ckeys;
     HIP_TRY(hipMemsetAsync(db->counters, 0, KCTR_COUNT * 4, st));
-    HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, (KMDB_PAIR_REGIONS + 1) * 16 * 4, st));
+    if (decode) HIP_TRY(hipMemsetAsync(db->pair_cursor, 0, (KMDB_PAIR_REGIONS + 1) * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->sub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->wsub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->run_ctr, 0, K1W_CTRS * 16 * 4, st));
@@ -2470,7 +2477,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     if (stage("init")) return 1;
     // ---- K0  (the two launches one after the other: both are bound by instruction issue, side by side on two streams they take
     // exactly as long — measured, profiles/r03_k0side_ab.sh)
-    {
+    if (decode) {
         K0Params q{};
         q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.perm = nullptr; q.P = P; q.bm = bm;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
@@ -2702,8 +2709,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         }
         if (c[KCTR_WIDE_OVERFLOW]) {
             const uint64_t want = db->wide_pool_cap * 2;
-            if ((want << WCH_SHIFT) >= (1ull << 31)) {
-                if (db->n_slices >= (1u << 16)) { db->fallback_reason = "more than 2^31 block records from the nodes with many blocks in a 65536th of the patterns"; return 0; }
+            if ((want << WCH_SHIFT) >= pool_slot_limit(db)) {
+                if (db->n_slices >= (1u << 16)) { db->fallback_reason = "more block records than a pool can index from the nodes with many blocks in a 65536th of the patterns"; return 0; }
                 db->n_slices *= 2;                                  // the pools stay as they are: half as many patterns per pass
                 if (verbose) fprintf(stderr, "[kmdb] wide record pool at its limit: %u slices of the pattern stream per call\n", db->n_slices);
                 db->have_counts = false; *retry = true;
@@ -2726,9 +2733,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                 if (verbose) fprintf(stderr, "[kmdb] record chunks of the narrow kernel are evicted nearly empty: its records go through the row chunks too\n");
                 if (alloc_wide_pool(db, db->wide_pool_cap + db->est_records * 5 / 4 / WCH_REC)) return 1;
                 want = 0;
-            } else if ((want << CH_SHIFT) >= (1ull << 31)) {
+            } else if ((want << CH_SHIFT) >= pool_slot_limit(db)) {
                 if (db->n_slices >= (1u << 16)) {
-                    db->fallback_reason = "more than 2^31 block records in a 65536th of the patterns (" + std::to_string(db->n_states) + " streams, " + std::to_string(db->pool_cap) + " chunks were not enough)";
+                    db->fallback_reason = "more block records than a pool can index in a 65536th of the patterns (" + std::to_string(db->n_states) + " streams, " + std::to_string(db->pool_cap) + " chunks were not enough)";
                     return 0;
                 }
                 db->n_slices *= 2;
@@ -2759,6 +2766,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
 
 }  // namespace
 
+// an attempt that fails half way may have work under way on the side streams: nothing of it may outlive the call (the caller frees M)
+static void blocks_join_side_streams(kmdb_db* db) {
+    if (db->stream2) (void)hipStreamSynchronize(db->stream2);
+    if (db->stream3) (void)hipStreamSynchronize(db->stream3);
+}
+
 int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, hipStream_t st) {
     const uint64_t cells = db->N * (db->N - 1) / 2;
     for (int round = 0; round < 64; ++round) {
@@ -2767,18 +2780,29 @@ int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi
         const uint32_t S = std::max<uint32_t>(1u, db->n_slices);
         bool again = false;
         uint64_t records = 0;
+        // the launch sizes a call measures belong to one emit range: kept per slice, so that a sliced database reaches the warm path too
+        if (db->slice_counts.size() != S) db->slice_counts.assign(S, kmdb_db::SliceCounts{});
+        bool decoded = false;
+        db->last_call_sized = false;
         for (uint32_t k = 0; k < S && !again; ++k) {
             const uint32_t lo = emit_lo + (uint32_t)((uint64_t)(emit_hi - emit_lo) * k / S), hi = emit_lo + (uint32_t)((uint64_t)(emit_hi - emit_lo) * (k + 1) / S);
             if (lo == hi) continue;
-            if (db->last_emit_lo != lo || db->last_emit_hi != hi) db->have_counts = false;   // launch sizes belong to one emit range
+            kmdb_db::SliceCounts& sc = db->slice_counts[k];
+            db->have_counts = sc.valid && sc.lo == lo && sc.hi == hi;
+            if (db->have_counts) { db->last_n_wide = sc.n_wide; db->last_n_chunks = sc.n_chunks; db->last_n_raw = sc.n_raw; db->last_n_rowjobs = sc.n_rowjobs; db->last_n_sorted = sc.n_sorted; }
             db->last_emit_lo = lo; db->last_emit_hi = hi;
+            if (!db->have_counts) db->last_call_sized = true;
             bool retry = false;
-            if (blocks_attempt(db, M, lo, hi, st, &retry)) return 1;
+            if (blocks_attempt(db, M, lo, hi, !decoded, st, &retry)) { blocks_join_side_streams(db); return 1; }
+            decoded = true;
             if (!db->fallback_reason.empty()) return 0;
-            if (retry) again = true;
-            else { db->have_counts = true; records += db->last_records; }
+            if (retry) { again = true; for (auto& c : db->slice_counts) c.valid = false; }
+            else {
+                sc = kmdb_db::SliceCounts{true, lo, hi, db->last_n_wide, db->last_n_chunks, db->last_n_raw, db->last_n_rowjobs, db->last_n_sorted};
+                records += db->last_records;
+            }
         }
-        if (!again) { db->last_records = records; return 0; }
+        if (!again) { db->last_records = records; db->have_counts = true; return 0; }
         HIP_TRY(hipMemsetAsync(M, 0, cells * 4, st));
     }
     return kmdb_set_error("kmdb_blocks_run: the record pools did not converge");

@@ -25,6 +25,7 @@
 #include "prim.h"
 
 #include <algorithm>
+#include <cstring>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -130,14 +131,15 @@ __device__ __forceinline__ void d2_list_bits(const D2Db& db, uint32_t node, unsi
 // (done[] holds round + 1; a parent filled in this very round reads as either 0 or round + 1, both mean "not yet").
 constexpr uint32_t D2_SETS_MAX_NB = 64;                       // parts of up to 4096 samples
 constexpr uint64_t D2_SETS_MAX_BYTES = 8ull << 30;
-__global__ __launch_bounds__(256) void d2_sets_round_kernel(D2Db db, uint32_t P, uint32_t nb, uint32_t round, uint32_t* __restrict__ done,
-                                                            unsigned long long* __restrict__ sets, uint32_t* __restrict__ n_done) {
+// (done is read and written by different threads of one launch: no __restrict__, relaxed atomic loads)
+__global__ __launch_bounds__(256) void d2_sets_round_kernel(D2Db db, uint32_t P, uint32_t nb, uint32_t round, uint32_t* done,
+                                                            unsigned long long* sets, uint32_t* __restrict__ n_done) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool fill = i < P && done[i] == 0;
+    bool fill = i < P && __atomic_load_n(&done[i], __ATOMIC_RELAXED) == 0;
     int32_t par = -1;
     if (fill) {
         par = db.parent[i];
-        if (par >= 0) { const uint32_t dr = done[par]; fill = dr != 0 && dr != round + 1u; }
+        if (par >= 0) { const uint32_t dr = __atomic_load_n(&done[par], __ATOMIC_RELAXED); fill = dr != 0 && dr != round + 1u; }
     }
     if (fill) {
         unsigned long long* s = sets + (size_t)i * nb;
@@ -281,8 +283,9 @@ D2Db view_of(const kmdb_engine_view& e) {
     return D2Db{e.n_buckets, e.bucket_offset, e.slots, e.pid2dfs, e.meta, e.bitpos, e.parent, e.bits};
 }
 
-// the handle's list store (nullptr: this part does without one)
-const unsigned long long* d2_list_store(const kmdb_engine_view& e, hipStream_t st) {
+// the handle's list store (nullptr: this part does without one).  reserve: bytes the call still has to allocate after it (record pool,
+// sort): a store that would leave less than that — or take more than a third of what is free — is not made (the part's pairs then climb)
+const unsigned long long* d2_list_store(const kmdb_engine_view& e, hipStream_t st, uint64_t reserve) {
     if (*e.list_sets) return *e.list_sets;
     if (*e.list_sets_tried || !e.P) return nullptr;
     *e.list_sets_tried = true;
@@ -290,6 +293,14 @@ const unsigned long long* d2_list_store(const kmdb_engine_view& e, hipStream_t s
     const uint32_t nb = (uint32_t)((e.N + 63) / 64);
     const uint64_t bytes = e.P * nb * 8;
     if (nb > D2_SETS_MAX_NB || bytes > D2_SETS_MAX_BYTES || e.P >= (1ull << 31)) return nullptr;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (bytes + (e.P + 1) * 4 + reserve > free_b || bytes > free_b / 3) {
+            if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] db2db: no list store (%.2f GB wanted, %.2f GB free, %.2f GB kept for the call)\n", bytes / 1e9, free_b / 1e9, reserve / 1e9);
+            return nullptr;
+        }
+    }
     unsigned long long* sets = nullptr;
     uint32_t* done = nullptr;
     if (hipMalloc((void**)&sets, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -320,8 +331,35 @@ const unsigned long long* d2_list_store(const kmdb_engine_view& e, hipStream_t s
             return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmdb_opts* opts, bool allow_store);
+
 extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmdb_opts* opts) {
     if (!db_row || !db_col || !out) return kmdb_set_error("kmdb_db2db_dense: null argument");
+    int rc = db2db_impl(db_row, db_col, out, opts, true);
+    if (rc && std::strstr(kmdb_last_error(), hipGetErrorString(hipErrorOutOfMemory))) {
+        // out of HBM inside the call: the handles' list stores (up to 8 GB each) are the part that can go — the pairs' lists are then built
+        // by climbing, as on handles that never had a store — and the call is tried once more
+        kmdb_engine_view er, ec;
+        if (kmdb_engine_get(db_row, &er) || kmdb_engine_get(db_col, &ec)) return 1;
+        bool freed = false;
+        for (kmdb_engine_view* e : {&er, &ec})
+            if (*e->list_sets) {
+                (void)hipSetDevice(e->device);
+                (void)hipFree(*e->list_sets);
+                *e->device_bytes -= (uint64_t)e->P * *e->list_sets_nb * 8;
+                *e->list_sets = nullptr; *e->list_sets_nb = 0; *e->list_sets_tried = true;
+                freed = true;
+            }
+        (void)hipGetLastError();
+        if (freed) {
+            if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] db2db: out of device memory; list stores dropped, the call is repeated on the climbing path\n");
+            rc = db2db_impl(db_row, db_col, out, opts, false);
+        }
+    }
+    return rc;
+}
+
+static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmdb_opts* opts, bool allow_store) {
     kmdb_engine_view er, ec;
     if (kmdb_engine_get(db_row, &er)) return 1;
     if (kmdb_engine_get(db_col, &ec)) return 1;
@@ -386,8 +424,10 @@ extern "C" int kmdb_db2db_dense(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out,
             const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nruns + 3) / 4, 256 * 8);
             const size_t lds = (size_t)4 * 2 * (nbr + nbc) * 8;
             // both parts' list stores, or neither (a wave that climbs one side's root paths gains nothing from the other's store)
-            const unsigned long long* rsets = d2_list_store(er, st);
-            const unsigned long long* csets = rsets ? (db_col == db_row ? rsets : d2_list_store(ec, st)) : nullptr;
+            // (what the call allocates after the stores: six records of 20 bytes per pair, twice — the pool and the sort's copy — and slack)
+            const uint64_t reserve = (uint64_t)nruns * 6 * 20 * 2 + (1ull << 30);
+            const unsigned long long* rsets = allow_store ? d2_list_store(er, st, reserve) : nullptr;
+            const unsigned long long* csets = rsets ? (db_col == db_row ? rsets : d2_list_store(ec, st, reserve)) : nullptr;
             const bool store = rsets && csets;
             phase("list stores");
             DevBuf d_nrec, d_cursor;

@@ -238,8 +238,10 @@ int kmdb_engine_get(kmdb_db* db, kmdb_engine_view* o) {
 void kmdb_engine_set_times(kmdb_db* db, double kernel_ms, double dominant_ms) {
     kmdb_release_staging(db);                                   // (end of a new2all / db2db call)
     db->stats.kernel_ms = kernel_ms;
-    db->stats.dominant_kernel_ms = dominant_ms;
+    (void)dominant_ms;
 }
+
+extern "C" const char* kmdb_db_fallback_reason(const kmdb_db* db) { return db ? db->fallback_reason.c_str() : ""; }
 
 extern "C" int kmdb_db_stats(const kmdb_db* db, kmdb_stats* out) {
     if (!db || !out) return kmdb_set_error("kmdb_db_stats: null argument");
@@ -278,8 +280,8 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
     if (!forced_v1 && db->fallback_reason.empty()) {
         // block-record pipeline (flat form: on-disk weights, no subtree sums needed)
         HIP_TRY(hipEventRecord(db->ev[1], st));
-        const bool sized = !db->have_counts;
         if (kmdb_blocks_run(db, M, lo, hi, st)) return 1;
+        const bool sized = db->last_call_sized;
         if (db->fallback_reason.empty()) {
             HIP_TRY(hipEventRecord(db->ev[2], st));
             db->stats.path = KMDB_PATH_RECORDS;
@@ -318,11 +320,9 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
 int finish_stats(kmdb_db* db, hipStream_t st) {
     HIP_TRY(hipEventRecord(db->ev[3], st));
     HIP_TRY(hipEventSynchronize(db->ev[3]));
-    float a = 0, b = 0;
+    float a = 0;
     HIP_TRY(hipEventElapsedTime(&a, db->ev[0], db->ev[3]));
-    HIP_TRY(hipEventElapsedTime(&b, db->ev[1], db->ev[2]));
     db->stats.kernel_ms = a;
-    db->stats.dominant_kernel_ms = b;
     if (db->stats.path == KMDB_PATH_RECORDS) {
         float k0 = 0, k1n = 0, k1g = 0, k2 = 0;
         HIP_TRY(hipEventElapsedTime(&k0, db->ev[1], db->ev_k[0]));
@@ -330,7 +330,6 @@ int finish_stats(kmdb_db* db, hipStream_t st) {
         HIP_TRY(hipEventElapsedTime(&k1g, db->ev_k[1], db->ev_k[2]));
         HIP_TRY(hipEventElapsedTime(&k2, db->ev_k[2], db->ev_k[3]));
         db->stats.k0_ms = k0; db->stats.k1n_ms = k1n; db->stats.k1g_ms = k1g; db->stats.k1_ms = k1n + k1g; db->stats.k2_ms = k2;
-        db->stats.dominant_kernel_ms = std::max(std::max(k0, k1n), std::max(k1g, k2));
         db->stats.n_records = db->last_records; db->stats.n_wide = db->last_n_wide; db->stats.n_chunks = db->last_n_chunks;
         db->stats.n_slow_wide = db->last_n_slow;
     } else if (db->v1_counters && db->stats.path != KMDB_PATH_NONE) {

@@ -137,10 +137,13 @@ struct kmdb_db {
     uint64_t est_records = 0;       // sampled estimate for the chosen width
     // what the previous call found (the pipeline is deterministic per database: grid sizes of the next call)
     bool have_counts = false;
+    bool last_call_sized = false;   // the last call measured launch sizes (first call on a handle / a new emit range: extra host syncs)
     uint32_t last_n_wide = 0, last_n_chunks = 0, last_n_raw = 0, last_n_slow = 0;
     uint64_t last_records = 0;
     uint32_t last_emit_lo = 0, last_emit_hi = 0;
     uint32_t n_slices = 1;          // passes over the pattern stream per call (a database whose records do not fit one)
+    struct SliceCounts { bool valid = false; uint32_t lo = 0, hi = 0, n_wide = 0, n_chunks = 0, n_raw = 0, n_rowjobs = 0, n_sorted = 0; };
+    std::vector<SliceCounts> slice_counts;   // what the previous call found, per slice of the pattern stream
     void* scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     // ---- v1 kernels (A/B reference, fallback) and new2all: built lazily on the device from the arrays above

@@ -14,8 +14,26 @@
 
 namespace {
 
-// decimal digits of v, returns length (no terminator)
+// "00" "01" ... "99"
+struct Pairs {
+    char d[200];
+    constexpr Pairs() : d() { for (int i = 0; i < 100; ++i) { d[2 * i] = (char)('0' + i / 10); d[2 * i + 1] = (char)('0' + i % 10); } }
+};
+constexpr Pairs PAIRS{};
+
+// decimal digits of v, returns length (no terminator): the number of digits first, then two digits per division from the right
+// (the cells of a 10 000-sample table are fifty million numbers)
 inline size_t put_u64(uint64_t v, char* out) {
+    if (v < 10) { out[0] = (char)('0' + v); return 1; }
+    if (v <= 0xFFFFFFFFull) {
+        uint32_t x = (uint32_t)v;
+        const size_t n = x < 100u ? 2 : x < 1000u ? 3 : x < 10000u ? 4 : x < 100000u ? 5 : x < 1000000u ? 6 : x < 10000000u ? 7 : x < 100000000u ? 8 : x < 1000000000u ? 9 : 10;
+        char* p = out + n;
+        while (x >= 100u) { const uint32_t q = x / 100u, r = x - q * 100u; p -= 2; p[0] = PAIRS.d[2 * r]; p[1] = PAIRS.d[2 * r + 1]; x = q; }
+        if (x >= 10u) { p -= 2; p[0] = PAIRS.d[2 * x]; p[1] = PAIRS.d[2 * x + 1]; }
+        else *--p = (char)('0' + x);
+        return n;
+    }
     char tmp[24];
     size_t n = 0;
     do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);

@@ -212,11 +212,13 @@ __global__ void lay_keep_init_kernel(const uint32_t* __restrict__ w, uint32_t P,
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P) keep[i] = w[i] != 0u ? 1u : 0u;
 }
-__global__ void lay_keep_up_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* __restrict__ keep, uint32_t* __restrict__ changed) {
+// (keep is read and written by different threads of one launch: no __restrict__, relaxed atomic accesses — a flag seen too late only
+// costs another round)
+__global__ void lay_keep_up_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* keep, uint32_t* __restrict__ changed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P || !keep[i]) return;
+    if (i >= P || !__atomic_load_n(&keep[i], __ATOMIC_RELAXED)) return;
     const int32_t par = parent[i];
-    if (par >= 0 && !keep[par]) { keep[par] = 1u; *changed = 1u; }
+    if (par >= 0 && !__atomic_load_n(&keep[par], __ATOMIC_RELAXED)) { __atomic_store_n(&keep[par], 1u, __ATOMIC_RELAXED); *changed = 1u; }
 }
 __global__ void lay_compact_kernel(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ newidx, const int32_t* __restrict__ parent,
                                    const uint32_t* __restrict__ ll, const uint32_t* __restrict__ n, const uint32_t* __restrict__ nbits, const uint32_t* __restrict__ w,
@@ -398,15 +400,19 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         DevTmp<uint64_t> spos;
         if (keep.alloc(P + 1) || newidx.alloc(P + 1) || flag.alloc(1) || spos.alloc(P + 1)) return 1;
         hipLaunchKernelGGL(lay_keep_init_kernel, dim3(G), dim3(B), 0, st, d_w.p, (uint32_t)P, keep.p);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(keep.p + P, 0, 4, st));
-        for (int round = 0; round < 1 << 16; round += 8) {
+        // a flag climbs at least one parent link per launch: a path of d nodes is done after d launches (the depth is not known yet here,
+        // P bounds it); the loop ends when a group of launches changed nothing — and the upload fails if it never does
+        uint32_t changed = 1;
+        for (uint64_t round = 0; changed && round <= P + 8; round += 8) {
             HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
             for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(lay_keep_up_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, keep.p, flag.p);
-            uint32_t changed = 0;
+            HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&changed, flag.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (!changed) break;
         }
+        if (changed) return kmdb_set_error("kmdb_db_upload_shard: the keep flags of the shard's tree did not settle (parent links form a cycle?)");
         size_t tb = 0, tb2 = 0;
         rocprim::transform_iterator<uint32_t*, U32toU64, uint64_t> it_nb(d_nbits.p, U32toU64());
         HIP_TRY(prim::exclusive_sum(nullptr, tb, keep.p, newidx.p, (int)(P + 1), st));

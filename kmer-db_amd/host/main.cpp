@@ -115,15 +115,39 @@ void check(int rc) {
 struct Db {
     kmdbh_db* h = nullptr;
     kmdb_db* d = nullptr;
-    ~Db() { if (d) kmdb_db_free(d); if (h) kmdbh_db_free(h); }
+    kmdb_node* node = nullptr;               // -gpus N: the database prefix-sharded over the devices of the node
+    ~Db() { if (node) kmdb_node_free(node); if (d) kmdb_db_free(d); if (h) kmdbh_db_free(h); }
 };
 
 struct Common {
     int threads = 0;
     int device = 0;
+    int gpus = 0;                            // -gpus N: N prefix-bucket shards over the node's devices (0: one device, no sharding)
     bool sparse = false;
     Filters filters;
 };
+
+// -gpus N (all2all, all2all-sp): the database is read WITH its hashtables (the shard weights come from the items' prefix buckets),
+// shard s of N goes to device s % D of the D devices the node has (from -gpu on), and the partial matrices meet in one RCCL
+// reduce-scatter (kmdb_node_*).  On a node with fewer devices than shards the shards of a device run one after the other.
+void node_upload(Db& db, const std::string& path, const Common& c) {
+    check(kmdbh_db_load(path.c_str(), c.gpus > 1 ? 0 : 2, &db.h));
+    const int have = kmdb_device_count();
+    if (have <= c.device) throw std::runtime_error("no usable GPU (device " + std::to_string(c.device) + ")");
+    std::vector<int32_t> devs;
+    for (int d = c.device; d < have && (int)devs.size() < c.gpus; ++d) devs.push_back(d);
+    check(kmdb_node_upload(kmdbh_db_view(db.h), (uint32_t)c.gpus, devs.data(), (uint32_t)devs.size(), &db.node));
+    kmdb_node_stats st{};
+    check(kmdb_node_stats_get(db.node, &st));
+    std::cerr << "Database sharded by k-mer prefix bucket: " << st.n_shards << " shards on " << st.n_devices << " GPU(s)" << std::endl;
+}
+void node_report(const Db& db) {
+    kmdb_node_stats st{};
+    if (kmdb_node_stats_get(db.node, &st)) return;
+    std::cerr << "  per device: compute " << st.call_ms << " ms, RCCL reduce-scatter " << st.collective_ms << " ms";
+    if (st.rccl_version) std::cerr << " (RCCL " << st.rccl_version << ")";
+    std::cerr << ", result to host " << st.d2h_ms << " ms" << std::endl;
+}
 
 void write_header(const Db& db, std::ofstream& ofs) {
     uint64_t n = kmdbh_db_n_samples(db.h);
@@ -145,37 +169,74 @@ int run_all2all(std::vector<std::string>& args, Common& c) {
     Db db;
     std::cerr << "Loading k-mer database " << args[0] << "..." << std::endl;
     std::ofstream ofs(args[1]);
-    check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
     kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1;
-    check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
+    if (c.gpus > 0) node_upload(db, args[0], c);
+    else {
+        check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
+        check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
+    }
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const int k = (int)kmdbh_db_kmer_length(db.h);
     std::cerr << "Calculating matrix of common k-mers..." << std::endl;
     auto t0 = clk::now();
     std::vector<uint32_t> m(n ? n * (n - 1) / 2 + 1 : 1);
-    check(kmdb_all2all_dense(db.d, m.data(), &o));
+    if (db.node) { check(kmdb_node_all2all_dense(db.node, m.data(), nullptr)); node_report(db); }
+    else {
+        check(kmdb_all2all_dense(db.d, m.data(), &o));
+        kmdb_stats st{};
+        if (!kmdb_db_stats(db.d, &st) && st.path == KMDB_PATH_GLOBAL)
+            std::cerr << "WARNING: the fast pipeline could not take this database (" << kmdb_db_fallback_reason(db.d) << "); the slow HBM-atomics kernel ran" << std::endl;
+    }
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
     std::cerr << "Storing matrix of common k-mers in " << args[1] << "...";
     t0 = clk::now();
     write_header(db, ofs);
-    std::vector<char> row(10000 + n * 100);
-    std::vector<uint32_t> cols, vals;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint32_t* r = m.data() + i * (i - 1) / 2;
-        const char* name = kmdbh_db_sample_name(db.h, i);
-        if (row.size() < 10000 + n * 100 + std::strlen(name)) row.resize(10000 + n * 100 + std::strlen(name));
-        size_t len;
-        if (c.sparse) {
-            cols.clear(); vals.clear();
-            for (uint64_t j = 0; j < i; ++j)     // LowerTriangularMatrix::compact + saveRowSparse (array.h:169-181,259-262)
-                if (r[j] && c.filters.pass(r[j], (uint32_t)kmdbh_db_sample_kmers(db.h, i), (uint32_t)kmdbh_db_sample_kmers(db.h, j), k)) {
-                    cols.push_back((uint32_t)j); vals.push_back(r[j]);
+    // rows formatted by a pool of threads, a stripe of rows at a time (about 32 M cells: the text of a 10 000-sample table is 300 MB), and
+    // written in order (console_all2all.cpp:53-75 formats and writes row by row on one thread)
+    const int nthr = (int)std::max<size_t>(1, std::min<size_t>(c.threads > 0 ? (size_t)c.threads : 16, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 1));
+    size_t name_max = 0;
+    for (uint64_t i = 0; i < n; ++i) name_max = std::max(name_max, std::strlen(kmdbh_db_sample_name(db.h, i)));
+    for (uint64_t i0 = 0; i0 < n;) {
+        uint64_t i1 = i0, cells_in = 0;
+        while (i1 < n && (i1 == i0 || cells_in + i1 <= (32u << 20))) { cells_in += i1; ++i1; }
+        std::vector<std::vector<char>> text(nthr);
+        std::atomic<int> failed{0};
+        auto work = [&](int t) {
+            // thread t: the rows [a, b) of the stripe holding its share of the cells
+            auto cut = [&](int q) -> uint64_t {
+                const double lo = (double)i0 * (double)i0, hi = (double)i1 * (double)i1;
+                uint64_t r = (uint64_t)std::sqrt(lo + (hi - lo) * q / nthr);
+                return std::min<uint64_t>(i1, std::max<uint64_t>(i0, r));
+            };
+            const uint64_t a = t == 0 ? i0 : cut(t), b = t + 1 == nthr ? i1 : cut(t + 1);
+            std::vector<char>& out = text[t];
+            std::vector<uint32_t> cols, vals;
+            size_t used = 0;
+            for (uint64_t i = a; i < b; ++i) {
+                const uint32_t* r = m.data() + i * (i - 1) / 2;
+                const char* name = kmdbh_db_sample_name(db.h, i);
+                const size_t need = 64 + name_max + i * (c.sparse ? 22 : 11);
+                if (out.size() < used + need) out.resize(std::max(out.size() * 2, used + need));
+                if (c.sparse) {
+                    cols.clear(); vals.clear();
+                    for (uint64_t j = 0; j < i; ++j)     // LowerTriangularMatrix::compact + saveRowSparse (array.h:169-181,259-262)
+                        if (r[j] && c.filters.pass(r[j], (uint32_t)kmdbh_db_sample_kmers(db.h, i), (uint32_t)kmdbh_db_sample_kmers(db.h, j), k)) {
+                            cols.push_back((uint32_t)j); vals.push_back(r[j]);
+                        }
+                    used += kmdbh_format_sparse_row(name, kmdbh_db_sample_kmers(db.h, i), cols.data(), vals.data(), cols.size(), out.data() + used);
+                } else {
+                    used += kmdbh_format_dense_row(name, kmdbh_db_sample_kmers(db.h, i), r, i, out.data() + used);
                 }
-            len = kmdbh_format_sparse_row(name, kmdbh_db_sample_kmers(db.h, i), cols.data(), vals.data(), cols.size(), row.data());
-        } else {
-            len = kmdbh_format_dense_row(name, kmdbh_db_sample_kmers(db.h, i), r, i, row.data());
-        }
-        ofs.write(row.data(), (std::streamsize)len);
+            }
+            out.resize(used);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthr; ++t) pool.emplace_back([&, t]() { try { work(t); } catch (...) { failed = 1; } });
+        work(0);
+        for (auto& th : pool) th.join();
+        if (failed) throw std::runtime_error("out of memory while formatting the table");
+        for (auto& tx : text) ofs.write(tx.data(), (std::streamsize)tx.size());
+        i0 = i1;
     }
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
     return 0;
@@ -195,9 +256,12 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     Db db;
     std::cerr << "Loading k-mer database " << args[0] << "..." << std::endl;
     std::ofstream ofs(args[1], std::ios::binary);
-    check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
     kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1; o.bubble_size = bubble;
-    check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
+    if (c.gpus > 0) node_upload(db, args[0], c);
+    else {
+        check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
+        check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
+    }
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const int k = (int)kmdbh_db_kmer_length(db.h);
     std::cerr << "Calculating matrix of common k-mers...";
@@ -211,7 +275,9 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
             fl.push_back(kmdb_cell_filter{KMDB_METRIC_NUM_KMERS, 0, (double)c.filters.kmer_lo, (double)c.filters.kmer_hi});
         std::vector<uint32_t> counts(n);
         for (uint64_t i = 0; i < n; ++i) counts[i] = (uint32_t)kmdbh_db_sample_kmers(db.h, i);
-        if (fl.empty() || fl.size() > 8) check(kmdb_all2all_sparse(db.d, &sp, &o));
+        if (fl.size() > 8) fl.clear();                          // (the host-side pass below applies every bound anyway)
+        if (db.node) { check(kmdb_node_all2all_sparse(db.node, fl.data(), fl.size(), counts.data(), -1, &sp, nullptr)); node_report(db); }
+        else if (fl.empty()) check(kmdb_all2all_sparse(db.d, &sp, &o));
         else check(kmdb_all2all_sparse_filtered(db.d, fl.data(), fl.size(), counts.data(), -1, &sp, &o));
     }
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
@@ -785,7 +851,9 @@ void usage() {
                  "    kmer-db-amd one2all <database> <sample> <similarity_vector>\n"
                  "    kmer-db-amd all2all-parts [-min ...] [-max ...] <db_list> <common_table>\n"
                  "    kmer-db-amd distance [-sparse] [-phylip-out] [-min [<criterion>:]<v>]* [-max [<criterion>:]<v>]* <measure> <common_table> <output>\n"
-                 "Common options: -t <threads>, -gpu <device>\n";
+                 "Common options: -t <threads>, -gpu <device>\n"
+                 "all2all / all2all-sp: -gpus <N>  the k-mer space in N prefix-bucket shards over the node's GPUs (from -gpu on), partial matrices\n"
+                 "                                  summed by one RCCL reduce-scatter; more shards than devices: a device runs its shards in turn\n";
 }
 
 }  // namespace
@@ -801,6 +869,11 @@ int main(int argc, char** argv) {
         if (take_option(args, "-t", v)) c.threads = std::atoi(v.c_str());
         take_option(args, "-rt", v);
         if (take_option(args, "-gpu", v)) c.device = std::atoi(v.c_str());
+        if (take_option(args, "-gpus", v)) {
+            c.gpus = std::atoi(v.c_str());
+            if (c.gpus < 1 || c.gpus > 4096) throw std::runtime_error("-gpus expects a number of prefix-bucket shards (1 or more)");
+            if (mode != "all2all" && mode != "all2all-sp") throw std::runtime_error("-gpus applies to all2all and all2all-sp");
+        }
         take_switch(args, "-v");
         take_switch(args, "-vv");
         if (mode == "all2all") return run_all2all(args, c);

@@ -334,6 +334,14 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
     _cli("all2all-sp", g("virus_k18.db"), t("k18.sp.csv")); _same(t("k18.sp.csv"), g("virus.k18.sparse.csv"))
     _cli("all2all", "-t", "2", g("virus_k18_f01.db"), t("frac.csv")); _same(t("frac.csv"), g("virus.k18.frac.csv"))
     _cli("all2all", g("virus_k24.db"), t("k24.csv")); _same(t("k24.csv"), g("virus.k24.csv"))
+    # the same through the multi-GPU driver of the front-end (kmdb_node_*): N prefix-bucket shards over the devices of the box — on a one-GPU
+    # box the shards of the device run one after the other and are summed on the device; with more devices RCCL reduce-scatters
+    r = _cli("all2all", "-gpus", "2", g("virus_k18_parts.db"), t("k18.g2.csv")); _same(t("k18.g2.csv"), g("virus.k18.csv"))
+    assert "2 shards on" in r.stderr
+    _cli("all2all", "-sparse", "-gpus", "5", g("virus_k18_parts.db"), t("k18.g5.sparse.csv")); _same(t("k18.g5.sparse.csv"), g("virus.k18.sparse.csv"))
+    _cli("all2all-sp", "-gpus", "3", g("virus_k18.db"), t("k18.sp.g3.csv")); _same(t("k18.sp.g3.csv"), g("virus.k18.sparse.csv"))
+    _cli("all2all", "-gpus", "1", g("virus_k24.db"), t("k24.g1.csv")); _same(t("k24.g1.csv"), g("virus.k24.csv"))
+    _cli("all2all-sp", "-gpus", "4", "-max", "39", "-min", "num-kmers:31", g("synth_k21.db"), t("a2a-sp-mm.g4")); _same(t("a2a-sp-mm.g4"), g("synth.a2a.sparse.above-below"))
     # self-hosted.yml:110-146 (synth, with min/max filters)
     _cli("all2all", g("synth_k21.db"), t("a2a")); _same(t("a2a"), g("synth.a2a"))
     _cli("all2all", "-sparse", g("synth_k21.db"), t("a2a-sparse")); _same(t("a2a-sparse"), g("synth.a2a-sparse"))
@@ -451,6 +459,38 @@ def test_upload_shards_of_a_real_db_sum_to_full_matrix(K, golden_dir, dev, stem,
     assert sum(kept) < shards * d.P                               # the front half of the pipeline is sharded too, not only the weights
     with pytest.raises(K.KmdbError, match="no hashtables"):
         K.DeviceDB(K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True), device=dev, prefix_shard=(0, 2))
+
+
+@pytest.mark.parametrize("stem,shards", [("virus_k18", 3), ("clade64", 8), ("clade64_k25_f01", 2)])
+def test_node_driver_over_the_devices_of_the_box(K, golden_dir, dev, stem, shards):
+    """kmdb_node_* (the C++ multi-GPU driver behind `kmer-db-amd all2all -gpus N`): shards over every device the box has (one here: the shards
+    run in turn and are summed on the device; more: one RCCL reduce-scatter), dense matrix == the reference's, sparse rows (with bounds and a
+    measure on the complete sums) == the single-device filtered call."""
+    h = K.HostDB(os.path.join(golden_dir, stem + ".db"))
+    ref = np.fromfile(os.path.join(golden_dir, stem + ".a2a.ref.u32"), dtype=np.uint32)
+    devices = list(range(K.device_count()))
+    nd = K.NodeDB(h, shards, devices)
+    assert np.array_equal(nd.all2all_dense(), ref)
+    st = nd.stats()
+    assert st["n_shards"] == shards and st["n_devices"] == min(shards, len(devices)) and st["call_ms"] > 0
+    assert (st["rccl_version"] > 0) == (st["n_devices"] > 1)
+    assert np.array_equal(nd.all2all_dense(), ref)                    # warm call
+    cnt = h.sample_kmers.astype(np.uint32)
+    d1 = K.DeviceDB(h, device=dev)
+    a = d1.all2all_sparse()
+    b = nd.all2all_sparse()
+    assert a.nnz == b.nnz and np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.col, b.col) and np.array_equal(a.val, b.val)
+    flt = [("jaccard", 0.02, None), ("num-kmers", None, 5000.0)]
+    a = d1.all2all_sparse_filtered(flt, cnt, measure="mash")
+    b = nd.all2all_sparse(flt, cnt, measure="mash")
+    assert a.nnz == b.nnz and np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.col, b.col) and np.array_equal(a.val, b.val)
+    assert np.array_equal(a.measure, b.measure, equal_nan=True)
+    nd.close()
+    d1.close()
+    with pytest.raises(K.KmdbError, match="need the hashtables"):
+        K.NodeDB(K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True), 2, devices)
+    with pytest.raises(K.KmdbError, match="listed twice"):
+        K.NodeDB(h, 2, [0, 0])
 
 
 @pytest.mark.parametrize("stem,shards", [("clade64_k25_f01", 2), ("virus_k18", 3), ("clade64", 8)])
@@ -808,8 +848,8 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
         assert "full" in d["cpu_baseline"]["sample"]           # the reference timed on the whole database of the timed workload
     # `--gpus 2` with NO launcher: bench.py starts its own two ranks (weak scaling: per-rank databases)
     for scaling, collective in (("weak", "reduce"), ("strong", "reduce"), ("strong", "reduce_scatter")):
-        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling, "--collective", collective,
-                             "--length", "30000" if scaling == "weak" else "60000", "--steps", "2", "--warmup", "1"],
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "c2", "--scaling", scaling,
+                             "--collective", collective, "--length", "30000" if scaling == "weak" else "60000", "--steps", "2", "--warmup", "1"],
                             capture_output=True, text=True, env=env, timeout=900)
         assert r2.returncode == 0, r2.stderr[-3000:]
         lines = [ln for ln in r2.stdout.splitlines() if ln.strip().startswith("{")]
@@ -819,6 +859,15 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
         assert d2["config"]["path"] == "block-record pipeline"
         # all runs cover a 60 kbp genome set of the same model: two prefix shards do the same total work
         assert abs(d2["value"] * d2["ms_per_step"] - d["value"] * d["ms_per_step"]) / (d["value"] * d["ms_per_step"]) < 1e-9
+        pr = d2["config"]["per_rank"]
+        assert d2["config"]["n_ranks_seen"] == 2 and len(pr["call_ms"]) == 2 and len(pr["collective_ms"]) == 2 and min(pr["call_ms"]) > 0
+    # with more than one GPU and no --workload the job is BASELINE configs[2]'s: 10 000 samples, weak scaling (here at a toy genome length)
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--length", "2000", "--steps", "1", "--warmup", "1"],
+                        capture_output=True, text=True, env=env, timeout=900)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    d3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d3["n_gpus"] == 2 and d3["scaling"] == "weak" and d3["config"]["samples"] == 10000 and d3["config"]["workload"].startswith("c3gpu: 10000 synthetic")
+    assert d3["config"]["genome_length_bp"] == 4000 and d3["config"]["n_ranks_seen"] == 2
 
 
 @pytest.mark.parametrize("mode", ["all2all-sp", "new2all", "db2db"])
