@@ -86,6 +86,7 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
+    uint32_t nostore;              // timing experiment (KMDB_K1W_DEBUG=1): the wide kernel's records are placed but not written
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
@@ -223,7 +224,7 @@ __device__ __forceinline__ void wide_emit(WaveArena& A, const PoolView& pv, bool
         const unsigned long long grp = __ballot(on);
         if (!grp) break;
         const Resv r = arena_reserve_wide(A, pv, (uint32_t)__popcll(grp), lane);
-        if (on) {
+        if (on && !pv.nostore) {
             const uint32_t slot = resv_slot(r, (uint32_t)__popcll(grp & lt_mask));
             pv.wrec[slot] = WideRec{rows, cols};
             pv.wkey[slot] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
@@ -295,7 +296,7 @@ __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const
             ovf = ovf && !mine;
             pend = __ballot(ovf);
         }
-        if (on) {
+        if (on && !pv.nostore) {
             ((WideRec*)pv.rec)[p] = WideRec{rows, cols};
             pv.recw[p] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
         }
@@ -804,6 +805,7 @@ struct WParams {
     uint32_t chain_cap, arena_cap, e_cap;
     uint32_t n_rows;               // row mode: block rows (0 otherwise)
     uint32_t emit_lo, emit_hi;
+    uint32_t debug;                // KMDB_K1W_DEBUG (timing experiments, results wrong): 1 = no record stores, 2 = no emission at all, 3 = no owner search
     PoolView pool;
 };
 constexpr int K1W_WAVES = 2;
@@ -898,6 +900,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     // record-parallel emission of the lanes in `on` (list of lane j: m entries from st_start[j]): a node with m blocks owns
     // m (m + 1) / 2 records (block pairs a >= b), one record per lane and step
     auto emit = [&](bool on, uint32_t m, uint32_t wv) {
+        if (q.debug == 2u) return;
         // a node with many blocks is taken by the whole wave: lane t builds pair t of the node
         {
             unsigned long long hb = __ballot(on && m >= K1W_HEAVY);
@@ -949,9 +952,18 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             unsigned long long FX = 0, FY = 0;
             if (t < T) {
                 uint32_t own = 0;                               // the first lane whose inclusive sum exceeds t
+                uint32_t r0;
+                if (q.debug == 3u) {                            // (timing experiment: no search — a record of the lane's own node, or none)
+                    own = lane;
+                    const uint32_t c0 = L.queue[own] - (own ? L.queue[own - 1u] : 0u);
+                    r0 = c0 ? t % c0 : 0u;
+                    if (!c0) own = 64u;
+                } else {
 #pragma unroll
-                for (uint32_t sft = 32; sft >= 1u; sft >>= 1) if (L.queue[own + sft - 1u] <= t) own += sft;
-                const uint32_t r0 = t - (own ? L.queue[own - 1u] : 0u);
+                    for (uint32_t sft = 32; sft >= 1u; sft >>= 1) if (L.queue[own + sft - 1u] <= t) own += sft;
+                    r0 = t - (own ? L.queue[own - 1u] : 0u);
+                }
+                if (own < 64u) {
                 uint32_t a = (uint32_t)((__fsqrt_rn(8.0f * (float)r0 + 1.0f) - 1.0f) * 0.5f);
                 while (tri32(a) > r0) --a;
                 while (tri32(a + 1u) <= r0) ++a;
@@ -964,6 +976,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 diag = a == b;
                 rec_on = !diag || __popcll(FX) >= 2;               // a diagonal record needs two ids to have a pair
                 stream = tri32(X) + Y;
+                }
             }
             // few streams: the step's records go to the wide pool in arrival order (one reservation for all lanes); many: to
             // the chunks of their block rows
@@ -1183,48 +1196,55 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
 // ------------------------------------------------------------------------------------------
 // K2: records -> matrix
 // ------------------------------------------------------------------------------------------
-// 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit
-__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, uint32_t lane) {
+// 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit.  Six butterfly stages; stage
+// 32 is one v_permlane32_swap over the two words.  Every stage below works on the 32-bit words separately: fetch the partner lane's
+// word (lane ^ s), rotate it by s towards this lane's side (v_alignbit_b32: right for the upper lane of a pair, left for the lower one)
+// and splice it in under a per-lane mask (v_bfi_b32) — three instructions per word and stage, with the rotate amounts and masks of
+// the five stages in ten registers that are computed once per run (TrConst).  The fetches of the stages 16 / 8 / 4 go over the LDS
+// crossbar (ds_swizzle_b32, swap mode: no LDS memory involved) — the apply kernels are bound by VALU issue, the LDS pipe has room —
+// and the stages 2 / 1 are DPP quad permutes.  29 VALU + 6 LDS-pipe instructions per transpose; round 3's version (v_permlane16_swap +
+// v_perm for stage 16, ds_bpermute shuffles and 64-bit mask arithmetic below) took 72 VALU.  profiles/r04_transpose_probe.hip checks both
+// against the definition and times them.
+struct TrConst { uint32_t amt[5], msk[5]; };
+__device__ __forceinline__ TrConst tr_const(uint32_t lane) {
+    TrConst c;
+    const uint32_t m[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t s = 16u >> k;
+        const bool up = (lane & s) != 0;
+        c.amt[k] = up ? s : 32u - s;          // the partner's word rotated right by s (upper lane of the pair) or left by s (lower lane)
+        c.msk[k] = up ? m[k] : ~m[k];         // the bits taken from the partner
+    }
+    return c;
+}
+constexpr int K2_TR_SWIZZLE = 1;              // 1: stages 16 / 8 / 4 fetch over the LDS crossbar (ds_swizzle); 0: ds_bpermute / DPP (A/B)
+__device__ __forceinline__ uint32_t tr_fetch(uint32_t v, int k) {
+    // the word of lane ^ (16 >> k)
+    if (k == 0) return K2_TR_SWIZZLE ? (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F) : (uint32_t)__shfl_xor((int)v, 16, WAVE);
+    if (k == 1) return K2_TR_SWIZZLE ? (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x201F) : (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    if (k == 2) {
+        if (K2_TR_SWIZZLE) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);
+        const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);      // row_shl:4 into the banks 0 and 2: lane i <- i + 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);        // row_shr:4 into the banks 1 and 3: lane i <- i - 4
+    }
+    if (k == 3) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);               // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, const TrConst& c) {
     uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    // stage 32: the upper half of the wave swaps its low words with the high words of the lower half — one
-    // v_permlane32_swap on gfx950
     {
         const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
         lo = r[0]; hi = r[1];
     }
-    // stage 16: 16-bit halves of every word between the lanes that differ in bit 4: v_permlane16_swap brings the
-    // partner's word, v_perm_b32 splices the halves
-    {
-        const bool up = (lane & 16u) != 0;
-        const uint32_t sel = up ? 0x03020706u : 0x05040100u;
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const uint32_t plo = up ? a[0] : a[1];
-        lo = __builtin_amdgcn_perm(plo, lo, sel);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        const uint32_t phi = up ? b[0] : b[1];
-        hi = __builtin_amdgcn_perm(phi, hi, sel);
-    }
-    x = ((unsigned long long)hi << 32) | lo;
-    const unsigned long long masks[4] = {0x00FF00FF00FF00FFull, 0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
-    int s = 8;
 #pragma unroll
-    for (int k = 0; k < 4; ++k, s >>= 1) {
-        const unsigned long long m = masks[k];
-        uint32_t plo, phi;
-        if (s == 2) {               // quad_perm [2,3,0,1]
-            plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0x4E, 0xF, 0xF, false);
-            phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0x4E, 0xF, 0xF, false);
-        } else if (s == 1) {        // quad_perm [1,0,3,2]
-            plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0xB1, 0xF, 0xF, false);
-            phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0xB1, 0xF, 0xF, false);
-        } else {
-            plo = (uint32_t)__shfl_xor((int)(uint32_t)x, s, WAVE);
-            phi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), s, WAVE);
-        }
-        const unsigned long long pv = ((unsigned long long)phi << 32) | plo;
-        x = (lane & (uint32_t)s) ? ((x & ~m) | ((pv >> s) & m)) : ((x & m) | ((pv & m) << s));
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t pl = tr_fetch(lo, k), ph = tr_fetch(hi, k);
+        const uint32_t rl = __builtin_amdgcn_alignbit(pl, pl, c.amt[k]), rh = __builtin_amdgcn_alignbit(ph, ph, c.amt[k]);
+        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(lo) : "v"(c.msk[k]), "v"(rl));      // (mask & partner) | (~mask & own)
+        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(hi) : "v"(c.msk[k]), "v"(rh));
     }
-    return x;
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 struct K2Item {
@@ -1293,6 +1313,7 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
     };
     unsigned long long nR = 0, nC = 0;
     uint32_t nW = 0, wor = 0;
+    const TrConst trc = tr_const(lane);
     // this wave's steps: every fourth one; in chunk mode the steps past a chunk's fill are skipped without a fetch
     auto next_step = [&](uint32_t st) -> uint32_t {
         if (!SORTED) while (st < it.count && (st % CH_STEPS) * 64u >= it.fills[st / CH_STEPS]) st += 4;
@@ -1306,8 +1327,8 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
         cur = next_step(cur + 4);
         k2_fetch<SORTED>(it, DIAG, cur, lane, true, nR, nC, nW);
         wor |= W;
-        const unsigned long long Ct = transpose64(C, lane);
-        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, lane);       // on the diagonal rows == cols
+        const unsigned long long Ct = transpose64(C, trc);
+        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, trc);        // on the diagonal rows == cols
         if (!DIAG) ctbuf[wave][lane] = Ct;
         wbuf[wave][lane] = (unsigned char)((W >> (7u * digit)) & 127u);
         lds_sync();
@@ -2018,7 +2039,7 @@ inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -2575,6 +2596,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.dflag = db->dflag; q.wide_base = db->wide_base;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
+        if (const char* e = getenv("KMDB_K1W_DEBUG")) { q.debug = (uint32_t)atoi(e); q.pool.nostore = q.debug == 1u ? 1u : 0u; }
         q.run_nodes = K1W_RUN_NODES;
         if (const char* e = getenv("KMDB_K1W_RUN")) q.run_nodes = std::max<uint32_t>(64u, (uint32_t)atoi(e) / 64u * 64u);
         q.n_runs = (n_wide + q.run_nodes - 1) / q.run_nodes;

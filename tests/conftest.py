@@ -47,4 +47,4 @@ def golden_dir(tmp_path_factory):
 
 
 DBS = ["virus_k18", "virus_k18_part1", "virus_k18_parts", "virus_k24", "virus_k18_f01", "synth_k21", "clade64",
-       "clade64_k25_f01"]
+       "clade64_k25_f01", "protein_dna_k24", "protein_dna_k24_preserve"]

@@ -74,8 +74,25 @@ def clade_genomes(n_clades, per_clade, length, r1, r2, seed):
     return out
 
 
+def protein_dna():
+    """test/protein/{dna,dna-preserve}.a2a (self-hosted.yml:393-403): k = 24 all2all of the 100 records of dna_100x1000.fasta as samples
+    (-multisample-fasta), canonical k-mers and -preserve-strand.  The k-mers come from the oracle's extractor, the databases from the
+    real reference's addKmers + serialize; the goldens are the reference's own files."""
+    copy("test/protein/dna.a2a", "protein.dna.a2a")
+    copy("test/protein/dna-preserve.a2a", "protein.dna-preserve.a2a")
+    recs = O._split_records(O._read_fasta_text(os.path.join(REF, "test/protein/dna_100x1000")))
+    for preserve, name in ((False, "protein_dna_k24.db"), (True, "protein_dna_k24_preserve.db")):
+        samples = [(h, O.sort_unique(O.extract_seq(s, 24, 1.0, 0.0, preserve))) for h, s in recs]
+        db = build_db(samples, 24, 1.0, name)
+        ref_outputs(db, name[:-3])
+
+
 def main():
     assert O.have_ref(), "build oracle/_ref first (make -C oracle)"
+    if sys.argv[1:] == ["protein"]:
+        protein_dna()
+        print("done (protein only)")
+        return
     # ---- 1. reference goldens + inputs -------------------------------------------------
     for f in ["k18.csv", "k18.sparse.csv", "k18.frac.csv", "k24.csv", "k18.n2a.csv",
               "k18.n2a.sparse.csv", "k18.n2a.itself.csv"]:
@@ -141,6 +158,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "clade64.queries.npz"), **{n: km for n, km in qs})
         rows, _ = O.ref_one2all(db_cl, qb, os.path.join(td, "o2.u32"), threads=1)
         rows.tofile(os.path.join(HERE, "clade64.n2a.ref.u32"))
+    protein_dna()
     print("done")
 
 

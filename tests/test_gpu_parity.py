@@ -342,6 +342,10 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
     _cli("all2all-sp", "-gpus", "3", g("virus_k18.db"), t("k18.sp.g3.csv")); _same(t("k18.sp.g3.csv"), g("virus.k18.sparse.csv"))
     _cli("all2all", "-gpus", "1", g("virus_k24.db"), t("k24.g1.csv")); _same(t("k24.g1.csv"), g("virus.k24.csv"))
     _cli("all2all-sp", "-gpus", "4", "-max", "39", "-min", "num-kmers:31", g("synth_k21.db"), t("a2a-sp-mm.g4")); _same(t("a2a-sp-mm.g4"), g("synth.a2a.sparse.above-below"))
+    # self-hosted.yml:393-403 (test/protein: DNA records as samples, k = 24, canonical and strand-preserving k-mers)
+    _cli("all2all", g("protein_dna_k24.db"), t("dna.a2a")); _same(t("dna.a2a"), g("protein.dna.a2a"))
+    _cli("all2all", g("protein_dna_k24_preserve.db"), t("dna-p.a2a")); _same(t("dna-p.a2a"), g("protein.dna-preserve.a2a"))
+    _cli("all2all", "-gpus", "3", g("protein_dna_k24_preserve.db"), t("dna-p3.a2a")); _same(t("dna-p3.a2a"), g("protein.dna-preserve.a2a"))
     # self-hosted.yml:110-146 (synth, with min/max filters)
     _cli("all2all", g("synth_k21.db"), t("a2a")); _same(t("a2a"), g("synth.a2a"))
     _cli("all2all", "-sparse", g("synth_k21.db"), t("a2a-sparse")); _same(t("a2a-sparse"), g("synth.a2a-sparse"))

@@ -29,7 +29,9 @@ def test_dense_matches_reference_raw(O, golden_dir, stem):
     ("virus_k18", "virus.k18.csv", False), ("virus_k18_parts", "virus.k18.csv", False),
     ("virus_k18", "virus.k18.sparse.csv", True), ("virus_k24", "virus.k24.csv", False),
     ("virus_k18_f01", "virus.k18.frac.csv", False), ("synth_k21", "synth.a2a", False),
-    ("synth_k21", "synth.a2a-sparse", True)])
+    ("synth_k21", "synth.a2a-sparse", True),
+    # test/protein/{dna,dna-preserve}.a2a (self-hosted.yml:393-403): k = 24, the records of one FASTA as samples; canonical k-mers / -preserve-strand
+    ("protein_dna_k24", "protein.dna.a2a", False), ("protein_dna_k24_preserve", "protein.dna-preserve.a2a", False)])
 def test_all2all_csv_matches_reference_golden(O, golden_dir, stem, golden, sparse):
     db = O.OracleDB(os.path.join(golden_dir, stem + ".db"))
     csv = O.format_all2all(db.k, db.fraction, db.names, db.sample_kmers, db.all2all_dense(), sparse=sparse)
