@@ -48,6 +48,16 @@ namespace {
 
 __host__ __device__ __forceinline__ uint32_t tri32(uint32_t x) { return x * (x + 1u) / 2u; }
 
+// Workgroups are dealt to the eight XCDs round-robin (workgroup b runs on XCD b % 8), and every XCD has its own L2.  Where neighbouring
+// work items write neighbouring memory (the sort kernels: consecutive jobs fill adjacent stretches of every stream, the cache lines at
+// the seams are shared), item = xcd_contiguous(b, n) keeps every XCD on ONE contiguous range of items, so that a line is completed in
+// one L2 instead of leaving two of them half written.  n must be a multiple of 8 (the launches round up).
+constexpr uint32_t RS_XCD_MAP = 1;          // 0: items in workgroup order (A/B)
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
+    if (!RS_XCD_MAP) return b;
+    return (b & 7u) * (n >> 3) + (b >> 3);
+}
+
 __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
     const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE);
@@ -811,8 +821,9 @@ struct WParams {
 constexpr int K1W_WAVES = 2;
 constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
 constexpr uint32_t K1W_HEAVY = 11;         // a node with that many blocks (66 records and more) is emitted by the whole wave
-constexpr uint32_t K1W_OXCAP = 256;        // further own pairs of a batch's nodes kept in LDS
+constexpr uint32_t K1W_OXCAP = 128;        // further own pairs of a batch's nodes kept in LDS
 constexpr uint32_t K1W_CTRS = 16;          // run counters: a wave takes its next run from the counter of its class
+constexpr uint32_t K1W_ARENA_MIN = 256;    // entries of a wave's row arena at least (and always one full list: as many as there are blocks)
 enum : uint32_t { WB_NONE = 0, WB_FN = 1, WB_LANE = 2, WB_CHAIN = 3 };
 // LDS of one wave, carved from the dynamic allocation (the sizes depend on the database: blocks, depth of the tree)
 struct K1WLds {
@@ -1218,10 +1229,14 @@ __device__ __forceinline__ TrConst tr_const(uint32_t lane) {
     }
     return c;
 }
-constexpr int K2_TR_SWIZZLE = 1;              // 1: stages 16 / 8 / 4 fetch over the LDS crossbar (ds_swizzle); 0: ds_bpermute / DPP (A/B)
-__device__ __forceinline__ uint32_t tr_fetch(uint32_t v, int k) {
+constexpr int K2_TR_SWIZZLE = 0;              // 1: stages 16 / 8 / 4 fetch over the LDS crossbar (ds_swizzle); 0: v_permlane16_swap / DPP: VALU only (A/B)
+__device__ __forceinline__ uint32_t tr_fetch(uint32_t v, int k, bool up16) {
     // the word of lane ^ (16 >> k)
-    if (k == 0) return K2_TR_SWIZZLE ? (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F) : (uint32_t)__shfl_xor((int)v, 16, WAVE);
+    if (k == 0) {
+        if (K2_TR_SWIZZLE) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+        const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // [0]: odd rows <- the even rows below them, [1]: even rows <- the odd rows above
+        return up16 ? a[0] : a[1];
+    }
     if (k == 1) return K2_TR_SWIZZLE ? (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x201F) : (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
     if (k == 2) {
         if (K2_TR_SWIZZLE) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);
@@ -1237,9 +1252,10 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
         const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
         lo = r[0]; hi = r[1];
     }
+    const bool up16 = c.msk[0] == 0x0000FFFFu;                         // (lane & 16) != 0
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const uint32_t pl = tr_fetch(lo, k), ph = tr_fetch(hi, k);
+        const uint32_t pl = tr_fetch(lo, k, up16), ph = tr_fetch(hi, k, up16);
         const uint32_t rl = __builtin_amdgcn_alignbit(pl, pl, c.amt[k]), rh = __builtin_amdgcn_alignbit(ph, ph, c.amt[k]);
         asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(lo) : "v"(c.msk[k]), "v"(rl));      // (mask & partner) | (~mask & own)
         asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(hi) : "v"(c.msk[k]), "v"(rh));
@@ -1295,6 +1311,9 @@ __device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t s
 // weight is split into base-128 digits, the run is accumulated once per digit that occurs (`digit`), and the digit's tile is
 // merged shifted left by 7 * digit — exact in the matrix's uint32 wrap-around arithmetic.  Almost every weight is below 128
 // (99.98 % at the benchmark database), so nearly every run takes one pass.  Returns (to every thread) the OR of the weights.
+constexpr int K2_SPREAD_LUT = 1;           // 1: bits -> operand bytes through the 256-entry table in LDS; 0: in the ALU (A/B)
+constexpr int K2_DEBUG = 0;                // timing experiments (results wrong): 1 no MFMA, 2 no byte spreading, 3 no transposes, 4 records fetched once per run,
+                                           // 5 no merge of the waves' tiles / no flush
 typedef int k2_v4i __attribute__((ext_vector_type(4)));
 typedef int k2_v16i __attribute__((ext_vector_type(16)));
 
@@ -1306,9 +1325,21 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
     k2_v16i c00 = {}, c01 = {}, c10 = {}, c11 = {};
     auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> k2_v4i {
         const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
-        const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
         k2_v4i r;
-        r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
+        if (K2_SPREAD_LUT) {
+            const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
+            r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
+        } else {
+            // four bits -> four bytes in the ALU: n * 0x204081 puts bit i of the nibble at bit 8 i (24-bit multiply), and a packed
+            // 16-bit multiply by 255 turns the 0x01 bytes into 0xFF where the operand wants a mask for the weights
+            const bool ff = lut == lut_ff;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t v = __umul24((f >> (4 * j)) & 0xFu, 0x204081u) & 0x01010101u;
+                if (ff) v = (v << 8) - v;
+                r[j] = (int)v;
+            }
+        }
         return r;
     };
     unsigned long long nR = 0, nC = 0;
@@ -1325,32 +1356,53 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
         cur = next_step(cur + 4);
-        k2_fetch<SORTED>(it, DIAG, cur, lane, true, nR, nC, nW);
+        if (K2_DEBUG != 4) k2_fetch<SORTED>(it, DIAG, cur, lane, true, nR, nC, nW);
         wor |= W;
-        const unsigned long long Ct = transpose64(C, trc);
-        rtbuf[wave][lane] = DIAG ? Ct : transpose64(R, trc);        // on the diagonal rows == cols
-        if (!DIAG) ctbuf[wave][lane] = Ct;
+        // lane r now holds row r of the step's bit matrices R^T / C^T (bit k <=> record k has row / column r).  The operand layout wants
+        // in every lane the rows l31 and 32 + l31: the lower half of the wave keeps its own word and fetches the upper half's, and
+        // the other way round — one v_permlane32_swap per 32-bit word, nothing parked in LDS (round 3 wrote the 64 words to LDS and read
+        // four back per lane; with the byte-spreading table that made 25 LDS instructions per step and a third of the LDS cycles lost to
+        // bank conflicts).
+        const unsigned long long Ct = K2_DEBUG == 3 ? C : transpose64(C, trc);
+        const unsigned long long Rt = DIAG ? Ct : (K2_DEBUG == 3 ? R : transpose64(R, trc));           // on the diagonal rows == cols
+        auto halves = [&](unsigned long long w, unsigned long long& w0, unsigned long long& w1) {
+            const auto a = __builtin_amdgcn_permlane32_swap((uint32_t)w, (uint32_t)w, false, false);                 // [0]: the lower half's words everywhere, [1]: the upper half's
+            const auto b = __builtin_amdgcn_permlane32_swap((uint32_t)(w >> 32), (uint32_t)(w >> 32), false, false);
+            w0 = ((unsigned long long)b[0] << 32) | a[0];
+            w1 = ((unsigned long long)b[1] << 32) | a[1];
+        };
+        unsigned long long ra0, ra1, cb0, cb1;
+        halves(Rt, ra0, ra1);
+        if (DIAG) { cb0 = ra0; cb1 = ra1; } else halves(Ct, cb0, cb1);
         wbuf[wave][lane] = (unsigned char)((W >> (7u * digit)) & 127u);
         lds_sync();
-        const unsigned long long* rtp = rtbuf[wave];
-        const unsigned long long* ctp = DIAG ? rtbuf[wave] : ctbuf[wave];
-        const unsigned long long ra0 = rtp[l31], ra1 = rtp[32u + l31], cb0 = ctp[l31], cb1 = ctp[32u + l31];
 #pragma unroll
         for (uint32_t kh = 0; kh < 2; ++kh) {
             const uint32_t shift = 32u * kh + 16u * half;            // records 32 kh + 16 half .. + 15 of the step
-            k2_v4i a0 = spread(ra0, shift, lut_ff), a1 = spread(ra1, shift, lut_ff);
+            k2_v4i a0, a1, b0, b1;
+            if (K2_DEBUG == 2) {
+                const k2_v4i x = {(int)(uint32_t)(ra0 >> shift), (int)(uint32_t)(ra1 >> shift), (int)(uint32_t)(cb0 >> shift), (int)(uint32_t)(cb1 >> shift)};
+                a0 = x; a1 = x; b0 = x; b1 = x;
+            } else {
+                a0 = spread(ra0, shift, lut_ff); a1 = spread(ra1, shift, lut_ff);
+                b0 = spread(cb0, shift, lut_01); b1 = spread(cb1, shift, lut_01);
+            }
             const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
             a0 &= wv; a1 &= wv;
-            const k2_v4i b0 = spread(cb0, shift, lut_01), b1 = spread(cb1, shift, lut_01);
+            if (K2_DEBUG == 1) { c00[0] += a0[0] ^ b0[1]; c01[0] += a0[1] ^ b1[2]; c10[0] += a1[2] ^ b0[3]; c11[0] += a1[3] ^ b1[0]; c00[1] += a0[2] + a0[3] + a1[0] + a1[1] + b0[0] + b0[2] + b1[1] + b1[3]; }
+            else {
             c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
             c01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, c01, 0, 0, 0);
             c10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, c10, 0, 0, 0);
             c11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c11, 0, 0, 0);
+            }
         }
         lds_sync();
     }
     // merge the four waves' tiles through the LDS block (on the diagonal only c < r)
     const uint32_t sh = 7u * digit;
+    if (K2_DEBUG == 5) { if ((c00[0] ^ c01[1] ^ c10[2] ^ c11[3]) == 0x12345u) acc[lane] = 1u; }
+    else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
@@ -1394,7 +1446,8 @@ __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t
 }
 
 constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup at most; the launch picks 16 (few streams: measured better) or 32
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
+constexpr int K2A_MIN_WAVES = 3;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAVES, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
                                                        const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
                                                        const uint32_t* __restrict__ chunk_fill, uint32_t n_states, const uint32_t* __restrict__ n_chunks_ptr,
                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, uint32_t win) {
@@ -1484,9 +1537,11 @@ struct CsJob { uint32_t lo, hi, n_bins, sub, tab, stride; };
 __device__ __forceinline__ CsJob cs_job(int mode, uint32_t n, uint32_t n_keys, const CsRows& rows) {
     CsJob j{0u, 0u, n_keys, 0u, blockIdx.x, gridDim.x};
     if (mode != CS_IN_ROW) {
-        // equal shares of whole 1024-record tiles
+        // equal shares of whole 1024-record tiles; the shares in XCD-contiguous order (the grids are multiples of 8)
+        const uint32_t vb = (gridDim.x & 7u) ? blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x);
+        j.tab = vb;
         const uint32_t per_block = ((n + gridDim.x - 1u) / gridDim.x + 1023u) / 1024u * 1024u;
-        const uint32_t lo = blockIdx.x * per_block;
+        const uint32_t lo = vb * per_block;
         if (lo < n) { j.lo = lo; j.hi = n - lo < per_block ? n : lo + per_block; }
         return j;
     }
@@ -1537,7 +1592,7 @@ __global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict
 // The scatter stages tiles of CS_TILE records in LDS sorted by bin, so that the records of one stream leave the tile as one
 // contiguous burst.  LDS: the staged records, their destinations, and three per-bin arrays (tile histogram = rank source,
 // tile offsets, the workgroup's running global cursor).
-constexpr uint32_t CS_TILE = 1024, CS_THREADS = 256;
+constexpr uint32_t CS_TILE = 2048, CS_THREADS = 256;
 __host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + CS_THREADS * 4 + 64; }
 __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_valid,
                                                          uint32_t n_keys, int mode, const CsRows rows, uint32_t kmask, const uint32_t* __restrict__ O,
@@ -1731,6 +1786,7 @@ __global__ void rs_bands_kernel(const uint32_t* __restrict__ row_job, const uint
     band_rec[b] = O[row_tab[B.x[b]]];
 }
 struct RsJob { uint32_t X, nj, cb, ce, tab; const uint32_t* ids; };
+
 __device__ __forceinline__ bool rs_job(const RsRows& R, uint32_t job, uint32_t job_end, RsJob& j) {
     const uint32_t NB = R.NB;
     if (job >= job_end || job >= R.row_job[NB]) return false;
@@ -1783,7 +1839,9 @@ __global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, 
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
     __shared__ uint32_t s_id[RS_JOB_CHUNKS], s_fill[RS_JOB_CHUNKS];
     RsJob job;
-    if (!rs_job(R, band[0] + blockIdx.x, band[1], job)) return;
+    // consecutive jobs write neighbouring stretches of every stream of their row (the lines at the seams are shared): workgroups are dealt
+    // to the eight XCDs round-robin, so job = f(blockIdx) keeps every XCD on ONE contiguous range of jobs and the seams in one L2
+    if (!rs_job(R, band[0] + xcd_contiguous(blockIdx.x, gridDim.x), band[1], job)) return;
     const uint32_t NB = R.NB;
     const uint32_t nb = job.X + 1u, sub = tri32(job.X), nch = job.ce - job.cb;
     WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
@@ -2324,7 +2382,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2;          // streams = block pairs
     if (n_states + 1 >= (1ull << 22)) { db->fallback_reason = "too many block pairs"; return 0; }          // 22 stream bits + 8-bit weight digits in a key word
     db->n_states = (uint32_t)n_states;
-    if (k1w_wave_bytes(std::max<uint32_t>(512u, (db->NB + 2u + 63u) & ~63u), (db->NB + 2u + 3u) & ~3u, db->chain_cap, db->NB) > (size_t)(152u << 10)) {
+    if (k1w_wave_bytes(std::max<uint32_t>(K1W_ARENA_MIN, (db->NB + 2u + 63u) & ~63u), (db->NB + 2u + 3u) & ~3u, db->chain_cap, db->NB) > (size_t)(152u << 10)) {
         db->fallback_reason = "the lists of the wide-node kernel do not fit the LDS (" + std::to_string(db->NB) + " blocks, root paths of up to " +
                               std::to_string(db->max_depth) + " nodes)";
         return 0;
@@ -2606,7 +2664,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.seg_anc = db->wrun_anc; q.seg_anc_n = db->wrun_anc_n;
         
         // LDS of a wave: rows of a batch (at least one full list: as many entries as there are blocks), the chain list, the chain
-        q.chain_cap = db->chain_cap; q.e_cap = (db->NB + 2u + 3u) & ~3u; q.arena_cap = std::max<uint32_t>(512u, (db->NB + 2u + 63u) & ~63u);
+        q.chain_cap = db->chain_cap; q.e_cap = (db->NB + 2u + 3u) & ~3u; q.arena_cap = std::max<uint32_t>(K1W_ARENA_MIN, (db->NB + 2u + 63u) & ~63u);
         q.n_rows = row_mode ? db->NB : 0u;
         const size_t wave_lds = k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap, q.n_rows);
         const uint32_t waves = wave_lds * K1W_WAVES <= (size_t)(64u << 10) ? (uint32_t)K1W_WAVES : 1u;
@@ -2674,7 +2732,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         const uint32_t g2 = (nsorted + K2S_WIN - 1) / K2S_WIN + 1;
         hipStream_t s3 = n_bands > 1 ? db->stream3 : st;
         for (uint32_t b = 0; b < n_bands; ++b) {
-            hipLaunchKernelGGL(rs_scatter_kernel, dim3(jobs), dim3(CS_THREADS), rs_scatter_lds(NB), st, R, band_job + b, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
+            hipLaunchKernelGGL(rs_scatter_kernel, dim3((jobs + 7u) & ~7u), dim3(CS_THREADS), rs_scatter_lds(NB), st, R, band_job + b, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
                                db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters);
             if (s3 != st) { HIP_TRY(hipEventRecord(db->ev_band[b], st)); HIP_TRY(hipStreamWaitEvent(s3, db->ev_band[b], 0)); }
             hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, s3, db->swkey, (const WideRec*)db->swrec, (uint32_t)db->sorted_cap, band_rec + b + 1, band_rec + b,

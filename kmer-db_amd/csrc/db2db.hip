@@ -23,6 +23,7 @@
 
 #include <hip/hip_runtime.h>
 #include "prim.h"
+#include "hash_probe.h"
 
 #include <algorithm>
 #include <cstring>
@@ -65,16 +66,8 @@ __global__ void d2_probe_kernel(D2Db row, D2Db col, uint64_t n_col_slots, uint32
         if (b < row.n_buckets) {
             const uint64_t off = row.bucket_offset[b], cap = row.bucket_offset[b + 1] - off;
             if (cap) {
-                const uint64_t mask = cap - 1;
-                const uint32_t kk = (uint32_t)it;
-                uint64_t h = (uint64_t)d2_fmix32(kk) & mask;
-                for (uint64_t step = 0; step < cap; ++step) {        // a full table (corrupt file) ends the probe too
-                    const uint64_t r = row.slots[off + h];
-                    const int32_t pr = (int32_t)(r >> 32);
-                    if (pr == 0x7fffffff) break;
-                    if ((uint32_t)r == kk) { key = ((unsigned long long)row.pid2dfs[pr] << cbits) | col.pid2dfs[pc]; break; }
-                    h = (h + 1) & mask;
-                }
+                const int32_t pr = kmdb_probe(row.slots, off, cap, (uint32_t)it);
+                if (pr != 0x7fffffff) key = ((unsigned long long)row.pid2dfs[pr] << cbits) | col.pid2dfs[pc];
             }
         }
     }

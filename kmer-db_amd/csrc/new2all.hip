@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include "prim.h"
+#include "hash_probe.h"
 
 #include <algorithm>
 #include <cmath>
@@ -60,24 +61,15 @@ __global__ void n2a_probe_kernel(const uint64_t* __restrict__ kmers, const uint6
             const uint64_t off = bucket_offset[b];
             const uint64_t cap = bucket_offset[b + 1] - off;
             if (cap) {
-                const uint64_t mask = cap - 1;
-                const uint32_t kk = (uint32_t)k;
-                uint64_t h = (uint64_t)fmix32(kk) & mask;
-                for (uint64_t step = 0; step < cap; ++step) {        // a full table (corrupt file) ends the probe too
-                    const uint64_t it = slots[off + h];
-                    const int32_t val = (int32_t)(it >> 32);
-                    if (val == 0x7fffffff) break;                // empty slot ends the probe (src/hashmap_lp.h:78)
-                    if ((uint32_t)it == kk) {
-                        const uint32_t d = pid2dfs[val];
-                        if (w[d] != 0) {                          // :847-848 skips patterns without k-mers
-                            // query of this k-mer: binary search in the batch's offsets
-                            uint32_t lo = 0, hi = nq;
-                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (qoff[mid] <= i) lo = mid; else hi = mid; }
-                            key = ((unsigned long long)lo << 32) | d;
-                        }
-                        break;
+                const int32_t val = kmdb_probe(slots, off, cap, (uint32_t)k);
+                if (val != 0x7fffffff) {
+                    const uint32_t d = pid2dfs[val];
+                    if (w[d] != 0) {                              // :847-848 skips patterns without k-mers
+                        // query of this k-mer: binary search in the batch's offsets
+                        uint32_t lo = 0, hi = nq;
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (qoff[mid] <= i) lo = mid; else hi = mid; }
+                        key = ((unsigned long long)lo << 32) | d;
                     }
-                    h = (h + 1) & mask;
                 }
             }
         }

@@ -301,6 +301,12 @@ def ref_one2all(db_path, queries_bin, out_path, threads=1):
     return np.fromfile(out_path, dtype=np.uint32), info
 
 
+def ref_new2all(db_path, queries_bin, out_path, workers):
+    """the reference's new2all compute: `workers` threads, one one2all<false> per query (console_new2all.cpp:64-95); wall clock"""
+    info = _run_ref(["new2all", db_path, queries_bin, out_path, workers])
+    return np.fromfile(out_path, dtype=np.uint32), info
+
+
 def ref_one2all_sp(db_path, queries_bin, out_path, threads=1):
     info = _run_ref(["one2all_sp", db_path, queries_bin, out_path, threads])
     with open(out_path, "rb") as f:

@@ -17,6 +17,8 @@
 //   ref_driver all2all_sp <db> <out.txt> [threads] [bufferMb] [bubbleSize]
 //   ref_driver one2all  <db> <queries.bin> <out.u32> [threads]   nq x N dense rows
 //   ref_driver one2all_sp <db> <queries.bin> <out.txt> [threads]
+//   ref_driver new2all  <db> <queries.bin> <out.u32> <workers>   the reference's new2all: `workers` threads each running one2all<false>
+//                                                                 on its next query (console_new2all.cpp:64-95); wall clock of all queries
 //   ref_driver db2db_sp <db_row> <db_col> <out.txt> [threads]    sparse rows of the cell (row part, column part)
 //
 // kmers.bin / queries.bin (little endian): u32 magic 'KMRS', u32 k, f64 fraction,
@@ -35,6 +37,8 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 #include <algorithm>
 
@@ -164,6 +168,37 @@ int main(int argc, char** argv) {
             fclose(o);
             printf("{\"cmd\":\"db2db_sp\",\"rows\":%zu,\"cols\":%zu,\"threads\":%d,\"seconds\":%.6f}\n", db_row.getSamplesCount(),
                    db_col.getSamplesCount(), threads, t1 - t0);
+            return 0;
+        }
+        if (cmd == "new2all") {
+            // console_new2all.cpp:64-95: numThreads workers share the database and the calculator; each takes the next query,
+            // makes its k-mers unique (:73) and calls one2all<false> (:82).  The rows are kept in query order.
+            if (argc < 6) return 2;
+            const int workers = std::max(1, atoi(argv[5]));
+            PrefixKmerDb db(workers);
+            if (!db.deserialize(dbFile)) return 1;
+            uint32_t k; double fraction; std::vector<SampleBlob> qs;
+            if (!read_samples(argv[3], k, fraction, qs)) { fprintf(stderr, "cannot read %s\n", argv[3]); return 1; }
+            SimilarityCalculator calc(workers, bufferMb);
+            std::vector<std::vector<uint32_t>> rows(qs.size());
+            std::atomic<size_t> next{0};
+            double t0 = now_s();
+            std::vector<std::thread> th;
+            for (int t = 0; t < workers; ++t)
+                th.emplace_back([&]() {
+                    for (size_t i; (i = next.fetch_add(1)) < qs.size();) {
+                        auto& q = qs[i];
+                        std::sort(q.kmers.begin(), q.kmers.end());
+                        q.kmers.erase(std::unique(q.kmers.begin(), q.kmers.end()), q.kmers.end());
+                        calc.one2all<false>(db, q.kmers.data(), q.kmers.size(), rows[i]);
+                    }
+                });
+            for (auto& x : th) x.join();
+            double t1 = now_s();
+            FILE* o = fopen(argv[4], "wb");
+            for (auto& r : rows) fwrite(r.data(), 4, r.size(), o);
+            fclose(o);
+            printf("{\"cmd\":\"new2all\",\"queries\":%zu,\"threads\":%d,\"seconds\":%.6f}\n", qs.size(), workers, t1 - t0);
             return 0;
         }
         if (cmd == "one2all" || cmd == "one2all_sp") {

@@ -35,7 +35,19 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--length="):
             length = int(a.split("=")[1])
-    arr, names, counts, nk, _ = B.generate_in_child(0, n_samples=wl["samples"], clade_size=wl["clade_size"], length=length, k=18, seed=20260929, rank=0, world=1)
+    # the generated arrays are kept in shared memory for the other processes of the same job (compile-time variants: one process each)
+    cache = "/dev/shm/kmdb_r04_ab_%s_%d" % (args[0], length)
+    if os.path.isdir(cache) and os.path.exists(os.path.join(cache, "done")):
+        arr = {nm[:-4]: np.load(os.path.join(cache, nm)) for nm in os.listdir(cache) if nm.endswith(".npy")}
+    else:
+        arr, names, counts, nk, _ = B.generate_in_child(0, n_samples=wl["samples"], clade_size=wl["clade_size"], length=length, k=18, seed=20260929, rank=0, world=1)
+        try:
+            os.makedirs(cache, exist_ok=True)
+            for nm, a in arr.items():
+                np.save(os.path.join(cache, nm + ".npy"), a)
+            open(os.path.join(cache, "done"), "w").close()
+        except OSError:
+            pass
     db = None
     ref = None
     out = []
