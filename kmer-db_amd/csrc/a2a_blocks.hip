@@ -358,6 +358,8 @@ struct K0Params {
     uint32_t* counters;
 };
 
+constexpr int K0_RELW = 8;                 // non-empty 64-id words of a long list kept in registers (more: the list is walked twice)
+constexpr int K0_SINGLE_PASS = 1;          // 0: every list spanning 64 ids or more is walked twice, as in round 3 (A/B)
 template <bool LONG>
 __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     // two launches cover the nodes: perm == nullptr walks ALL nodes in DFS order (coalesced) and skips the ones whose
@@ -405,8 +407,52 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     using Cursor = RunCursor32<LONG ? 16 : 6, LONG>;
     uint32_t npairs = 0, blk0 = 0, need = 0, span = 0, bit0 = 0;
     unsigned long long mask0 = 0, m1 = 0, m2 = 0;
-    bool second_pass = false;
+    bool second_pass = false, from_words = false;
     uint64_t pos = 0;
+    // (long launch) the non-empty 64-id words of the relative list: K0_RELW of them in registers, filled in order
+    unsigned long long rel_w[K0_RELW];
+    uint32_t rel_i[K0_RELW], rel_n = 0;
+#pragma unroll
+    for (int e = 0; e < K0_RELW; ++e) { rel_w[e] = 0; rel_i[e] = 0; }
+    auto rel_push = [&](uint32_t idx, unsigned long long w) {
+#pragma unroll
+        for (int e = 0; e < K0_RELW; ++e) if (rel_n == (uint32_t)e) { rel_w[e] = w; rel_i[e] = idx; }     // (static register indices: no scratch)
+        ++rel_n;                                                  // beyond K0_RELW: the list takes the second walk after all
+    };
+    // the words cut at the block boundaries: (block, mask) pairs in ascending order.  WRITE = false counts them, true stores them
+    // (the first one inline, the others in the pair pool from `o` on)
+    auto rel_blocks = [&](bool write, uint32_t id0, uint32_t o) -> uint32_t {
+        const unsigned long long wm = bm.width == 64 ? ~0ull : (1ull << bm.width) - 1ull;
+        uint32_t curblk = 0xFFFFFFFFu, cnt = 0;
+        unsigned long long cacc = 0;
+        auto flushb = [&]() {
+            if (curblk == 0xFFFFFFFFu) return;
+            if (write) { if (cnt == 0) mask0 = cacc; else { q.pair_blk[o] = (uint16_t)curblk; q.pair_mask[o] = cacc; ++o; } }
+            ++cnt;
+        };
+#pragma unroll
+        for (int e = 0; e < K0_RELW; ++e) {
+            if ((uint32_t)e < rel_n) {
+                const uint32_t base = id0 + 64u * rel_i[e];
+                const unsigned long long word = rel_w[e];
+                const uint32_t b = bm.blk(base);
+                uint32_t bit = bm.bit(base, b), sh = 0;
+#pragma unroll
+                for (uint32_t part = 0; part < 3; ++part) {       // 64 ids meet at most three blocks (width >= 32)
+                    if (sh < 64u) {
+                        const unsigned long long m = ((word >> sh) << bit) & wm;
+                        if (m) {
+                            if (b + part != curblk) { flushb(); curblk = b + part; cacc = 0; }
+                            cacc |= m;
+                        }
+                        sh += bm.width - bit; bit = 0;
+                    }
+                }
+            }
+        }
+        flushb();
+        return cnt;
+    };
     if (live && l == 1) {
         blk0 = bm.blk(last); mask0 = 1ull << bm.bit(last, blk0); npairs = 1;
     } else if (live && l) {
@@ -418,18 +464,36 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
         {
             Cursor c(q.bits, pos);
             uint32_t rem = l - 1;
+            // the long launch keeps the WHOLE relative list, not only its first 64 ids: the non-empty 64-id words (word index, mask)
+            // in registers, in ascending order (ids ascend, so a word is complete when the next one starts).  A list that spans 64 ids or
+            // more — four fifths of the long nodes of a 10 000-sample collection (profiles/r04_record_stats.py) — then needs no second
+            // walk over its stream: its words are cut at the block boundaries once the first id is known.
+            uint32_t wk = 0;
+            unsigned long long acc = 1ull;
+            auto add = [&](uint32_t s0, uint32_t cnt) {               // relative ids [s0, s0 + cnt), cnt >= 1
+                while (cnt) {
+                    const uint32_t k = s0 >> 6, o = s0 & 63u;
+                    const uint32_t take = cnt < 64u - o ? cnt : 64u - o;
+                    if (k != wk) { rel_push(wk, acc); wk = k; acc = 0; }
+                    acc |= (take == 64u ? ~0ull : ((1ull << take) - 1ull)) << o;
+                    s0 += take; cnt -= take;
+                }
+            };
             while (rem) {
                 uint32_t z, v;
                 c.step(rem, z, v);                                     // a run of z consecutive ids, then a gap of v
                 if (z) {
-                    if (span + z < 64u) R |= ((2ull << (z - 1)) - 1ull) << (span + 1);
+                    if (LONG) add(span + 1u, z);
+                    else if (span + z < 64u) R |= ((2ull << (z - 1)) - 1ull) << (span + 1);
                     span += z; rem -= z;
                 }
                 if (v) {
                     span += v; --rem;
-                    if (span < 64u) R |= 1ull << span;
+                    if (LONG) add(span, 1u);
+                    else if (span < 64u) R |= 1ull << span;
                 }
             }
+            if (LONG) { if (span < 64u) R = acc; else rel_push(wk, acc); }
         }
         const uint32_t id0 = last - span;
         blk0 = bm.blk(id0);
@@ -444,6 +508,11 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
             mask0 = lo & wm;
             m1 = ext(bm.width) & wm; m2 = ext(2 * bm.width) & wm;
             npairs = 1u + (m1 != 0) + (m2 != 0);
+            need = npairs - 1u;
+        } else if (LONG && K0_SINGLE_PASS && rel_n <= (uint32_t)K0_RELW) {
+            // wide list, all its words at hand: the pairs are counted now (exactly) and stored after the reservation
+            from_words = true;
+            npairs = rel_blocks(false, id0, 0u);
             need = npairs - 1u;
         } else {
             // wide list: second pass with absolute ids; the blocks it can touch bound the reservation
@@ -471,13 +540,15 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
                 if (sb + total <= q.spill_cap) out = q.n_regions * q.region_cap + sb + (incl - need);
                 else {
                     if (lane == 0) atomicOr(&q.counters[KCTR_PAIR_OVERFLOW], 1u);
-                    need = 0; second_pass = false; npairs = npairs ? 1u : 0u; m1 = m2 = 0;    // results invalid; the call is repeated with a larger pool
+                    need = 0; second_pass = false; from_words = false; npairs = npairs ? 1u : 0u; m1 = m2 = 0;    // results invalid; the call is repeated with a larger pool
                 }
             }
         }
     }
     if (!live) return;
-    if (!second_pass) {
+    if (from_words) {
+        (void)rel_blocks(true, last - span, out);
+    } else if (!second_pass) {
         if (m1) { q.pair_blk[out] = (uint16_t)(blk0 + 1); q.pair_mask[out] = m1; }
         if (m2) { const uint32_t o2 = out + (m1 != 0); q.pair_blk[o2] = (uint16_t)(blk0 + 2); q.pair_mask[o2] = m2; }
     } else {

@@ -27,7 +27,10 @@ for g in $GROUPS_WANTED; do
   C=${G[$g]}
   rm -rf /tmp/pmc_$g
   ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$KRE" --output-format csv -d /tmp/pmc_$g -- python $R/bench.py $BA --no-cpu-baseline --steps 2 --warmup 1 > /tmp/pmc_$g.json 2> /tmp/pmc_$g.err )
-  f=$(find /tmp/pmc_$g -name '*counter_collection.csv' -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2)      # (the bench process', not its generator child's)
+  f=""                                                                 # the bench process' file, not its generator child's: the one with the engine's kernels
+  for c in $(find /tmp/pmc_$g -name '*counter_collection.csv'); do
+    if grep -q -E "k0_decode_kernel|n2a_|d2_|row_nnz_kernel" $c; then f=$c; fi
+  done
   if [ -n "$f" ]; then cp $f /tmp/pmc_$g.csv; FILES="$FILES /tmp/pmc_$g.csv"; else echo "group $g: no counter file"; tail -5 /tmp/pmc_$g.err; fi
 done
 python profiles/summarize_counters.py $TAG $OUT $FILES

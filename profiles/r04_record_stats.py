@@ -76,6 +76,25 @@ def main():
     for a, b in zip(edges[:-1], edges[1:]):
         m = (ce >= a) & (ce < b)
         print("%5d..%-5s %12d %8.2f %14d %8.2f" % (a, "" if b > 1 << 20 else b - 1, int(m.sum()), 100.0 * int(m.sum()) / max(1, ce.numel()), int(recs[m].sum()), 100.0 * int(recs[m].sum()) / max(1, tot)))
+    # K0's long launch: nodes with more than 32 local ids or more than 128 stream bits; the ones whose local list spans 64 ids or more are
+    # decoded twice
+    delta = torch.zeros_like(ids)
+    if ids.numel() > 1:
+        delta[1:] = ids[1:] - ids[:-1]
+    first = torch.ones_like(ids, dtype=torch.bool)
+    if ids.numel() > 1:
+        first[1:] = owner[1:] != owner[:-1]
+    bl = torch.frexp(delta.clamp(min=1).to(torch.float64))[1].to(torch.int64)
+    clen = torch.where(first, torch.zeros_like(bl), 2 * bl - 1)
+    nbits = torch.zeros(P, dtype=torch.int64, device=ids.device).index_add_(0, owner, clen)
+    span = torch.zeros(P, dtype=torch.int64, device=ids.device)
+    span[has] = ids[lp[1:][has] - 1] - ids[lp[:-1][has]]
+    long_ = (l > 32) | (nbits > 128)
+    print("long nodes (l > 32 or bits > 128): %d = %.1f %% of the nodes; of them span >= 64 (two passes): %.1f %%; mean l of the long nodes %.1f, mean stream bits %.1f; "
+          "short nodes with span >= 64: %.2f %% of all nodes" % (int(long_.sum()), 100.0 * float(long_.double().mean()), 100.0 * float((span[long_] >= 64).double().mean()),
+                                                               float(l[long_].double().mean()), float(nbits[long_].double().mean()), 100.0 * float(((~long_) & (span >= 64)).double().mean())))
+    nonone = torch.zeros(P, dtype=torch.int64, device=ids.device).index_add_(0, owner, ((delta > 1) & ~first).to(torch.int64))
+    print("codes other than '0' per long node: mean %.1f; per short node with l > 1: mean %.2f" % (float(nonone[long_].double().mean()), float(nonone[(~long_) & (l > 1)].double().mean())))
     # weights of the emitting nodes
     we = w[emit]
     print("weights: mean %.2f, >=128: %d of %d; w==1: %.1f %%" % (float(we.double().mean()), int((we >= 128).sum()), we.numel(), 100.0 * float((we == 1).double().mean())))

@@ -874,6 +874,22 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
     assert d3["config"]["genome_length_bp"] == 4000 and d3["config"]["n_ranks_seen"] == 2
 
 
+def test_bench_one_gpu_share_of_configs2(dev):
+    """BASELINE configs[2] (10 000 genomes of 5 Mbp over 8 GPUs) at its real per-GPU size: `--workload c3gpu` = 10 000 samples x 625 kbp,
+    140 M patterns, more than 2^31 local ids in the tree, 1.08 G block records — ONE pass of the block-record pipeline (record pools
+    beyond 2^31 slots on the many-streams path).  bench.py itself asserts the checksum identity over the whole 50 M-cell matrix
+    (sum M == sum_p w_p C(n_p, 2)) and warm == cold."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3gpu", "--no-cpu-baseline", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=dict(os.environ, KMDB_VERBOSE="1"), timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["config"]["samples"] == 10000 and d["config"]["genome_length_bp"] == 625000 and d["config"]["path"] == "block-record pipeline"
+    assert d["roofline"]["block_records_per_launch"] > 10 ** 9
+    assert "slices of the pattern stream" not in r.stderr, "one GPU's share of configs[2] should be one pass"
+
+
 @pytest.mark.parametrize("mode", ["all2all-sp", "new2all", "db2db"])
 def test_bench_secondary_modes(dev, mode):
     """`bench.py --mode`: the all2all-sp / new2all / db2db rows as driver-runnable lines in the same contract; each run checks a
