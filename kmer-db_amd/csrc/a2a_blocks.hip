@@ -96,7 +96,7 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
-    uint32_t nostore;              // timing experiment (KMDB_K1W_DEBUG=1): the wide kernel's records are placed but not written
+    uint32_t nostore;              // timing experiment (K1W_DEBUG == 1, compile time): the wide kernel's records are placed but not written
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
@@ -886,10 +886,10 @@ struct WParams {
     uint32_t chain_cap, arena_cap, e_cap;
     uint32_t n_rows;               // row mode: block rows (0 otherwise)
     uint32_t emit_lo, emit_hi;
-    uint32_t debug;                // KMDB_K1W_DEBUG (timing experiments, results wrong): 1 = no record stores, 2 = no emission at all, 3 = no owner search
     PoolView pool;
 };
 constexpr int K1W_WAVES = 2;
+constexpr uint32_t K1W_DEBUG = 0;          // timing experiments at compile time (results wrong): 1 = no record stores, 2 = no emission at all, 3 = no owner search
 constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
 constexpr uint32_t K1W_HEAVY = 11;         // a node with that many blocks (66 records and more) is emitted by the whole wave
 constexpr uint32_t K1W_OXCAP = 128;        // further own pairs of a batch's nodes kept in LDS
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     // record-parallel emission of the lanes in `on` (list of lane j: m entries from st_start[j]): a node with m blocks owns
     // m (m + 1) / 2 records (block pairs a >= b), one record per lane and step
     auto emit = [&](bool on, uint32_t m, uint32_t wv) {
-        if (q.debug == 2u) return;
+        if (K1W_DEBUG == 2u) return;
         // a node with many blocks is taken by the whole wave: lane t builds pair t of the node
         {
             unsigned long long hb = __ballot(on && m >= K1W_HEAVY);
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             if (t < T) {
                 uint32_t own = 0;                               // the first lane whose inclusive sum exceeds t
                 uint32_t r0;
-                if (q.debug == 3u) {                            // (timing experiment: no search — a record of the lane's own node, or none)
+                if (K1W_DEBUG == 3u) {                            // (timing experiment: no search — a record of the lane's own node, or none)
                     own = lane;
                     const uint32_t c0 = L.queue[own] - (own ? L.queue[own - 1u] : 0u);
                     r0 = c0 ? t % c0 : 0u;
@@ -2725,7 +2725,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.dflag = db->dflag; q.wide_base = db->wide_base;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
-        if (const char* e = getenv("KMDB_K1W_DEBUG")) { q.debug = (uint32_t)atoi(e); q.pool.nostore = q.debug == 1u ? 1u : 0u; }
+        q.pool.nostore = K1W_DEBUG == 1u ? 1u : 0u;
         q.run_nodes = K1W_RUN_NODES;
         if (const char* e = getenv("KMDB_K1W_RUN")) q.run_nodes = std::max<uint32_t>(64u, (uint32_t)atoi(e) / 64u * 64u);
         q.n_runs = (n_wide + q.run_nodes - 1) / q.run_nodes;

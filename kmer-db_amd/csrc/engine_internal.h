@@ -31,6 +31,10 @@ struct kmdb_engine_view {
     unsigned long long** list_sets;
     uint32_t* list_sets_nb;
     bool* list_sets_tried;
+    // run index of new2all.hip, kept with the handle: node i's local ids as runs rl_runs[rl_ofs[i] .. rl_ofs[i + 1]) (start | length << 16)
+    uint32_t** rl_ofs;
+    uint32_t** rl_runs;
+    bool* rl_tried;
     uint64_t* device_bytes;
     void* stream;
     void* ev[4];

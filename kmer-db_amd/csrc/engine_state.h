@@ -67,6 +67,11 @@ struct kmdb_db {
     unsigned long long* list_sets = nullptr;
     uint32_t list_sets_nb = 0;
     bool list_sets_tried = false;
+    // new2all's run index (new2all.hip): the local list of every node as runs of consecutive ids (start | length << 16), built on the
+    // first new2all call of the handle
+    uint32_t* rl_ofs = nullptr;     // [P + 1]
+    uint32_t* rl_runs = nullptr;
+    bool rl_tried = false;
     bool chain_ok = false;          // root paths fit the chain table of the emit kernel
     // ---- per-call working set of the block-record pipeline (contents rebuilt by every call)
     uint32_t width = 64;            // sample ids per block, picked at upload from a sampled estimate

@@ -8,7 +8,7 @@
 // Here a whole BATCH of queries runs through four device steps, all sized by the number of
 // k-mers / hits, never by the size of the database:
 //   probe   one thread per k-mer: bucket = kmer >> 32 (src/types.h:25-27), murmur3 fmix32 probe
-//           (src/hashmap_lp.h:53-64), key (query << 32 | DFS index of the hit pattern) or ~0
+//           (src/hashmap_lp.h:53-64), key (query << pbits | DFS index of the hit pattern; 2^pbits > patterns: only the bits in use are sorted) or ~0
 //   sort    radix sort of the keys: hits grouped by query, ascending DFS index inside a query
 //   count   run-length encode (pattern, hits) + exclusive scan of the hit counts
 //   walk    step (2) restated on the DFS layout of engine.hip.  With H(r) = hits in subtree(r) =
@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {        // murmur3 final
 // (1) probe: one thread per k-mer of the batch
 __global__ void n2a_probe_kernel(const uint64_t* __restrict__ kmers, const uint64_t* __restrict__ qoff, uint32_t nq, size_t total,
                                  uint64_t n_buckets, const uint64_t* __restrict__ bucket_offset, const uint64_t* __restrict__ slots,
-                                 const uint32_t* __restrict__ pid2dfs, const uint32_t* __restrict__ w,
+                                 const uint32_t* __restrict__ pid2dfs, const uint32_t* __restrict__ w, uint32_t pbits,
                                  unsigned long long* __restrict__ keys) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -68,7 +68,7 @@ __global__ void n2a_probe_kernel(const uint64_t* __restrict__ kmers, const uint6
                         // query of this k-mer: binary search in the batch's offsets
                         uint32_t lo = 0, hi = nq;
                         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (qoff[mid] <= i) lo = mid; else hi = mid; }
-                        key = ((unsigned long long)lo << 32) | d;
+                        key = ((unsigned long long)lo << pbits) | d;
                     }
                 }
             }
@@ -78,10 +78,10 @@ __global__ void n2a_probe_kernel(const uint64_t* __restrict__ kmers, const uint6
 }
 
 // first run of every query in the sorted, run-length-encoded hit list
-__global__ void n2a_query_ranges_kernel(const unsigned long long* __restrict__ uniq, uint32_t nruns, uint32_t nq, uint32_t* __restrict__ qstart) {
+__global__ void n2a_query_ranges_kernel(const unsigned long long* __restrict__ uniq, uint32_t nruns, uint32_t nq, uint32_t pbits, uint32_t* __restrict__ qstart) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nq) return;
-    const unsigned long long target = (unsigned long long)q << 32;
+    const unsigned long long target = (unsigned long long)q << pbits;
     uint32_t lo = 0, hi = nruns;                                  // first run with key >= target
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (uniq[mid] < target) lo = mid + 1; else hi = mid; }
     qstart[q] = lo;
@@ -123,14 +123,64 @@ struct N2Cursor {                                                 // gamma strea
 // The threads of a workgroup share one per-query histogram in LDS (4 B per sample).  512 threads: with 10 000 samples two
 // workgroups fit a CU (4 waves per SIMD).  1024 threads would fill the SIMDs, and were measured slower (71.4 against 59.0 ms per
 // 1000 queries: twice the threads behind every workgroup barrier and on the same histogram); KMDB_N2A_THREADS=1024 runs them.
-template <bool LDS_HIST, uint32_t N2_THREADS, uint32_t N2_QCAP>
+// ---- the run index: node i's local ids as runs of consecutive ids.  FILL = false counts the runs, true writes them (start | length << 16;
+// sample ids are below 2^16).  One thread per node; pattern_t::decodeSamples (src/pattern.cpp:99-109): first id = last - sum of the deltas.
+template <bool FILL>
+__global__ void n2a_runs_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos, const uint64_t* __restrict__ bits, uint32_t P,
+                                uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ofs, uint32_t* __restrict__ runs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > P) return;
+    uint32_t n = 0;
+    if (i < P) {
+        const uint4 m = meta[i];
+        const uint32_t l = m.y;
+        if (l) {
+            uint32_t id = m.z;
+            if (l > 1) {
+                N2Cursor c1(bits, bitpos[i]);
+                uint32_t sum = 0;
+                for (uint32_t rem = l - 1u; rem;) {
+                    const uint32_t z = c1.zeros(rem);
+                    sum += z; rem -= z;
+                    if (rem) { sum += c1.next(); --rem; }
+                }
+                id = m.z - sum;
+            }
+            uint32_t o = FILL ? ofs[i] : 0u, start = id, len = 1;
+            if (l > 1) {
+                N2Cursor c2(bits, bitpos[i]);
+                for (uint32_t rem = l - 1u; rem;) {
+                    const uint32_t z = c2.zeros(rem);
+                    len += z; rem -= z;
+                    if (rem) {
+                        const uint32_t d = c2.next();
+                        --rem;
+                        if (d == 1u) ++len;
+                        else { if (FILL) runs[o] = start | (len << 16); ++o; ++n; start += len - 1u + d; len = 1; }
+                    }
+                }
+            }
+            if (FILL) runs[o] = start | (len << 16);
+            ++n;
+        }
+    }
+    if (!FILL) cnt[i] = n;
+}
+
+// RUNIDX: the local lists come from the handle's run index (runs of consecutive ids, decoded once per handle) instead of the gamma
+// streams: every query used to decode the same lists again — the clade-level nodes are on the root paths of all queries of the clade —
+// and the queued long lists were half of the walk's time.
+constexpr uint32_t N2_RUNS_PER_PIECE = 8;  // runs of a queued long list per thread and step
+template <bool LDS_HIST, uint32_t N2_THREADS, uint32_t N2_QCAP, bool RUNIDX>
 __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned long long* __restrict__ uniq, const uint32_t* __restrict__ csum,
                                                        const uint32_t* __restrict__ qstart, uint32_t nruns, uint32_t nq,
                                                        const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos,
                                                        const int32_t* __restrict__ parent, const uint32_t* __restrict__ sub_end,
                                                        const uint64_t* __restrict__ bits, const uint32_t* __restrict__ ck_ofs,
-                                                       const uint64_t* __restrict__ ck_bit, const uint32_t* __restrict__ ck_id, uint32_t N,
+                                                       const uint64_t* __restrict__ ck_bit, const uint32_t* __restrict__ ck_id,
+                                                       const uint32_t* __restrict__ rl_ofs, const uint32_t* __restrict__ rl_runs, uint32_t N, uint32_t pbits,
                                                        uint32_t* __restrict__ sim) {
+    const unsigned long long pmask = (1ull << pbits) - 1ull;             // key = query << pbits | pattern; an unused slot's ~0 reads as the largest pattern
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[N2_THREADS / 64];      // part: wave totals of the scans
     __shared__ uint32_t q_n;
@@ -141,15 +191,15 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
     const uint32_t i = blk0 + threadIdx.x;
     const unsigned long long my_key = i < nruns ? uniq[i] : N2_INVALID;
     const bool live = my_key != N2_INVALID;
-    const uint32_t myq = live ? (uint32_t)(my_key >> 32) : 0xFFFFFFFFu;
-    w_pat[threadIdx.x] = (uint32_t)my_key;
+    const uint32_t myq = live ? (uint32_t)(my_key >> pbits) : 0xFFFFFFFFu;
+    w_pat[threadIdx.x] = (uint32_t)(my_key & pmask);
     w_cs[threadIdx.x] = i <= nruns ? csum[i] : 0u;
     if (threadIdx.x == 0) {
         const uint32_t j = blk0 + N2_THREADS;
-        w_pat[N2_THREADS] = j < nruns ? (uint32_t)uniq[j] : 0xFFFFFFFFu;
+        w_pat[N2_THREADS] = j < nruns ? (uint32_t)(uniq[j] & pmask) : 0xFFFFFFFFu;
         w_cs[N2_THREADS] = j <= nruns ? csum[j] : 0u;
     }
-    auto pat_at = [&](uint32_t x) -> uint32_t { const uint32_t o = x - blk0; return o <= N2_THREADS ? w_pat[o] : (uint32_t)uniq[x]; };      // x >= blk0
+    auto pat_at = [&](uint32_t x) -> uint32_t { const uint32_t o = x - blk0; return o <= N2_THREADS ? w_pat[o] : (uint32_t)(uniq[x] & pmask); };      // x >= blk0
     auto cs_at = [&](uint32_t x) -> uint32_t { const uint32_t o = x - blk0; return o <= N2_THREADS ? w_cs[o] : csum[x]; };
     // the block's runs are sorted by query: loop over the (few) queries it spans
     __shared__ uint32_t q_lo, q_hi;
@@ -166,8 +216,8 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
         uint32_t* acc = LDS_HIST ? hist : (sim + (size_t)q * N);
         if (live && myq == q) {
             const uint32_t qs = qstart[q], qe = qstart[q + 1];
-            const uint32_t h = (uint32_t)my_key;
-            const int64_t prev = i > qs ? (int64_t)(threadIdx.x ? w_pat[threadIdx.x - 1u] : (uint32_t)uniq[i - 1]) : -1;
+            const uint32_t h = (uint32_t)(my_key & pmask);
+            const int64_t prev = i > qs ? (int64_t)(threadIdx.x ? w_pat[threadIdx.x - 1u] : (uint32_t)(uniq[i - 1] & pmask)) : -1;
             const uint32_t cbase = w_cs[threadIdx.x];
             int64_t r = h;
             uint32_t ub = i + 1;                               // grows while climbing: an ancestor's subtree contains the node's
@@ -177,14 +227,19 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
             uint32_t se = sub_end[r];
             uint4 m = meta[r];
             int32_t par = parent[r];
-            uint64_t bp = bitpos[r];
+            uint64_t bp = RUNIDX ? 0ull : bitpos[r];
+            uint32_t ro = RUNIDX ? rl_ofs[r] : 0u, re = RUNIDX ? rl_ofs[r + 1] : 0u;
             while (r > prev) {
                 const int64_t rn = par;
                 uint32_t se_n = 0;
                 uint4 m_n = make_uint4(0u, 0u, 0u, 0u);
                 int32_t par_n = -1;
                 uint64_t bp_n = 0;
-                if (rn > prev) { se_n = sub_end[rn]; m_n = meta[rn]; par_n = parent[rn]; bp_n = bitpos[rn]; }
+                uint32_t ro_n = 0, re_n = 0;
+                if (rn > prev) {
+                    se_n = sub_end[rn]; m_n = meta[rn]; par_n = parent[rn];
+                    if (RUNIDX) { ro_n = rl_ofs[rn]; re_n = rl_ofs[rn + 1]; } else bp_n = bitpos[rn];
+                }
                 // hits below r: indices [i, ub), ub = first run of this query whose pattern is >= sub_end[r].  Searched from the
                 // previous ub in doubling steps: near the leaves a subtree holds a handful of hits, one or two probes find its end
                 uint32_t lo = ub, hi = ub, step = 1;
@@ -197,9 +252,14 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                 bool inl = l != 0;
                 if (l > KMDB_CK_IDS) {
                     const uint32_t slot = atomicAdd(&q_n, 1u);
-                    if (slot < N2_QCAP) { q_node[slot] = ck_ofs[r]; q_h[slot] = H; q_l[slot] = l; inl = false; }      // (the node's first checkpoint)      // a full queue: decoded here
+                    if (slot < N2_QCAP) { q_node[slot] = RUNIDX ? ro : ck_ofs[r]; q_h[slot] = H; q_l[slot] = RUNIDX ? re - ro : l; inl = false; }      // (the node's first run / checkpoint; a full queue: added here)
                 }
-                if (inl) {
+                if (inl && RUNIDX && l > 1) {
+                    for (uint32_t k = ro; k < re; ++k) {
+                        const uint32_t run = rl_runs[k];
+                        for (uint32_t id = run & 0xFFFFu, t = run >> 16; t; --t, ++id) atomicAdd(&acc[id], H);
+                    }
+                } else if (inl) {
                     uint32_t id = m.z;
                     if (l > 1) {
                         // pattern_t::decodeSamples (src/pattern.cpp:99-109): first id = last - sum of the deltas
@@ -221,7 +281,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                     }
                     atomicAdd(&acc[id], H);
                 }
-                r = rn; se = se_n; m = m_n; par = par_n; bp = bp_n;
+                r = rn; se = se_n; m = m_n; par = par_n; bp = bp_n; ro = ro_n; re = re_n;
             }
         }
         __syncthreads();
@@ -230,7 +290,8 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
         if (nt) {
             constexpr uint32_t PER = N2_QCAP / N2_THREADS ? N2_QCAP / N2_THREADS : 1u;
             uint32_t sum = 0;
-            for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) sum += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS;
+            constexpr uint32_t UNIT = RUNIDX ? N2_RUNS_PER_PIECE : KMDB_CK_IDS;      // runs / ids per piece
+            for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) sum += (q_l[t] + UNIT - 1u) / UNIT;
             // exclusive scan of the threads' piece counts: inside the waves by shuffles, the wave totals through LDS
             const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
             uint32_t incl = sum;
@@ -243,7 +304,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
             __syncthreads();
             uint32_t run = incl - sum, all = 0;
             for (uint32_t w2 = 0; w2 < N2_THREADS / 64u; ++w2) { const uint32_t pw = part[w2]; if (w2 < wv) run += pw; all += pw; }
-            for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) { q_pre[t] = run; run += (q_l[t] + KMDB_CK_IDS - 1u) / KMDB_CK_IDS; }
+            for (uint32_t t = threadIdx.x * PER; t < nt && t < (threadIdx.x + 1u) * PER; ++t) { q_pre[t] = run; run += (q_l[t] + UNIT - 1u) / UNIT; }
             if (threadIdx.x == 0) q_pre[nt] = all;
             __syncthreads();
             const uint32_t S = q_pre[nt];
@@ -265,6 +326,17 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                 uint32_t lo = 0, hi = nt;                       // the task whose pieces contain g: last t with q_pre[t] <= g
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (q_pre[mid] <= g) lo = mid; else hi = mid; }
                 const uint32_t piece = g - q_pre[lo], H = q_h[lo], l = q_l[lo];
+                if (RUNIDX) {
+                    const uint32_t k0 = q_node[lo] + piece * UNIT, left_r = l - piece * UNIT, nk = left_r < UNIT ? left_r : UNIT;
+                    for (uint32_t k = 0; k < nk; ++k) {
+                        const uint32_t run = rl_runs[k0 + k], start = run & 0xFFFFu, len = run >> 16;
+                        if (LDS_HIST) {
+                            atomicAdd(&hist[start], H);
+                            if (start + len < N) atomicAdd(&hist[start + len], 0u - H);
+                        } else for (uint32_t t = 0; t < len; ++t) atomicAdd(&acc[start + t], H);
+                    }
+                    continue;
+                }
                 const uint32_t o = q_node[lo] + piece;
                 uint32_t id = ck_id[o];
                 const uint32_t left = l - piece * KMDB_CK_IDS, cnt = left < KMDB_CK_IDS ? left : KMDB_CK_IDS;
@@ -337,6 +409,35 @@ struct DevBuf {
             return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+// the handle's run index (false: this handle does without one — no memory for it — and the walk decodes the gamma streams as before)
+static bool n2a_run_index(const kmdb_engine_view& e, hipStream_t st) {
+    if (*e.rl_ofs && *e.rl_runs) return true;
+    if (*e.rl_tried || !e.P || getenv("KMDB_N2A_NO_RUNS")) return false;
+    *e.rl_tried = true;
+    const uint32_t P = (uint32_t)e.P;
+    uint32_t *cnt = nullptr, *ofs = nullptr, *runs = nullptr;
+    void* tmp = nullptr;
+    auto fail = [&]() { (void)hipGetLastError(); for (void* p : {(void*)cnt, (void*)ofs, (void*)runs, tmp}) if (p) (void)hipFree(p); return false; };
+    if (hipMalloc((void**)&cnt, ((size_t)P + 1) * 4) != hipSuccess || hipMalloc((void**)&ofs, ((size_t)P + 1) * 4) != hipSuccess) return fail();
+    hipLaunchKernelGGL((n2a_runs_kernel<false>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, e.meta, e.bitpos, e.bits, P, cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    size_t tb = 0;
+    if (prim::exclusive_sum(nullptr, tb, cnt, ofs, (int)(P + 1), st) != hipSuccess || hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess) return fail();
+    if (prim::exclusive_sum(tmp, tb, cnt, ofs, (int)(P + 1), st) != hipSuccess) return fail();
+    uint32_t total = 0;
+    if (hipMemcpyAsync(&total, ofs + P, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
+    // (the running sum is 32 bits wide: a database with 2^32 runs or more would need far more than the sample limit allows)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)total * 4 + (1ull << 30) > free_b / 2) return fail();
+    if (hipMalloc((void**)&runs, std::max<size_t>((size_t)total, 1) * 4) != hipSuccess) return fail();
+    hipLaunchKernelGGL((n2a_runs_kernel<true>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, e.meta, e.bitpos, e.bits, P, (uint32_t*)nullptr, (const uint32_t*)ofs, runs);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
+    (void)hipFree(cnt); (void)hipFree(tmp);
+    *e.rl_ofs = ofs; *e.rl_runs = runs;
+    *e.device_bytes += ((uint64_t)P + 1) * 4 + (uint64_t)total * 4;
+    if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] new2all: run index of %u nodes, %u runs (%.2f GB)\n", P, total, (((double)P + 1) * 4 + (double)total * 4) / 1e9);
+    return true;
+}
+
 // probe / sort / count / walk over a batch whose k-mers (sorted and unique per query, query by query) and
 // query offsets are already on the device
 static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, const uint64_t* d_kmers, const uint64_t* d_qoff_p,
@@ -360,20 +461,24 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
     N2_TRY(d_tmp.alloc(std::max(tb_sort, std::max(tb_rle, tb_scan))));
     N2_TRY(hipMemsetAsync(d_sim.p, 0, std::max<uint64_t>(nq * N * 4, 4), st));
 
+    // the run index of the handle: made on its first new2all call (outside the call's device time, inside its wall time)
+    const bool runidx = n2a_run_index(e, st);
     hipEvent_t ev0 = (hipEvent_t)e.ev[0], ev3 = (hipEvent_t)e.ev[3];
     N2_TRY(hipEventRecord(ev0, st));
     uint32_t nruns = 0;
     if (total) {
         const unsigned blocks = (unsigned)std::min<size_t>(65535, (total + 255) / 256);
-        hipLaunchKernelGGL(n2a_probe_kernel, dim3(blocks), dim3(256), 0, st, d_kmers, d_qoff_p, (uint32_t)nq,
-                           total, e.n_buckets, e.bucket_offset, e.slots, e.pid2dfs, e.w, d_keys.as<unsigned long long>());
-        N2_TRY(hipGetLastError());
-        // only the bits in use are sorted: 32 of the pattern, and as many as the queries need (the unused slots' ~0 is all ones in
-        // those too, and no key in use is)
-        unsigned qbits = 1;
+        // key = query << pbits | pattern with 2^pbits > patterns, 2^qbits >= queries: only the bits in use are sorted (the unused slots' ~0
+        // is all ones in those too, and no key in use is — its pattern bits are below 2^pbits - 1 or its query bits below 2^qbits - 1...
+        // the pattern field of a key in use is a DFS index < P <= 2^pbits - 1)
+        uint32_t pbits = 1, qbits = 1;
+        while ((1ull << pbits) <= e.P) ++pbits;
         while ((1ull << qbits) < nq) ++qbits;
+        hipLaunchKernelGGL(n2a_probe_kernel, dim3(blocks), dim3(256), 0, st, d_kmers, d_qoff_p, (uint32_t)nq,
+                           total, e.n_buckets, e.bucket_offset, e.slots, e.pid2dfs, e.w, pbits, d_keys.as<unsigned long long>());
+        N2_TRY(hipGetLastError());
         N2_TRY(prim::sort_keys(d_tmp.p, tb_sort, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
-                                                 (int)total, 0, std::min(64u, 32u + qbits), st));
+                                                 (int)total, 0, std::min(64u, pbits + qbits), st));
         N2_TRY(hipMemsetAsync(d_cnt.p, 0, (total + 2) * 4, st));
         N2_TRY(prim::run_length_encode(d_tmp.p, tb_rle, d_keys2.as<unsigned long long>(), d_uniq.as<unsigned long long>(),
                                                      d_cnt.as<uint32_t>(), d_nruns.as<uint32_t>(), (int)total, st));
@@ -381,7 +486,7 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
         N2_TRY(hipStreamSynchronize(st));
         N2_TRY(prim::exclusive_sum(d_tmp.p, tb_scan, d_cnt.as<uint32_t>(), d_csum.as<uint32_t>(), (int)(nruns + 1), st));
         hipLaunchKernelGGL(n2a_query_ranges_kernel, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st,
-                           d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, d_qstart.as<uint32_t>());
+                           d_uniq.as<unsigned long long>(), nruns, (uint32_t)nq, pbits, d_qstart.as<uint32_t>());
         if (nruns) {
             // LDS of a workgroup: the per-query histogram (4 B per sample) + the queue of long lists (16 B per entry) + 12 B per thread
             // (scan scratch, the workgroup's stretch of the hit list)
@@ -392,12 +497,17 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
             if (const char* ev = getenv("KMDB_N2A_THREADS")) if (atoi(ev) == 1024) threads = 1024;
             const bool lds_hist = N * 4 + qcap * 16 + threads * 8 + 1024 <= 64 * 1024;
             const unsigned wblocks = (nruns + threads - 1) / threads;
-#define N2A_WALK(H, T, Q)                                                                                                                \
-    hipLaunchKernelGGL((n2a_walk_kernel<H, T, Q>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),         \
+#define N2A_WALK(H, T, Q, R)                                                                                                             \
+    hipLaunchKernelGGL((n2a_walk_kernel<H, T, Q, R>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),      \
                        d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent, e.sub_end,       \
-                       e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (uint32_t)N, d_sim.as<uint32_t>())
-            if (threads == 1024) { if (lds_hist) N2A_WALK(true, 1024, 1024); else N2A_WALK(false, 1024, 1024); }
-            else { if (lds_hist) N2A_WALK(true, 512, 1024); else N2A_WALK(false, 512, 1024); }
+                       e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (const uint32_t*)*e.rl_ofs, (const uint32_t*)*e.rl_runs, (uint32_t)N, pbits, d_sim.as<uint32_t>())
+            if (runidx) {
+                if (threads == 1024) { if (lds_hist) N2A_WALK(true, 1024, 1024, true); else N2A_WALK(false, 1024, 1024, true); }
+                else { if (lds_hist) N2A_WALK(true, 512, 1024, true); else N2A_WALK(false, 512, 1024, true); }
+            } else {
+                if (threads == 1024) { if (lds_hist) N2A_WALK(true, 1024, 1024, false); else N2A_WALK(false, 1024, 1024, false); }
+                else { if (lds_hist) N2A_WALK(true, 512, 1024, false); else N2A_WALK(false, 512, 1024, false); }
+            }
 #undef N2A_WALK
         }
         N2_TRY(hipGetLastError());
