@@ -380,12 +380,12 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
         __shared__ uint16_t order[256];
         if (threadIdx.x < 64) bins[threadIdx.x] = 0;
         __syncthreads();
-        const uint2 kt = t < q.P ? q.k0in[t] : make_uint2(0u, 0u);          // {l | last id << 16, stream bits}
-        const uint32_t tl = kt.x & 0xFFFFu;
+        const uint2 kt = t < q.P ? q.k0in[t] : make_uint2(0u, 0u);          // l, last id, stream bits (kmdb_k0_pack)
+        const uint32_t tl = kmdb_k0_l(kt), tbits = kmdb_k0_bits(kt);
         // work of a node ~ number of codes that are not "0" ~ stream bits beyond one per delta
         uint32_t key = 0;                                                    // 0: nothing to decode here
-        if (t < q.P && tl > 1 && !kmdb_long_node(tl, kt.y)) {
-            key = 1u + (kt.y - (tl - 1u));
+        if (t < q.P && tl > 1 && !kmdb_long_node(tl, tbits)) {
+            key = 1u + (tbits - (tl - 1u));
             key = key > 63u ? 63u : key;
         }
         atomicAdd(&bins[63u - key], 1u);                                     // bin 0 = most work
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     }
     const BlockMap bm = q.bm;
     const uint2 km = live ? q.k0in[i] : make_uint2(0u, 0u);
-    const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16, nbits = km.y;
+    const uint32_t l = kmdb_k0_l(km), last = kmdb_k0_last(km), nbits = kmdb_k0_bits(km);
     if (!q.perm && kmdb_long_node(l, nbits)) live = false;
     using Cursor = RunCursor32<LONG ? 16 : 6, LONG>;
     uint32_t npairs = 0, blk0 = 0, need = 0, span = 0, bit0 = 0;
@@ -619,7 +619,7 @@ __device__ __forceinline__ NSum nsum_shfl_up(const NSum& s, int d) {
 }
 
 struct NParams {
-    const uint32_t* nl;            // n | l << 16
+    const uint32_t* nl;            // n
     const int32_t* parent;
     const uint32_t* w;
     const uint16_t* dflag;         // depth | has-child << 15
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         }
         // ---- records (flat form): (w0, w0, F0), and with a second block (w1, w0, F1, F0) and (w1, w1, F1).  A diagonal
         // record needs two ids to have a pair.
-        const bool act = valid && !wide && w != 0 && (nl & 0xFFFFu) >= 2u && w0 != BNONE && idx >= q.emit_lo && idx < q.emit_hi;
+        const bool act = valid && !wide && w != 0 && nl >= 2u && w0 != BNONE && idx >= q.emit_lo && idx < q.emit_hi;
         // (w0, w0, F0): the lanes of a batch mostly share the block — one reservation per block in that block's open chunk.
         // (In wide mode, q.all_wide, these records take the wide pool as well.)
         const bool d0 = act && __popcll(F0) >= 2;
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             const uint32_t node = valid ? q.widx[k0 + lane] : 0u;
             const uint32_t nlv = valid ? q.nl[node] : 0u;
             const uint32_t wv = valid ? q.w[node] : 0u;
-            const bool act = valid && wv != 0 && (nlv & 0xFFFFu) >= 2u && node >= q.emit_lo && node < q.emit_hi;
+            const bool act = valid && wv != 0 && nlv >= 2u && node >= q.emit_lo && node < q.emit_hi;
             const int32_t par = valid ? q.parent[node] : -1;
             const uint32_t dep = valid ? (uint32_t)(q.dflag[node] & 0x7FFFu) : 0x7FFFu;
             const uint32_t info = valid ? q.p0_info[node] : 0u;
@@ -2084,14 +2084,14 @@ __global__ void width_estimate_kernel(const EstParams q) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t i0 = (uint64_t)t * q.stride + (t * 2654435761u) % q.stride;
     const uint32_t node = (uint32_t)i0;
-    const bool on = i0 < q.P && q.w[node] != 0 && (q.nl[node] & 0xFFFFu) >= 2u;
+    const bool on = i0 < q.P && q.w[node] != 0 && q.nl[node] >= 2u;
     uint32_t nblk[EST_NW], lower_first[EST_NW];
 #pragma unroll
     for (int c = 0; c < EST_NW; ++c) { nblk[c] = 0; lower_first[c] = 0xFFFFFFFFu; }
     int32_t y = on ? (int32_t)node : -1;
     while (y >= 0) {
         const uint2 km = q.k0in[y];
-        const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16;
+        const uint32_t l = kmdb_k0_l(km), last = kmdb_k0_last(km);
         if (l) {
             const uint64_t pos = q.blkbase[(uint32_t)y >> 8] + q.bitrel[y];
             uint32_t sum = 0;
@@ -2137,7 +2137,7 @@ __global__ void pair_estimate_kernel(const uint2* __restrict__ k0in, const uint3
     unsigned long long need = 0;
     if (i0 < P) {
         const uint2 km = k0in[i0];
-        const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16;
+        const uint32_t l = kmdb_k0_l(km), last = kmdb_k0_last(km);
         if (l > 1) {
             BitCursor c(bits, blkbase[(uint32_t)i0 >> 8] + bitrel[i0]);
             uint32_t span = 0;
@@ -2159,7 +2159,7 @@ __global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t*
     if (i >= P) return;
     const uint2 km = k0in[i];
     const uint32_t v = nl[i];
-    meta[i] = make_uint4(v & 0xFFFFu, km.x & 0xFFFFu, km.x >> 16, km.y);
+    meta[i] = make_uint4(v, kmdb_k0_l(km), kmdb_k0_last(km), kmdb_k0_bits(km));
     bitpos[i] = blkbase[i >> 8] + bitrel[i];
 }
 
@@ -2266,7 +2266,7 @@ int alloc_pair_pool(kmdb_db* db, uint64_t entries) {
 __global__ void ck_count_kernel(const uint2* __restrict__ k0in, uint32_t P, uint32_t* __restrict__ cnt) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > P) return;
-    const uint32_t l = i < P ? (k0in[i].x & 0xFFFFu) : 0u;
+    const uint32_t l = i < P ? kmdb_k0_l(k0in[i]) : 0u;
     cnt[i] = l > KMDB_CK_IDS ? (l + KMDB_CK_IDS - 1u) / KMDB_CK_IDS : 0u;
 }
 __global__ void ck_fill_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ bitrel, const uint64_t* __restrict__ blkbase,
@@ -2275,7 +2275,7 @@ __global__ void ck_fill_kernel(const uint2* __restrict__ k0in, const uint32_t* _
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const uint2 km = k0in[i];
-    const uint32_t l = km.x & 0xFFFFu, last = km.x >> 16;
+    const uint32_t l = kmdb_k0_l(km), last = kmdb_k0_last(km);
     if (l <= KMDB_CK_IDS) return;
     const uint64_t pos = blkbase[i >> 8] + bitrel[i];
     uint32_t sum = 0;

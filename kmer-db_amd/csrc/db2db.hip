@@ -360,7 +360,7 @@ static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmd
         return kmdb_set_error("kmdb_db2db_dense: both databases must be uploaded with hashtables");
     if (er.kmer_length != ec.kmer_length) return kmdb_set_error("kmdb_db2db_dense: the databases have different k-mer lengths");
     if (er.device != ec.device) return kmdb_set_error("kmdb_db2db_dense: the databases live on different devices");
-    if (er.N > 65535 || ec.N > 65535) return kmdb_set_error("kmdb_db2db_dense: more than 65535 samples is not supported yet");
+    if (er.N > KMDB_V1_MAX_SAMPLES || ec.N > KMDB_V1_MAX_SAMPLES) return kmdb_set_error("kmdb_db2db_dense: more than 65535 samples per database is not supported (16-bit block index of the pair kernel)");
     D2_TRY(hipSetDevice(er.device));
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : (hipStream_t)er.stream;
     const uint64_t nr = er.N, nc = ec.N;

@@ -145,7 +145,7 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     if (opts && (opts->flags & ~KMDB_FLAG_ALL)) return kmdb_set_error("kmdb_db_upload: unknown bits in kmdb_opts.flags");
     const uint64_t P = v->n_patterns, N = v->n_samples;
     if (P >= (1ull << 31)) return kmdb_set_error("kmdb_db_upload: more than 2^31 patterns");
-    if (N > 65535) return kmdb_set_error("kmdb_db_upload: more than 65535 samples is not supported yet");
+    if (N >= KMDB_MAX_SAMPLES) return kmdb_set_error("kmdb_db_upload: " + std::to_string(KMDB_MAX_SAMPLES) + " samples or more are not supported (sample ids take " + std::to_string(KMDB_ID_BITS) + " bits in the device layout)");
     if (shard_count == 0 || shard_index >= shard_count) return kmdb_set_error("kmdb_db_upload_shard: shard_index >= shard_count");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -305,6 +305,9 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
         if (shard_count > 1) return kmdb_set_error("kmdb_all2all: slices of the pattern stream (kmdb_opts.shard_count > 1) need the block-record pipeline: " + db->fallback_reason);
     }
     // v1 kernels: tree form, subtree weights (reference similarity_calculator.cpp:64-72) = exclusive scan of w in DFS order
+    if (N > KMDB_V1_MAX_SAMPLES)
+        return kmdb_set_error("kmdb_all2all: the HBM-atomics kernels keep sample ids in 16 bits (at most " + std::to_string(KMDB_V1_MAX_SAMPLES) + " samples)" +
+                              (forced_v1 ? std::string() : "; the block-record pipeline cannot take this database: " + db->fallback_reason));
     if (kmdb_ensure_v1_arrays(db)) return 1;
     HIP_TRY(hipMemsetAsync(db->v1_counters, 0, 8 * sizeof(unsigned long long), st));
     HIP_TRY(prim::exclusive_sum(db->v1_scan_tmp, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1), st));

@@ -3,6 +3,7 @@
 #pragma once
 #include "kmdb_amd.h"
 #include "kmdb_internal.h"
+#include "engine_internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -45,12 +46,12 @@ struct kmdb_db {
     uint32_t kmer_length = 0;
     // ---- structural layout (upload): a pure format conversion of the on-disk pattern section, DFS pre-order.
     // Nothing here depends on a decoded sample id.
-    uint2* k0in = nullptr;          // [P] {l | last id << 16, stream bits}
+    uint2* k0in = nullptr;          // [P] local-list head of the node: l, last id, stream bits (packed: kmdb_k0_pack)
     uint32_t* bitrel = nullptr;     // [P] stream position relative to blkbase[i / 256]
     uint64_t* blkbase = nullptr;    // [P / 256]
     uint64_t* bits = nullptr;       // gamma streams bit-packed back to back
     uint64_t n_bit_words = 0;
-    uint32_t* nl = nullptr;         // [P] n | l << 16
+    uint32_t* nl = nullptr;         // [P] n = ids of the node's full list
     int32_t* parent = nullptr;      // [P] DFS index of the parent, -1 for roots
     uint32_t* w = nullptr;          // [P+1] on-disk num_kmers truncated to u32 (last = 0); a prefix shard keeps only its own k-mers
     uint16_t* dflag = nullptr;      // [P] root path length (root = 1) | has-child << 15
@@ -67,7 +68,7 @@ struct kmdb_db {
     unsigned long long* list_sets = nullptr;
     uint32_t list_sets_nb = 0;
     bool list_sets_tried = false;
-    // new2all's run index (new2all.hip): the local list of every node as runs of consecutive ids (start | length << 16), built on the
+    // new2all's run index (new2all.hip): the local list of every node as runs of consecutive ids (start | length << rs), built on the
     // first new2all call of the handle
     uint32_t* rl_ofs = nullptr;     // [P + 1]
     uint32_t* rl_runs = nullptr;
@@ -192,6 +193,18 @@ struct kmdb_db {
 
 // K0 decodes a node in the coalesced DFS-order launch when its stream is short enough to sit in three
 // registers; the others (a few percent) go to a second launch, longest list first.
+// Head of a node's local list as K0 reads it, 8 bytes: l and the last id in 20 bits each, the length of the gamma stream in 24 (l ids below
+// 2^20 need fewer than 1.6 * 2^20 stream bits: a delta of 2 costs 3 bits, the dearest per unit of id range).  Sample ids are therefore
+// below KMDB_MAX_SAMPLES; the upload checks all three fields.
+constexpr uint32_t KMDB_MAX_STREAM_BITS = 1u << 24;            // (KMDB_ID_BITS, KMDB_MAX_SAMPLES: engine_internal.h)
+__host__ __device__ inline uint2 kmdb_k0_pack(uint32_t l, uint32_t last, uint32_t nbits) {
+    uint2 r;
+    r.x = l | ((nbits >> 12) << KMDB_ID_BITS); r.y = last | ((nbits & 0xFFFu) << KMDB_ID_BITS);
+    return r;
+}
+__host__ __device__ inline uint32_t kmdb_k0_l(uint2 km) { return km.x & (KMDB_MAX_SAMPLES - 1u); }
+__host__ __device__ inline uint32_t kmdb_k0_last(uint2 km) { return km.y & (KMDB_MAX_SAMPLES - 1u); }
+__host__ __device__ inline uint32_t kmdb_k0_bits(uint2 km) { return ((km.x >> KMDB_ID_BITS) << 12) | (km.y >> KMDB_ID_BITS); }
 constexpr uint32_t KMDB_SHORT_MAX_IDS = 32, KMDB_SHORT_MAX_BITS = 128;
 __host__ __device__ inline bool kmdb_long_node(uint32_t l, uint32_t num_bits) { return l > KMDB_SHORT_MAX_IDS || num_bits > KMDB_SHORT_MAX_BITS; }
 constexpr int KMDB_CHAIN_MAX = 4096;  // longest root path (in nodes) the chain table of the narrow kernel holds (20 B of LDS per node and wave:

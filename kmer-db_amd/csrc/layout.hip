@@ -97,7 +97,7 @@ __global__ void lay_order_kernel(const uint32_t* __restrict__ acc, uint32_t P, u
 struct LayStats { unsigned long long alg, upd, pairs; uint32_t max_n, max_depth, bad, n_long; };
 __global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ acc, const uint32_t* __restrict__ dep,
                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ size, const int32_t* __restrict__ parent,
-                                  const uint32_t* __restrict__ h_ll, const uint32_t* __restrict__ h_n, const uint32_t* __restrict__ h_nbits,
+                                  const uint32_t* __restrict__ h_l, const uint32_t* __restrict__ h_last, const uint32_t* __restrict__ h_n, const uint32_t* __restrict__ h_nbits,
                                   const uint32_t* __restrict__ h_w, const unsigned long long* __restrict__ h_wfull, uint32_t P,
                                   uint2* __restrict__ k0in, uint32_t* __restrict__ nl, int32_t* __restrict__ dparent, uint32_t* __restrict__ w,
                                   uint16_t* __restrict__ dflag, uint32_t* __restrict__ sub_end, LayStats* __restrict__ st) {
@@ -107,9 +107,9 @@ __global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= P; i += gridDim.x * blockDim.x) {
         if (i == P) { w[P] = 0; break; }
         const uint32_t pid = order[i];
-        const uint32_t ll = h_ll[pid], n = h_n[pid], nb = h_nbits[pid], l = ll & 0xFFFFu;
-        k0in[i] = make_uint2(ll, nb);
-        nl[i] = n | (l << 16);
+        const uint32_t l = h_l[pid], n = h_n[pid], nb = h_nbits[pid];
+        k0in[i] = kmdb_k0_pack(l, h_last[pid], nb);
+        nl[i] = n;
         const int32_t par = parent[pid];
         dparent[i] = par < 0 ? -1 : (int32_t)(acc[par] - 1u);
         w[i] = h_w[pid];
@@ -141,7 +141,7 @@ __global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint
 }
 __global__ void lay_nbits_dfs_kernel(const uint2* __restrict__ k0in, uint32_t P, uint32_t* __restrict__ nb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) nb[i] = k0in[i].y;
+    if (i < P) nb[i] = kmdb_k0_bits(k0in[i]);
 }
 __global__ void lay_blkbase_kernel(const uint64_t* __restrict__ dstpos, uint32_t P, uint64_t* __restrict__ blkbase, uint32_t* __restrict__ bitrel) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,7 +156,7 @@ __global__ void lay_copy_bits_kernel(const uint32_t* __restrict__ order, const u
                                      const uint2* __restrict__ k0in, const uint64_t* __restrict__ src, uint32_t P, unsigned long long* __restrict__ dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const uint32_t nb = k0in[i].y;
+    const uint32_t nb = kmdb_k0_bits(k0in[i]);
     if (!nb) return;
     uint64_t sp = srcpos[order[i]], dp = dstpos[i];
     for (uint32_t done = 0; done < nb; done += 64) {
@@ -174,14 +174,14 @@ __global__ void lay_copy_bits_kernel(const uint32_t* __restrict__ order, const u
 // long nodes: selected in DFS order (stable partition), then ordered by work
 struct LongNodePred {
     const uint2* k0in;
-    __host__ __device__ bool operator()(uint32_t i) const { const uint2 km = k0in[i]; return kmdb_long_node(km.x & 0xFFFFu, km.y); }
+    __host__ __device__ bool operator()(uint32_t i) const { const uint2 km = k0in[i]; return kmdb_long_node(kmdb_k0_l(km), kmdb_k0_bits(km)); }
 };
 __global__ void lay_long_keys_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ keys) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint2 km = k0in[idx[t]];
-    const uint32_t l = km.x & 0xFFFFu;
-    keys[t] = km.y - (l ? l - 1u : 0u);                     // work of a node ~ stream bits beyond one per delta
+    const uint32_t l = kmdb_k0_l(km);
+    keys[t] = kmdb_k0_bits(km) - (l ? l - 1u : 0u);                     // work of a node ~ stream bits beyond one per delta
 }
 // root path of the first node of every slice, root first
 __global__ void lay_seg_anc_kernel(const int32_t* __restrict__ parent, const uint16_t* __restrict__ dflag, uint32_t P, uint32_t nseg_nodes, uint32_t n_segs,
@@ -221,15 +221,16 @@ __global__ void lay_keep_up_kernel(const int32_t* __restrict__ parent, uint32_t 
     if (par >= 0 && !__atomic_load_n(&keep[par], __ATOMIC_RELAXED)) { __atomic_store_n(&keep[par], 1u, __ATOMIC_RELAXED); *changed = 1u; }
 }
 __global__ void lay_compact_kernel(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ newidx, const int32_t* __restrict__ parent,
-                                   const uint32_t* __restrict__ ll, const uint32_t* __restrict__ n, const uint32_t* __restrict__ nbits, const uint32_t* __restrict__ w,
-                                   const uint64_t* __restrict__ spos, uint32_t P, int32_t* __restrict__ parent2, uint32_t* __restrict__ ll2, uint32_t* __restrict__ n2,
+                                   const uint32_t* __restrict__ ll, const uint32_t* __restrict__ last, const uint32_t* __restrict__ n, const uint32_t* __restrict__ nbits,
+                                   const uint32_t* __restrict__ w, const uint64_t* __restrict__ spos, uint32_t P, int32_t* __restrict__ parent2, uint32_t* __restrict__ ll2,
+                                   uint32_t* __restrict__ last2, uint32_t* __restrict__ n2,
                                    uint32_t* __restrict__ nbits2, uint32_t* __restrict__ w2, uint64_t* __restrict__ spos2) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P || !keep[i]) return;
     const uint32_t o = newidx[i];
     const int32_t par = parent[i];
     parent2[o] = par < 0 ? -1 : (int32_t)newidx[par];
-    ll2[o] = ll[i]; n2[o] = n[i]; nbits2[o] = nbits[i]; w2[o] = w[i]; spos2[o] = spos[i];
+    ll2[o] = ll[i]; last2[o] = last[i]; n2[o] = n[i]; nbits2[o] = nbits[i]; w2[o] = w[i]; spos2[o] = spos[i];
 }
 
 // Host staging buffers of the upload: anonymous mappings, handed to the database handle and given back piece by piece by a helper
@@ -297,8 +298,8 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned T = (unsigned)std::min<uint64_t>(std::min(64u, hw), std::max<uint64_t>(1, P / 65536));
     HostBuf<int32_t> h_parent(P);                             // not zero-filled: the pages are first touched by the worker threads
-    HostBuf<uint32_t> h_ll(P), h_n(P), h_nbits(P), h_w(P);
-    if (!h_parent.p || !h_ll.p || !h_n.p || !h_nbits.p || !h_w.p) return kmdb_set_error("kmdb_db_upload: out of host memory");
+    HostBuf<uint32_t> h_ll(P), h_last(P), h_n(P), h_nbits(P), h_w(P);
+    if (!h_parent.p || !h_ll.p || !h_last.p || !h_n.p || !h_nbits.p || !h_w.p) return kmdb_set_error("kmdb_db_upload: out of host memory");
     std::vector<uint64_t> part_bits(T + 1, 0);
     std::atomic<int> bad{0};
     auto run_parts = [&](auto&& fn) {
@@ -313,9 +314,10 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
             const int64_t par = v->parent_id[p];
             const uint32_t n = v->num_samples[p], l = v->num_local[p], nb = v->num_bits[p], last = v->last_sample_id[p];
             if (par >= (int64_t)p) bad = 1;
-            if (l > n || n > N || l > 0xFFFFu || (l && last >= N) || n > 0xFFFFu) bad = 2;
+            if (l > n || n > N || (l && last >= N) || nb >= KMDB_MAX_STREAM_BITS) bad = 2;      // (N < KMDB_MAX_SAMPLES: checked by the caller)
             h_parent[p] = par < 0 ? -1 : (int32_t)par;
-            h_ll[p] = l | (last << 16);
+            h_ll[p] = l;
+            h_last[p] = l ? last : 0u;
             h_n[p] = n;
             h_nbits[p] = nb;
             h_w[p] = (uint32_t)v->num_kmers[p];                // truncated exactly like the reference's to_add (similarity_calculator.cpp:222)
@@ -352,11 +354,12 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
 
     // ---- H2D
     DevTmp<int32_t> d_parent;
-    DevTmp<uint32_t> d_ll, d_n, d_nbits, d_w;
+    DevTmp<uint32_t> d_ll, d_last, d_n, d_nbits, d_w;
     DevTmp<uint64_t> d_src;
-    if (d_parent.alloc(P) || d_ll.alloc(P) || d_n.alloc(P) || d_nbits.alloc(P) || d_w.alloc(P) || d_src.alloc(n_bit_words)) return 1;
+    if (d_parent.alloc(P) || d_ll.alloc(P) || d_last.alloc(P) || d_n.alloc(P) || d_nbits.alloc(P) || d_w.alloc(P) || d_src.alloc(n_bit_words)) return 1;
     HIP_TRY(hipMemcpyAsync(d_parent.p, h_parent.p, P * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_ll.p, h_ll.p, P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_last.p, h_last.p, P * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_n.p, h_n.p, P * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_nbits.p, h_nbits.p, P * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_w.p, h_w.p, P * 4, hipMemcpyHostToDevice, st));
@@ -426,20 +429,20 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         HIP_TRY(hipStreamSynchronize(st));
         if (P2 && P2 < P) {
             DevTmp<int32_t> parent2;
-            DevTmp<uint32_t> ll2, n2, nbits2, w2;
-            if (parent2.alloc(P2) || ll2.alloc(P2) || n2.alloc(P2) || nbits2.alloc(P2) || w2.alloc(P2) || d_spos.alloc(P2 + 1)) return 1;
-            hipLaunchKernelGGL(lay_compact_kernel, dim3(G), dim3(B), 0, st, keep.p, newidx.p, d_parent.p, d_ll.p, d_n.p, d_nbits.p, d_w.p, spos.p, (uint32_t)P,
-                               parent2.p, ll2.p, n2.p, nbits2.p, w2.p, d_spos.p);
+            DevTmp<uint32_t> ll2, last2, n2, nbits2, w2;
+            if (parent2.alloc(P2) || ll2.alloc(P2) || last2.alloc(P2) || n2.alloc(P2) || nbits2.alloc(P2) || w2.alloc(P2) || d_spos.alloc(P2 + 1)) return 1;
+            hipLaunchKernelGGL(lay_compact_kernel, dim3(G), dim3(B), 0, st, keep.p, newidx.p, d_parent.p, d_ll.p, d_last.p, d_n.p, d_nbits.p, d_w.p, spos.p, (uint32_t)P,
+                               parent2.p, ll2.p, last2.p, n2.p, nbits2.p, w2.p, d_spos.p);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(st));
-            std::swap(d_parent.p, parent2.p); std::swap(d_ll.p, ll2.p); std::swap(d_n.p, n2.p); std::swap(d_nbits.p, nbits2.p); std::swap(d_w.p, w2.p);
+            std::swap(d_parent.p, parent2.p); std::swap(d_ll.p, ll2.p); std::swap(d_last.p, last2.p); std::swap(d_n.p, n2.p); std::swap(d_nbits.p, nbits2.p); std::swap(d_w.p, w2.p);
             if (verbose) fprintf(stderr, "[kmdb] upload: prefix shard %u / %u keeps %u of %llu patterns\n", shard_index, shard_count, P2, (unsigned long long)P);
             P = P2; db->P = P2;
             G = (unsigned)((P + B - 1) / B); G1 = (unsigned)((P + 1 + B - 1) / B);
         }
         phase("shard: nodes the shard needs");
     }
-    for (HostRegion r : {h_parent.release(), h_ll.release(), h_n.release(), h_nbits.release(), h_w.release(), h_bits.release()})
+    for (HostRegion r : {h_parent.release(), h_ll.release(), h_last.release(), h_n.release(), h_nbits.release(), h_w.release(), h_bits.release()})
         if (r.p) db->staging.emplace_back(r.p, r.bytes);
 
     // ---- device: DFS pre-order
@@ -548,7 +551,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         if (d_wfull.alloc(P)) return 1;
         HIP_TRY(hipMemcpyAsync(d_wfull.p, v->num_kmers, P * 8, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(lay_gather_kernel, dim3(std::min<unsigned>(G1, 2048u)), dim3(B), 0, st, order.p, acc[cur].p, dep[dcur].p, cnt.p, size.p, d_parent.p, d_ll.p, d_n.p, d_nbits.p, d_w.p,
+    hipLaunchKernelGGL(lay_gather_kernel, dim3(std::min<unsigned>(G1, 2048u)), dim3(B), 0, st, order.p, acc[cur].p, dep[dcur].p, cnt.p, size.p, d_parent.p, d_ll.p, d_last.p, d_n.p, d_nbits.p, d_w.p,
                        d_wfull.p, (uint32_t)P, db->k0in, db->nl, db->parent, db->w, db->dflag, db->sub_end, d_stats.p);
     HIP_TRY(hipGetLastError());
     LayStats hs{};
@@ -563,7 +566,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         hipLaunchKernelGGL(lay_pid2dfs_kernel, dim3(G), dim3(B), 0, st, acc[cur].p, (uint32_t)P, db->pid2dfs);
         HIP_TRY(hipStreamSynchronize(st));
     }
-    d_wfull.reset(); d_ll.reset(); d_n.reset(); d_w.reset(); size.reset(); cnt.reset(); dep[dcur].reset(); d_parent.reset();
+    d_wfull.reset(); d_ll.reset(); d_last.reset(); d_n.reset(); d_w.reset(); size.reset(); cnt.reset(); dep[dcur].reset(); d_parent.reset();
     phase("device: node arrays");
 
     // ---- streams re-packed in DFS order

@@ -123,14 +123,17 @@ struct N2Cursor {                                                 // gamma strea
 // The threads of a workgroup share one per-query histogram in LDS (4 B per sample).  512 threads: with 10 000 samples two
 // workgroups fit a CU (4 waves per SIMD).  1024 threads would fill the SIMDs, and were measured slower (71.4 against 59.0 ms per
 // 1000 queries: twice the threads behind every workgroup barrier and on the same histogram); KMDB_N2A_THREADS=1024 runs them.
-// ---- the run index: node i's local ids as runs of consecutive ids.  FILL = false counts the runs, true writes them (start | length << 16;
-// sample ids are below 2^16).  One thread per node; pattern_t::decodeSamples (src/pattern.cpp:99-109): first id = last - sum of the deltas.
+// ---- the run index: node i's local ids as runs of consecutive ids.  FILL = false counts the runs, true writes them (start | length << rs,
+// rs = n2a_run_shift(N): 16 bits of start up to 65 536 samples, else KMDB_ID_BITS, and a run too long for the bits left is stored as
+// several).  One thread per node; pattern_t::decodeSamples (src/pattern.cpp:99-109): first id = last - sum of the deltas.
+__host__ __device__ inline uint32_t n2a_run_shift(uint32_t N) { return N <= 65536u ? 16u : KMDB_ID_BITS; }
 template <bool FILL>
-__global__ void n2a_runs_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos, const uint64_t* __restrict__ bits, uint32_t P,
+__global__ void n2a_runs_kernel(const uint4* __restrict__ meta, const uint64_t* __restrict__ bitpos, const uint64_t* __restrict__ bits, uint32_t P, uint32_t N,
                                 uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ofs, uint32_t* __restrict__ runs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > P) return;
     uint32_t n = 0;
+    const uint32_t rs = n2a_run_shift(N), max_len = (1u << (32u - rs)) - 1u;
     if (i < P) {
         const uint4 m = meta[i];
         const uint32_t l = m.y;
@@ -147,6 +150,14 @@ __global__ void n2a_runs_kernel(const uint4* __restrict__ meta, const uint64_t* 
                 id = m.z - sum;
             }
             uint32_t o = FILL ? ofs[i] : 0u, start = id, len = 1;
+            auto put = [&]() {                                       // the run [start, start + len)
+                uint32_t s0 = start, left = len;
+                while (left) {
+                    const uint32_t take = left < max_len ? left : max_len;
+                    if (FILL) runs[o] = s0 | (take << rs);
+                    ++o; ++n; s0 += take; left -= take;
+                }
+            };
             if (l > 1) {
                 N2Cursor c2(bits, bitpos[i]);
                 for (uint32_t rem = l - 1u; rem;) {
@@ -156,12 +167,11 @@ __global__ void n2a_runs_kernel(const uint4* __restrict__ meta, const uint64_t* 
                         const uint32_t d = c2.next();
                         --rem;
                         if (d == 1u) ++len;
-                        else { if (FILL) runs[o] = start | (len << 16); ++o; ++n; start += len - 1u + d; len = 1; }
+                        else { put(); start += len - 1u + d; len = 1; }
                     }
                 }
             }
-            if (FILL) runs[o] = start | (len << 16);
-            ++n;
+            put();
         }
     }
     if (!FILL) cnt[i] = n;
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                                                        const uint32_t* __restrict__ rl_ofs, const uint32_t* __restrict__ rl_runs, uint32_t N, uint32_t pbits,
                                                        uint32_t* __restrict__ sim) {
     const unsigned long long pmask = (1ull << pbits) - 1ull;             // key = query << pbits | pattern; an unused slot's ~0 reads as the largest pattern
+    const uint32_t rs = n2a_run_shift(N), rmask = (1u << rs) - 1u;       // run of the run index = start | length << rs
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t q_node[N2_QCAP], q_h[N2_QCAP], q_l[N2_QCAP], q_pre[N2_QCAP + 1], part[N2_THREADS / 64];      // part: wave totals of the scans
     __shared__ uint32_t q_n;
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                 if (inl && RUNIDX && l > 1) {
                     for (uint32_t k = ro; k < re; ++k) {
                         const uint32_t run = rl_runs[k];
-                        for (uint32_t id = run & 0xFFFFu, t = run >> 16; t; --t, ++id) atomicAdd(&acc[id], H);
+                        for (uint32_t id = run & rmask, t = run >> rs; t; --t, ++id) atomicAdd(&acc[id], H);
                     }
                 } else if (inl) {
                     uint32_t id = m.z;
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                 if (RUNIDX) {
                     const uint32_t k0 = q_node[lo] + piece * UNIT, left_r = l - piece * UNIT, nk = left_r < UNIT ? left_r : UNIT;
                     for (uint32_t k = 0; k < nk; ++k) {
-                        const uint32_t run = rl_runs[k0 + k], start = run & 0xFFFFu, len = run >> 16;
+                        const uint32_t run = rl_runs[k0 + k], start = run & rmask, len = run >> rs;
                         if (LDS_HIST) {
                             atomicAdd(&hist[start], H);
                             if (start + len < N) atomicAdd(&hist[start + len], 0u - H);
@@ -419,7 +430,7 @@ static bool n2a_run_index(const kmdb_engine_view& e, hipStream_t st) {
     void* tmp = nullptr;
     auto fail = [&]() { (void)hipGetLastError(); for (void* p : {(void*)cnt, (void*)ofs, (void*)runs, tmp}) if (p) (void)hipFree(p); return false; };
     if (hipMalloc((void**)&cnt, ((size_t)P + 1) * 4) != hipSuccess || hipMalloc((void**)&ofs, ((size_t)P + 1) * 4) != hipSuccess) return fail();
-    hipLaunchKernelGGL((n2a_runs_kernel<false>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, e.meta, e.bitpos, e.bits, P, cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL((n2a_runs_kernel<false>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, e.meta, e.bitpos, e.bits, P, (uint32_t)e.N, cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     size_t tb = 0;
     if (prim::exclusive_sum(nullptr, tb, cnt, ofs, (int)(P + 1), st) != hipSuccess || hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess) return fail();
     if (prim::exclusive_sum(tmp, tb, cnt, ofs, (int)(P + 1), st) != hipSuccess) return fail();
@@ -429,7 +440,7 @@ static bool n2a_run_index(const kmdb_engine_view& e, hipStream_t st) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)total * 4 + (1ull << 30) > free_b / 2) return fail();
     if (hipMalloc((void**)&runs, std::max<size_t>((size_t)total, 1) * 4) != hipSuccess) return fail();
-    hipLaunchKernelGGL((n2a_runs_kernel<true>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, e.meta, e.bitpos, e.bits, P, (uint32_t*)nullptr, (const uint32_t*)ofs, runs);
+    hipLaunchKernelGGL((n2a_runs_kernel<true>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, e.meta, e.bitpos, e.bits, P, (uint32_t)e.N, (uint32_t*)nullptr, (const uint32_t*)ofs, runs);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
     (void)hipFree(cnt); (void)hipFree(tmp);
     *e.rl_ofs = ofs; *e.rl_runs = runs;

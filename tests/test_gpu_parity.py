@@ -705,6 +705,90 @@ def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local, ch
         assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
 
 
+@pytest.mark.gpu
+def test_more_than_65535_samples(K, O, dev, tmp_path):
+    """Sample ids take 20 bits in the device layout (reference: 32-bit ids, src/types.h:15-18; its own 2019 collection data/pathogens.list
+    has 40 715 samples).  (a) a random forest over 66 000 samples — local lists whose ids and deltas need 17 bits, long lists, deep
+    chains — whole matrix against the oracle, block-record pipeline only (the HBM-atomics kernels keep 16-bit ids and refuse);
+    (b) a clade collection of 70 000 samples: checksum identity, rows from the definition, new2all rows against the oracle."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    device = torch.device("cuda", dev)
+    # (a)
+    N = 66000
+    rng = np.random.default_rng(65536)
+    pat = _random_forest(rng, N, 4000, 300, chain_frac=0.5)
+    arr = S.to_view_arrays(pat)
+    assert int(arr["last_sample_id"].max()) > 65535 and int(arr["num_samples"].max()) > 500 and int(arr["num_bits"].max()) > 4096
+    path = str(tmp_path / "f.db")
+    S.write_db(path, 18, 1.0, ["s%d" % i for i in range(N)], [1] * N, arr)
+    exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+    view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"])
+    d = K.DeviceDB(view, device=dev)
+    got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+    st = d.stats()
+    assert st["path"] == K.capi.PATH_RECORDS              # (no checksum identity here: the forest's heavy weights wrap the uint32 cells)
+    assert np.array_equal(got, exp)
+    del got
+    acc = d.all2all_dense(shard=(0, 2))
+    acc += d.all2all_dense(shard=(1, 2))
+    assert np.array_equal(acc, exp)
+    del acc
+    with pytest.raises(K.KmdbError, match="16 bits"):
+        d.all2all_dense(flags=K.capi.FLAG_FORCE_GLOBAL_ATOMICS)
+    sp = d.all2all_sparse()
+    assert sp.n_rows == N and sp.nnz == int(np.count_nonzero(exp))
+    for i in (1, 65535, 65536, N - 1):
+        c, v = sp.row(i)
+        row = O.tri_row(exp, i)
+        nz = np.nonzero(row)[0]
+        assert np.array_equal(c, nz) and np.array_equal(v, row[nz])
+    d.close()
+    del exp, sp
+    # (b)
+    N, cs, L, k = 70000, 50, 300, 18
+    g, pat = S.synth_database(N, cs, L, k=k, seed=17, device=device)
+    arr = S.to_view_arrays(pat)
+    tables = S.build_hashtables(pat["dictionary"], pat["kmer_pid"], k)
+    view = K.make_view(k, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"], bucket_offset=tables[0], slots=tables[1])
+    d = K.DeviceDB(view, device=dev, with_hashtables=True)
+    M = torch.zeros(d.tri_size(), dtype=torch.int32, device=device)
+    d.all2all_dense_device(M.data_ptr(), flags=K.capi.FLAG_NO_FALLBACK)
+    st = d.stats()
+    assert st["path"] == K.capi.PATH_RECORDS and st["n_records"] > 0
+    total = sum(int(M[o: o + (1 << 28)].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) for o in range(0, M.numel(), 1 << 28))
+    assert total == st["sum_pairs"]
+    allk = torch.cat([S.kmers_of(g.sample(j), k) for j in range(N)])
+    sid = torch.repeat_interleave(torch.arange(N, device=device), torch.tensor(pat["sample_counts"], device=device))
+    for i in (1, cs, 65535, 65536, 65537, N - cs, N - 1):
+        hit = torch.isin(allk, allk[sid == i])
+        want = torch.bincount(sid[hit], minlength=N)[:i].to(torch.int32)
+        o = i * (i - 1) // 2
+        assert torch.equal(M[o: o + i], want), i
+    del M
+    # new2all: members on both sides of 65 536, fresh strains of the last clades, an unrelated genome, an empty query
+    g_more = S.CladeGenomes(N + 100, cs, L, seed=17, device=device)
+    other = S.CladeGenomes(10, 5, L, seed=77, device=device)
+    qs = [S.kmers_of(g.sample(i), k).cpu().numpy().view(np.uint64) for i in (0, 65535, 65536, N - 1)]
+    qs += [S.kmers_of(g_more.sample(i), k).cpu().numpy().view(np.uint64) for i in (N, N + 99)]
+    qs += [S.kmers_of(other.sample(2), k).cpu().numpy().view(np.uint64), np.zeros(0, np.uint64)]
+    got = d.new2all(qs)
+    for qi, q in enumerate(qs):
+        hit = torch.isin(allk, torch.from_numpy(q.view(np.int64)).to(device))
+        want = torch.bincount(sid[hit], minlength=N).cpu().numpy().astype(np.uint32)
+        assert np.array_equal(got[qi], want), qi
+    assert got[1, 65535] == qs[1].size and got[2, 65536] == qs[2].size and got[3, N - 1] == qs[3].size
+    sp = d.new2all_sparse(qs)
+    for qi in range(len(qs)):
+        c, v = sp.row(qi)
+        nz = np.nonzero(got[qi])[0]
+        assert np.array_equal(c, nz) and np.array_equal(v, got[qi][nz])
+    d.close()
+
+
 @pytest.mark.parametrize("rowmode", ["0", "1"])
 def test_pools_too_small_are_enlarged_and_the_call_repeated(K, O, dev, tmp_path, rowmode):
     """The record pools are sized from a 1-in-1024 sample; a pool that turns out too small is enlarged and the call repeated

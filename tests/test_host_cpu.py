@@ -152,6 +152,15 @@ def test_unknown_flag_bits_are_rejected(K, golden_dir):
     # the shard arguments of the prefix-shard upload are checked up front as well
     with pytest.raises(K.KmdbError, match="shard_index"):
         K.DeviceDB(h, prefix_shard=(2, 2))
+    # and so is the sample count: ids take 20 bits in the device layout (the reference has 32-bit ids, src/types.h:15-18; 2^20 samples
+    # would be a 2 TB matrix)
+    z = np.zeros(1, np.int64)
+    for n, ok in ((1 << 20, False), ((1 << 20) - 1, True)):
+        view = K.make_view(18, n, z, z - 1, z.astype(np.uint32), z.astype(np.uint32), z.astype(np.uint32), z.astype(np.uint32), z.astype(np.uint64), z.astype(np.uint64))
+        if ok and K.device_count() > 0:
+            continue                                            # (with a GPU the upload would go on and build a database of 2^20 - 1 empty samples)
+        with pytest.raises(K.KmdbError, match="no HIP device" if ok else "1048576 samples or more"):
+            K.DeviceDB(view)
 
 
 def test_hashtable_headers_are_validated(K, golden_dir, tmp_path):
