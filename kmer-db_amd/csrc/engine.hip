@@ -209,7 +209,7 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     kmdb_blocks_release(db);
     void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
                     db->nseg_anc_n, db->meta, db->bitpos, db->ck_ofs, db->ck_bit, db->ck_id, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,
-                    db->bucket_offset, db->slots, db->pid2dfs, db->list_sets, db->rl_ofs, db->rl_runs};
+                    db->bucket_offset, db->slots, db->pid2dfs, db->list_sets, db->rl_ofs, db->rl_runs, db->rl_node};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_k) if (e) (void)hipEventDestroy(e);
@@ -230,7 +230,7 @@ int kmdb_engine_get(kmdb_db* db, kmdb_engine_view* o) {
     o->bits = db->bits; o->n_buckets = db->n_buckets; o->bucket_offset = db->bucket_offset; o->slots = db->slots;
     o->pid2dfs = db->pid2dfs; o->stream = db->stream;
     o->max_depth = db->max_depth; o->list_sets = &db->list_sets; o->list_sets_nb = &db->list_sets_nb; o->list_sets_tried = &db->list_sets_tried;
-    o->rl_ofs = &db->rl_ofs; o->rl_runs = &db->rl_runs; o->rl_tried = &db->rl_tried;
+    o->rl_ofs = &db->rl_ofs; o->rl_runs = &db->rl_runs; o->rl_node = &db->rl_node; o->rl_tried = &db->rl_tried;
     o->device_bytes = &db->stats.device_bytes;
     for (int i = 0; i < 4; ++i) o->ev[i] = db->ev[i];
     return 0;

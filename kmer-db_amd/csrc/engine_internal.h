@@ -36,6 +36,7 @@ struct kmdb_engine_view {
     // run index of new2all.hip, kept with the handle: node i's local ids as runs rl_runs[rl_ofs[i] .. rl_ofs[i + 1]) (start | length << rs, n2a_run_shift)
     uint32_t** rl_ofs;
     uint32_t** rl_runs;
+    uint4** rl_node;               // and the walk's 16-byte node records {subtree end, parent, first run or the only id, min(l, 65535) | min(runs, 65535) << 16}
     bool* rl_tried;
     uint64_t* device_bytes;
     void* stream;

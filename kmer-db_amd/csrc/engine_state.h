@@ -72,6 +72,7 @@ struct kmdb_db {
     // first new2all call of the handle
     uint32_t* rl_ofs = nullptr;     // [P + 1]
     uint32_t* rl_runs = nullptr;
+    uint4* rl_node = nullptr;       // [P] the node as the walk reads it, one 16-byte load: subtree end, parent, first run (or the id of a one-id list), l | runs << 16
     bool rl_tried = false;
     bool chain_ok = false;          // root paths fit the chain table of the emit kernel
     // ---- per-call working set of the block-record pipeline (contents rebuilt by every call)

@@ -177,6 +177,17 @@ __global__ void n2a_runs_kernel(const uint4* __restrict__ meta, const uint64_t* 
     if (!FILL) cnt[i] = n;
 }
 
+// the node as the walk's climb reads it: ONE 16-byte record instead of five loads from four arrays (subtree end, list header, parent, two run
+// offsets).  The climb is random access, a node per step and thread: what it moves are memory sectors, not bytes.
+__global__ void n2a_nodes_kernel(const uint4* __restrict__ meta, const int32_t* __restrict__ parent, const uint32_t* __restrict__ sub_end,
+                                 const uint32_t* __restrict__ ofs, uint32_t P, uint4* __restrict__ node) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint4 m = meta[i];
+    const uint32_t l = m.y, ro = ofs[i], nr = ofs[i + 1] - ro;
+    node[i] = make_uint4(sub_end[i], (uint32_t)parent[i], l == 1u ? m.z : ro, (l < 0xFFFFu ? l : 0xFFFFu) | ((nr < 0xFFFFu ? nr : 0xFFFFu) << 16));
+}
+
 // RUNIDX: the local lists come from the handle's run index (runs of consecutive ids, decoded once per handle) instead of the gamma
 // streams: every query used to decode the same lists again — the clade-level nodes are on the root paths of all queries of the clade —
 // and the queued long lists were half of the walk's time.
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                                                        const int32_t* __restrict__ parent, const uint32_t* __restrict__ sub_end,
                                                        const uint64_t* __restrict__ bits, const uint32_t* __restrict__ ck_ofs,
                                                        const uint64_t* __restrict__ ck_bit, const uint32_t* __restrict__ ck_id,
-                                                       const uint32_t* __restrict__ rl_ofs, const uint32_t* __restrict__ rl_runs, uint32_t N, uint32_t pbits,
+                                                       const uint32_t* __restrict__ rl_ofs, const uint32_t* __restrict__ rl_runs, const uint4* __restrict__ rl_node, uint32_t N, uint32_t pbits,
                                                        uint32_t* __restrict__ sim) {
     const unsigned long long pmask = (1ull << pbits) - 1ull;             // key = query << pbits | pattern; an unused slot's ~0 reads as the largest pattern
     const uint32_t rs = n2a_run_shift(N), rmask = (1u << rs) - 1u;       // run of the run index = start | length << rs
@@ -235,11 +246,23 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
             // A step's loads depend on each other (subtree end -> search over the hits -> count; list header -> stream -> ids; parent):
             // the records of the NEXT node of the path are fetched at the top of a step, before the current node's search and decode,
             // so the dependent round trips of consecutive steps overlap.
-            uint32_t se = sub_end[r];
-            uint4 m = meta[r];
-            int32_t par = parent[r];
-            uint64_t bp = RUNIDX ? 0ull : bitpos[r];
-            uint32_t ro = RUNIDX ? rl_ofs[r] : 0u, re = RUNIDX ? rl_ofs[r + 1] : 0u;
+            // (RUNIDX: the whole node is one 16-byte record — m.y = l (clipped), m.z = the only id of a one-id list; else the arrays of the engine)
+            uint32_t se, ro = 0, re = 0;
+            uint4 m;
+            int32_t par;
+            uint64_t bp = 0;
+            auto node_of = [&](int64_t x, uint32_t& o_se, uint4& o_m, int32_t& o_par, uint64_t& o_bp, uint32_t& o_ro, uint32_t& o_re) {
+                if (RUNIDX && rl_node) {
+                    const uint4 v = rl_node[x];
+                    const uint32_t nr = v.w >> 16;
+                    o_se = v.x; o_par = (int32_t)v.y; o_m = make_uint4(0u, v.w & 0xFFFFu, v.z, 0u); o_ro = v.z;
+                    o_re = nr == 0xFFFFu ? rl_ofs[x + 1] : v.z + nr;
+                } else {
+                    o_se = sub_end[x]; o_m = meta[x]; o_par = parent[x];
+                    if (RUNIDX) { o_ro = rl_ofs[x]; o_re = rl_ofs[x + 1]; } else o_bp = bitpos[x];
+                }
+            };
+            node_of(r, se, m, par, bp, ro, re);
             while (r > prev) {
                 const int64_t rn = par;
                 uint32_t se_n = 0;
@@ -247,10 +270,7 @@ __global__ __launch_bounds__(N2_THREADS) void n2a_walk_kernel(const unsigned lon
                 int32_t par_n = -1;
                 uint64_t bp_n = 0;
                 uint32_t ro_n = 0, re_n = 0;
-                if (rn > prev) {
-                    se_n = sub_end[rn]; m_n = meta[rn]; par_n = parent[rn];
-                    if (RUNIDX) { ro_n = rl_ofs[rn]; re_n = rl_ofs[rn + 1]; } else bp_n = bitpos[rn];
-                }
+                if (rn > prev) node_of(rn, se_n, m_n, par_n, bp_n, ro_n, re_n);
                 // hits below r: indices [i, ub), ub = first run of this query whose pattern is >= sub_end[r].  Searched from the
                 // previous ub in doubling steps: near the leaves a subtree holds a handful of hits, one or two probes find its end
                 uint32_t lo = ub, hi = ub, step = 1;
@@ -422,7 +442,7 @@ struct DevBuf {
 
 // the handle's run index (false: this handle does without one — no memory for it — and the walk decodes the gamma streams as before)
 static bool n2a_run_index(const kmdb_engine_view& e, hipStream_t st) {
-    if (*e.rl_ofs && *e.rl_runs) return true;
+    if (*e.rl_ofs && *e.rl_runs && *e.rl_node) return true;
     if (*e.rl_tried || !e.P || getenv("KMDB_N2A_NO_RUNS")) return false;
     *e.rl_tried = true;
     const uint32_t P = (uint32_t)e.P;
@@ -438,13 +458,17 @@ static bool n2a_run_index(const kmdb_engine_view& e, hipStream_t st) {
     if (hipMemcpyAsync(&total, ofs + P, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
     // (the running sum is 32 bits wide: a database with 2^32 runs or more would need far more than the sample limit allows)
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)total * 4 + (1ull << 30) > free_b / 2) return fail();
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)total * 4 + (size_t)P * sizeof(uint4) + (1ull << 30) > free_b / 2) return fail();
     if (hipMalloc((void**)&runs, std::max<size_t>((size_t)total, 1) * 4) != hipSuccess) return fail();
     hipLaunchKernelGGL((n2a_runs_kernel<true>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, e.meta, e.bitpos, e.bits, P, (uint32_t)e.N, (uint32_t*)nullptr, (const uint32_t*)ofs, runs);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
+    uint4* nodes = nullptr;
+    if (hipMalloc((void**)&nodes, (size_t)P * sizeof(uint4)) != hipSuccess) return fail();
+    hipLaunchKernelGGL(n2a_nodes_kernel, dim3((P + 255) / 256), dim3(256), 0, st, e.meta, e.parent, e.sub_end, (const uint32_t*)ofs, P, nodes);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(nodes); return fail(); }
     (void)hipFree(cnt); (void)hipFree(tmp);
-    *e.rl_ofs = ofs; *e.rl_runs = runs;
-    *e.device_bytes += ((uint64_t)P + 1) * 4 + (uint64_t)total * 4;
+    *e.rl_ofs = ofs; *e.rl_runs = runs; *e.rl_node = nodes;
+    *e.device_bytes += ((uint64_t)P + 1) * 4 + (uint64_t)total * 4 + (uint64_t)P * sizeof(uint4);
     if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] new2all: run index of %u nodes, %u runs (%.2f GB)\n", P, total, (((double)P + 1) * 4 + (double)total * 4) / 1e9);
     return true;
 }
@@ -507,11 +531,12 @@ static int n2a_run(kmdb_db* dbh, const kmdb_engine_view& e, hipStream_t st, cons
             const uint32_t qcap = 1024;          // (512 entries: a third workgroup per CU, and 47.1 against 45.9 ms — the queue fills up)
             if (const char* ev = getenv("KMDB_N2A_THREADS")) if (atoi(ev) == 1024) threads = 1024;
             const bool lds_hist = N * 4 + qcap * 16 + threads * 8 + 1024 <= 64 * 1024;
+            const bool packed_nodes = getenv("KMDB_N2A_NO_NODES") == nullptr;        // (A/B: the climb reads the engine's arrays, five loads per node)
             const unsigned wblocks = (nruns + threads - 1) / threads;
 #define N2A_WALK(H, T, Q, R)                                                                                                             \
     hipLaunchKernelGGL((n2a_walk_kernel<H, T, Q, R>), dim3(wblocks), dim3(T), (H) ? N * 4 : 0, st, d_uniq.as<unsigned long long>(),      \
                        d_csum.as<uint32_t>(), d_qstart.as<uint32_t>(), nruns, (uint32_t)nq, e.meta, e.bitpos, e.parent, e.sub_end,       \
-                       e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (const uint32_t*)*e.rl_ofs, (const uint32_t*)*e.rl_runs, (uint32_t)N, pbits, d_sim.as<uint32_t>())
+                       e.bits, e.ck_ofs, e.ck_bit, e.ck_id, (const uint32_t*)*e.rl_ofs, (const uint32_t*)*e.rl_runs, packed_nodes ? (const uint4*)*e.rl_node : (const uint4*)nullptr, (uint32_t)N, pbits, d_sim.as<uint32_t>())
             if (runidx) {
                 if (threads == 1024) { if (lds_hist) N2A_WALK(true, 1024, 1024, true); else N2A_WALK(false, 1024, 1024, true); }
                 else { if (lds_hist) N2A_WALK(true, 512, 1024, true); else N2A_WALK(false, 512, 1024, true); }
