@@ -662,6 +662,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the matrix reduce goes through host memory); never used for reported numbers")
+    ap.add_argument("--one-rank-group", action="store_true",
+                    help="--gpus 1 only: run the multi-rank code path (process group, collective of every step, per-rank figures) on a ONE-rank "
+                         "RCCL group — what a one-GPU box can exercise of the --gpus N path; a functional check, never a reported number")
     args = ap.parse_args()
     if args.generate_spec is not None:
         generator_child(json.loads(args.generate_spec))
@@ -681,13 +684,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.one_rank_group and world != 1:
+        raise SystemExit("bench.py: --one-rank-group is for --gpus 1")
+    multi = world > 1 or args.one_rank_group              # the process group and the collectives are used
+    if args.one_rank_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
+        os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = "0", "1", "0"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU path to time")
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     rccl = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
@@ -702,7 +712,7 @@ def main():
     S = importlib.import_module("kmerdb_amd.synth")
 
     if args.mode != "all2all":
-        if world != 1 and args.mode == "all2all-sp":
+        if multi and args.mode == "all2all-sp":
             sparse_multi(args, K, S, device, rank, world, dist, rccl)
             return
         if world != 1:
@@ -734,7 +744,7 @@ def main():
     stc = db.stats()
     log("[rank %d] cold call %.1f ms (device pipeline %.2f ms, path %d)" % (rank, cold_ms, stc["kernel_ms"], stc["path"]))
 
-    scatter = world > 1 and args.collective == "reduce_scatter"
+    scatter = multi and args.collective == "reduce_scatter"
     per = (cells + world - 1) // world if scatter else 0
     M = torch.zeros(max(per * world if scatter else cells, 1), dtype=torch.int32, device=device)      # (reduce_scatter: the triangle padded to equal chunks)
     mine = torch.zeros(max(per, 1), dtype=torch.int32, device=device) if scatter else None
@@ -745,7 +755,7 @@ def main():
 
     def step():
         db.all2all_dense_device(M.data_ptr(), stream=stream)
-        if world > 1:
+        if multi:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
             if scatter:
@@ -771,7 +781,7 @@ def main():
             coll_ev.append(ev)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -788,7 +798,7 @@ def main():
         parts.append((_s["k0_ms"], _s["k1n_ms"], _s["k1g_ms"], _s["k2_ms"]))
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         cdev = device if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed, upload_s, cold_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -829,7 +839,7 @@ def main():
         # HBM bytes per call come from separate rocprofv3 --pmc runs of this same command (profiles/): they
         # cannot be collected from inside the timed process; quoted only for the default workload
         traffic, traffic_src = None, None
-        if world == 1 and args.length == WORKLOADS[args.workload]["length"] and args.samples == WORKLOADS[args.workload]["samples"]:
+        if not multi and args.length == WORKLOADS[args.workload]["length"] and args.samples == WORKLOADS[args.workload]["samples"]:
             traffic, traffic_src = replayed_traffic(args.workload)
         out = {
             "metric": "all2all k-mer pair-comparisons/sec",
@@ -845,7 +855,7 @@ def main():
             "config": {
                 "workload": "%s: %d synthetic %g Mbp genomes (clade-mutation model, clades of %d, r1=0.10 r2=0.01), k=%d f=1.0, "
                             "dense all2all%s" % (args.workload, args.samples, total_len / 1e6, args.clade_size, args.k,
-                                                 "" if world == 1 else ", k-mer space sharded by prefix bucket over %d GPUs (%s) + RCCL %s"
+                                                 "" if not multi else ", k-mer space sharded by prefix bucket over %d GPUs (%s) + RCCL %s"
                                                  % (world, "one database, kmdb_db_upload_shard" if strong else "per-rank databases",
                                                     "reduce-scatter by flat chunks + D2H of every rank's chunk" if scatter else "reduce")),
                 "samples": args.samples, "genome_length_bp": total_len, "k": args.k, "fraction": 1.0,
@@ -879,7 +889,7 @@ def main():
                 "record_chunks": stl["n_chunks"],
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             from oracle import oracle as O
             db.close()
             out["cpu_baseline"] = cpu_baseline(K, S, O, args, device, arr, names, counts, nk, first)
@@ -890,14 +900,14 @@ def main():
                 # front-end's read + upload + call + CSV
                 out["wall"]["reference_process_s"] = cb["process_seconds"]
                 out["wall"].update(cb.pop("frontend"))
-        if world == 1 and args.workload == "c2" and args.length == WORKLOADS["c2"]["length"] and args.samples == WORKLOADS["c2"]["samples"] and not args.no_extra:
+        if not multi and args.workload == "c2" and args.length == WORKLOADS["c2"]["length"] and args.samples == WORKLOADS["c2"]["samples"] and not args.no_extra:
             # the 10 000-sample workload rides along in the same line (the configuration BASELINE's target is written for)
             db.close()
             del arr
             torch.cuda.empty_cache()
             out["extra"] = {"c3part": extra_workload(K, S, args, device, "c3part")}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,7 +7,8 @@
 // shards (several shards of one device one after the other, summed on the device), then — with more than one device — ONE RCCL
 // reduce-scatter over flat chunks of the lower triangle (xGMI is point to point: every peer pair sums its chunk over its own link,
 // SURVEY 8e), and every device brings ITS chunk to the host (dense) or compacts it where it is (sparse:
-// kmdb_sparse_from_dense_device).  RCCL is loaded with dlopen when a second device is used, so a one-GPU box needs no librccl.
+// kmdb_sparse_from_dense_device).  RCCL is loaded with dlopen when a second device is used, so a one-GPU box needs no librccl
+// (KMDB_NODE_FORCE_RCCL=1 runs the same RCCL calls on a one-rank communicator: the part of the path a one-GPU box can exercise).
 #include "engine_state.h"
 
 #include <rccl/rccl.h>
@@ -16,6 +17,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -80,6 +82,8 @@ struct kmdb_node {
     std::vector<DevSlot> dev;
     Rccl rccl;
     int rccl_version = 0;
+    bool use_rccl = false;                                   // more than one device — or KMDB_NODE_FORCE_RCCL=1 on one device: the same calls on a
+                                                             // one-rank communicator (what a one-GPU box can exercise of the RCCL path)
     kmdb_node_stats stats{};
 };
 
@@ -129,7 +133,7 @@ int node_accumulate(kmdb_node* nd, size_t d, const kmdb_opts* opts) {
     NODE_TRY(hipStreamSynchronize(s.stream));
     s.call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     s.collective_ms = 0;
-    if (D > 1 && nd->per) {
+    if (nd->use_rccl && nd->per) {
         NODE_TRY(hipEventRecord(s.ev[0], s.stream));
         const ncclResult_t r = nd->rccl.ReduceScatter(s.acc, s.chunk, nd->per, ncclUint32, ncclSum, s.comm, s.stream);
         if (r != ncclSuccess) return kmdb_set_error(std::string("ncclReduceScatter: ") + nd->rccl.GetErrorString(r));
@@ -145,7 +149,7 @@ int node_accumulate(kmdb_node* nd, size_t d, const kmdb_opts* opts) {
 // where device slot d's cells of the reduced matrix are: the pointer and the flat range of the triangle
 void node_chunk(const kmdb_node* nd, size_t d, const uint32_t*& p, uint64_t& lo, uint64_t& hi) {
     const DevSlot& s = nd->dev[d];
-    if (nd->dev.size() == 1) { p = s.acc; lo = 0; hi = nd->cells; return; }
+    if (!nd->use_rccl) { p = s.acc; lo = 0; hi = nd->cells; return; }
     p = s.chunk;
     lo = std::min<uint64_t>(nd->cells, nd->per * d);
     hi = std::min<uint64_t>(nd->cells, nd->per * (d + 1));
@@ -179,6 +183,8 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
     nd->per = D > 1 ? (nd->cells + D - 1) / D : nd->cells;
     nd->dev.resize(D);
     for (uint32_t d = 0; d < D; ++d) nd->dev[d].device = devices[d];
+    const char* force = getenv("KMDB_NODE_FORCE_RCCL");
+    nd->use_rccl = D > 1 || (force && force[0] == '1');
     const auto t0 = std::chrono::steady_clock::now();
     int rc = on_devices(nd, [&](size_t d) -> int {
         DevSlot& s = nd->dev[d];
@@ -193,11 +199,11 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
         }
         NODE_TRY(hipMalloc((void**)&s.acc, std::max<uint64_t>(nd->per * D, 1) * 4));
         if (s.shards.size() > 1) NODE_TRY(hipMalloc((void**)&s.tmp, std::max<uint64_t>(nd->cells, 1) * 4));
-        if (D > 1) NODE_TRY(hipMalloc((void**)&s.chunk, std::max<uint64_t>(nd->per, 1) * 4));
+        if (nd->use_rccl) NODE_TRY(hipMalloc((void**)&s.chunk, std::max<uint64_t>(nd->per, 1) * 4));
         s.upload_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
         return 0;
     });
-    if (!rc && D > 1) {
+    if (!rc && nd->use_rccl) {
         // one communicator per device, made by this thread for all of them (ncclCommInitAll); every device thread then uses its own
         rc = rccl_load(nd->rccl);
         if (!rc) {

@@ -497,6 +497,30 @@ def test_node_driver_over_the_devices_of_the_box(K, golden_dir, dev, stem, shard
         K.NodeDB(h, 2, [0, 0])
 
 
+def test_node_driver_rccl_calls_on_a_one_rank_communicator(K, golden_dir, dev, monkeypatch):
+    """The RCCL half of kmdb_node_* on a one-GPU box: KMDB_NODE_FORCE_RCCL=1 makes the driver dlopen librccl, build its communicator with
+    ncclCommInitAll and run the per-call ncclReduceScatter (uint32 sum, on the device's stream, events around it) on ONE rank — the same
+    calls, arguments and ordering the multi-GPU run makes, minus the peers.  Three shards on the device are summed first; the chunk that
+    comes out of the collective is the matrix (dense) or is compacted where it is (sparse)."""
+    monkeypatch.setenv("KMDB_NODE_FORCE_RCCL", "1")
+    h = K.HostDB(os.path.join(golden_dir, "virus_k18.db"))
+    ref = np.fromfile(os.path.join(golden_dir, "virus_k18.a2a.ref.u32"), dtype=np.uint32)
+    nd = K.NodeDB(h, 3, [dev])
+    assert np.array_equal(nd.all2all_dense(), ref)
+    st = nd.stats()
+    assert st["n_devices"] == 1 and st["n_shards"] == 3 and st["rccl_version"] > 0 and st["collective_ms"] > 0
+    assert np.array_equal(nd.all2all_dense(), ref)                    # warm call
+    d1 = K.DeviceDB(h, device=dev)
+    a, b = d1.all2all_sparse(), nd.all2all_sparse()
+    assert a.nnz == b.nnz and np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.col, b.col) and np.array_equal(a.val, b.val)
+    nd.close()
+    d1.close()
+    monkeypatch.delenv("KMDB_NODE_FORCE_RCCL")
+    nd = K.NodeDB(h, 3, [dev])
+    assert np.array_equal(nd.all2all_dense(), ref) and nd.stats()["rccl_version"] == 0        # without the switch one device needs no librccl
+    nd.close()
+
+
 @pytest.mark.parametrize("stem,shards", [("clade64_k25_f01", 2), ("virus_k18", 3), ("clade64", 8)])
 def test_sharded_all2all_sp_from_the_reduced_matrix(K, golden_dir, dev, stem, shards):
     """BASELINE configs[3] on several GPUs, emulated on one: every prefix-bucket shard (kmdb_db_upload_shard) accumulates its partial
@@ -956,6 +980,24 @@ def test_bench_contract_single_and_two_ranks(dev, tmp_path):
     d3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.strip().startswith("{")][0])
     assert d3["n_gpus"] == 2 and d3["scaling"] == "weak" and d3["config"]["samples"] == 10000 and d3["config"]["workload"].startswith("c3gpu: 10000 synthetic")
     assert d3["config"]["genome_length_bp"] == 4000 and d3["config"]["n_ranks_seen"] == 2
+
+
+@pytest.mark.parametrize("extra", [["--collective", "reduce"], ["--collective", "reduce_scatter"], ["--mode", "all2all-sp", "--samples", "600"]])
+def test_bench_rccl_branch_on_a_one_rank_group(dev, extra):
+    """The `--backend nccl` branch of bench.py (what the driver's --gpus N run executes) on a one-GPU box: `--one-rank-group` builds a
+    ONE-rank RCCL process group and runs the multi-rank code as it is — init_process_group(nccl, device_id), the int32 reduce /
+    reduce_scatter_tensor of every step on the call's stream with events around it, the float64 all_reduce / all_gather of the figures,
+    barrier, destroy — and the line's checksum identity holds over the collective's output."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-rank-group", "--length", "20000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extra"] + extra, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl"] not in (None, "unknown") and d["value"] > 0
+    if "--mode" not in extra:
+        pr = d["config"]["per_rank"]
+        assert d["config"]["n_ranks_seen"] == 1 and pr["backend"] == "nccl" and pr["call_ms"][0] > 0 and pr["collective_ms"][0] > 0
 
 
 def test_bench_one_gpu_share_of_configs2(dev):
