@@ -249,8 +249,19 @@ def frontend_run(K, db_path, td, ref_matrix, names, counts, k):
         raise SystemExit("bench.py: the front-end failed: %s" % r.stderr[-2000:])
     import re
     secs = [float(x) for x in re.findall(r"OK \(([0-9.eE+-]+) seconds\)", r.stderr)]
-    res = {"frontend_s": wall, "frontend_compute_s": secs[0] if secs else None, "frontend_csv_s": secs[1] if len(secs) > 1 else None,
+    lu = re.search(r"Database loaded in ([0-9.eE+-]+) s, uploaded in ([0-9.eE+-]+) s", r.stderr)
+    res = {"frontend_s": wall, "frontend_load_s": float(lu.group(1)) if lu else None, "frontend_upload_s": float(lu.group(2)) if lu else None,
+           "frontend_compute_s": secs[0] if secs else None, "frontend_csv_s": secs[1] if len(secs) > 1 else None,
            "frontend_csv_bytes": os.path.getsize(out_csv)}
+    with open(out_csv, "rb") as f:
+        got = f.read()
+    # the same command with the ordinary process teardown (KMDB_FULL_TEARDOWN=1: host image and device pools freed one by one, runtime exit
+    # handlers): what ending the process at once is worth
+    t0 = time.time()
+    r2 = subprocess.run([exe, "all2all", db_path, out_csv], capture_output=True, text=True, env=dict(os.environ, KMDB_FULL_TEARDOWN="1"))
+    res["frontend_full_teardown_s"] = time.time() - t0
+    with open(out_csv, "rb") as f:
+        assert r2.returncode == 0 and f.read() == got, "front-end with full teardown: different output"
     # expected text: header lines + one row per sample from the reference's matrix
     n = len(names)
     h = K.HostDB(db_path, skip_hashtables=True)
@@ -260,8 +271,6 @@ def frontend_run(K, db_path, td, ref_matrix, names, counts, k):
     for i in range(n):
         exp.append(K.format_dense_row(names[i], int(counts[i]), m[i * (i - 1) // 2: i * (i - 1) // 2 + i]))
     exp = b"".join(exp)
-    with open(out_csv, "rb") as f:
-        got = f.read()
     assert got == exp, "front-end CSV differs from the CSV of the reference's matrix"
     res["frontend_csv_matches_reference_matrix"] = True
     os.unlink(out_csv)

@@ -5,19 +5,47 @@
 // the two modes the hot path uses: Everything (new2all, console_new2all.cpp:32) and
 // SkipHashtables (all2all / all2all-sp, console_all2all.cpp:26).  File layout (SURVEY §8a
 // a13): header | sample table | raw hashtables (hashmap_lp.h:481-528) | pattern blocks
-// (pattern.cpp:15-46).  The file is mapped once and walked with a cursor; patterns land in
+// (pattern.cpp:15-46).  The file is mapped once; the hashtables and the 64 MB pattern blocks are found header to header
+// by one thread and then restored / parsed side by side on up to 16 threads (KMDB_LOAD_THREADS); patterns land in
 // struct-of-arrays form and all gamma streams in one contiguous uint64 array.
 #include "kmdb_amd.h"
 #include "kmdb_internal.h"
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+namespace {
+
+// a flat array that is NOT zero-filled when it is made: every element is written by the loader (the arrays of a 100 M-pattern database
+// are 4 GB of pattern fields + 5 GB of streams: zero-filling them first costs as much as reading the file)
+template <class T>
+struct Buf {
+    T* p = nullptr;
+    size_t n = 0;
+    Buf() = default;
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+    ~Buf() { std::free(p); }
+    bool alloc(size_t k) { std::free(p); p = (T*)std::malloc(std::max<size_t>(k, 1) * sizeof(T)); n = p ? k : 0; return p != nullptr; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+};
+
+}  // namespace
 
 struct kmdbh_db {
     uint64_t format_word = 0;
@@ -28,10 +56,10 @@ struct kmdbh_db {
     uint64_t kmers_count = 0;
     std::vector<std::string> names;
     std::vector<uint64_t> sample_kmers;
-    std::vector<int64_t> num_kmers, parent_id;
-    std::vector<uint32_t> num_samples, num_local, last_id, num_bits;
-    std::vector<uint64_t> data_offset, data;
-    std::vector<uint64_t> bucket_offset, slots;
+    Buf<int64_t> num_kmers, parent_id;
+    Buf<uint32_t> num_samples, num_local, last_id, num_bits;
+    Buf<uint64_t> data_offset, data;
+    Buf<uint64_t> bucket_offset, slots;
     uint64_t pattern_section_bytes = 0;
     kmdb_db_view view{};
 };
@@ -59,6 +87,29 @@ struct Cursor {
 
 constexpr uint64_t EMPTY_SLOT = (uint64_t)0x7fffffffu << 32;   // key 0, val INT32_MAX (hashmap_lp.h:78)
 
+// fn(item) for item in [0, n) on up to `threads` host threads (items are dealt by an atomic counter: they differ in size)
+template <class F>
+void parallel_items(size_t n, unsigned threads, F&& fn) {
+    if (n == 0) return;
+    threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n));
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i); };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+}
+
+unsigned loader_threads() {
+    if (const char* e = std::getenv("KMDB_LOAD_THREADS")) { const int v = std::atoi(e); if (v > 0) return (unsigned)v; }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(16u, hc ? hc : 1u));
+}
+
+struct HtBucket { const uint8_t* bv; const uint8_t* items; uint64_t filled, allocated; };
+struct PatBlock { const uint8_t* p; uint64_t bytes, patterns, words; bool bad; };
+constexpr size_t PAT_HEADER = 40;     // num_kmers, parent_id (8 + 8), num_samples, num_local, last id, num_bits (4 x 4), is_parent (4 written, 8 advanced: pattern.cpp:35-37)
+
 }  // namespace
 
 extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
@@ -70,7 +121,6 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
     void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (map == MAP_FAILED) return kmdb_set_error(std::string("Cannot map k-mer database ") + path);
-    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
 
     auto* db = new kmdbh_db();
     Cursor c{(const uint8_t*)map, (const uint8_t*)map + st.st_size};
@@ -78,6 +128,15 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
         munmap(map, (size_t)st.st_size);
         delete db;
         return kmdb_set_error(std::string("Cannot open k-mer database ") + path + " (" + what + ")");
+    };
+    const unsigned T = loader_threads();
+    const bool verbose = std::getenv("KMDB_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[kmdb] load: %-44s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
     };
 
     db->format_word = c.get<uint64_t>();
@@ -99,12 +158,12 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
         db->names[i].assign((const char*)s, len);
     }
     uint64_t nb = c.get<uint64_t>();
-    if (!c.ok) return fail("bad bucket count");
+    if (!c.ok || nb > (uint64_t)st.st_size) return fail("bad bucket count");
     if (!(db->format_word & 1ull)) return fail("compressed hashtable serialisation is not supported");
     const bool want_ht = (mode == 0);
-    if (want_ht) db->bucket_offset.assign(nb + 1, 0);
-    // pass 1 over hashtables: sizes (and skip when not wanted)
-    const uint8_t* ht_begin = c.p;
+    // ---- hashtables, pass 1 (one thread: header to header): where every table's fill vector and items are, and the slot offsets
+    std::vector<HtBucket> ht(want_ht ? nb : 0);
+    if (want_ht && !db->bucket_offset.alloc(nb + 1)) return fail("out of memory");
     uint64_t total_slots = 0;
     for (uint64_t b = 0; b < nb; ++b) {
         c.take(8);                                   // max_fill_factor
@@ -115,77 +174,121 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
         // hashmap_lp invariants (reference src/hashmap_lp.h:150,427-437): power-of-two capacity with at least one empty slot —
         // the device probes rely on both
         if (allocated == 0 || (allocated & (allocated - 1)) || filled >= allocated || allocated > (1ull << 40)) return fail("bad hashtable header");
-        if (!c.take(8 * ((allocated + 63) / 64)) || !c.take(8 * filled)) return fail("bad hashtable body");
-        if (want_ht) { db->bucket_offset[b] = total_slots; total_slots += allocated; }
+        const uint8_t* bv = c.take(8 * ((allocated + 63) / 64));
+        const uint8_t* items = bv ? c.take(8 * filled) : nullptr;
+        if (!bv || (!items && filled)) return fail("bad hashtable body");
+        if (want_ht) { ht[b] = HtBucket{bv, items, filled, allocated}; db->bucket_offset[b] = total_slots; total_slots += allocated; }
     }
+    uint64_t P = c.get<uint64_t>();
+    if (!c.ok || P > (uint64_t)st.st_size) return fail("bad pattern count");
+    phase("header, sample table, hashtable headers");
     if (want_ht) {
+        // ---- pass 2 (the buckets side by side): slot-exact restore (hashmap_lp.h:580-600); every stored pattern id must exist (the
+        // device indexes with it)
         db->bucket_offset[nb] = total_slots;
-        db->slots.assign(total_slots, EMPTY_SLOT);
-        Cursor h{ht_begin, c.p};
-        for (uint64_t b = 0; b < nb; ++b) {
-            h.take(8);
-            uint64_t filled = h.get<uint64_t>();
-            uint64_t allocated = h.get<uint64_t>();
-            h.take(8 * 5);
-            const uint8_t* bv = h.take(8 * ((allocated + 63) / 64));
-            const uint8_t* items = h.take(8 * filled);
+        if (!db->slots.alloc(total_slots)) return fail("out of memory");
+        std::atomic<int> err{0};              // 1: fill vector overflow, 2: item count mismatch, 3: pattern id out of range
+        parallel_items(nb, T, [&](size_t b) {
+            const HtBucket& h = ht[b];
             uint64_t* dst = db->slots.data() + db->bucket_offset[b];
+            std::fill(dst, dst + h.allocated, EMPTY_SLOT);
             uint64_t it = 0;
-            for (uint64_t w = 0; w < (allocated + 63) / 64; ++w) {
+            for (uint64_t w = 0; w < (h.allocated + 63) / 64; ++w) {
                 uint64_t word;
-                std::memcpy(&word, bv + 8 * w, 8);
-                while (word) {                        // slot-exact restore (hashmap_lp.h:580-600)
+                std::memcpy(&word, h.bv + 8 * w, 8);
+                while (word) {
                     int bit = __builtin_ctzll(word);
                     word &= word - 1;
-                    if (it >= filled || w * 64 + (uint64_t)bit >= allocated) return fail("hashtable fill vector overflow");
-                    std::memcpy(&dst[w * 64 + bit], items + 8 * it, 8);
+                    if (it >= h.filled || w * 64 + (uint64_t)bit >= h.allocated) { err = 1; return; }
+                    uint64_t sl;
+                    std::memcpy(&sl, h.items + 8 * it, 8);
+                    const int32_t val = (int32_t)(sl >> 32);
+                    if (val != INT32_MAX && (val < 0 || (uint64_t)val >= P)) { err = 3; return; }
+                    dst[w * 64 + bit] = sl;
                     ++it;
                 }
             }
-            if (it != filled) return fail("hashtable fill vector does not match the item count");
-        }
+            if (it != h.filled) err = 2;
+        });
+        if (err == 1) return fail("hashtable fill vector overflow");
+        if (err == 2) return fail("hashtable fill vector does not match the item count");
+        if (err == 3) return fail("hashtable item points past the pattern table");
+        phase("hashtables restored");
     }
 
-    uint64_t P = c.get<uint64_t>();
-    if (!c.ok || P > (uint64_t)st.st_size) return fail("bad pattern count");
-    for (uint64_t sl : db->slots) {                     // every stored pattern id must exist (the device indexes with it)
-        const int32_t val = (int32_t)(sl >> 32);
-        if (val != INT32_MAX && (val < 0 || (uint64_t)val >= P)) return fail("hashtable item points past the pattern table");
-    }
-    db->num_kmers.resize(P); db->parent_id.resize(P);
-    db->num_samples.resize(P); db->num_local.resize(P);
-    db->last_id.resize(P); db->num_bits.resize(P); db->data_offset.resize(P);
-    db->data.reserve((size_t)((c.end - c.p) / 8));
-    uint64_t pid = 0;
-    while (pid < P) {
-        uint64_t bs = c.get<uint64_t>();
-        const uint8_t* blk = c.ok ? c.take(bs) : nullptr;
-        if (!blk && bs) return fail("bad pattern block");
-        Cursor q{blk, blk + bs};
-        while (q.p < q.end) {
-            if (pid >= P) return fail("too many patterns");
-            db->num_kmers[pid] = q.get<int64_t>();
-            db->parent_id[pid] = q.get<int64_t>();
-            db->num_samples[pid] = q.get<uint32_t>();
-            db->num_local[pid] = q.get<uint32_t>();
-            db->last_id[pid] = q.get<uint32_t>();
-            uint32_t bits = q.get<uint32_t>();
-            q.take(8);                               // is_parent: 4 bytes written, 8 advanced (pattern.cpp:35-37)
-            db->num_bits[pid] = bits;
-            size_t words = (size_t)((bits + 127) / 128) * 2;
-            const uint8_t* d = q.take(words * 8);
-            if (!q.ok) return fail("bad pattern");
-            db->data_offset[pid] = db->data.size();
-            size_t o = db->data.size();
-            db->data.resize(o + words);
-            if (words) std::memcpy(db->data.data() + o, d, words * 8);
-            db->pattern_section_bytes += 40 + words * 8;
-            ++pid;
+    // ---- patterns: the file holds them in blocks of at most 64 MB, each behind its byte count (prefix_kmer_db.cpp:544-571).  The blocks are
+    // found header to header, then taken side by side: one walk counts a block's patterns and stream words, a prefix sum places the blocks
+    // in the arrays, a second walk fills them.
+    std::vector<PatBlock> blocks;
+    {
+        uint64_t bytes_seen = 0;
+        // a pattern is at least PAT_HEADER bytes: stop collecting once the blocks seen could already hold P of them and the next header is bad
+        while (c.p < c.end) {
+            Cursor probe = c;
+            uint64_t bs = probe.get<uint64_t>();
+            const uint8_t* blk = probe.ok ? probe.take(bs) : nullptr;
+            if (!blk && bs) break;                   // not a block: the patterns must be complete by now (checked below)
+            if (!probe.ok) break;
+            blocks.push_back(PatBlock{blk, bs, 0, 0, false});
+            bytes_seen += bs;
+            c = probe;
         }
+        (void)bytes_seen;
     }
+    parallel_items(blocks.size(), T, [&](size_t b) {
+        PatBlock& B = blocks[b];
+        const uint8_t* q = B.p;
+        const uint8_t* e = B.p + B.bytes;
+        while (q < e) {
+            if ((size_t)(e - q) < PAT_HEADER) { B.bad = true; return; }
+            uint32_t bits;
+            std::memcpy(&bits, q + 28, 4);
+            const size_t words = (size_t)(((uint64_t)bits + 127) / 128) * 2;
+            if ((size_t)(e - q) - PAT_HEADER < words * 8) { B.bad = true; return; }
+            q += PAT_HEADER + words * 8;
+            ++B.patterns; B.words += words;
+        }
+    });
+    phase("pattern blocks counted");
+    // the blocks that hold the P patterns (the reference reads block after block until it has them all: prefix_kmer_db.cpp:700-748)
+    std::vector<uint64_t> pid0(blocks.size() + 1, 0), word0(blocks.size() + 1, 0);
+    size_t used_blocks = 0;
+    for (; used_blocks < blocks.size() && pid0[used_blocks] < P; ++used_blocks) {
+        const PatBlock& B = blocks[used_blocks];
+        if (B.bad) return fail("bad pattern");
+        pid0[used_blocks + 1] = pid0[used_blocks] + B.patterns;
+        word0[used_blocks + 1] = word0[used_blocks] + B.words;
+        if (pid0[used_blocks + 1] > P) return fail("too many patterns");
+    }
+    if (pid0[used_blocks] < P) return fail("bad pattern block");
+    const uint64_t n_words = word0[used_blocks];
+    if (!db->num_kmers.alloc(P) || !db->parent_id.alloc(P) || !db->num_samples.alloc(P) || !db->num_local.alloc(P) || !db->last_id.alloc(P) ||
+        !db->num_bits.alloc(P) || !db->data_offset.alloc(P) || !db->data.alloc(n_words + 2))
+        return fail("out of memory");
+    parallel_items(used_blocks, T, [&](size_t b) {
+        const PatBlock& B = blocks[b];
+        const uint8_t* q = B.p;
+        uint64_t pid = pid0[b], o = word0[b];
+        uint64_t* data = db->data.data();
+        for (uint64_t k = 0; k < B.patterns; ++k, ++pid) {
+            uint32_t f[4];
+            std::memcpy(&db->num_kmers[pid], q, 8);
+            std::memcpy(&db->parent_id[pid], q + 8, 8);
+            std::memcpy(f, q + 16, 16);
+            db->num_samples[pid] = f[0]; db->num_local[pid] = f[1]; db->last_id[pid] = f[2]; db->num_bits[pid] = f[3];
+            const size_t words = (size_t)(((uint64_t)f[3] + 127) / 128) * 2;
+            db->data_offset[pid] = o;
+            if (words) std::memcpy(data + o, q + PAT_HEADER, words * 8);
+            o += words;
+            q += PAT_HEADER + words * 8;
+        }
+    });
+    phase("pattern blocks parsed");
+    db->pattern_section_bytes = PAT_HEADER * P + 8 * n_words;
     munmap(map, (size_t)st.st_size);
-    db->data.push_back(0);                            // one padding word for 2-word decode windows
-    db->data.push_back(0);
+    phase("file unmapped");
+    db->data[n_words] = 0;                            // one padding pair for 2-word decode windows
+    db->data[n_words + 1] = 0;
 
     kmdb_db_view& v = db->view;
     v.abi_version = KMDB_ABI_VERSION;

@@ -89,6 +89,113 @@ def test_db_reader_errors(K, tmp_path):
         K.HostDB(str(p))
 
 
+def _pattern_section(raw):
+    """(offset of the pattern count, P, [(offset, bytes) of every pattern]) of a .db image (layout: host_db.cpp / prefix_kmer_db.cpp:438-571)"""
+    import struct
+    off = 8 + 4 + 8 + 8 + 4 + 1 + 8
+    n, = struct.unpack_from("<Q", raw, off)
+    off += 8
+    for _ in range(n):
+        off += 8
+        ln, = struct.unpack_from("<Q", raw, off)
+        off += 8 + ln
+    nb, = struct.unpack_from("<Q", raw, off)
+    off += 8
+    for _ in range(nb):
+        filled, alloc = struct.unpack_from("<QQ", raw, off + 8)
+        off += 64 + 8 * ((alloc + 63) // 64) + 8 * filled
+    p_off = off
+    P, = struct.unpack_from("<Q", raw, off)
+    off += 8
+    pats = []
+    while off < len(raw) and len(pats) < P:
+        bs, = struct.unpack_from("<Q", raw, off)
+        off += 8
+        end = off + bs
+        while off < end:
+            bits, = struct.unpack_from("<I", raw, off + 28)
+            size = 40 + 16 * ((bits + 127) // 128)
+            pats.append((off, size))
+            off += size
+    return p_off, P, pats
+
+
+@pytest.mark.parametrize("stem", ["virus_k18", "clade64", "virus_k18_f01"])
+def test_db_reader_takes_the_pattern_blocks_side_by_side(K, golden_dir, tmp_path, monkeypatch, stem):
+    """The reader finds the pattern blocks header to header and parses them on several threads.  The same database re-written with
+    many small blocks (3, 1 and 7 patterns per block in turn, an empty block in between: any split is a valid file,
+    prefix_kmer_db.cpp:544-571 / 700-748) must give the same arrays on 1, 2 and 16 threads, with and without the hashtables."""
+    import struct
+    raw = open(os.path.join(golden_dir, stem + ".db"), "rb").read()
+    p_off, P, pats = _pattern_section(raw)
+    assert len(pats) == P and P > 50
+    out = bytearray(raw[:p_off + 8])
+    i, sizes, k = 0, (3, 1, 7), 0
+    while i < P:
+        take = pats[i: i + sizes[k % 3]]
+        blk = b"".join(raw[o: o + s] for o, s in take)
+        out += struct.pack("<Q", len(blk)) + blk
+        if k == 4:
+            out += struct.pack("<Q", 0)                       # an empty block
+        i += len(take)
+        k += 1
+    p2 = str(tmp_path / "reblocked.db")
+    open(p2, "wb").write(bytes(out))
+    ref = K.HostDB(os.path.join(golden_dir, stem + ".db")).view_arrays()
+    for threads in ("1", "2", "16"):
+        monkeypatch.setenv("KMDB_LOAD_THREADS", threads)
+        for skip in (False, True):
+            h = K.HostDB(p2, skip_hashtables=skip)
+            v = h.view_arrays()
+            for key, a in ref.items():
+                if skip and key in ("bucket_offset", "slots", "n_buckets"):
+                    continue
+                assert np.array_equal(v[key], a), (key, threads)
+            assert h.pattern_section_bytes == sum(s for _, s in pats)
+            h.close()
+    # damaged pattern sections are refused, wherever the damage is
+    good = bytes(out)
+    last_off = len(good) - pats[-1][1]
+    cases = {
+        "truncated inside the last pattern": good[:-9],
+        "the last block is missing": good[:len(raw[:p_off + 8]) + 8 + sum(s for _, s in pats[:3])],
+        # (announcing one pattern less is only noticed when the surplus pattern shares a block with announced ones: the reader, like the
+        # reference, stops taking blocks once it has P patterns)
+        "more patterns in a block than announced": good[:p_off] + struct.pack("<Q", 2) + good[p_off + 8:],
+        "a stream longer than its block": good[:last_off + 28] + struct.pack("<I", 1 << 20) + good[last_off + 32:],
+    }
+    for what, img in cases.items():
+        p3 = str(tmp_path / "bad.db")
+        open(p3, "wb").write(img)
+        for threads in ("1", "16"):
+            monkeypatch.setenv("KMDB_LOAD_THREADS", threads)
+            with pytest.raises(K.KmdbError, match="Cannot open k-mer database"):
+                K.HostDB(p3, skip_hashtables=True)
+                pytest.fail(what)
+    # a hashtable item that points past the pattern table
+    if stem == "clade64":
+        img = bytearray(raw)
+        off = 8 + 4 + 8 + 8 + 4 + 1 + 8
+        n, = struct.unpack_from("<Q", raw, off)
+        off += 8
+        for _ in range(n):
+            ln, = struct.unpack_from("<Q", raw, off + 8)
+            off += 16 + ln
+        off += 8
+        while True:                                            # first non-empty table: its first item's value
+            filled, alloc = struct.unpack_from("<QQ", raw, off + 8)
+            items = off + 64 + 8 * ((alloc + 63) // 64)
+            if filled:
+                struct.pack_into("<i", img, items + 4, P + 5)
+                break
+            off = items
+        p4 = str(tmp_path / "badht.db")
+        open(p4, "wb").write(bytes(img))
+        with pytest.raises(K.KmdbError, match="points past the pattern table"):
+            K.HostDB(p4)
+        K.HostDB(p4, skip_hashtables=True).close()            # the all2all modes never look at the tables
+
+
 def test_kmer_extraction_matches_oracle(K, O, golden_dir):
     rng = np.random.default_rng(3)
     alphabet = np.frombuffer(b"ACGTacgtNnUuRYX-", dtype=np.uint8)
