@@ -75,7 +75,11 @@ typedef struct kmdb_opts {
 #define KMDB_FLAG_FORCE_TILE           4u   /* A/B reference: tree-form walk, wave-private LDS tile */
 #define KMDB_FLAG_NO_FALLBACK          8u   /* fail instead of taking the HBM-atomics kernel when the block-record pipeline cannot
                                               take the database (kmdb_stats.path tells which one ran) */
-#define KMDB_FLAG_ALL                  15u  /* any other bit in kmdb_opts.flags is rejected */
+#define KMDB_FLAG_ONE_SHOT             16u  /* at upload: the handle serves a process that ends after its call (the command-line front-end):
+                                              the upload's host staging buffers stay mapped until kmdb_db_free / process exit instead of being
+                                              unmapped by a helper thread after the first call (3.5 GB at 100 M patterns: 0.3 s of address-space
+                                              work that stalls every other thread's allocations meanwhile) */
+#define KMDB_FLAG_ALL                  31u  /* any other bit in kmdb_opts.flags is rejected */
 
 /* kmdb_stats.path */
 #define KMDB_PATH_NONE     0u

@@ -68,6 +68,7 @@ FLAG_FORCE_GLOBAL_ATOMICS = 1
 FLAG_FORCE_DIRECT = 2
 FLAG_FORCE_TILE = 4
 FLAG_NO_FALLBACK = 8
+FLAG_ONE_SHOT = 16
 PATH_NONE, PATH_RECORDS, PATH_TILE, PATH_GLOBAL = 0, 1, 2, 3
 
 # every symbol include/kmdb_amd.h declares

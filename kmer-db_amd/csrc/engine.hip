@@ -157,6 +157,7 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     HIP_TRY(hipSetDevice(device));
     auto* db = new kmdb_db();
     db->device = device; db->N = N; db->P = P; db->kmer_length = v->kmer_length;
+    db->one_shot = opts && (opts->flags & KMDB_FLAG_ONE_SHOT);
     auto fail = [&]() { kmdb_db_free(db); return 1; };
     if (hipStreamCreate(&db->stream) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
     for (auto& e : db->ev) if (hipEventCreate(&e) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
@@ -205,6 +206,7 @@ extern "C" int kmdb_db_upload_shard(const kmdb_db_view* v, const kmdb_opts* opts
 extern "C" void kmdb_db_free(kmdb_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
+    db->one_shot = false;
     kmdb_release_staging(db);
     kmdb_blocks_release(db);
     void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,

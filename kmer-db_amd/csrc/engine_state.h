@@ -157,6 +157,7 @@ struct kmdb_db {
     // host staging buffers of the upload, given back by a helper thread after the first call (or when the handle is freed):
     // unmapping them costs 0.3 s (the HIP runtime had them registered for the copies) and blocks every hipMalloc meanwhile
     std::vector<std::pair<void*, size_t>> staging;
+    bool one_shot = false;         // KMDB_FLAG_ONE_SHOT at upload: the staging buffers stay until the handle is freed
     bool v1_ready = false;          // the arrays below exist (all of them)
     uint4* meta = nullptr;          // {n, l, last_id, nbits} per node, DFS order
     uint64_t* bitpos = nullptr;     // absolute bit offset of the node's gamma stream

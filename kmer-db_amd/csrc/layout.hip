@@ -268,7 +268,7 @@ struct DevTmp {
 }  // namespace
 
 void kmdb_release_staging(kmdb_db* db) {
-    if (db->staging.empty()) return;
+    if (db->staging.empty() || db->one_shot) return;
     std::vector<std::pair<void*, size_t>> regions;
     regions.swap(db->staging);
     std::thread([regions]() {

@@ -183,7 +183,7 @@ int run_all2all(std::vector<std::string>& args, Common& c) {
     Db db;
     std::cerr << "Loading k-mer database " << args[0] << "..." << std::endl;
     std::ofstream ofs(args[1]);
-    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1;
+    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1; o.flags = KMDB_FLAG_ONE_SHOT;
     if (c.gpus > 0) node_upload(db, args[0], c);
     else {
         const auto tl = clk::now();
@@ -274,7 +274,7 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     Db db;
     std::cerr << "Loading k-mer database " << args[0] << "..." << std::endl;
     std::ofstream ofs(args[1], std::ios::binary);
-    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1; o.bubble_size = bubble;
+    kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = c.device; o.shard_count = 1; o.bubble_size = bubble; o.flags = KMDB_FLAG_ONE_SHOT;
     if (c.gpus > 0) node_upload(db, args[0], c);
     else {
         const auto tl = clk::now();

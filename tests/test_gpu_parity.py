@@ -46,6 +46,10 @@ def test_all2all_dense_bit_exact(K, O, golden_dir, dev, stem):
     assert np.array_equal(d2.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), ref)
     assert d2.stats()["sized_call"] == 1
     d2.close()
+    # a handle uploaded for a process that ends after its call (the front-end): the staging buffers stay mapped, calls are what they were
+    d3 = K.DeviceDB(h, device=dev, flags=K.capi.FLAG_ONE_SHOT)
+    assert np.array_equal(d3.all2all_dense(flags=K.capi.FLAG_ONE_SHOT), ref) and np.array_equal(d3.all2all_dense(), ref)
+    d3.close()
     # the A/B kernels: generic (global stack + HBM atomics), LDS stack + HBM atomics, wave-private LDS tile
     for fl in (K.capi.FLAG_FORCE_GLOBAL_ATOMICS, K.capi.FLAG_FORCE_DIRECT, K.capi.FLAG_FORCE_TILE):
         assert np.array_equal(d.all2all_dense(flags=fl), ref), fl

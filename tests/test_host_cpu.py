@@ -253,7 +253,7 @@ def test_unknown_flag_bits_are_rejected(K, golden_dir):
     """kmdb_opts.flags: only the documented bits are accepted (the library used to read timing experiments from the high
     bits); the check comes before any device work, so it holds on a box without a GPU too."""
     h = K.HostDB(os.path.join(golden_dir, "synth_k21.db"))
-    for bad in (1 << 8, 1 << 9, 1 << 13, 16, 0x80000000):
+    for bad in (1 << 8, 1 << 9, 1 << 13, 32, 0x80000000):
         with pytest.raises(K.KmdbError, match="unknown bits"):
             K.DeviceDB(h, flags=bad)
     # the shard arguments of the prefix-shard upload are checked up front as well
