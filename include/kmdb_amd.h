@@ -149,6 +149,10 @@ const char* kmdb_last_error(void);
 int  kmdb_abi_version(void);
 /* number of usable gfx950 devices, 0 if none (never fails) */
 int  kmdb_device_count(void);
+/* First use of a device (runtime start, the device's context, a first allocation and stream): 0.15 - 0.3 s that depend on nothing the
+ * database holds.  The front-end calls this on a helper thread while kmdbh_db_load reads the file (the reference has no counterpart:
+ * console_all2all.cpp:25-29 goes straight from deserialize to the computation).  0, or 1 with kmdb_last_error() set in the calling thread. */
+int  kmdb_device_prepare(int32_t device);
 
 /* Lay the database out in HBM (replaces PrefixKmerDb living in host RAM after
  * deserialize, prefix_kmer_db.cpp:578-748).  with_hashtables != 0 also uploads the

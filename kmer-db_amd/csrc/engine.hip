@@ -29,6 +29,21 @@ int kmdb_set_error(const std::string& msg) { g_last_error = msg; return 1; }
 extern "C" const char* kmdb_last_error(void) { return g_last_error.c_str(); }
 extern "C" int kmdb_abi_version(void) { return KMDB_ABI_VERSION; }
 
+extern "C" int kmdb_device_prepare(int32_t device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return kmdb_set_error("kmdb_device_prepare: no such HIP device"); }
+    HIP_TRY(hipSetDevice(device));
+    void* p = nullptr;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipMalloc(&p, 1 << 20));
+    HIP_TRY(hipStreamCreate(&s));
+    HIP_TRY(hipMemsetAsync(p, 0, 1 << 20, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamDestroy(s));
+    HIP_TRY(hipFree(p));
+    return 0;
+}
+
 extern "C" int kmdb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

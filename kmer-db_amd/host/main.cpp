@@ -187,7 +187,11 @@ int run_all2all(std::vector<std::string>& args, Common& c) {
     if (c.gpus > 0) node_upload(db, args[0], c);
     else {
         const auto tl = clk::now();
-        check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
+        std::thread warm([&]() { (void)kmdb_device_prepare(c.device); });      // the device's first use, next to the read of the file (an error shows at the upload)
+        const int load_rc = kmdbh_db_load(args[0].c_str(), 2, &db.h);
+        const std::string load_err = load_rc ? kmdb_last_error() : "";
+        warm.join();
+        if (load_rc) throw std::runtime_error(load_err);
         const double load_s = since(tl);
         const auto tu = clk::now();
         check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
@@ -278,7 +282,11 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     if (c.gpus > 0) node_upload(db, args[0], c);
     else {
         const auto tl = clk::now();
-        check(kmdbh_db_load(args[0].c_str(), 2, &db.h));
+        std::thread warm([&]() { (void)kmdb_device_prepare(c.device); });      // the device's first use, next to the read of the file (an error shows at the upload)
+        const int load_rc = kmdbh_db_load(args[0].c_str(), 2, &db.h);
+        const std::string load_err = load_rc ? kmdb_last_error() : "";
+        warm.join();
+        if (load_rc) throw std::runtime_error(load_err);
         const double load_s = since(tl);
         const auto tu = clk::now();
         check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
