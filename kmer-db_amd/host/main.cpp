@@ -28,6 +28,8 @@
 #include <stdexcept>
 #include <string>
 #include <memory>
+#include <ctime>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -153,9 +155,25 @@ void node_report(const Db& db) {
 // patterns —, the device pools allocation by allocation, the runtime's own teardown) only adds to the wall clock of the command: the OS and
 // the driver reclaim everything at once when the process ends.  KMDB_FULL_TEARDOWN=1 keeps the ordinary exit (profilers that write their
 // files from exit handlers need it).
+// seconds since the kernel started this process (exec, dynamic loading and static initialisers included; 10 ms resolution)
+double since_process_start() {
+    std::ifstream st("/proc/self/stat");
+    std::string line;
+    std::getline(st, line);
+    const size_t rp = line.rfind(')');                          // the command name may hold spaces
+    if (rp == std::string::npos) return -1;
+    std::istringstream is(line.substr(rp + 2));
+    std::string tok;
+    for (int f = 3; f <= 22 && (is >> tok); ++f) {}            // field 22: starttime in clock ticks since boot
+    timespec ts{};
+    clock_gettime(CLOCK_BOOTTIME, &ts);
+    return (double)ts.tv_sec + ts.tv_nsec * 1e-9 - std::strtod(tok.c_str(), nullptr) / (double)sysconf(_SC_CLK_TCK);
+}
+
 int finish(std::ofstream& ofs, const std::string& path) {
     ofs.close();
     if (!ofs) throw std::runtime_error("Cannot write the output file " + path);
+    std::cerr << "Process up for " << since_process_start() << " s" << std::endl;
     std::cout.flush();
     std::cerr.flush();
     const char* e = std::getenv("KMDB_FULL_TEARDOWN");
@@ -889,6 +907,8 @@ void usage() {
 }  // namespace
 
 int main(int argc, char** argv) {
+    const double up_at_main = since_process_start();
+    if (std::getenv("KMDB_VERBOSE")) std::cerr << "[kmdb] main() entered " << up_at_main << " s after the process started" << std::endl;
     std::vector<std::string> args(argv + 1, argv + argc);
     try {
         if (args.empty()) { usage(); return 0; }
