@@ -283,6 +283,10 @@ typedef struct kmdbh_db kmdbh_db;  /* a .db file parsed into flat host arrays */
 int  kmdbh_db_load(const char* path, int mode, kmdbh_db** out);
 void kmdbh_db_free(kmdbh_db* db);
 const kmdb_db_view* kmdbh_db_view(const kmdbh_db* db);
+/* Once the database is on the device (kmdb_db_upload / kmdb_node_upload returned) a front-end that needs only the names and k-mer counts
+ * from here on gives the pages of the pattern arrays and hashtables back (9 GB at 100 M patterns: otherwise the end of the process pays
+ * for them, 0.07 s per GB).  The view's arrays must not be read afterwards; kmdbh_db_free is still due. */
+void kmdbh_db_release_patterns(kmdbh_db* db);
 uint32_t    kmdbh_db_kmer_length(const kmdbh_db* db);
 double      kmdbh_db_fraction(const kmdbh_db* db);
 double      kmdbh_db_start_fraction(const kmdbh_db* db);

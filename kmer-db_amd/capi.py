@@ -77,7 +77,7 @@ EXPORTS = [
     "kmdb_node_upload", "kmdb_node_free", "kmdb_node_stats_get", "kmdb_node_all2all_dense", "kmdb_node_all2all_sparse",
     "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdb_sparse_from_dense_device", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
     "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
-    "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
+    "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_release_patterns", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
     "kmdbh_db_start_fraction", "kmdbh_db_alphabet", "kmdbh_db_n_samples", "kmdbh_db_sample_name",
     "kmdbh_db_sample_kmers", "kmdbh_db_pattern_section_bytes", "kmdbh_extract_kmers", "kmdbh_sort_unique",
     "kmdbh_format_header", "kmdbh_format_dense_row", "kmdbh_format_sparse_row",
@@ -129,6 +129,8 @@ def lib():
                                          C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdbh_db_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.kmdbh_db_free.argtypes = [C.c_void_p]
+    L.kmdbh_db_release_patterns.argtypes = [C.c_void_p]
+    L.kmdbh_db_release_patterns.restype = None
     L.kmdbh_db_view.restype = C.POINTER(_View)
     L.kmdbh_db_view.argtypes = [C.c_void_p]
     L.kmdbh_db_kmer_length.restype = C.c_uint32
@@ -201,6 +203,10 @@ class HostDB:
     @property
     def view(self):
         return lib().kmdbh_db_view(self._h)
+
+    def release_patterns(self):
+        """kmdbh_db_release_patterns: the pattern arrays' pages go back to the kernel (after the upload); names and counts stay"""
+        lib().kmdbh_db_release_patterns(self._h)
 
     def view_arrays(self):
         """numpy copies of the flat view (for tests of the reader)."""

@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -309,6 +310,27 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
     v.slots = want_ht ? db->slots.data() : nullptr;
     *out = db;
     return 0;
+}
+
+void kmdb_drop_pages(const std::vector<std::pair<void*, size_t>>& regions, unsigned threads) {
+    const size_t page = 4096, step = (size_t)32 << 20;
+    std::vector<std::pair<char*, size_t>> chunks;
+    for (const auto& r : regions) {
+        if (!r.first || r.second < 2 * page) continue;
+        char* a = (char*)(((uintptr_t)r.first + page - 1) & ~(uintptr_t)(page - 1));       // (a malloc'ed block keeps its header page)
+        char* e = (char*)(((uintptr_t)r.first + r.second) & ~(uintptr_t)(page - 1));
+        for (; a < e; a += step) chunks.emplace_back(a, std::min<size_t>(step, (size_t)(e - a)));
+    }
+    parallel_items(chunks.size(), threads, [&](size_t i) { (void)madvise(chunks[i].first, chunks[i].second, MADV_DONTNEED); });
+}
+
+extern "C" void kmdbh_db_release_patterns(kmdbh_db* db) {
+    if (!db) return;
+    std::vector<std::pair<void*, size_t>> regions;
+    auto add = [&](auto& b) { regions.emplace_back((void*)b.data(), b.size() * sizeof(*b.data())); };
+    add(db->num_kmers); add(db->parent_id); add(db->num_samples); add(db->num_local); add(db->last_id); add(db->num_bits);
+    add(db->data_offset); add(db->data); add(db->slots);
+    kmdb_drop_pages(regions, loader_threads());
 }
 
 extern "C" void kmdbh_db_free(kmdbh_db* db) { delete db; }

@@ -268,13 +268,16 @@ struct DevTmp {
 }  // namespace
 
 void kmdb_release_staging(kmdb_db* db) {
-    if (db->staging.empty() || db->one_shot) return;
+    if (db->staging.empty()) return;
     std::vector<std::pair<void*, size_t>> regions;
     regions.swap(db->staging);
-    std::thread([regions]() {
-        const size_t step = (size_t)32 << 20;
-        for (const auto& r : regions)
-            for (size_t o = 0; o < r.second; o += step) (void)munmap((char*)r.first + o, std::min(step, r.second - o));
+    const bool unmap = !db->one_shot;
+    std::thread([regions, unmap]() {
+        // the pages first, on several threads under the shared address-space lock (kmdb_drop_pages); what munmap then holds the lock
+        // exclusively for is the bookkeeping of empty ranges.  A one-shot handle (the front-end's) leaves even that to the end of the process.
+        kmdb_drop_pages(regions, 8);
+        if (unmap)
+            for (const auto& r : regions) (void)munmap(r.first, r.second);
     }).detach();
 }
 

@@ -118,7 +118,10 @@ struct Db {
     kmdbh_db* h = nullptr;
     kmdb_db* d = nullptr;
     kmdb_node* node = nullptr;               // -gpus N: the database prefix-sharded over the devices of the node
-    ~Db() { if (node) kmdb_node_free(node); if (d) kmdb_db_free(d); if (h) kmdbh_db_free(h); }
+    std::thread dropper;                     // gives the host image's pages back while the run goes on (uploaded())
+    // the database is on the device: from here on only names and k-mer counts are read from the host image
+    void uploaded() { if (h && !dropper.joinable()) dropper = std::thread([hh = h]() { kmdbh_db_release_patterns(hh); }); }
+    ~Db() { if (dropper.joinable()) dropper.join(); if (node) kmdb_node_free(node); if (d) kmdb_db_free(d); if (h) kmdbh_db_free(h); }
 };
 
 struct Common {
@@ -215,6 +218,7 @@ int run_all2all(std::vector<std::string>& args, Common& c) {
         check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
         std::cerr << "Database loaded in " << load_s << " s, uploaded in " << since(tu) << " s" << std::endl;
     }
+    db.uploaded();
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const int k = (int)kmdbh_db_kmer_length(db.h);
     std::cerr << "Calculating matrix of common k-mers..." << std::endl;
@@ -310,6 +314,7 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
         check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
         std::cerr << "Database loaded in " << load_s << " s, uploaded in " << since(tu) << " s" << std::endl;
     }
+    db.uploaded();
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const int k = (int)kmdbh_db_kmer_length(db.h);
     std::cerr << "Calculating matrix of common k-mers...";

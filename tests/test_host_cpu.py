@@ -80,6 +80,22 @@ def test_db_reader_matches_oracle_reader(K, O, golden_dir, stem):
     assert np.array_equal(h2.view_arrays()["data"], v["data"])
 
 
+def test_host_image_pages_given_back(K, golden_dir):
+    """kmdbh_db_release_patterns (the front-end calls it once the database is on the device): the big arrays' pages are dropped — they
+    read as zeros where whole pages went —, names and k-mer counts stay, and the handle is freed as usual."""
+    h = K.HostDB(os.path.join(golden_dir, "clade64.db"))
+    names, counts, before = list(h.names), h.sample_kmers.copy(), h.view_arrays()
+    assert before["data"].nbytes > 3 * 4096 and before["data"].any()
+    h.release_patterns()
+    after = h.view_arrays()
+    assert not after["data"][1024:-1024].any()                         # (the first and last partial pages of a block keep their bytes)
+    L = K.lib()
+    assert [L.kmdbh_db_sample_name(h._h, i).decode() for i in range(h.N)] == names
+    assert [int(L.kmdbh_db_sample_kmers(h._h, i)) for i in range(h.N)] == [int(c) for c in counts]
+    h.release_patterns()                                               # harmless twice
+    h.close()
+
+
 def test_db_reader_errors(K, tmp_path):
     with pytest.raises(K.KmdbError, match="Cannot open k-mer database"):
         K.HostDB(str(tmp_path / "missing.db"))
