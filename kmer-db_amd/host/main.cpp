@@ -173,9 +173,10 @@ double since_process_start() {
     return (double)ts.tv_sec + ts.tv_nsec * 1e-9 - std::strtod(tok.c_str(), nullptr) / (double)sysconf(_SC_CLK_TCK);
 }
 
-int finish(std::ofstream& ofs, const std::string& path) {
+int finish(Db& db, std::ofstream& ofs, const std::string& path) {
     ofs.close();
     if (!ofs) throw std::runtime_error("Cannot write the output file " + path);
+    if (db.dropper.joinable()) db.dropper.join();              // (its threads free the host image many times faster than the end of the process would)
     std::cerr << "Process up for " << since_process_start() << " s" << std::endl;
     std::cout.flush();
     std::cerr.flush();
@@ -283,7 +284,7 @@ int run_all2all(std::vector<std::string>& args, Common& c) {
         i0 = i1;
     }
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
-    return finish(ofs, args[1]);
+    return finish(db, ofs, args[1]);
 }
 
 // ---- all2all-sp (console_all2all_sparse.cpp:13-111) -------------------------------------------------
@@ -355,7 +356,7 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     kmdb_sparse_free(&sp);
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
     std::cerr << "No. saved pairs: " << saved << std::endl;
-    return finish(ofs, args[1]);
+    return finish(db, ofs, args[1]);
 }
 
 // ---- all2all-parts (console_all2all_parts.cpp:21-399): a collection split into several databases --------------

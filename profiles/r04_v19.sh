@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 4, job 18: default bench line; the front-end prints where its wall clock goes (process start -> main, load phases, upload parts, process up time)
-OUT=$PWD/gpurun_out; mkdir -p $OUT; TAG=r04_v18
+# round 4, job 19 (= 18 after the page drops): default bench line; the front-end prints where its wall clock goes (process start -> main, load phases, upload parts, process up time)
+OUT=$PWD/gpurun_out; mkdir -p $OUT; TAG=r04_v19
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; grep -A14 "front-end:" $OUT/${TAG}_bench.err
 python - <<PY
 import json
