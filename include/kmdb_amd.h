@@ -166,6 +166,10 @@ int  kmdb_db_upload(const kmdb_db_view* view, const kmdb_opts* opts, int with_ha
 int  kmdb_db_upload_shard(const kmdb_db_view* view, const kmdb_opts* opts, int with_hashtables, uint32_t shard_index,
                           uint32_t shard_count, kmdb_db** out);
 void kmdb_db_free(kmdb_db* db);
+/* Waits for the handle's background housekeeping (the upload's host staging buffers are given back by a helper thread after the first
+ * call).  A front-end that ends the process right after its call waits here first: the helper's threads free the pages several times
+ * faster than the end of the process would. */
+void kmdb_db_settle(kmdb_db* db);
 int  kmdb_db_stats(const kmdb_db* db, kmdb_stats* out);
 /* Why the last all2all call on this handle could not take the block-record pipeline ("" when it did, or before any call): the
  * note the engine prints once on stderr when it falls back to the HBM-atomics kernel (kmdb_stats.path == KMDB_PATH_GLOBAL), e.g.

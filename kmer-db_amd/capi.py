@@ -73,7 +73,7 @@ PATH_NONE, PATH_RECORDS, PATH_TILE, PATH_GLOBAL = 0, 1, 2, 3
 
 # every symbol include/kmdb_amd.h declares
 EXPORTS = [
-    "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_device_prepare", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_stats", "kmdb_db_fallback_reason",
+    "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_device_prepare", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_settle", "kmdb_db_stats", "kmdb_db_fallback_reason",
     "kmdb_node_upload", "kmdb_node_free", "kmdb_node_stats_get", "kmdb_node_all2all_dense", "kmdb_node_all2all_sparse",
     "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdb_sparse_from_dense_device", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
     "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",

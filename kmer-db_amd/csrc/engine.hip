@@ -218,11 +218,16 @@ extern "C" int kmdb_db_upload_shard(const kmdb_db_view* v, const kmdb_opts* opts
     return upload_impl(v, opts, with_hashtables, shard_index, shard_count, out);
 }
 
+extern "C" void kmdb_db_settle(kmdb_db* db) {
+    if (db && db->staging_thread.joinable()) db->staging_thread.join();
+}
+
 extern "C" void kmdb_db_free(kmdb_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
     db->one_shot = false;
     kmdb_release_staging(db);
+    if (db->staging_thread.joinable()) db->staging_thread.join();
     kmdb_blocks_release(db);
     void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
                     db->nseg_anc_n, db->meta, db->bitpos, db->ck_ofs, db->ck_bit, db->ck_id, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,

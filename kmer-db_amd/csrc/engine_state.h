@@ -3,6 +3,8 @@
 #pragma once
 #include "kmdb_amd.h"
 #include "kmdb_internal.h"
+
+#include <thread>
 #include "engine_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -157,6 +159,7 @@ struct kmdb_db {
     // host staging buffers of the upload, given back by a helper thread after the first call (or when the handle is freed):
     // unmapping them costs 0.3 s (the HIP runtime had them registered for the copies) and blocks every hipMalloc meanwhile
     std::vector<std::pair<void*, size_t>> staging;
+    std::thread staging_thread;    // gives the staging buffers back (kmdb_release_staging); joined by kmdb_db_settle / kmdb_db_free
     bool one_shot = false;         // KMDB_FLAG_ONE_SHOT at upload: the staging buffers stay until the handle is freed
     bool v1_ready = false;          // the arrays below exist (all of them)
     uint4* meta = nullptr;          // {n, l, last_id, nbits} per node, DFS order

@@ -272,13 +272,14 @@ void kmdb_release_staging(kmdb_db* db) {
     std::vector<std::pair<void*, size_t>> regions;
     regions.swap(db->staging);
     const bool unmap = !db->one_shot;
-    std::thread([regions, unmap]() {
+    if (db->staging_thread.joinable()) db->staging_thread.join();
+    db->staging_thread = std::thread([regions, unmap]() {
         // the pages first, on several threads under the shared address-space lock (kmdb_drop_pages); what munmap then holds the lock
         // exclusively for is the bookkeeping of empty ranges.  A one-shot handle (the front-end's) leaves even that to the end of the process.
         kmdb_drop_pages(regions, 8);
         if (unmap)
             for (const auto& r : regions) (void)munmap(r.first, r.second);
-    }).detach();
+    });                                                       // joined by kmdb_db_settle / kmdb_db_free
 }
 
 int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count) {

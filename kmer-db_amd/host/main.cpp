@@ -177,6 +177,7 @@ int finish(Db& db, std::ofstream& ofs, const std::string& path) {
     ofs.close();
     if (!ofs) throw std::runtime_error("Cannot write the output file " + path);
     if (db.dropper.joinable()) db.dropper.join();              // (its threads free the host image many times faster than the end of the process would)
+    if (db.d) kmdb_db_settle(db.d);                            // the same for the upload's staging buffers
     std::cerr << "Process up for " << since_process_start() << " s" << std::endl;
     std::cout.flush();
     std::cerr.flush();
@@ -219,7 +220,6 @@ int run_all2all(std::vector<std::string>& args, Common& c) {
         check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
         std::cerr << "Database loaded in " << load_s << " s, uploaded in " << since(tu) << " s" << std::endl;
     }
-    db.uploaded();
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const int k = (int)kmdbh_db_kmer_length(db.h);
     std::cerr << "Calculating matrix of common k-mers..." << std::endl;
@@ -233,6 +233,7 @@ int run_all2all(std::vector<std::string>& args, Common& c) {
             std::cerr << "WARNING: the fast pipeline could not take this database (" << kmdb_db_fallback_reason(db.d) << "); the slow HBM-atomics kernel ran" << std::endl;
     }
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    db.uploaded();                                             // (after the call: the page drop and the call's first allocations get in each other's way)
     std::cerr << "Storing matrix of common k-mers in " << args[1] << "...";
     t0 = clk::now();
     write_header(db, ofs);
@@ -315,7 +316,6 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
         check(kmdb_db_upload(kmdbh_db_view(db.h), &o, 0, &db.d));
         std::cerr << "Database loaded in " << load_s << " s, uploaded in " << since(tu) << " s" << std::endl;
     }
-    db.uploaded();
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const int k = (int)kmdbh_db_kmer_length(db.h);
     std::cerr << "Calculating matrix of common k-mers...";
@@ -335,6 +335,7 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
         else check(kmdb_all2all_sparse_filtered(db.d, fl.data(), fl.size(), counts.data(), -1, &sp, &o));
     }
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
+    db.uploaded();                                             // (after the call: the page drop and the call's first allocations get in each other's way)
     std::cerr << "Storing matrix of common k-mers in " << args[1] << "...";
     t0 = clk::now();
     write_header(db, ofs);
