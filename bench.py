@@ -261,8 +261,11 @@ def frontend_run(K, db_path, td, ref_matrix, names, counts, k):
     # the same command with the ordinary process teardown (KMDB_FULL_TEARDOWN=1: host image and device pools freed one by one, runtime exit
     # handlers): what ending the process at once is worth
     t0 = time.time()
-    r2 = subprocess.run([exe, "all2all", db_path, out_csv], capture_output=True, text=True, env=dict(os.environ, KMDB_FULL_TEARDOWN="1"))
+    r2 = subprocess.run([exe, "all2all", db_path, out_csv], capture_output=True, text=True,
+                        env=dict(os.environ, KMDB_FULL_TEARDOWN="1", KMDB_LOAD_POPULATE="0", KMDB_VERBOSE="1"))
     res["frontend_full_teardown_s"] = time.time() - t0
+    log("front-end with the ordinary teardown and without the bulk prefault of the reader's arrays:\n  " +
+        "\n  ".join(ln for ln in r2.stderr.splitlines() if ln.startswith(("[kmdb] load", "Database", "Process"))))
     with open(out_csv, "rb") as f:
         assert r2.returncode == 0 and f.read() == got, "front-end with full teardown: different output"
     # expected text: header lines + one row per sample from the reference's matrix

@@ -266,11 +266,30 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
     if (!db->num_kmers.alloc(P) || !db->parent_id.alloc(P) || !db->num_samples.alloc(P) || !db->num_local.alloc(P) || !db->last_id.alloc(P) ||
         !db->num_bits.alloc(P) || !db->data_offset.alloc(P) || !db->data.alloc(n_words + 2))
         return fail("out of memory");
+    // the arrays are fresh memory: 2.3 M first-touch faults at 100 M patterns.  Every thread asks for the pages of its block's stretches in
+    // bulk first (MADV_POPULATE_WRITE, Linux 5.14: one call instead of a trap per page; ignored where the kernel does not know it)
+    const char* pe = std::getenv("KMDB_LOAD_POPULATE");
+    const bool populate = !(pe && pe[0] == '0');
+    auto prefault = [&](void* base, size_t lo_bytes, size_t hi_bytes) {
+#ifdef MADV_POPULATE_WRITE
+        const uintptr_t a = ((uintptr_t)base + lo_bytes + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)base + hi_bytes) & ~(uintptr_t)4095;
+        if (populate && e > a) (void)madvise((void*)a, e - a, MADV_POPULATE_WRITE);
+#else
+        (void)base; (void)lo_bytes; (void)hi_bytes;
+#endif
+    };
     parallel_items(used_blocks, T, [&](size_t b) {
         const PatBlock& B = blocks[b];
         const uint8_t* q = B.p;
         uint64_t pid = pid0[b], o = word0[b];
         uint64_t* data = db->data.data();
+        {
+            const uint64_t p0 = pid0[b], p1 = pid0[b + 1];
+            prefault(db->num_kmers.data(), p0 * 8, p1 * 8); prefault(db->parent_id.data(), p0 * 8, p1 * 8); prefault(db->data_offset.data(), p0 * 8, p1 * 8);
+            prefault(db->num_samples.data(), p0 * 4, p1 * 4); prefault(db->num_local.data(), p0 * 4, p1 * 4);
+            prefault(db->last_id.data(), p0 * 4, p1 * 4); prefault(db->num_bits.data(), p0 * 4, p1 * 4);
+            prefault(data, word0[b] * 8, word0[b + 1] * 8);
+        }
         for (uint64_t k = 0; k < B.patterns; ++k, ++pid) {
             uint32_t f[4];
             std::memcpy(&db->num_kmers[pid], q, 8);
