@@ -23,6 +23,12 @@ def main():
     while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 200_000 and not any(x in ev[i0 - 1][2] for x in ("k2_sorted", "k2_apply", "row_compact")):
         i0 -= 1
     call = ev[i0:]
+    # the call ends with the copy of its counters after the last apply kernel: what follows (the caller's own kernels) is not part of it
+    last = max((i for i, t in enumerate(call) if any(x in t[2] for x in ("k2_sorted", "k2_apply", "row_compact"))), default=len(call) - 1)
+    end = last
+    while end + 1 < len(call) and "rocclr_copyBuffer" in call[end + 1][2] and call[end + 1][0] - call[end][1] < 100_000:
+        end += 1
+    call = call[:end + 1]
     t0 = call[0][0]
     last_end = {}
     out = ["| kernel | queue | start (us) | duration (us) | queue idle before (us) |", "|---|---|---|---|---|"]
@@ -30,7 +36,7 @@ def main():
     for s, e, n, q in call:
         idle = (s - last_end[q]) / 1e3 if q in last_end else 0.0
         last_end[q] = max(e, last_end.get(q, 0))
-        short = n.split("(")[0].replace("void ", "")
+        short = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if len(short) > 70:
             short = short[:67] + "..."
         out.append("| `%s` | %s | %.1f | %.1f | %.1f |" % (short, q, (s - t0) / 1e3, (e - s) / 1e3, idle))
