@@ -888,8 +888,10 @@ def main():
                 "note": "upload = kmdb_db_upload (format conversion: host narrowing + H2D + device DFS layout; no sample id decoded except "
                         "the 1-in-%d sample of the block-width estimate); cold call = first kmdb_all2all_dense incl. D2H of the matrix; every "
                         "call, warm or cold, decodes, places and accumulates everything itself; the upload's host staging buffers (3.5 GB at c2) are "
-                        "unmapped by a helper thread after the first call, not inside upload (0.3 s of address-space work that blocks nothing "
-                        "the calls need)" % max(1, min(1024, db.P // 65536)),
+                        "given back by a helper thread after the first call, not inside upload (their pages dropped on several threads under the "
+                        "shared address-space lock, then unmapped); frontend_*: `kmer-db-amd all2all full.db out.csv` as a process on the "
+                        "reference's own .db file — load / upload / compute / csv as it prints them, process_up = kernel start of the process to "
+                        "the table on disk (incl. waiting for its page drops), frontend_s - process_up = the end of the process" % max(1, min(1024, db.P // 65536)),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
