@@ -96,6 +96,18 @@ def test_host_image_pages_given_back(K, golden_dir):
     h.close()
 
 
+def test_db_reader_survives_damaged_files(golden_dir, tmp_path):
+    """400 damaged images of a valid database (truncated anywhere, random bytes, wild 32 / 64-bit fields), each read with and without
+    the hashtables on 1 - 8 threads: the reader refuses or accepts, never walks off its mapping (the fuzz runs as a process of its own and
+    must end normally), and what it accepts is consistent (every stream inside the data array)."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "reader_fuzz.py"), os.path.join(golden_dir, "clade64.db"), str(tmp_path / "fz.db"), "7", "200"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    acc, ref = (int(x) for x in re.findall(r"accepted (\d+) refused (\d+)", r.stdout)[0])
+    assert acc + ref == 400 and ref > 50 and acc > 50
+
+
 def test_db_reader_errors(K, tmp_path):
     with pytest.raises(K.KmdbError, match="Cannot open k-mer database"):
         K.HostDB(str(tmp_path / "missing.db"))
