@@ -21,7 +21,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 constexpr uint32_t WAVES = 4;
-constexpr uint32_t QCAP = 448;                 // queued matches per wave: fewer than 64 left over + one wave step's matches (165 on average here)
+constexpr uint32_t QCAP = 576;                 // queued matches per wave: fewer than 64 left over + at most eight per lane and round
 
 template <bool GATHER>
 __global__ __launch_bounds__(64 * WAVES) void join_kernel(const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R, const unsigned long long* __restrict__ L,
@@ -68,27 +68,28 @@ __global__ __launch_bounds__(64 * WAVES) void join_kernel(const unsigned long lo
         unsigned long long m = 0, wx = 0, wy = 0;
         uint32_t bxr = 0, byr = 0;
         if (w < W) { wx = bx[w]; wy = by[w]; m = wx & wy; bxr = rx[w]; byr = ry[w]; }
-        uint32_t k = (uint32_t)__popcll(m);
-        // exclusive prefix of the match counts over the wave
-        uint32_t incl = k;
+        cnt += (uint32_t)__popcll(m);
+        // a word's matches enter the queue at most eight per lane and round (a diagonal tile, X == Y, matches every node of the list: 13 per word)
+        while (__ballot(m != 0ull)) {
+            const uint32_t left = (uint32_t)__popcll(m);
+            const uint32_t k = left < 8u ? left : 8u;
+            uint32_t incl = k;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += v; }
-        const uint32_t total = __shfl(incl, 63, 64);
-        uint32_t pos = qn + incl - k;
-        cnt += k;
-        // up to 64 * 64 matches per wave step in the worst case: the queue is drained whenever it could overflow
-        while (m) {
-            const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1;
-            const unsigned long long below = (1ull << bit) - 1ull;
-            if (pos < QCAP) { q[wave][pos] = bxr + (uint32_t)__popcll(wx & below); q2[wave][pos] = byr + (uint32_t)__popcll(wy & below); }
-            ++pos;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += v; }
+            const uint32_t total = __shfl(incl, 63, 64);
+            uint32_t pos = qn + incl - k;
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const unsigned long long below = (1ull << bit) - 1ull;
+                q[wave][pos] = bxr + (uint32_t)__popcll(wx & below); q2[wave][pos] = byr + (uint32_t)__popcll(wy & below);
+                ++pos;
+            }
+            if (qn + total > QCAP) { if (lane == 0) atomicAdd(n_match + 1, 1ull); }     // (cannot happen: fewer than 64 + 512)
+            qn += total;
+            __builtin_amdgcn_wave_barrier();
+            drain_full_steps();
         }
-        // (synthetic density: 2.6 matches per word on average, 64 words: ~165 per wave step; an overflow of the queue is counted and shows as a wrong checksum)
-        if (qn + total > QCAP) { if (lane == 0) atomicAdd(n_match + 1, 1ull); }
-        qn = min(qn + total, QCAP);
-        __builtin_amdgcn_wave_barrier();
-        drain_full_steps();
     }
     if (qn) step(0u, qn);
     // tile checksum
