@@ -71,7 +71,8 @@ typedef int k2_v4i __attribute__((ext_vector_type(4)));
 typedef int k2_v16i __attribute__((ext_vector_type(16)));
 
 // APPLY = false: the join and the gathers alone (a checksum in place of the tile); true: the whole kernel
-template <bool APPLY>
+// PF: the gathers of the next step and the bitmap words of the next round are under way while a step is applied
+template <bool APPLY, bool PF>
 __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R, const unsigned long long* __restrict__ L,
                                                                 const unsigned char* __restrict__ Wt, const uint32_t* __restrict__ loff, uint32_t NB, uint32_t W,
                                                                 uint32_t* __restrict__ tiles_out, unsigned long long* __restrict__ sums, unsigned long long* __restrict__ n_match) {
@@ -119,13 +120,14 @@ __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned l
         w0 = ((unsigned long long)b[0] << 32) | a[0];
         w1 = ((unsigned long long)b[1] << 32) | a[1];
     };
-    auto step = [&](uint32_t base, uint32_t n) {          // 64 matches = 64 block records (X, Y, rows, cols, weight), one per lane
-        unsigned long long Rm = 0, Cm = 0;
-        uint32_t Wg = 0;
+    auto fetch = [&](uint32_t base, uint32_t n, unsigned long long& Rm, unsigned long long& Cm, uint32_t& Wg) {
+        Rm = 0; Cm = 0; Wg = 0;
         if (lane < n) {
             const uint32_t a = q[wave][base + lane], b = q2[wave][base + lane];
             Rm = lx[a]; Cm = ly[b]; Wg = wx8[a];
         }
+    };
+    auto apply = [&](unsigned long long Rm, unsigned long long Cm, uint32_t Wg) {      // 64 block records (X, Y, rows, cols, weight), one per lane
         if (!APPLY) { csum += (Rm ^ (Cm * 0x9E3779B97F4A7C15ull)) + Wg; return; }
         const unsigned long long Ct = transpose64(Cm, trc);
         const unsigned long long Rt = transpose64(Rm, trc);
@@ -150,7 +152,15 @@ __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned l
     };
     auto drain_full_steps = [&]() {
         uint32_t head = 0;
-        while (qn - head >= 64u) { step(head, 64u); head += 64u; }
+        unsigned long long nR = 0, nC = 0; uint32_t nW = 0;
+        if (PF && qn >= 64u) fetch(0u, 64u, nR, nC, nW);
+        while (qn - head >= 64u) {
+            unsigned long long Rm, Cm; uint32_t Wg;
+            if (PF) { Rm = nR; Cm = nC; Wg = nW; } else fetch(head, 64u, Rm, Cm, Wg);
+            head += 64u;
+            if (PF && qn - head >= 64u) fetch(head, 64u, nR, nC, nW);
+            apply(Rm, Cm, Wg);
+        }
         if (head) {
             const uint32_t rest = qn - head;
             uint32_t a = 0, b = 0;
@@ -161,11 +171,19 @@ __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned l
             qn = rest;
         }
     };
-    for (uint32_t w0 = wave * 64u; w0 < W; w0 += 64u * WAVES) {
+    unsigned long long pwx = 0, pwy = 0; uint32_t pbx = 0, pby = 0;
+    auto load_words = [&](uint32_t w0, unsigned long long& wx, unsigned long long& wy, uint32_t& bxr, uint32_t& byr) {
         const uint32_t w = w0 + lane;
-        unsigned long long m = 0, wx = 0, wy = 0;
-        uint32_t bxr = 0, byr = 0;
-        if (w < W) { wx = bx[w]; wy = by[w]; m = wx & wy; bxr = rx[w]; byr = ry[w]; }
+        wx = 0; wy = 0; bxr = 0; byr = 0;
+        if (w0 < W && w < W) { wx = bx[w]; wy = by[w]; bxr = rx[w]; byr = ry[w]; }
+    };
+    if (PF) load_words(wave * 64u, pwx, pwy, pbx, pby);
+    for (uint32_t w0 = wave * 64u; w0 < W; w0 += 64u * WAVES) {
+        unsigned long long wx, wy;
+        uint32_t bxr, byr;
+        if (PF) { wx = pwx; wy = pwy; bxr = pbx; byr = pby; load_words(w0 + 64u * WAVES, pwx, pwy, pbx, pby); }
+        else load_words(w0, wx, wy, bxr, byr);
+        unsigned long long m = wx & wy;
         cnt += (uint32_t)__popcll(m);
         while (__ballot(m != 0ull)) {
             const uint32_t left = (uint32_t)__popcll(m);
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned l
             drain_full_steps();
         }
     }
-    if (qn) step(0u, qn);
+    if (qn) { unsigned long long Rm, Cm; uint32_t Wg; fetch(0u, qn, Rm, Cm, Wg); apply(Rm, Cm, Wg); }
 #pragma unroll
     for (int d = 32; d; d >>= 1) cnt += __shfl_down(cnt, d, 64);
     if (lane == 0) atomicAdd(n_match, cnt);
@@ -267,19 +285,21 @@ int main() {
     CK(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(doff, loff.data(), loff.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, Wt.data(), Wt.size(), hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    float best_full = 1e9f, best_join = 1e9f;
-    for (int rep = 0; rep < 5; ++rep) {
+    float best_full = 1e9f, best_join = 1e9f, best_pf = 1e9f, best_join_pf = 1e9f;
+    auto timed = [&](auto kern, float& best) -> int {
         float ms;
         CK(hipMemset(dsum, 0, (size_t)tiles * 8)); CK(hipMemset(dn, 0, 16));
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(join_apply_kernel<false>, dim3(tiles), dim3(64 * WAVES), 0, 0, dB, dR, dL, dW, doff, NB, W, dtiles, dsum, dn);
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES), 0, 0, dB, dR, dL, dW, doff, NB, W, dtiles, dsum, dn);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-        CK(hipEventElapsedTime(&ms, e0, e1)); best_join = std::min(best_join, ms);
-        CK(hipMemset(dn, 0, 16));
-        CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(join_apply_kernel<true>, dim3(tiles), dim3(64 * WAVES), 0, 0, dB, dR, dL, dW, doff, NB, W, dtiles, dsum, dn);
-        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-        CK(hipEventElapsedTime(&ms, e0, e1)); best_full = std::min(best_full, ms);
+        CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+        return 0;
+    };
+    for (int rep = 0; rep < 5; ++rep) {
+        if (timed(join_apply_kernel<false, false>, best_join)) return 1;
+        if (timed(join_apply_kernel<false, true>, best_join_pf)) return 1;
+        if (timed(join_apply_kernel<true, false>, best_full)) return 1;
+        if (timed(join_apply_kernel<true, true>, best_pf)) return 1;          // (last: its tiles are the ones checked)
     }
     CK(hipGetLastError());
     unsigned long long n[2];
@@ -295,8 +315,9 @@ int main() {
     }
     printf("G %u many-block nodes x %u of %u blocks, weights 1..3: %u tiles, %.1f M matches (block records), lists %.1f MB, bitmaps %.1f MB\n", G, C, NB, tiles, n[0] / 1e6,
            L.size() * 8 / 1e6, B.size() * 8 / 1e6);
-    printf("join + gather alone: %.3f ms; join + gather + transposes + MFMA accumulation + one write per tile: %.3f ms best of 5 (%.1f G records/s); "
-           "6 probed tiles (%llu cell updates) %s\n", best_join, best_full, n[0] / best_full / 1e6, cells, bad ? "DIFFER from the definition" : "equal the definition on the host");
+    printf("join + gather alone: %.3f ms (with prefetch %.3f); join + gather + transposes + MFMA accumulation + one write per tile: %.3f ms, with the next step's gathers "
+           "and the next round's bitmap words under way %.3f ms, best of 5 (%.1f G records/s); 6 probed tiles (%llu cell updates) %s\n", best_join, best_join_pf, best_full, best_pf,
+           n[0] / best_pf / 1e6, cells, bad ? "DIFFER from the definition" : "equal the definition on the host");
     if (bad) printf("  differing cells: %d\n", bad);
     return bad ? 1 : 0;
 }
