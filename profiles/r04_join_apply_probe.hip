@@ -72,8 +72,10 @@ typedef int k2_v16i __attribute__((ext_vector_type(16)));
 
 // APPLY = false: the join and the gathers alone (a checksum in place of the tile); true: the whole kernel
 // PF: the gathers of the next step and the bitmap words of the next round are under way while a step is applied
-template <bool APPLY, bool PF>
-__global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R, const unsigned long long* __restrict__ L,
+// (one call site of the apply step — the tail of the queue is drained by a last, empty round of the same loop — and at least four waves per
+// SIMD asked of the register allocator: the first edition inlined the step twice and ran at two.)
+template <bool APPLY, bool PF, int MINW>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void join_apply_kernel(const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R, const unsigned long long* __restrict__ L,
                                                                 const unsigned char* __restrict__ Wt, const uint32_t* __restrict__ loff, uint32_t NB, uint32_t W,
                                                                 uint32_t* __restrict__ tiles_out, unsigned long long* __restrict__ sums, unsigned long long* __restrict__ n_match) {
     __shared__ uint32_t q[WAVES][QCAP];
@@ -150,15 +152,17 @@ __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned l
         }
         lds_sync();
     };
-    auto drain_full_steps = [&]() {
+    auto drain_steps = [&](bool all) {                    // the full steps of the queue; all: the partly filled last one too
         uint32_t head = 0;
         unsigned long long nR = 0, nC = 0; uint32_t nW = 0;
-        if (PF && qn >= 64u) fetch(0u, 64u, nR, nC, nW);
-        while (qn - head >= 64u) {
+        auto avail = [&]() -> uint32_t { const uint32_t r = qn - head; return r >= 64u ? 64u : (all ? r : 0u); };
+        if (PF && avail()) fetch(0u, avail(), nR, nC, nW);
+        while (avail()) {
             unsigned long long Rm, Cm; uint32_t Wg;
-            if (PF) { Rm = nR; Cm = nC; Wg = nW; } else fetch(head, 64u, Rm, Cm, Wg);
-            head += 64u;
-            if (PF && qn - head >= 64u) fetch(head, 64u, nR, nC, nW);
+            const uint32_t n = avail();
+            if (PF) { Rm = nR; Cm = nC; Wg = nW; } else fetch(head, n, Rm, Cm, Wg);
+            head += n;
+            if (PF && avail()) fetch(head, avail(), nR, nC, nW);
             apply(Rm, Cm, Wg);
         }
         if (head) {
@@ -178,14 +182,15 @@ __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned l
         if (w0 < W && w < W) { wx = bx[w]; wy = by[w]; bxr = rx[w]; byr = ry[w]; }
     };
     if (PF) load_words(wave * 64u, pwx, pwy, pbx, pby);
-    for (uint32_t w0 = wave * 64u; w0 < W; w0 += 64u * WAVES) {
+    for (uint32_t w0 = wave * 64u;; w0 += 64u * WAVES) {
+        const bool last = w0 >= W;                            // one round past the bitmap: nothing to match, the queue's tail is drained
         unsigned long long wx, wy;
         uint32_t bxr, byr;
         if (PF) { wx = pwx; wy = pwy; bxr = pbx; byr = pby; load_words(w0 + 64u * WAVES, pwx, pwy, pbx, pby); }
         else load_words(w0, wx, wy, bxr, byr);
         unsigned long long m = wx & wy;
         cnt += (uint32_t)__popcll(m);
-        while (__ballot(m != 0ull)) {
+        do {
             const uint32_t left = (uint32_t)__popcll(m);
             const uint32_t k = left < 8u ? left : 8u;
             uint32_t incl = k;
@@ -202,10 +207,10 @@ __global__ __launch_bounds__(64 * WAVES) void join_apply_kernel(const unsigned l
             }
             qn += total;
             lds_sync();
-            drain_full_steps();
-        }
+            drain_steps(last);
+        } while (__ballot(m != 0ull));
+        if (last) break;
     }
-    if (qn) { unsigned long long Rm, Cm; uint32_t Wg; fetch(0u, qn, Rm, Cm, Wg); apply(Rm, Cm, Wg); }
 #pragma unroll
     for (int d = 32; d; d >>= 1) cnt += __shfl_down(cnt, d, 64);
     if (lane == 0) atomicAdd(n_match, cnt);
@@ -295,12 +300,19 @@ int main() {
         CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
         return 0;
     };
+    float b3 = 1e9f, b3pf = 1e9f, b4 = 1e9f, b2pf = 1e9f;
     for (int rep = 0; rep < 5; ++rep) {
-        if (timed(join_apply_kernel<false, false>, best_join)) return 1;
-        if (timed(join_apply_kernel<false, true>, best_join_pf)) return 1;
-        if (timed(join_apply_kernel<true, false>, best_full)) return 1;
-        if (timed(join_apply_kernel<true, true>, best_pf)) return 1;          // (last: its tiles are the ones checked)
+        if (timed(join_apply_kernel<false, false, 4>, best_join)) return 1;
+        if (timed(join_apply_kernel<false, true, 4>, best_join_pf)) return 1;
+        if (timed(join_apply_kernel<true, false, 2>, best_full)) return 1;
+        if (timed(join_apply_kernel<true, true, 2>, b2pf)) return 1;
+        if (timed(join_apply_kernel<true, false, 3>, b3)) return 1;
+        if (timed(join_apply_kernel<true, false, 4>, b4)) return 1;
+        if (timed(join_apply_kernel<true, true, 4>, best_pf)) return 1;
+        if (timed(join_apply_kernel<true, true, 3>, b3pf)) return 1;          // (last: its tiles are the ones checked)
     }
+    printf("whole kernel by waves per SIMD asked of the register allocator: 2: %.3f ms (prefetch %.3f), 3: %.3f (prefetch %.3f), 4: %.3f (prefetch %.3f, spills)\n", best_full, b2pf, b3, b3pf, b4, best_pf);
+    best_pf = std::min(std::min(best_pf, b3pf), b2pf);
     CK(hipGetLastError());
     unsigned long long n[2];
     CK(hipMemcpy(n, dn, 16, hipMemcpyDeviceToHost));
