@@ -235,6 +235,42 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(MINW
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 64 * WAVES) dst[k] = acc[k];
 }
 
+// ---- the structures built on the device from what the wide kernel would write for a many-block node: its c entries (node index g, block,
+// mask) in arrival order and its weight.  No sort: an entry's place in its block's list is its rank in the block's bitmap.
+__global__ void build_bitmaps_kernel(const uint32_t* __restrict__ ent_g, const uint16_t* __restrict__ ent_blk, uint32_t n, uint32_t W, unsigned long long* __restrict__ B) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicOr(&B[(size_t)ent_blk[i] * W + (ent_g[i] >> 6)], 1ull << (ent_g[i] & 63u));
+}
+// one workgroup of 256 threads per block: exclusive prefix popcounts of its W bitmap words, and the list length
+__global__ __launch_bounds__(256) void build_ranks_kernel(const unsigned long long* __restrict__ B, uint32_t W, uint32_t* __restrict__ R, uint32_t* __restrict__ len) {
+    __shared__ uint32_t part[256];
+    const unsigned long long* b = B + (size_t)blockIdx.x * W;
+    uint32_t* r = R + (size_t)blockIdx.x * W;
+    const uint32_t per = (W + 255u) / 256u, lo = threadIdx.x * per, hi = lo + per < W ? lo + per : W;
+    uint32_t s = 0;
+    for (uint32_t w = lo; w < hi; ++w) s += (uint32_t)__popcll(b[w]);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < 256; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; } len[blockIdx.x] = run; }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t w = lo; w < hi; ++w) { r[w] = run; run += (uint32_t)__popcll(b[w]); }
+}
+__global__ void build_offsets_kernel(const uint32_t* __restrict__ len, uint32_t NB, uint32_t* __restrict__ loff) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { uint32_t run = 0; for (uint32_t x = 0; x < NB; ++x) { loff[x] = run; run += len[x]; } loff[NB] = run; }
+}
+__global__ void build_lists_kernel(const uint32_t* __restrict__ ent_g, const uint16_t* __restrict__ ent_blk, const unsigned long long* __restrict__ ent_mask,
+                                   const unsigned char* __restrict__ wnode, uint32_t n, uint32_t W, const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R,
+                                   const uint32_t* __restrict__ loff, unsigned long long* __restrict__ L, unsigned char* __restrict__ Wt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = ent_g[i], X = ent_blk[i];
+    const unsigned long long word = B[(size_t)X * W + (g >> 6)];
+    const uint32_t pos = loff[X] + R[(size_t)X * W + (g >> 6)] + (uint32_t)__popcll(word & ((1ull << (g & 63u)) - 1ull));
+    L[pos] = ent_mask[i];
+    Wt[pos] = wnode[g];
+}
+
 int main() {
     const uint32_t G = 262144, NB = 200, C = 40, W = G / 64;
     std::mt19937_64 rng(12345);
@@ -250,6 +286,7 @@ int main() {
     std::vector<uint32_t> R((size_t)NB * W), loff(NB + 1, 0);
     std::vector<unsigned long long> L;
     std::vector<unsigned char> Wt;
+    std::vector<uint32_t> ent_g; std::vector<uint16_t> ent_blk; std::vector<unsigned long long> ent_mask;      // the entries as the wide kernel would write them: node by node
     for (uint32_t X = 0; X < NB; ++X) {
         loff[X] = (uint32_t)L.size();
         uint32_t run = 0;
@@ -257,7 +294,8 @@ int main() {
             R[(size_t)X * W + w] = run;
             unsigned long long m = B[(size_t)X * W + w];
             run += (uint32_t)__builtin_popcountll(m);
-            while (m) { const int bit = __builtin_ctzll(m); m &= m - 1; L.push_back(rng() & rng() & ((1ull << 50) - 1)); Wt.push_back(wnode[w * 64 + bit]); }
+            while (m) { const int bit = __builtin_ctzll(m); m &= m - 1; L.push_back(rng() & rng() & ((1ull << 50) - 1)); Wt.push_back(wnode[w * 64 + bit]);
+                        ent_g.push_back(w * 64 + bit); ent_blk.push_back((uint16_t)X); ent_mask.push_back(L.back()); }
         }
     }
     loff[NB] = (uint32_t)L.size();
@@ -290,6 +328,40 @@ int main() {
     CK(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(doff, loff.data(), loff.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, Wt.data(), Wt.size(), hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // ---- the same structures built on the device from the entries (shuffled into node order first: the host loop above listed them block by block)
+    float build_ms = 0;
+    {
+        const uint32_t n = (uint32_t)ent_g.size();
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ent_g[a] != ent_g[b] ? ent_g[a] < ent_g[b] : ent_blk[a] < ent_blk[b]; });
+        std::vector<uint32_t> eg(n); std::vector<uint16_t> eb(n); std::vector<unsigned long long> em(n);
+        for (uint32_t i = 0; i < n; ++i) { eg[i] = ent_g[order[i]]; eb[i] = ent_blk[order[i]]; em[i] = ent_mask[order[i]]; }
+        uint32_t *deg, *dR2, *dlen, *doff2; uint16_t* deb; unsigned long long *dem, *dB2, *dL2; unsigned char *dwn, *dW2;
+        CK(hipMalloc(&deg, n * 4)); CK(hipMalloc(&deb, n * 2)); CK(hipMalloc(&dem, (size_t)n * 8)); CK(hipMalloc(&dwn, G));
+        CK(hipMalloc(&dB2, B.size() * 8)); CK(hipMalloc(&dR2, R.size() * 4)); CK(hipMalloc(&dlen, NB * 4)); CK(hipMalloc(&doff2, (NB + 1) * 4));
+        CK(hipMalloc(&dL2, (size_t)n * 8)); CK(hipMalloc(&dW2, n));
+        CK(hipMemcpy(deg, eg.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(deb, eb.data(), n * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dem, em.data(), (size_t)n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dwn, wnode.data(), G, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            CK(hipMemsetAsync(dB2, 0, B.size() * 8, 0));
+            hipLaunchKernelGGL(build_bitmaps_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, deg, deb, n, W, dB2);
+            hipLaunchKernelGGL(build_ranks_kernel, dim3(NB), dim3(256), 0, 0, dB2, W, dR2, dlen);
+            hipLaunchKernelGGL(build_offsets_kernel, dim3(1), dim3(64), 0, 0, dlen, NB, doff2);
+            hipLaunchKernelGGL(build_lists_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, deg, deb, dem, dwn, n, W, dB2, dR2, doff2, dL2, dW2);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&build_ms, e0, e1));
+        }
+        std::vector<unsigned long long> B2(B.size()), L2(n); std::vector<uint32_t> R2(R.size()), off2(NB + 1); std::vector<unsigned char> W2(n);
+        CK(hipMemcpy(B2.data(), dB2, B.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(R2.data(), dR2, R.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(off2.data(), doff2, (NB + 1) * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(L2.data(), dL2, (size_t)n * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(W2.data(), dW2, n, hipMemcpyDeviceToHost));
+        const bool same = B2 == B && R2 == R && off2 == loff && L2 == L && W2 == Wt;
+        printf("structures built on the device from %u entries in node order (bitmaps by atomicOr, rank directories, lists placed by rank: no sort): %.3f ms, %s\n",
+               n, build_ms, same ? "equal the host's" : "DIFFER from the host's");
+        if (!same) return 1;
+    }
     float best_full = 1e9f, best_join = 1e9f, best_pf = 1e9f, best_join_pf = 1e9f;
     auto timed = [&](auto kern, float& best) -> int {
         float ms;
