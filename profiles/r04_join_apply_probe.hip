@@ -271,12 +271,27 @@ __global__ void build_lists_kernel(const uint32_t* __restrict__ ent_g, const uin
     Wt[pos] = wnode[g];
 }
 
-int main() {
-    const uint32_t G = 262144, NB = 200, C = 40, W = G / 64;
+int main(int argc, char** argv) {
+    // node classes "count:blocks" on the command line (default: 262 144 nodes with 40 of the 200 blocks each); the classes are interleaved
+    // over the node indices as the DFS order would mix them
+    std::vector<std::pair<uint32_t, uint32_t>> classes;
+    for (int a = 1; a < argc; ++a) { unsigned n = 0, c = 0; if (sscanf(argv[a], "%u:%u", &n, &c) == 2 && n && c) classes.emplace_back(n, c); }
+    if (classes.empty()) classes.emplace_back(262144u, 40u);
+    uint32_t G = 0;
+    for (auto& cl : classes) G += cl.first;
+    G = (G + 63u) & ~63u;
+    const uint32_t NB = 200, W = G / 64;
     std::mt19937_64 rng(12345);
     std::vector<unsigned long long> B((size_t)NB * W, 0);
     std::vector<uint32_t> perm(NB);
-    for (uint32_t g = 0; g < G; ++g) {
+    std::vector<uint32_t> cls_left;
+    for (auto& cl : classes) cls_left.push_back(cl.first);
+    uint64_t n_left = 0; for (auto v : cls_left) n_left += v;
+    for (uint32_t g = 0; g < G && n_left; ++g) {
+        uint64_t pick = rng() % n_left; uint32_t k = 0;
+        while (pick >= cls_left[k]) { pick -= cls_left[k]; ++k; }
+        --cls_left[k]; --n_left;
+        const uint32_t C = std::min(classes[k].second, NB);
         for (uint32_t i = 0; i < NB; ++i) perm[i] = i;
         for (uint32_t i = 0; i < C; ++i) std::swap(perm[i], perm[i + rng() % (NB - i)]);
         for (uint32_t i = 0; i < C; ++i) B[(size_t)perm[i] * W + g / 64] |= 1ull << (g & 63);
@@ -397,8 +412,9 @@ int main() {
         CK(hipMemcpy(got.data(), dtiles + (size_t)(p[0] * (p[0] + 1) / 2 + p[1]) * 4096, 4096 * 4, hipMemcpyDeviceToHost));
         for (uint32_t k = 0; k < 4096; ++k) { if (want[k] != got[k]) ++bad; cells += want[k]; }
     }
-    printf("G %u many-block nodes x %u of %u blocks, weights 1..3: %u tiles, %.1f M matches (block records), lists %.1f MB, bitmaps %.1f MB\n", G, C, NB, tiles, n[0] / 1e6,
-           L.size() * 8 / 1e6, B.size() * 8 / 1e6);
+    printf("%u many-block nodes (", G);
+    for (auto& cl : classes) printf(" %u x %u blocks", cl.first, cl.second);
+    printf(" ) of %u blocks, weights 1..3: %u tiles, %.1f M matches (block records), lists %.1f MB, bitmaps %.1f MB\n", NB, tiles, n[0] / 1e6, L.size() * 8 / 1e6, B.size() * 8 / 1e6);
     printf("join + gather alone: %.3f ms (with prefetch %.3f); join + gather + transposes + MFMA accumulation + one write per tile: %.3f ms, with the next step's gathers "
            "and the next round's bitmap words under way %.3f ms, best of 5 (%.1f G records/s); 6 probed tiles (%llu cell updates) %s\n", best_join, best_join_pf, best_full, best_pf,
            n[0] / best_pf / 1e6, cells, bad ? "DIFFER from the definition" : "equal the definition on the host");
