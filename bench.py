@@ -902,7 +902,7 @@ def main():
                                   "whole_call": kern_ms},
                 "cold_call_frac": alg / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "measured_copy_GBs": measured_copy_gbs(device),      # what a plain copy reaches on this box (peak above is the nominal figure)
-                "block_records_per_launch": stl["n_records"], "wide_nodes": stl["n_wide"], "wide_nodes_climbing": stl["n_slow_wide"],
+                "block_records_per_launch": stl["n_records"], "wide_nodes": stl["n_wide"], "nodes_joined_per_tile": stl["n_joined"],
                 "record_chunks": stl["n_chunks"],
             },
         }

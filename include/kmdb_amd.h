@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KMDB_ABI_VERSION 5
+#define KMDB_ABI_VERSION 6
 
 /* ---------------------------------------------------------------------------------------
  * Host-side view of a loaded database = what the reference hands to SimilarityCalculator:
@@ -140,7 +140,7 @@ typedef struct kmdb_stats {        /* measurements of the LAST call on this db h
     uint32_t path;                 /* KMDB_PATH_* of the last all2all call */
     uint32_t width;                /* sample ids per block */
     uint32_t sized_call;           /* 1: the last call measured its own grid sizes (first call on a handle, two host syncs more) */
-    uint32_t n_slow_wide;          /* always 0 since ABI 4 (round 2's wide-node kernel let some nodes climb their parent links) */
+    uint32_t n_joined;             /* nodes with many blocks whose records were never written: joined per tile by the second level (ABI 6; 0 when it is off) */
     uint64_t n_patterns;           /* patterns resident in HBM: all of the view's, or for kmdb_db_upload_shard only the nodes whose subtree
                                       holds a k-mer of the shard */
 } kmdb_stats;

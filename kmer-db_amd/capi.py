@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -56,7 +56,7 @@ class _Stats(C.Structure):
                 ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64), ("k0_ms", C.c_double),
                 ("k1n_ms", C.c_double), ("k1g_ms", C.c_double), ("upload_ms", C.c_double), ("n_wide", C.c_uint64),
                 ("n_chunks", C.c_uint64), ("path", C.c_uint32), ("width", C.c_uint32), ("sized_call", C.c_uint32),
-                ("n_slow_wide", C.c_uint32), ("n_patterns", C.c_uint64)]
+                ("n_joined", C.c_uint32), ("n_patterns", C.c_uint64)]
 
 
 class _NodeStats(C.Structure):

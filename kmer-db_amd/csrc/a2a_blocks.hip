@@ -862,6 +862,22 @@ __device__ __forceinline__ LSum lsum_of_fn(uint32_t fb, const ulonglong2& fm) {
     return LSum{fm.y, 2u, b0, b1};
 }
 
+// Second level above the block records.  A node whose full list has c >= min_blocks blocks would write c (c + 1) / 2 records; instead the wave
+// that emits it takes a node index g, appends the node's c (g, block, mask) entries to an entry pool and sets bit g in the bitmap of every
+// block of the list.  After the wide kernel: rank directories of the bitmaps, every entry placed in its block's list by its rank (no sort),
+// and one job per tile (X, Y) that ANDs the two bitmaps, ranks the matches in both lists and feeds them, 64 at a time, to the apply step
+// (l2_join_apply_kernel).  Prototype and measurements: profiles/r04_join_apply_probe.hip.
+struct L2View {
+    uint32_t on, min_blocks;
+    uint32_t node_cap, W;          // node indices (a multiple of 64 * L2_SUB), bitmap words per block
+    uint32_t ent_cap;              // entries (a multiple of L2_SUB)
+    uint32_t* cursors;             // [2 * L2_SUB * 16]: node indices handed out per sub-range, then entries handed out per sub-range
+    unsigned long long* bitmap;    // [blocks][W]
+    uint32_t* ent_g;               // [ent_cap]
+    uint16_t* ent_blk;             // [ent_cap], 0xFFFF: never written
+    unsigned long long* ent_mask;  // [ent_cap]
+    uint32_t* node_w;              // [node_cap]
+};
 struct WParams {
     const uint32_t* widx;          // the wide nodes, DFS order
     uint32_t n_wide;
@@ -887,8 +903,11 @@ struct WParams {
     uint32_t n_rows;               // row mode: block rows (0 otherwise)
     uint32_t emit_lo, emit_hi;
     PoolView pool;
+    L2View l2;
 };
 constexpr int K1W_WAVES = 2;
+constexpr uint32_t L2_MIN_BLOCKS = 24;     // nodes with that many blocks take the second level (measured at 10 000 samples: 11 -> 21.9 ms, 24 -> 20.0; KMDB_L2_MIN moves it)
+constexpr uint32_t L2_NODE_GRAB = 16, L2_ENT_GRAB = 1024, L2_SUB = 16;   // node indices / entries a wave takes per device atomic, from one of L2_SUB cursors each
 constexpr uint32_t K1W_DEBUG = 0;          // timing experiments at compile time (results wrong): 1 = no record stores, 2 = no emission at all, 3 = no owner search
 constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
 constexpr uint32_t K1W_HEAVY = 11;         // a node with that many blocks (66 records and more) is emitted by the whole wave
@@ -979,6 +998,8 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     arena_init(A, nullptr, 0u, 0u, wid + 64u, lane);
     uint32_t n_miss = 0;
 
+    uint32_t l2_nodes = 0;
+    uint32_t l2_gnext = 0, l2_gstock = 0, l2_enext = 0, l2_estock = 0;     // second level: the wave's stock of node indices and entries (wave-uniform)
     // record-parallel emission of the lanes in `on` (list of lane j: m entries from st_start[j]): a node with m blocks owns
     // m (m + 1) / 2 records (block pairs a >= b), one record per lane and step
     auto emit = [&](bool on, uint32_t m, uint32_t wv) {
@@ -993,6 +1014,41 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 const uint32_t stj = L.st_start[j];
                 const unsigned long long* cmask = L.ent_mask + stj;
                 const uint16_t* cblk = L.ent_blk + stj;
+                if (q.l2.on && mj >= q.l2.min_blocks) {
+                    // second level: the node's entries instead of its records
+                    const uint32_t sub = wid % L2_SUB;
+                    if (l2_gstock == 0u) {
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(&q.l2.cursors[sub * 16u], L2_NODE_GRAB);
+                        b = bcast(b, 0);
+                        // the grabs of the L2_SUB cursors interleave (grab n of cursor k = indices [(n L2_SUB + k) GRAB, + GRAB)): the indices in use
+                        // stay dense from 0 on as long as the cursors advance alike, and the tile jobs scan the bitmaps only that far
+                        const uint32_t g0 = ((b / L2_NODE_GRAB) * L2_SUB + sub) * L2_NODE_GRAB;
+                        if (g0 + L2_NODE_GRAB <= q.l2.node_cap) { l2_gnext = g0; l2_gstock = L2_NODE_GRAB; }
+                    }
+                    if (l2_estock < mj) {
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(&q.l2.cursors[(L2_SUB + sub) * 16u], L2_ENT_GRAB);
+                        b = bcast(b, 0);
+                        if (b + L2_ENT_GRAB <= q.l2.ent_cap / L2_SUB) { l2_enext = sub * (q.l2.ent_cap / L2_SUB) + b; l2_estock = L2_ENT_GRAB; }
+                        else l2_estock = 0u;
+                    }
+                    if (l2_gstock == 0u || l2_estock < mj) {             // out of indices or entries: the call is repeated with larger arrays
+                        if (lane == 0) atomicOr(&q.pool.counters[KCTR_L2_OVERFLOW], 1u);
+                        continue;
+                    }
+                    const uint32_t g = l2_gnext;
+                    ++l2_gnext; --l2_gstock;
+                    for (uint32_t e = lane; e < mj; e += WAVE) {
+                        const uint32_t idx = l2_enext + e, blk = cblk[e];
+                        q.l2.ent_g[idx] = g; q.l2.ent_blk[idx] = (uint16_t)blk; q.l2.ent_mask[idx] = cmask[e];
+                        atomicOr(&q.l2.bitmap[(size_t)blk * q.l2.W + (g >> 6)], 1ull << (g & 63u));
+                    }
+                    l2_enext += mj; l2_estock -= mj;
+                    if (lane == 0) q.l2.node_w[g] = wj;
+                    ++l2_nodes;
+                    continue;
+                }
                 const uint32_t Tj = mj * (mj + 1u) / 2u;
                 for (uint32_t t0 = 0; t0 < Tj; t0 += WAVE) {
                     const uint32_t t = t0 + lane;
@@ -1273,6 +1329,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     arena_finish(A, q.pool, lane);
     if (q.n_rows) rowtab_finish(RT, q.pool, lane);
     if (lane == 0 && n_miss) atomicAdd(&q.pool.counters[KCTR_SLOW], n_miss);
+    if (lane == 0 && l2_nodes) atomicAdd(&q.pool.counters[KCTR_L2_NODES], l2_nodes);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1514,6 +1571,222 @@ __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t
         else if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
     }
     __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// second level above the block records: bitmaps -> rank directories -> lists -> tile joins (L2View; profiles/r04_join_apply_probe.hip)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t stream_row(uint32_t s);
+// one workgroup per block: exclusive prefix popcounts of its W bitmap words, and the length of its list
+__global__ __launch_bounds__(256) void l2_ranks_kernel(const unsigned long long* __restrict__ B, uint32_t W, uint32_t* __restrict__ R, uint32_t* __restrict__ len) {
+    __shared__ uint32_t part[256];
+    const unsigned long long* b = B + (size_t)blockIdx.x * W;
+    uint32_t* r = R + (size_t)blockIdx.x * W;
+    const uint32_t per = (W + 255u) / 256u, lo = threadIdx.x * per < W ? threadIdx.x * per : W, hi = lo + per < W ? lo + per : W;
+    uint32_t s = 0;
+    for (uint32_t w = lo; w < hi; ++w) s += (uint32_t)__popcll(b[w]);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < 256; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; } len[blockIdx.x] = run; }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t w = lo; w < hi; ++w) { r[w] = run; run += (uint32_t)__popcll(b[w]); }
+}
+// list offsets; and loff[NB + 1] = bitmap words in use (the highest node index handed out, from the cursors' interleaved grabs)
+__global__ void l2_offsets_kernel(const uint32_t* __restrict__ len, uint32_t NB, const uint32_t* __restrict__ cursors, uint32_t W, uint32_t* __restrict__ loff) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t x = 0; x < NB; ++x) { loff[x] = run; run += len[x]; }
+        loff[NB] = run;
+        uint32_t top = 0;
+        for (uint32_t k = 0; k < L2_SUB; ++k) {
+            const uint32_t c = cursors[k * 16u];                 // indices this cursor handed out (a multiple of the grab)
+            if (c) { const uint32_t end = ((c / L2_NODE_GRAB - 1u) * L2_SUB + k + 1u) * L2_NODE_GRAB; top = end > top ? end : top; }
+        }
+        const uint32_t wu = (top + 63u) / 64u;
+        loff[NB + 1] = wu < W ? wu : W;
+    }
+}
+// an entry's place in its block's list is its node's rank in the block's bitmap: no sort
+__global__ void l2_lists_kernel(const uint32_t* __restrict__ ent_g, const uint16_t* __restrict__ ent_blk, const unsigned long long* __restrict__ ent_mask,
+                                const uint32_t* __restrict__ node_w, uint32_t n, uint32_t W, const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R,
+                                const uint32_t* __restrict__ loff, unsigned long long* __restrict__ L, uint32_t* __restrict__ Wt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t X = ent_blk[i];
+    if (X == 0xFFFFu) return;                                 // a slot no wave wrote (the rest of a grab)
+    const uint32_t g = ent_g[i];
+    const unsigned long long word = B[(size_t)X * W + (g >> 6)];
+    const uint32_t pos = loff[X] + R[(size_t)X * W + (g >> 6)] + (uint32_t)__popcll(word & ((1ull << (g & 63u)) - 1ull));
+    L[pos] = ent_mask[i];
+    Wt[pos] = node_w[g];
+}
+// One workgroup of four waves per tile (X, Y), X >= Y.  A lane ANDs one word of the two bitmaps (64 nodes), ranks every match in both lists
+// and the wave queues (rank in L_X, rank in L_Y) in LDS, at most eight per lane and round; every 64 queued matches are one apply step — the
+// masks and the weight gathered (the next step's while this one is applied), two bit transposes, byte spreading, eight MFMAs, as
+// k2_apply_mfma does for 64 sorted records.  The queue's tail is drained by a last, empty round of the same loop (one call site of the step:
+// inlined twice, the kernel ran at two waves per SIMD).  Weights of 128 and more: one join per base-128 digit that occurs.
+constexpr uint32_t L2_WAVES = 4, L2_QCAP = 576;
+__global__ __launch_bounds__(64 * L2_WAVES) __attribute__((amdgpu_waves_per_eu(3, 8)))
+void l2_join_apply_kernel(const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R, const unsigned long long* __restrict__ L, const uint32_t* __restrict__ Wt,
+                          const uint32_t* __restrict__ loff, uint32_t w_stride, uint32_t nb_blocks, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+    uint32_t W;
+    __shared__ uint32_t q[L2_WAVES][L2_QCAP];
+    __shared__ uint32_t q2[L2_WAVES][L2_QCAP];
+    __shared__ unsigned long long lut_ff[256], lut_01[256];
+    __shared__ uint32_t acc[64 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[L2_WAVES][64];
+    __shared__ uint32_t wor_sh;
+    const uint32_t t = blockIdx.x;
+    const uint32_t X = stream_row(t), Y = t - tri32(X);
+    if (loff[X + 1] == loff[X] || loff[Y + 1] == loff[Y]) return;       // (uniform over the workgroup)
+    W = loff[nb_blocks + 1u];                       // the bitmap words in use (l2_offsets_kernel); rows of the bitmaps stay w_stride apart
+    const bool diag = X == Y;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t half = lane >> 5, l31 = lane & 31u;
+    {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= ((threadIdx.x >> i) & 1u) ? 0xFFull << (8 * i) : 0ull;
+        lut_ff[threadIdx.x] = v;
+        lut_01[threadIdx.x] = v & 0x0101010101010101ull;
+        for (uint32_t k = threadIdx.x; k < 64 * 64; k += 64 * L2_WAVES) acc[k] = 0;
+        if (threadIdx.x == 0) wor_sh = 0;
+        __syncthreads();
+    }
+    const unsigned long long* bx = B + (size_t)X * w_stride;
+    const unsigned long long* by = B + (size_t)Y * w_stride;
+    const uint32_t* rx = R + (size_t)X * w_stride;
+    const uint32_t* ry = R + (size_t)Y * w_stride;
+    const unsigned long long* lx = L + loff[X];
+    const unsigned long long* ly = L + loff[Y];
+    const uint32_t* wxl = Wt + loff[X];
+    const TrConst trc = tr_const(lane);
+    auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> k2_v4i {
+        const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
+        const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
+        k2_v4i r;
+        r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
+        return r;
+    };
+    auto halves = [&](unsigned long long w, unsigned long long& w0, unsigned long long& w1) {
+        const auto a = __builtin_amdgcn_permlane32_swap((uint32_t)w, (uint32_t)w, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap((uint32_t)(w >> 32), (uint32_t)(w >> 32), false, false);
+        w0 = ((unsigned long long)b[0] << 32) | a[0];
+        w1 = ((unsigned long long)b[1] << 32) | a[1];
+    };
+    for (uint32_t digit = 0; digit < 5; ++digit) {
+        k2_v16i c00 = {}, c01 = {}, c10 = {}, c11 = {};
+        uint32_t qn = 0, wor = 0;                             // qn wave-uniform
+        auto fetch = [&](uint32_t base, uint32_t n, unsigned long long& Rm, unsigned long long& Cm, uint32_t& Wg) {
+            Rm = 0; Cm = 0; Wg = 0;
+            if (lane < n) {
+                const uint32_t a = q[wave][base + lane], b = q2[wave][base + lane];
+                Rm = lx[a]; Cm = ly[b]; Wg = wxl[a];
+            }
+        };
+        auto apply = [&](unsigned long long Rm, unsigned long long Cm, uint32_t Wg) {
+            wor |= Wg;
+            const unsigned long long Ct = transpose64(Cm, trc);
+            const unsigned long long Rt = transpose64(Rm, trc);
+            unsigned long long ra0, ra1, cb0, cb1;
+            halves(Rt, ra0, ra1);
+            halves(Ct, cb0, cb1);
+            wbuf[wave][lane] = (unsigned char)((Wg >> (7u * digit)) & 127u);
+            lds_sync();
+#pragma unroll
+            for (uint32_t kh = 0; kh < 2; ++kh) {
+                const uint32_t shift = 32u * kh + 16u * half;
+                k2_v4i a0 = spread(ra0, shift, lut_ff), a1 = spread(ra1, shift, lut_ff);
+                const k2_v4i b0 = spread(cb0, shift, lut_01), b1 = spread(cb1, shift, lut_01);
+                const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
+                a0 &= wv; a1 &= wv;
+                c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c11, 0, 0, 0);
+            }
+            lds_sync();
+        };
+        auto drain_steps = [&](bool all) {                    // the full steps of the queue; all: the partly filled last one too
+            uint32_t head = 0;
+            unsigned long long nR = 0, nC = 0; uint32_t nW = 0;
+            auto avail = [&]() -> uint32_t { const uint32_t r = qn - head; return r >= 64u ? 64u : (all ? r : 0u); };
+            if (avail()) fetch(0u, avail(), nR, nC, nW);
+            while (avail()) {
+                const unsigned long long Rm = nR, Cm = nC;
+                const uint32_t Wg = nW;
+                head += avail();
+                if (avail()) fetch(head, avail(), nR, nC, nW);
+                apply(Rm, Cm, Wg);
+            }
+            if (head) {
+                const uint32_t rest = qn - head;
+                uint32_t a = 0, b = 0;
+                if (lane < rest) { a = q[wave][head + lane]; b = q2[wave][head + lane]; }
+                lds_sync();
+                if (lane < rest) { q[wave][lane] = a; q2[wave][lane] = b; }
+                lds_sync();
+                qn = rest;
+            }
+        };
+        unsigned long long pwx = 0, pwy = 0; uint32_t pbx = 0, pby = 0;
+        auto load_words = [&](uint32_t w0, unsigned long long& wx, unsigned long long& wy, uint32_t& bxr, uint32_t& byr) {
+            const uint32_t w = w0 + lane;
+            wx = 0; wy = 0; bxr = 0; byr = 0;
+            if (w0 < W && w < W) { wx = bx[w]; wy = by[w]; bxr = rx[w]; byr = ry[w]; }
+        };
+        load_words(wave * 64u, pwx, pwy, pbx, pby);
+        for (uint32_t w0 = wave * 64u;; w0 += 64u * L2_WAVES) {
+            const bool last = w0 >= W;                        // one round past the bitmap: nothing to match, the queue's tail is drained
+            const unsigned long long wx = pwx, wy = pwy;
+            const uint32_t bxr = pbx, byr = pby;
+            load_words(w0 + 64u * L2_WAVES, pwx, pwy, pbx, pby);
+            unsigned long long m = wx & wy;
+            do {
+                const uint32_t left = (uint32_t)__popcll(m);
+                const uint32_t k = left < 8u ? left : 8u;
+                const uint32_t incl = wave_incl_scan(k, lane);
+                const uint32_t total = bcast(incl, WAVE - 1);
+                uint32_t pos = qn + incl - k;
+                for (uint32_t j = 0; j < k; ++j) {
+                    const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const unsigned long long below = (1ull << bit) - 1ull;
+                    q[wave][pos] = bxr + (uint32_t)__popcll(wx & below); q2[wave][pos] = byr + (uint32_t)__popcll(wy & below);
+                    ++pos;
+                }
+                qn += total;
+                lds_sync();
+                drain_steps(last);
+            } while (__ballot(m != 0ull));
+            if (last) break;
+        }
+        // the four waves' tiles merged in LDS, shifted by the digit's weight (on the diagonal only c < r)
+        const uint32_t sh = 7u * digit;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
+            const uint32_t v00 = (uint32_t)c00[r] << sh, v01 = (uint32_t)c01[r] << sh, v10 = (uint32_t)c10[r] << sh, v11 = (uint32_t)c11[r] << sh;
+            if (v00 && (!diag || l31 < row0)) atomicAdd(&acc[row0 * 64 + l31], v00);
+            if (v01 && (!diag || 32u + l31 < row0)) atomicAdd(&acc[row0 * 64 + 32u + l31], v01);
+            if (v10 && (!diag || l31 < 32u + row0)) atomicAdd(&acc[(32u + row0) * 64 + l31], v10);
+            if (v11 && (!diag || l31 < row0)) atomicAdd(&acc[(32u + row0) * 64 + 32u + l31], v11);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wor |= (uint32_t)__shfl_xor((int)wor, d, WAVE);
+        if (lane == 0 && wor) atomicOr(&wor_sh, wor);
+        __syncthreads();
+        if ((wor_sh >> (7u * (digit + 1u))) == 0) break;      // no weight has a higher digit
+        __syncthreads();
+    }
+    // one HBM atomic per non-zero cell of the tile (the apply kernels add into the same matrix)
+    for (uint32_t k = threadIdx.x; k < 64 * 64; k += 64 * L2_WAVES) {
+        const uint32_t v = acc[k];
+        if (!v) continue;
+        const uint64_t row = (uint64_t)X * bwidth + (k >> 6), col = (uint64_t)Y * bwidth + (k & 63u);
+        if (row < N && col < row) atomicAdd(&M[tri64(row) + col], v);
+    }
 }
 
 constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup at most; the launch picks 16 (few streams: measured better) or 32
@@ -2575,6 +2848,9 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     FREE_NULL(db->ct_hist); FREE_NULL(db->ct_offs); FREE_NULL(db->ct_cursor); FREE_NULL(db->ct_tmp); FREE_NULL(db->rs_rows); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs);
     FREE_NULL(db->run_ctr); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->rs_bands);
+    FREE_NULL(db->l2_cursors); FREE_NULL(db->l2_bitmap); FREE_NULL(db->l2_rank); FREE_NULL(db->l2_len); FREE_NULL(db->l2_loff); FREE_NULL(db->l2_ent_g);
+    FREE_NULL(db->l2_node_w); FREE_NULL(db->l2_list_w); FREE_NULL(db->l2_ent_blk); FREE_NULL(db->l2_ent_mask); FREE_NULL(db->l2_list_mask);
+    db->l2_node_cap = 0; db->l2_ent_cap = 0;
     if (db->h_counters) { (void)hipHostFree(db->h_counters); db->h_counters = nullptr; }
     db->pool_cap = 0; db->pair_cap = 0; db->wide_cap = 0;
 }
@@ -2582,10 +2858,33 @@ void kmdb_blocks_release(kmdb_db* db) {
 uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
     if (!db->counters) return 0;
     return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 16 + db->wide_cap * 4 + (db->P / 64) * 16 +
-           (db->wide_pool_cap << WCH_SHIFT) * (db->row_mode ? 20 : 40) + db->rs_entries * 8 + (uint64_t)db->n_ckeys * 12;
+           (db->wide_pool_cap << WCH_SHIFT) * (db->row_mode ? 20 : 40) + db->rs_entries * 8 + (uint64_t)db->n_ckeys * 12 +
+           (uint64_t)db->NB * (db->l2_node_cap / 64u) * 12 + (uint64_t)db->l2_ent_cap * 26 + (uint64_t)db->l2_node_cap * 4;
 }
 
 namespace {
+
+// second level (L2View): arrays for node_cap node indices and ent_cap entries; frees what was there
+int alloc_l2(kmdb_db* db, uint32_t node_cap, uint32_t ent_cap) {
+    FREE_NULL(db->l2_cursors); FREE_NULL(db->l2_bitmap); FREE_NULL(db->l2_rank); FREE_NULL(db->l2_len); FREE_NULL(db->l2_loff); FREE_NULL(db->l2_ent_g);
+    FREE_NULL(db->l2_node_w); FREE_NULL(db->l2_list_w); FREE_NULL(db->l2_ent_blk); FREE_NULL(db->l2_ent_mask); FREE_NULL(db->l2_list_mask);
+    node_cap = (node_cap + 64u * L2_SUB - 1u) / (64u * L2_SUB) * (64u * L2_SUB);
+    ent_cap = (ent_cap + L2_ENT_GRAB * L2_SUB - 1u) / (L2_ENT_GRAB * L2_SUB) * (L2_ENT_GRAB * L2_SUB);
+    const size_t W = node_cap / 64u, NB = db->NB;
+    HIP_TRY(hipMalloc((void**)&db->l2_cursors, 2 * L2_SUB * 16 * 4));
+    HIP_TRY(hipMalloc((void**)&db->l2_bitmap, NB * W * 8));
+    HIP_TRY(hipMalloc((void**)&db->l2_rank, NB * W * 4));
+    HIP_TRY(hipMalloc((void**)&db->l2_len, NB * 4));
+    HIP_TRY(hipMalloc((void**)&db->l2_loff, (NB + 2) * 4));
+    HIP_TRY(hipMalloc((void**)&db->l2_ent_g, (size_t)ent_cap * 4));
+    HIP_TRY(hipMalloc((void**)&db->l2_ent_blk, (size_t)ent_cap * 2));
+    HIP_TRY(hipMalloc((void**)&db->l2_ent_mask, (size_t)ent_cap * 8));
+    HIP_TRY(hipMalloc((void**)&db->l2_list_mask, (size_t)ent_cap * 8));
+    HIP_TRY(hipMalloc((void**)&db->l2_list_w, (size_t)ent_cap * 4));
+    HIP_TRY(hipMalloc((void**)&db->l2_node_w, (size_t)node_cap * 4));
+    db->l2_node_cap = node_cap; db->l2_ent_cap = ent_cap;
+    return 0;
+}
 
 // one attempt of the whole pipeline; *retry is set when a pool was too small (it has been enlarged)
 // decode: run K0 (the first slice of a call does; what it leaves — the local (block, mask) pairs of every node — serves all slices)
@@ -2726,6 +3025,29 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
         q.pool.nostore = K1W_DEBUG == 1u ? 1u : 0u;
+        // ---- second level: many streams, few enough blocks that a tile job's bitmap scan stays small (tiles x nodes: quadratic in the
+        // blocks), KMDB_L2=0 switches it off, KMDB_L2_MIN=c moves the threshold
+        {
+            const char* l2_env = getenv("KMDB_L2");
+            const char* l2_min_env = getenv("KMDB_L2_MIN");
+            db->l2_on = row_mode && db->NB <= 256u && !(l2_env && l2_env[0] == '0');
+            db->l2_min_blocks = l2_min_env ? std::max<uint32_t>(K1W_HEAVY, (uint32_t)atoi(l2_min_env)) : L2_MIN_BLOCKS;
+            if (db->l2_on && !db->l2_bitmap) {
+                // a first guess from the wide list (at 10 000 samples 2 % of the wide nodes have 24 blocks or more); a call that runs out doubles both
+                // (KMDB_POOL_PERCENT, tests: the smallest arrays there are, so that the doubling path runs)
+                const bool tiny = getenv("KMDB_POOL_PERCENT") != nullptr;
+                if (alloc_l2(db, tiny ? 1u : std::max<uint32_t>(64u * L2_SUB * 4u, n_wide / 16u), tiny ? 1u : std::max<uint32_t>(L2_ENT_GRAB * L2_SUB * 4u, n_wide / 16u * 48u))) return 1;
+            }
+            q.l2 = L2View{};
+            if (db->l2_on) {
+                q.l2.on = 1u; q.l2.min_blocks = db->l2_min_blocks; q.l2.node_cap = db->l2_node_cap; q.l2.W = db->l2_node_cap / 64u; q.l2.ent_cap = db->l2_ent_cap;
+                q.l2.cursors = db->l2_cursors; q.l2.bitmap = db->l2_bitmap; q.l2.ent_g = db->l2_ent_g; q.l2.ent_blk = db->l2_ent_blk; q.l2.ent_mask = db->l2_ent_mask;
+                q.l2.node_w = db->l2_node_w;
+                HIP_TRY(hipMemsetAsync(db->l2_cursors, 0, 2 * L2_SUB * 16 * 4, st));
+                HIP_TRY(hipMemsetAsync(db->l2_bitmap, 0, (size_t)db->NB * q.l2.W * 8, st));
+                HIP_TRY(hipMemsetAsync(db->l2_ent_blk, 0xFF, (size_t)db->l2_ent_cap * 2, st));
+            }
+        }
         q.run_nodes = K1W_RUN_NODES;
         if (const char* e = getenv("KMDB_K1W_RUN")) q.run_nodes = std::max<uint32_t>(64u, (uint32_t)atoi(e) / 64u * 64u);
         q.n_runs = (n_wide + q.run_nodes - 1) / q.run_nodes;
@@ -2755,6 +3077,16 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.run_ctr = db->run_ctr;
         if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(db->k1w_waves, q.n_runs), (uint32_t)atoi(e)));
         hipLaunchKernelGGL(k1w_kernel, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
+        if (db->l2_on) {
+            // rank directories, list offsets, lists, and the tile joins adding into M (a tile whose blocks have no list leaves at once)
+            const uint32_t NB = db->NB, W = db->l2_node_cap / 64u;
+            hipLaunchKernelGGL(l2_ranks_kernel, dim3(NB), dim3(256), 0, st, db->l2_bitmap, W, db->l2_rank, db->l2_len);
+            hipLaunchKernelGGL(l2_offsets_kernel, dim3(1), dim3(64), 0, st, db->l2_len, NB, db->l2_cursors, W, db->l2_loff);
+            hipLaunchKernelGGL(l2_lists_kernel, dim3((db->l2_ent_cap + 255u) / 256u), dim3(256), 0, st, db->l2_ent_g, db->l2_ent_blk, db->l2_ent_mask, db->l2_node_w,
+                               db->l2_ent_cap, W, db->l2_bitmap, db->l2_rank, db->l2_loff, db->l2_list_mask, db->l2_list_w);
+            hipLaunchKernelGGL(l2_join_apply_kernel, dim3(NB * (NB + 1u) / 2u), dim3(64 * L2_WAVES), 0, st, db->l2_bitmap, db->l2_rank, db->l2_list_mask, db->l2_list_w,
+                               db->l2_loff, W, NB, M, (uint32_t)db->N, db->width);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (stage("wide emit")) return 1;
@@ -2852,6 +3184,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         db->fallback_reason = "internal: the wide-node kernel lost a list (chain miss " + std::to_string(c[KCTR_SLOW]) + ", arena overflow " + std::to_string(c[KCTR_LIST_OVERFLOW]) + ")";
         return 0;
     }
+    if (c[KCTR_L2_OVERFLOW]) {
+        if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] second level out of node indices or entries (%u / %u): doubling\n", db->l2_node_cap, db->l2_ent_cap);
+        if (alloc_l2(db, db->l2_node_cap * 2u, db->l2_ent_cap * 2u)) return 1;
+        db->have_counts = false; *retry = true;
+        return 0;
+    }
     if (c[KCTR_PAIR_OVERFLOW] || c[KCTR_POOL_OVERFLOW] || c[KCTR_WIDE_OVERFLOW]) {
         const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
         if (c[KCTR_PAIR_OVERFLOW]) {
@@ -2910,7 +3248,10 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         return 0;
     }
     db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW]; db->last_n_slow = c[KCTR_SLOW];
-    db->last_n_rowjobs = c[KCTR_ROWJOBS]; db->last_n_sorted = c[KCTR_WIDE_RECORDS];
+    db->last_n_rowjobs = c[KCTR_ROWJOBS]; db->last_n_sorted = c[KCTR_WIDE_RECORDS]; db->last_l2_nodes = c[KCTR_L2_NODES];
+    if (db->l2_on && !db->have_counts && getenv("KMDB_VERBOSE"))
+        fprintf(stderr, "[kmdb] second level: %u nodes with %u blocks or more joined per tile (indices for %u, entries for %u)\n", c[KCTR_L2_NODES], db->l2_min_blocks,
+                db->l2_node_cap, db->l2_ent_cap);
     db->last_records = ((uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32)) + (row_mode ? 0u : c[KCTR_WIDE_RECORDS]);
     return 0;
 }

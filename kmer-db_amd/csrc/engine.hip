@@ -357,7 +357,7 @@ int finish_stats(kmdb_db* db, hipStream_t st) {
         HIP_TRY(hipEventElapsedTime(&k2, db->ev_k[2], db->ev_k[3]));
         db->stats.k0_ms = k0; db->stats.k1n_ms = k1n; db->stats.k1g_ms = k1g; db->stats.k1_ms = k1n + k1g; db->stats.k2_ms = k2;
         db->stats.n_records = db->last_records; db->stats.n_wide = db->last_n_wide; db->stats.n_chunks = db->last_n_chunks;
-        db->stats.n_slow_wide = db->last_n_slow;
+        db->stats.n_joined = db->l2_on ? db->last_l2_nodes : 0u;
     } else if (db->v1_counters && db->stats.path != KMDB_PATH_NONE) {
         unsigned long long c[8];
         HIP_TRY(hipMemcpy(c, db->v1_counters, sizeof c, hipMemcpyDeviceToHost));

@@ -37,6 +37,8 @@ enum : uint32_t {
     KCTR_WIDE_OVERFLOW = 9, // != 0: the wide record pool was too small
     KCTR_WIDE_RECORDS = 10, // records written to the wide pool
     KCTR_ROWJOBS = 11,      // row mode: workgroups of the sort inside the block rows
+    KCTR_L2_OVERFLOW = 12,  // != 0: the second level's node indices or entries ran out (results invalid; repeated with larger arrays)
+    KCTR_L2_NODES = 13,     // nodes that went to the second level
     KCTR_COUNT = 16
 };
 constexpr uint32_t KMDB_PAIR_REGIONS = 4096;
@@ -143,6 +145,16 @@ struct kmdb_db {
     size_t sort2_tmp_bytes = 0;
     uint32_t* counters = nullptr;   // [KCTR_COUNT]
     uint32_t* h_counters = nullptr; // pinned host copy
+    // ---- second level above the block records (a2a_blocks.hip, L2View): the nodes with many blocks write (node, block, mask) entries instead of
+    // their c (c + 1) / 2 records; a tile job joins two blocks' lists and applies the matches.  Row mode with few enough blocks only.
+    bool l2_on = false;
+    uint32_t l2_min_blocks = 24, l2_node_cap = 0, l2_ent_cap = 0, last_l2_nodes = 0;
+    uint32_t* l2_cursors = nullptr;                    // [32 * 16]
+    unsigned long long* l2_bitmap = nullptr;           // [NB][l2_node_cap / 64]
+    uint32_t *l2_rank = nullptr, *l2_len = nullptr, *l2_loff = nullptr;   // [NB][W] rank directory, [NB] list lengths, [NB + 1] list offsets
+    uint32_t *l2_ent_g = nullptr, *l2_node_w = nullptr, *l2_list_w = nullptr;
+    uint16_t* l2_ent_blk = nullptr;
+    unsigned long long *l2_ent_mask = nullptr, *l2_list_mask = nullptr;
     uint64_t est_records = 0;       // sampled estimate for the chosen width
     // what the previous call found (the pipeline is deterministic per database: grid sizes of the next call)
     bool have_counts = false;

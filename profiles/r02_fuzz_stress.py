@@ -19,7 +19,9 @@ S = importlib.import_module("kmerdb_amd.synth")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 MAXP = int(sys.argv[3]) if len(sys.argv) > 3 else 30000
+rng_l2 = np.random.default_rng(7 + (int(sys.argv[2]) if len(sys.argv) > 2 else 1))     # (a generator of its own: the forests of a seed stay what they were)
 bad = 0
+joined = 0
 for c in range(cases):
     N = int(rng.choice([2, 3, 31, 64, 65, 100, 257, 600, 1000, 1500, 2048, 3000, 7000, 12000]))
     P = int(rng.integers(5, MAXP))
@@ -30,6 +32,7 @@ for c in range(cases):
     rowmode = int(rng.choice([0, 0, 1]))                   # 1: the many-streams path (per-block-row chunks + sort inside the rows) whatever the size
     wseg = int(rng.choice([0, 64, 128]))                   # wide nodes per run of the wide-node kernel (a chain seeded from the root path per run)
     k1w = int(rng.choice([0, 1, 3]))                       # waves of the wide-node kernel (few: every wave takes many runs)
+    l2min = int(rng_l2.choice([11, 11, 24, 0]))            # second level above the block records (row mode, <= 256 blocks): threshold; 0 = off
     pat = _random_forest(rng, N, P, max_local, heavy_frac=float(rng.random()) * 0.5, zero_frac=float(rng.random()) * 0.5, chain_frac=chain)
     arr = S.to_view_arrays(pat)
     view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
@@ -39,10 +42,13 @@ for c in range(cases):
             os.environ[name] = str(val)
         else:
             os.environ.pop(name, None)
+    os.environ["KMDB_L2"] = "1" if l2min else "0"
+    os.environ["KMDB_L2_MIN"] = str(l2min or 24)
     d = K.DeviceDB(view, device=0)
     ref = d.all2all_dense(flags=K.capi.FLAG_FORCE_GLOBAL_ATOMICS)
     got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
     st = d.stats()
+    joined += st["n_joined"]
     ok = np.array_equal(got, ref) and st["path"] == K.capi.PATH_RECORDS
     got2 = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)          # cached grid sizes
     ok = ok and np.array_equal(got2, ref) and d.stats()["sized_call"] == 0
@@ -53,9 +59,9 @@ for c in range(cases):
     d.close()
     if not ok:
         bad += 1
-        print("MISMATCH case", c, "N", N, "P", P, "max_local", max_local, "width", width, "nseg", nseg, "chain", chain, "rowmode", rowmode, "wseg", wseg, "k1w", k1w,
+        print("MISMATCH case", c, "N", N, "P", P, "max_local", max_local, "width", width, "nseg", nseg, "chain", chain, "rowmode", rowmode, "wseg", wseg, "k1w", k1w, "l2min", l2min,
               "diff cells", int((got != ref).sum()), flush=True)
-for name in ("KMDB_BLOCK_WIDTH", "KMDB_NSEG", "KMDB_ROW_MODE", "KMDB_K1W_RUN", "KMDB_K1W_WAVES"):
+for name in ("KMDB_BLOCK_WIDTH", "KMDB_NSEG", "KMDB_ROW_MODE", "KMDB_K1W_RUN", "KMDB_K1W_WAVES", "KMDB_L2", "KMDB_L2_MIN"):
     os.environ.pop(name, None)
-print("fuzz: %d cases, %d mismatches" % (cases, bad))
+print("fuzz: %d cases, %d mismatches (%d nodes took the second level)" % (cases, bad, joined))
 sys.exit(1 if bad else 0)

@@ -907,6 +907,115 @@ def test_patterns_that_touch_every_block_of_many(K, O, dev):
     d.close()
 
 
+@pytest.mark.parametrize("l2min", ["11", "24"])
+def test_second_level_above_the_block_records(K, O, dev, tmp_path, l2min):
+    """The nodes with many blocks (KMDB_L2_MIN, default 24) write (node, block, mask) entries instead of their c (c + 1) / 2 block
+    records and are joined per tile (l2_* kernels, reference src/similarity_calculator.cpp:42-438 at N = 10 000).  Forced here on small
+    inputs (row mode, width 32): random forests against the oracle — whole call, warm call, slices of the pattern stream — the arrays of
+    the second level far too small (doubled and the call repeated), a pattern in every block (definition on the host), a clade
+    collection in prefix shards, and the same with the second level switched off."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    device = torch.device("cuda", dev)
+    env = {"KMDB_ROW_MODE": "1", "KMDB_L2_MIN": l2min, "KMDB_BLOCK_WIDTH": "32"}
+    try:
+        os.environ.update(env)
+        for seed, N, P, max_local, chain, tiny in ((21, 2048, 4000, 64, 0.0, False), (22, 1500, 500, 1200, 0.0, False), (23, 3000, 20000, 40, 0.6, True),
+                                                   (24, 8000, 3000, 300, 0.3, False)):
+            rng = np.random.default_rng(seed)
+            pat = _random_forest(rng, N, P, max_local, chain_frac=chain)
+            arr = S.to_view_arrays(pat)
+            path = str(tmp_path / ("f%d.db" % seed))
+            S.write_db(path, 18, 1.0, ["s%d" % i for i in range(N)], [1] * N, arr)
+            exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+            view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                               arr["data_offset"], arr["data"])
+            if tiny:
+                os.environ["KMDB_POOL_PERCENT"] = "1"
+            d = K.DeviceDB(view, device=dev)
+            got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+            st = d.stats()
+            assert st["path"] == K.capi.PATH_RECORDS and st["n_joined"] > 0, (seed, st)
+            assert np.array_equal(got, exp), seed
+            assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp) and d.stats()["sized_call"] == 0
+            acc = np.zeros_like(exp)
+            for sh in range(3):
+                acc += d.all2all_dense(shard=(sh, 3), flags=K.capi.FLAG_NO_FALLBACK)
+            assert np.array_equal(acc, exp), seed
+            joined = st["n_joined"]
+            d.close()
+            os.environ.pop("KMDB_POOL_PERCENT", None)
+            os.environ["KMDB_L2"] = "0"
+            d = K.DeviceDB(view, device=dev)
+            assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp) and d.stats()["n_joined"] == 0
+            assert d.stats()["n_records"] > st["n_records"] or joined == 0
+            d.close()
+            os.environ.pop("KMDB_L2", None)
+        # a pattern in every block: 250 blocks of width 32, lists of 200 - 250 entries; flat form on the host
+        N, step = 8000, 40
+        ids0 = np.arange(0, N, step, dtype=np.int64)
+        locs, parent, w = [np.zeros(0, dtype=np.int64), ids0], [-1, -1], [0, 3]
+        for r in (1, 7, 13):
+            locs.append(np.arange(r, N, step, dtype=np.int64)); parent.append(-1); w.append(200 + r)          # (weights of two base-128 digits)
+        top, chain_par = int(ids0[-1]), 1
+        for j in range(1, 30):
+            if top + j >= N:
+                break
+            locs.append(np.array([top + j], dtype=np.int64)); parent.append(chain_par); w.append(j % 3); chain_par = len(locs) - 1
+        P = len(locs)
+        nloc = np.array([len(x) for x in locs], dtype=np.int64)
+        nsam = np.zeros(P, dtype=np.int64)
+        for q in range(1, P):
+            nsam[q] = nloc[q] + (nsam[parent[q]] if parent[q] >= 0 else 0)
+        lp = np.zeros(P + 1, dtype=np.int64); lp[1:] = np.cumsum(nloc)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int64)))      # noqa: E731
+        pat = {"num_kmers": t(w), "parent": t(parent), "num_samples": t(nsam), "num_local": t(nloc), "local_ptr": t(lp), "local_ids": t(np.concatenate(locs))}
+        arr = S.to_view_arrays(pat)
+        view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                           arr["data_offset"], arr["data"])
+        d = K.DeviceDB(view, device=dev)
+        got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+        assert d.stats()["n_joined"] >= 4
+        exp = np.zeros(N * (N - 1) // 2, dtype=np.uint32)
+        for q in range(1, P):
+            if w[q] == 0:
+                continue
+            full, y = [], q
+            while y >= 0:
+                full.append(locs[y]); y = parent[y]
+            full = np.sort(np.concatenate(full))
+            for a in range(1, full.size):
+                i = int(full[a])
+                exp[i * (i - 1) // 2 + full[:a]] += np.uint32(w[q])
+        assert np.array_equal(got, exp)
+        d.close()
+        # a clade collection, whole and in prefix-bucket shards (the pruned trees of kmdb_db_upload_shard)
+        N, cs, L, k = 1600, 50, 3000, 18
+        g, pat = S.synth_database(N, cs, L, k=k, seed=31, device=device)
+        arr = S.to_view_arrays(pat)
+        path = str(tmp_path / "c.db")
+        S.write_db_fast(path, k, 1.0, [g.name(i) for i in range(N)], pat["sample_counts"], arr, device=device)
+        exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+        tables = S.build_hashtables(pat["dictionary"], pat["kmer_pid"], k)
+        view = K.make_view(k, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                           arr["data_offset"], arr["data"], bucket_offset=tables[0], slots=tables[1])
+        d = K.DeviceDB(view, device=dev)
+        assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp)
+        whole = d.stats()["n_joined"]
+        assert whole > 0 or l2min == "24"
+        d.close()
+        acc = np.zeros_like(exp)
+        for s_ in range(3):
+            d = K.DeviceDB(view, device=dev, prefix_shard=(s_, 3))
+            acc += d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+            d.close()
+        assert np.array_equal(acc, exp)
+    finally:
+        for name in list(env) + ["KMDB_POOL_PERCENT", "KMDB_L2"]:
+            os.environ.pop(name, None)
+
+
 def test_degenerate_databases(K, O, dev, tmp_path):
     import importlib
     import torch
