@@ -143,6 +143,7 @@ typedef struct kmdb_stats {        /* measurements of the LAST call on this db h
     uint32_t n_joined;             /* nodes with many blocks whose records were never written: joined per tile by the second level (ABI 6; 0 when it is off) */
     uint64_t n_patterns;           /* patterns resident in HBM: all of the view's, or for kmdb_db_upload_shard only the nodes whose subtree
                                       holds a k-mer of the shard */
+    uint64_t h2d_bytes;            /* bytes kmdb_db_upload[_shard] copied to the device (ABI 6) */
 } kmdb_stats;
 
 const char* kmdb_last_error(void);
@@ -263,10 +264,24 @@ typedef struct kmdb_node_stats {   /* the LAST call on the node handle; maxima o
     int32_t  rccl_version;         /* ncclGetVersion, 0 when RCCL was not needed */
     uint32_t reserved;
     double   upload_s;             /* kmdb_node_upload, wall clock */
-    double   call_ms;              /* wall clock of the slowest device's kmdb_all2all_dense_device calls (all its shards) */
+    double   plan_s;               /* of it: the host's plan of all shards (one pass over the hashtable items, one sweep over the tree) */
+    double   call_ms;              /* HIP events around the slowest device's kmdb_all2all_dense_device calls (all its shards) */
     double   collective_ms;        /* HIP events around ncclReduceScatter on the slowest device */
     double   d2h_ms;               /* dense: copy of the device's chunk to the host; sparse: compaction + copy of its CSR */
 } kmdb_node_stats;
+/* One device slot of the node (slot < kmdb_node_stats.n_devices): what THAT device did — an imbalanced shard shows here, not in the maxima */
+typedef struct kmdb_node_device_stats {
+    int32_t  device;               /* HIP device of the slot */
+    uint32_t n_shards;             /* shards that live on it */
+    double   upload_s;             /* its thread's share of kmdb_node_upload */
+    double   call_ms;              /* HIP events around its own shards' all2all calls (last call) */
+    double   collective_ms;        /* ... around its ncclReduceScatter (0 without RCCL) */
+    double   d2h_ms;               /* ... around the copy of its chunk / the compaction of its chunk */
+    uint64_t h2d_bytes;            /* bytes its uploads sent over PCIe (sum over its shards) */
+    uint64_t n_patterns;           /* nodes resident on it (sum over its shards: a prefix shard keeps only the nodes it needs) */
+    uint64_t n_records;            /* block records of its shards in the last call */
+} kmdb_node_device_stats;
+int  kmdb_node_device_stats_get(const kmdb_node* node, uint32_t slot, kmdb_node_device_stats* out);
 int  kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, const int32_t* devices, uint32_t n_devices, kmdb_node** out);
 void kmdb_node_free(kmdb_node* node);
 int  kmdb_node_stats_get(const kmdb_node* node, kmdb_node_stats* out);
@@ -299,6 +314,11 @@ uint64_t    kmdbh_db_n_samples(const kmdbh_db* db);
 const char* kmdbh_db_sample_name(const kmdbh_db* db, uint64_t i);
 uint64_t    kmdbh_db_sample_kmers(const kmdbh_db* db, uint64_t i);
 uint64_t    kmdbh_db_pattern_section_bytes(const kmdbh_db* db);
+
+/* The host's plan of the prefix shards kmdb_node_upload / kmdb_db_upload_shard work from (no GPU): for every shard s of n_shards the nodes
+ * it keeps (those whose subtree holds a k-mer of a bucket b with b % n_shards == s; bucket = kmer >> 32, types.h:25-27) and the
+ * k-mers it owns (items of those buckets, hashmap_lp.h:71-78).  The view must carry the hashtables. */
+int  kmdbh_shard_plan_counts(const kmdb_db_view* view, uint32_t n_shards, uint64_t* kept_nodes, uint64_t* kmers);
 
 /* KmerHelper::extract + MinHashFilter (kmer_extract.h:13-97, filter.h:28-115), nt alphabets.
  * Writes at most len k-mers to out; returns the count. */

@@ -56,12 +56,17 @@ class _Stats(C.Structure):
                 ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64), ("k0_ms", C.c_double),
                 ("k1n_ms", C.c_double), ("k1g_ms", C.c_double), ("upload_ms", C.c_double), ("n_wide", C.c_uint64),
                 ("n_chunks", C.c_uint64), ("path", C.c_uint32), ("width", C.c_uint32), ("sized_call", C.c_uint32),
-                ("n_joined", C.c_uint32), ("n_patterns", C.c_uint64)]
+                ("n_joined", C.c_uint32), ("n_patterns", C.c_uint64), ("h2d_bytes", C.c_uint64)]
 
 
 class _NodeStats(C.Structure):
     _fields_ = [("n_shards", C.c_uint32), ("n_devices", C.c_uint32), ("rccl_version", C.c_int32), ("reserved", C.c_uint32),
-                ("upload_s", C.c_double), ("call_ms", C.c_double), ("collective_ms", C.c_double), ("d2h_ms", C.c_double)]
+                ("upload_s", C.c_double), ("plan_s", C.c_double), ("call_ms", C.c_double), ("collective_ms", C.c_double), ("d2h_ms", C.c_double)]
+
+
+class _NodeDeviceStats(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_shards", C.c_uint32), ("upload_s", C.c_double), ("call_ms", C.c_double), ("collective_ms", C.c_double),
+                ("d2h_ms", C.c_double), ("h2d_bytes", C.c_uint64), ("n_patterns", C.c_uint64), ("n_records", C.c_uint64)]
 
 
 FLAG_FORCE_GLOBAL_ATOMICS = 1
@@ -74,10 +79,10 @@ PATH_NONE, PATH_RECORDS, PATH_TILE, PATH_GLOBAL = 0, 1, 2, 3
 # every symbol include/kmdb_amd.h declares
 EXPORTS = [
     "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_device_prepare", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_settle", "kmdb_db_stats", "kmdb_db_fallback_reason",
-    "kmdb_node_upload", "kmdb_node_free", "kmdb_node_stats_get", "kmdb_node_all2all_dense", "kmdb_node_all2all_sparse",
+    "kmdb_node_upload", "kmdb_node_free", "kmdb_node_stats_get", "kmdb_node_device_stats_get", "kmdb_node_all2all_dense", "kmdb_node_all2all_sparse",
     "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdb_sparse_from_dense_device", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
     "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
-    "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_release_patterns", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
+    "kmdbh_shard_plan_counts", "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_release_patterns", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
     "kmdbh_db_start_fraction", "kmdbh_db_alphabet", "kmdbh_db_n_samples", "kmdbh_db_sample_name",
     "kmdbh_db_sample_kmers", "kmdbh_db_pattern_section_bytes", "kmdbh_extract_kmers", "kmdbh_sort_unique",
     "kmdbh_format_header", "kmdbh_format_dense_row", "kmdbh_format_sparse_row",
@@ -110,6 +115,7 @@ def lib():
     L.kmdb_node_upload.argtypes = [C.POINTER(_View), C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.kmdb_node_free.argtypes = [C.c_void_p]
     L.kmdb_node_stats_get.argtypes = [C.c_void_p, C.POINTER(_NodeStats)]
+    L.kmdb_node_device_stats_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_NodeDeviceStats)]
     L.kmdb_node_all2all_dense.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_node_all2all_sparse.argtypes = [C.c_void_p, C.POINTER(_CellFilter), C.c_size_t, C.c_void_p, C.c_int, C.POINTER(_Sparse), C.POINTER(_Opts)]
     L.kmdb_all2all_dense.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
@@ -203,6 +209,15 @@ class HostDB:
     @property
     def view(self):
         return lib().kmdbh_db_view(self._h)
+
+    def shard_plan_counts(self, n_shards):
+        """kmdbh_shard_plan_counts: (nodes kept, k-mers owned) per prefix shard, planned on the host"""
+        kept = np.zeros(n_shards, np.uint64)
+        kmers = np.zeros(n_shards, np.uint64)
+        L = lib()
+        L.kmdbh_shard_plan_counts.argtypes = [C.POINTER(_View), C.c_uint32, C.c_void_p, C.c_void_p]
+        _check(L.kmdbh_shard_plan_counts(self.view, n_shards, kept.ctypes.data, kmers.ctypes.data))
+        return kept, kmers
 
     def release_patterns(self):
         """kmdbh_db_release_patterns: the pattern arrays' pages go back to the kernel (after the upload); names and counts stay"""
@@ -473,7 +488,13 @@ class NodeDB:
     def stats(self):
         s = _NodeStats()
         _check(lib().kmdb_node_stats_get(self._n, C.byref(s)))
-        return {f: getattr(s, f) for f, _ in _NodeStats._fields_}
+        out = {f: getattr(s, f) for f, _ in _NodeStats._fields_}
+        out["devices"] = []
+        for slot in range(s.n_devices):
+            ds = _NodeDeviceStats()
+            _check(lib().kmdb_node_device_stats_get(self._n, slot, C.byref(ds)))
+            out["devices"].append({f: getattr(ds, f) for f, _ in _NodeDeviceStats._fields_})
+        return out
 
     def close(self):
         if self._n:

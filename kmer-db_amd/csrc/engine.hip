@@ -154,7 +154,7 @@ __global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t row_
 // ------------------------------------------------------------------------------------------
 namespace {
 
-int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, uint32_t shard_index, uint32_t shard_count, kmdb_db** out) {
+int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, uint32_t shard_index, uint32_t shard_count, kmdb_shard_plan* plan, kmdb_db** out) {
     *out = nullptr;
     if (!v || v->abi_version != KMDB_ABI_VERSION) return kmdb_set_error("kmdb_db_upload: bad view / ABI version");
     if (opts && (opts->flags & ~KMDB_FLAG_ALL)) return kmdb_set_error("kmdb_db_upload: unknown bits in kmdb_opts.flags");
@@ -170,6 +170,12 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     const int device = opts ? opts->device : 0;
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(device));
+    // a prefix shard uploaded by itself plans itself: its k-mer counts from its own buckets, its nodes by one sweep (host_shards.cpp)
+    kmdb_shard_plan own_plan;
+    if (shard_count > 1 && !plan) {
+        if (kmdb_shard_plan_build(v, shard_count, std::vector<uint32_t>{shard_index}, &own_plan)) return 1;
+        plan = &own_plan;
+    }
     auto* db = new kmdb_db();
     db->device = device; db->N = N; db->P = P; db->kmer_length = v->kmer_length;
     db->one_shot = opts && (opts->flags & KMDB_FLAG_ONE_SHOT);
@@ -192,7 +198,7 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
         t_mark = now;
     };
     part("streams + events (first use of the device)");
-    if (kmdb_layout_upload(db, v, with_hashtables, shard_index, shard_count)) return fail();
+    if (kmdb_layout_upload(db, v, with_hashtables, shard_index, shard_count, plan)) return fail();
     part("layout incl. release of its temporaries");
     // the working set of all2all: now for an all2all upload, on the first all2all call for a new2all / db2db upload
     if (!with_hashtables && kmdb_blocks_prepare(db)) return fail();
@@ -211,11 +217,16 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
 }  // namespace
 
 extern "C" int kmdb_db_upload(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, kmdb_db** out) {
-    return upload_impl(v, opts, with_hashtables, 0, 1, out);
+    return upload_impl(v, opts, with_hashtables, 0, 1, nullptr, out);
 }
 extern "C" int kmdb_db_upload_shard(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, uint32_t shard_index, uint32_t shard_count,
                                     kmdb_db** out) {
-    return upload_impl(v, opts, with_hashtables, shard_index, shard_count, out);
+    return upload_impl(v, opts, with_hashtables, shard_index, shard_count, nullptr, out);
+}
+int kmdb_db_upload_planned(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, uint32_t shard_index, uint32_t shard_count, kmdb_shard_plan* plan,
+                           kmdb_db** out) {
+    if (!out) return kmdb_set_error("kmdb_db_upload_shard: null argument");
+    return upload_impl(v, opts, with_hashtables, shard_index, shard_count, plan, out);
 }
 
 extern "C" void kmdb_db_settle(kmdb_db* db) {

@@ -228,7 +228,10 @@ constexpr int KMDB_CHAIN_MAX = 4096;  // longest root path (in nodes) the chain 
                                       // the deeper the tree, the fewer waves share a workgroup)
 
 // ---- layout.hip: host conversion + device layout of the view (fills the structural arrays and stats)
-int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count);
+int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count, kmdb_shard_plan* plan);
+// kmdb_db_upload_shard with a plan the caller made for several shards at once (node.hip); plan == nullptr: the shard is planned by itself
+int kmdb_db_upload_planned(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtables, uint32_t shard_index, uint32_t shard_count, kmdb_shard_plan* plan,
+                           kmdb_db** out);
 
 // ---- a2a_v1.hip: tree-form scatter kernels (LDS tile / HBM atomics); M is zeroed, wprefix is scanned
 int kmdb_v1_run(kmdb_db* db, uint32_t* M, uint32_t seg_begin, uint32_t seg_end, uint32_t flags, hipStream_t st);

@@ -194,44 +194,6 @@ __global__ void lay_seg_anc_kernel(const int32_t* __restrict__ parent, const uin
     anc_n[s] = d;
     while (cur >= 0 && d) { anc[(size_t)s * chain_cap + (--d)] = (uint32_t)cur; cur = parent[cur]; }
 }
-// a prefix shard keeps only its own k-mers: w_s[p] = #{slots of the shard's buckets that point to p}
-__global__ void lay_shard_weights_kernel(const uint64_t* __restrict__ slots, const uint64_t* __restrict__ bucket_offset, uint64_t n_buckets,
-                                         uint32_t shard_index, uint32_t shard_count, uint32_t P, uint32_t* __restrict__ w_pid) {
-    const uint64_t b = blockIdx.x;
-    if (b >= n_buckets || b % shard_count != shard_index) return;
-    for (uint64_t j = bucket_offset[b] + threadIdx.x; j < bucket_offset[b + 1]; j += blockDim.x) {
-        const int32_t val = (int32_t)(slots[j] >> 32);
-        if (val != INT32_MAX && val >= 0 && (uint32_t)val < P) atomicAdd(&w_pid[val], 1u);
-    }
-}
-
-// A prefix shard keeps only the part of the tree it needs (north_star: near-linear scaling): a node stays when its
-// subtree holds a k-mer of the shard — a dropped node emits no record and no kept node needs its ids (a kept node's ancestors are
-// kept).  Flags climb the parent links until nothing changes (at most as many rounds as the tree is deep).
-__global__ void lay_keep_init_kernel(const uint32_t* __restrict__ w, uint32_t P, uint32_t* __restrict__ keep) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) keep[i] = w[i] != 0u ? 1u : 0u;
-}
-// (keep is read and written by different threads of one launch: no __restrict__, relaxed atomic accesses — a flag seen too late only
-// costs another round)
-__global__ void lay_keep_up_kernel(const int32_t* __restrict__ parent, uint32_t P, uint32_t* keep, uint32_t* __restrict__ changed) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P || !__atomic_load_n(&keep[i], __ATOMIC_RELAXED)) return;
-    const int32_t par = parent[i];
-    if (par >= 0 && !__atomic_load_n(&keep[par], __ATOMIC_RELAXED)) { __atomic_store_n(&keep[par], 1u, __ATOMIC_RELAXED); *changed = 1u; }
-}
-__global__ void lay_compact_kernel(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ newidx, const int32_t* __restrict__ parent,
-                                   const uint32_t* __restrict__ ll, const uint32_t* __restrict__ last, const uint32_t* __restrict__ n, const uint32_t* __restrict__ nbits,
-                                   const uint32_t* __restrict__ w, const uint64_t* __restrict__ spos, uint32_t P, int32_t* __restrict__ parent2, uint32_t* __restrict__ ll2,
-                                   uint32_t* __restrict__ last2, uint32_t* __restrict__ n2,
-                                   uint32_t* __restrict__ nbits2, uint32_t* __restrict__ w2, uint64_t* __restrict__ spos2) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P || !keep[i]) return;
-    const uint32_t o = newidx[i];
-    const int32_t par = parent[i];
-    parent2[o] = par < 0 ? -1 : (int32_t)newidx[par];
-    ll2[o] = ll[i]; last2[o] = last[i]; n2[o] = n[i]; nbits2[o] = nbits[i]; w2[o] = w[i]; spos2[o] = spos[i];
-}
 
 // Host staging buffers of the upload: anonymous mappings, handed to the database handle and given back piece by piece by a helper
 // thread after the first call (kmdb_release_staging).  Unmapping them right after the copies took 0.31 s of a 0.63 s upload
@@ -282,8 +244,15 @@ void kmdb_release_staging(kmdb_db* db) {
     });                                                       // joined by kmdb_db_settle / kmdb_db_free
 }
 
-int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count) {
-    uint64_t P = v->n_patterns;                                // (a prefix shard may shrink it: only the nodes the shard needs are laid out)
+int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, uint32_t shard_index, uint32_t shard_count, kmdb_shard_plan* plan) {
+    const uint64_t P_view = v->n_patterns;
+    // A prefix shard planned on the host (host_shards.cpp) lays out only the nodes it keeps: the fields of those nodes are narrowed, their
+    // streams packed, and nothing else crosses PCIe — no hashtable slots, no node of another shard's part of the tree.  (A shard that owns
+    // no k-mer at all keeps the whole tree with zero weights: every array stays non-empty.)
+    // (An upload that carries the hashtables keeps the whole tree: new2all's pattern ids must all resolve.)
+    const bool pruned = plan && shard_count > 1 && !with_hashtables && !getenv("KMDB_SHARD_WHOLE_TREE") && plan->kept[shard_index] > 0 && plan->kept[shard_index] < P_view;
+    uint64_t P = pruned ? plan->kept[shard_index] : P_view;    // nodes laid out
+    uint64_t h2d_bytes = 0;
     const uint64_t N = v->n_samples;
     const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
     auto tphase0 = std::chrono::steady_clock::now();
@@ -300,32 +269,53 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
 
     // ---- host: narrow + validate the header fields, pack the streams in pid order
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned T = (unsigned)std::min<uint64_t>(std::min(64u, hw), std::max<uint64_t>(1, P / 65536));
+    const unsigned T = (unsigned)std::min<uint64_t>(std::min(64u, hw), std::max<uint64_t>(1, P_view / 65536));
     HostBuf<int32_t> h_parent(P);                             // not zero-filled: the pages are first touched by the worker threads
     HostBuf<uint32_t> h_ll(P), h_last(P), h_n(P), h_nbits(P), h_w(P);
     if (!h_parent.p || !h_ll.p || !h_last.p || !h_n.p || !h_nbits.p || !h_w.p) return kmdb_set_error("kmdb_db_upload: out of host memory");
     std::vector<uint64_t> part_bits(T + 1, 0);
     std::atomic<int> bad{0};
+    // (the parts are ranges of the VIEW's pattern ids; a pruned shard writes the kept nodes of a part to their places in the shorter arrays)
     auto run_parts = [&](auto&& fn) {
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; ++t) pool.emplace_back([&, t] { fn(t, P * t / T, P * (t + 1) / T); });
-        fn(0u, (uint64_t)0, P / T);
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back([&, t] { fn(t, P_view * t / T, P_view * (t + 1) / T); });
+        fn(0u, (uint64_t)0, P_view / T);
         for (auto& th : pool) th.join();
     };
+    const uint32_t* plan_w = plan && shard_count > 1 ? plan->w[shard_index] : nullptr;     // the shard's own k-mers per pattern
+    if (plan && shard_count > 1 && !plan_w) return kmdb_set_error("kmdb_db_upload_shard: the shard is not part of the plan");
+    HostBuf<uint32_t> h_newidx(pruned ? P_view : 1);           // pruned: a kept node's index among the kept ones
+    std::vector<uint64_t> part_kept(T + 1, 0);
+    if (pruned) {
+        if (!h_newidx.p) return kmdb_set_error("kmdb_db_upload: out of host memory");
+        run_parts([&](unsigned t, uint64_t lo, uint64_t hi) {
+            uint64_t c = 0;
+            for (uint64_t p = lo; p < hi; ++p) c += plan->keeps(shard_index, p) ? 1u : 0u;
+            part_kept[t + 1] = c;
+        });
+        for (unsigned t = 0; t < T; ++t) part_kept[t + 1] += part_kept[t];
+        if (part_kept[T] != P) return kmdb_set_error("kmdb_db_upload_shard: internal: the plan's count of kept nodes is off");
+        run_parts([&](unsigned t, uint64_t lo, uint64_t hi) {
+            uint64_t o = part_kept[t];
+            for (uint64_t p = lo; p < hi; ++p) if (plan->keeps(shard_index, p)) h_newidx[p] = (uint32_t)o++;
+        });
+    }
     run_parts([&](unsigned t, uint64_t lo, uint64_t hi) {
-        uint64_t nbsum = 0;
+        uint64_t nbsum = 0, o = pruned ? part_kept[t] : lo;
         for (uint64_t p = lo; p < hi; ++p) {
+            if (pruned && !plan->keeps(shard_index, p)) continue;
             const int64_t par = v->parent_id[p];
             const uint32_t n = v->num_samples[p], l = v->num_local[p], nb = v->num_bits[p], last = v->last_sample_id[p];
             if (par >= (int64_t)p) bad = 1;
             if (l > n || n > N || (l && last >= N) || nb >= KMDB_MAX_STREAM_BITS) bad = 2;      // (N < KMDB_MAX_SAMPLES: checked by the caller)
-            h_parent[p] = par < 0 ? -1 : (int32_t)par;
-            h_ll[p] = l;
-            h_last[p] = l ? last : 0u;
-            h_n[p] = n;
-            h_nbits[p] = nb;
-            h_w[p] = (uint32_t)v->num_kmers[p];                // truncated exactly like the reference's to_add (similarity_calculator.cpp:222)
+            h_parent[o] = par < 0 ? -1 : (pruned ? (int32_t)h_newidx[par] : (int32_t)par);         // (a kept node's parent is kept)
+            h_ll[o] = l;
+            h_last[o] = l ? last : 0u;
+            h_n[o] = n;
+            h_nbits[o] = nb;
+            h_w[o] = plan_w ? plan_w[p] : (uint32_t)v->num_kmers[p];     // truncated exactly like the reference's to_add (similarity_calculator.cpp:222)
             nbsum += nb;
+            ++o;
         }
         part_bits[t + 1] = nbsum;
     });
@@ -340,7 +330,8 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         // streams of different threads can share a word at the range boundaries: OR the words in atomically
         uint64_t pos = part_bits[t];
         for (uint64_t p = lo; p < hi; ++p) {
-            const uint32_t nb = h_nbits[p];
+            if (pruned && !plan->keeps(shard_index, p)) continue;
+            const uint32_t nb = v->num_bits[p];
             if (!nb) continue;
             const uint64_t* src = v->data + v->data_offset[p];
             for (uint32_t done = 0; done < nb; done += 64) {
@@ -368,6 +359,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     HIP_TRY(hipMemcpyAsync(d_nbits.p, h_nbits.p, P * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_w.p, h_w.p, P * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_src.p, h_bits.p, n_bit_words * 8, hipMemcpyHostToDevice, st));
+    h2d_bytes += P * 24 + n_bit_words * 8;
     DevTmp<unsigned long long> d_wfull;                       // sum_pairs uses the untruncated counts
     uint64_t dev_ht_bytes = 0;
     if (with_hashtables && v->n_buckets) {
@@ -377,75 +369,19 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         HIP_TRY(hipMalloc((void**)&db->slots, std::max<uint64_t>(n_slots, 1) * 8));
         HIP_TRY(hipMemcpyAsync(db->bucket_offset, v->bucket_offset, (v->n_buckets + 1) * 8, hipMemcpyHostToDevice, st));
         if (n_slots) HIP_TRY(hipMemcpyAsync(db->slots, v->slots, n_slots * 8, hipMemcpyHostToDevice, st));
+        h2d_bytes += (v->n_buckets + 1) * 8 + n_slots * 8;
         dev_ht_bytes = (v->n_buckets + 1) * 8 + n_slots * 8 + P * 4;
     }
-    if (shard_count > 1) {
-        // prefix-bucket shard (bucket = kmer >> 32, reference src/types.h:25-27): the tree stays whole, the weights become
-        // the shard's own k-mer counts — partial matrices of all shards sum to the full one
-        if (!v->n_buckets) return kmdb_set_error("kmdb_db_upload_shard: the view carries no hashtables (load the database with mode Everything)");
-        const uint64_t n_slots = v->bucket_offset[v->n_buckets];
-        DevTmp<uint64_t> t_off, t_slots;
-        const uint64_t* bo = db->bucket_offset;
-        const uint64_t* sl = db->slots;
-        if (!bo) {
-            if (t_off.alloc(v->n_buckets + 1) || t_slots.alloc(n_slots)) return 1;
-            HIP_TRY(hipMemcpyAsync(t_off.p, v->bucket_offset, (v->n_buckets + 1) * 8, hipMemcpyHostToDevice, st));
-            if (n_slots) HIP_TRY(hipMemcpyAsync(t_slots.p, v->slots, n_slots * 8, hipMemcpyHostToDevice, st));
-            bo = t_off.p; sl = t_slots.p;
-        }
-        HIP_TRY(hipMemsetAsync(d_w.p, 0, P * 4, st));
-        hipLaunchKernelGGL(lay_shard_weights_kernel, dim3((unsigned)v->n_buckets), dim3(256), 0, st, sl, bo, v->n_buckets, shard_index, shard_count, (uint32_t)P, d_w.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(st));
-    }
+    if (shard_count > 1 && !plan) return kmdb_set_error("kmdb_db_upload_shard: internal: a prefix shard without a plan");
+    // (prefix-bucket shard: the weights came from the plan — the shard's own k-mer counts, partial matrices of all shards sum to the full
+    // one — and, unless the upload carries the hashtables (new2all's pattern ids must all resolve: whole tree), only the kept nodes)
     HIP_TRY(hipStreamSynchronize(st));
     phase("H2D");
-    DevTmp<uint64_t> d_spos;                                  // pruned shard: where every kept node's stream starts in the uploaded bit array
-    if (shard_count > 1 && !with_hashtables && P > 1 && !getenv("KMDB_SHARD_WHOLE_TREE")) {
-        // (an upload that carries the hashtables keeps the whole tree: new2all's pattern ids must all resolve)
-        DevTmp<uint32_t> keep, newidx, flag;
-        DevTmp<uint64_t> spos;
-        if (keep.alloc(P + 1) || newidx.alloc(P + 1) || flag.alloc(1) || spos.alloc(P + 1)) return 1;
-        hipLaunchKernelGGL(lay_keep_init_kernel, dim3(G), dim3(B), 0, st, d_w.p, (uint32_t)P, keep.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemsetAsync(keep.p + P, 0, 4, st));
-        // a flag climbs at least one parent link per launch: a path of d nodes is done after d launches (the depth is not known yet here,
-        // P bounds it); the loop ends when a group of launches changed nothing — and the upload fails if it never does
-        uint32_t changed = 1;
-        for (uint64_t round = 0; changed && round <= P + 8; round += 8) {
-            HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
-            for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(lay_keep_up_kernel, dim3(G), dim3(B), 0, st, d_parent.p, (uint32_t)P, keep.p, flag.p);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(&changed, flag.p, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
-        if (changed) return kmdb_set_error("kmdb_db_upload_shard: the keep flags of the shard's tree did not settle (parent links form a cycle?)");
-        size_t tb = 0, tb2 = 0;
-        rocprim::transform_iterator<uint32_t*, U32toU64, uint64_t> it_nb(d_nbits.p, U32toU64());
-        HIP_TRY(prim::exclusive_sum(nullptr, tb, keep.p, newidx.p, (int)(P + 1), st));
-        HIP_TRY(prim::exclusive_sum(nullptr, tb2, it_nb, spos.p, (int)P, st));
-        DevTmp<unsigned char> tmp;
-        if (tmp.alloc(std::max(tb, tb2))) return 1;
-        HIP_TRY(prim::exclusive_sum(tmp.p, tb, keep.p, newidx.p, (int)(P + 1), st));
-        HIP_TRY(prim::exclusive_sum(tmp.p, tb2, it_nb, spos.p, (int)P, st));
-        uint32_t P2 = 0;
-        HIP_TRY(hipMemcpyAsync(&P2, newidx.p + P, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (P2 && P2 < P) {
-            DevTmp<int32_t> parent2;
-            DevTmp<uint32_t> ll2, last2, n2, nbits2, w2;
-            if (parent2.alloc(P2) || ll2.alloc(P2) || last2.alloc(P2) || n2.alloc(P2) || nbits2.alloc(P2) || w2.alloc(P2) || d_spos.alloc(P2 + 1)) return 1;
-            hipLaunchKernelGGL(lay_compact_kernel, dim3(G), dim3(B), 0, st, keep.p, newidx.p, d_parent.p, d_ll.p, d_last.p, d_n.p, d_nbits.p, d_w.p, spos.p, (uint32_t)P,
-                               parent2.p, ll2.p, last2.p, n2.p, nbits2.p, w2.p, d_spos.p);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(st));
-            std::swap(d_parent.p, parent2.p); std::swap(d_ll.p, ll2.p); std::swap(d_last.p, last2.p); std::swap(d_n.p, n2.p); std::swap(d_nbits.p, nbits2.p); std::swap(d_w.p, w2.p);
-            if (verbose) fprintf(stderr, "[kmdb] upload: prefix shard %u / %u keeps %u of %llu patterns\n", shard_index, shard_count, P2, (unsigned long long)P);
-            P = P2; db->P = P2;
-            G = (unsigned)((P + B - 1) / B); G1 = (unsigned)((P + 1 + B - 1) / B);
-        }
-        phase("shard: nodes the shard needs");
-    }
+    if (pruned && verbose) fprintf(stderr, "[kmdb] upload: prefix shard %u / %u keeps %llu of %llu patterns (%.1f MB over PCIe)\n", shard_index, shard_count,
+                                   (unsigned long long)P, (unsigned long long)P_view, h2d_bytes / 1e6);
+    if (pruned) db->P = P;
+    if (plan && shard_count > 1) plan->release_weights(shard_index);
+    h_newidx.reset();
     for (HostRegion r : {h_parent.release(), h_ll.release(), h_last.release(), h_n.release(), h_nbits.release(), h_w.release(), h_bits.release()})
         if (r.p) db->staging.emplace_back(r.p, r.bytes);
 
@@ -554,6 +490,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         // the checksum sum_p w_p C(n_p, 2) is defined on the full 64-bit counts
         if (d_wfull.alloc(P)) return 1;
         HIP_TRY(hipMemcpyAsync(d_wfull.p, v->num_kmers, P * 8, hipMemcpyHostToDevice, st));
+        h2d_bytes += P * 8;
     }
     hipLaunchKernelGGL(lay_gather_kernel, dim3(std::min<unsigned>(G1, 2048u)), dim3(B), 0, st, order.p, acc[cur].p, dep[dcur].p, cnt.p, size.p, d_parent.p, d_ll.p, d_last.p, d_n.p, d_nbits.p, d_w.p,
                        d_wfull.p, (uint32_t)P, db->k0in, db->nl, db->parent, db->w, db->dflag, db->sub_end, d_stats.p);
@@ -584,8 +521,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         HIP_TRY(prim::exclusive_sum(nullptr, tb, it_src, srcpos.p, (int)P, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
-        if (d_spos.p) HIP_TRY(hipMemcpyAsync(srcpos.p, d_spos.p, P * 8, hipMemcpyDeviceToDevice, st));          // pruned shard: the streams keep their uploaded places
-        else HIP_TRY(prim::exclusive_sum(tmp.p, tb, it_src, srcpos.p, (int)P, st));
+        HIP_TRY(prim::exclusive_sum(tmp.p, tb, it_src, srcpos.p, (int)P, st));
         HIP_TRY(prim::exclusive_sum(tmp.p, tb, it_dst, dstpos.p, (int)P, st));
         HIP_TRY(hipMalloc((void**)&db->bits, n_bit_words * 8));
         HIP_TRY(hipMemsetAsync(db->bits, 0, n_bit_words * 8, st));
@@ -645,6 +581,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
     db->stats.sum_pairs = hs.pairs;
     db->stats.n_segments = db->n_nsegs;
     db->stats.n_patterns = P;
+    db->stats.h2d_bytes = h2d_bytes;
     db->stats.device_bytes = P * (8 + 4 + 4 + 4 + 4 + 2 + 4) + n_bit_words * 8 + (uint64_t)db->n_nsegs * db->chain_cap * 4 + dev_ht_bytes;
     return 0;
 }

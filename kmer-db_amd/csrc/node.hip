@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -68,10 +69,30 @@ struct DevSlot {
     uint32_t* tmp = nullptr;                                 // [cells] a further shard's matrix before it is added (only with several shards per device)
     uint32_t* chunk = nullptr;                               // [per] this device's chunk of the reduced matrix (D > 1)
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // start of the call, end of the device's own shards, end of the collective, end of the copy
     ncclComm_t comm = nullptr;
     double call_ms = 0, collective_ms = 0, d2h_ms = 0, upload_s = 0;
+    uint64_t h2d_bytes = 0, n_patterns = 0, n_records = 0;
     std::string error;                                       // a device thread's failure (kmdb_last_error is per thread)
+};
+
+// The device threads of a call meet here before the collective: a thread that failed on its own shards (out of memory, a launch
+// error) must not leave the others waiting inside ncclReduceScatter for a rank that never comes.  arrive(ok) returns
+// true to everyone only when every thread arrived with ok.
+struct Rendezvous {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t n = 1, waiting = 0;
+    uint64_t gen = 0;
+    bool all_ok = true, result = true;
+    bool arrive(bool ok) {
+        std::unique_lock<std::mutex> g(mu);
+        all_ok = all_ok && ok;
+        if (++waiting == n) { result = all_ok; waiting = 0; all_ok = true; ++gen; cv.notify_all(); return result; }
+        const uint64_t my = gen;
+        cv.wait(g, [&] { return gen != my; });
+        return result;
+    }
 };
 
 }  // namespace
@@ -85,6 +106,7 @@ struct kmdb_node {
     bool use_rccl = false;                                   // more than one device — or KMDB_NODE_FORCE_RCCL=1 on one device: the same calls on a
                                                              // one-rank communicator (what a one-GPU box can exercise of the RCCL path)
     kmdb_node_stats stats{};
+    Rendezvous meet;
 };
 
 namespace {
@@ -96,8 +118,9 @@ int on_devices(kmdb_node* nd, F&& fn) {
     for (size_t d = 0; d < nd->dev.size(); ++d)
         th.emplace_back([&, d]() {
             nd->dev[d].error.clear();
-            if (hipSetDevice(nd->dev[d].device) != hipSuccess) { nd->dev[d].error = "hipSetDevice failed"; return; }
-            if (fn(d)) nd->dev[d].error = kmdb_last_error();
+            const bool dev_ok = hipSetDevice(nd->dev[d].device) == hipSuccess;
+            if (!dev_ok) (void)kmdb_set_error("hipSetDevice failed");
+            if (fn(d, dev_ok)) nd->dev[d].error = kmdb_last_error();      // (fn still runs: a call with a collective has a rendezvous every thread must reach)
         });
     for (auto& t : th) t.join();
     for (auto& s : nd->dev)
@@ -111,38 +134,56 @@ int on_devices(kmdb_node* nd, F&& fn) {
         if (e_ != hipSuccess) return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
-// the partial matrix of device slot d in acc (all its shards), then the node's reduce-scatter; leaves the device idle
-int node_accumulate(kmdb_node* nd, size_t d, const kmdb_opts* opts) {
+// the device's own shards into acc; everything stays on the device's stream, nothing waits on the host
+int node_own_shards(kmdb_node* nd, size_t d, const kmdb_opts* opts) {
     DevSlot& s = nd->dev[d];
     const size_t D = nd->dev.size();
     kmdb_opts o{};
     if (opts) o = *opts;
     o.abi_version = KMDB_ABI_VERSION; o.device = s.device; o.stream = s.stream;
     if (o.shard_count == 0) { o.shard_index = 0; o.shard_count = 1; }
-    const auto t0 = std::chrono::steady_clock::now();
+    NODE_TRY(hipEventRecord(s.ev[0], s.stream));
     if (nd->per * D > nd->cells) NODE_TRY(hipMemsetAsync(s.acc + nd->cells, 0, (nd->per * D - nd->cells) * 4, s.stream));     // the padding of the last chunk
+    s.n_records = 0;
     for (size_t k = 0; k < s.shards.size(); ++k) {
         uint32_t* dst = k == 0 ? s.acc : s.tmp;
         if (kmdb_all2all_dense_device(s.shards[k], dst, &o)) return 1;
+        kmdb_stats st{};
+        if (!kmdb_db_stats(s.shards[k], &st)) s.n_records += st.n_records;
         if (k && nd->cells) {
             hipLaunchKernelGGL(add_u32_kernel, dim3((unsigned)((nd->cells + 255) / 256)), dim3(256), 0, s.stream, s.acc, s.tmp, nd->cells);
             NODE_TRY(hipGetLastError());
         }
     }
     if (s.shards.empty() && nd->cells) NODE_TRY(hipMemsetAsync(s.acc, 0, nd->cells * 4, s.stream));
-    NODE_TRY(hipStreamSynchronize(s.stream));
-    s.call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    s.collective_ms = 0;
+    NODE_TRY(hipEventRecord(s.ev[1], s.stream));
+    return 0;
+}
+// the partial matrix of device slot d in acc (all its shards), then the node's reduce-scatter behind it ON THE SAME STREAM (no host
+// wait in between: the collective starts when the device's last kernel ends); ev[2] marks its end.  The caller queues its copy /
+// compaction behind that and waits once.
+int node_accumulate(kmdb_node* nd, size_t d, bool dev_ok, const kmdb_opts* opts) {
+    DevSlot& s = nd->dev[d];
+    s.call_ms = s.collective_ms = s.d2h_ms = 0;
+    const int own = dev_ok ? node_own_shards(nd, d, opts) : 1;
+    const std::string own_msg = own ? kmdb_last_error() : "";
     if (nd->use_rccl && nd->per) {
-        NODE_TRY(hipEventRecord(s.ev[0], s.stream));
+        // every device thread arrives here, failed or not; the collective is entered by all or by none
+        if (!nd->meet.arrive(own == 0)) return kmdb_set_error(own ? own_msg : std::string("another device failed before the reduce-scatter: the collective was not entered"));
         const ncclResult_t r = nd->rccl.ReduceScatter(s.acc, s.chunk, nd->per, ncclUint32, ncclSum, s.comm, s.stream);
         if (r != ncclSuccess) return kmdb_set_error(std::string("ncclReduceScatter: ") + nd->rccl.GetErrorString(r));
-        NODE_TRY(hipEventRecord(s.ev[1], s.stream));
-        NODE_TRY(hipStreamSynchronize(s.stream));
-        float ms = 0;
-        NODE_TRY(hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
-        s.collective_ms = ms;
-    }
+    } else if (own) return kmdb_set_error(own_msg);
+    NODE_TRY(hipEventRecord(s.ev[2], s.stream));
+    return 0;
+}
+// after the stream has drained: the device's times from its events
+int node_times(kmdb_node* nd, size_t d) {
+    DevSlot& s = nd->dev[d];
+    float a = 0, b = 0, c = 0;
+    NODE_TRY(hipEventElapsedTime(&a, s.ev[0], s.ev[1]));
+    NODE_TRY(hipEventElapsedTime(&b, s.ev[1], s.ev[2]));
+    NODE_TRY(hipEventElapsedTime(&c, s.ev[2], s.ev[3]));
+    s.call_ms = a; s.collective_ms = nd->use_rccl ? b : 0.0; s.d2h_ms = c;
     return 0;
 }
 
@@ -183,10 +224,21 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
     nd->per = D > 1 ? (nd->cells + D - 1) / D : nd->cells;
     nd->dev.resize(D);
     for (uint32_t d = 0; d < D; ++d) nd->dev[d].device = devices[d];
+    nd->meet.n = D;
     const char* force = getenv("KMDB_NODE_FORCE_RCCL");
     nd->use_rccl = D > 1 || (force && force[0] == '1');
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = on_devices(nd, [&](size_t d) -> int {
+    // all shards planned at once on the host: one pass over the hashtable items, one sweep over the tree (host_shards.cpp); every device
+    // thread then narrows, packs and copies only what its own shards keep
+    kmdb_shard_plan plan;
+    if (n_shards > 1) {
+        std::vector<uint32_t> all(n_shards);
+        for (uint32_t s = 0; s < n_shards; ++s) all[s] = s;
+        if (kmdb_shard_plan_build(view, n_shards, all, &plan)) { delete nd; return 1; }
+        nd->stats.plan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    int rc = on_devices(nd, [&](size_t d, bool dev_ok) -> int {
+        if (!dev_ok) return 1;
         DevSlot& s = nd->dev[d];
         const auto u0 = std::chrono::steady_clock::now();
         NODE_TRY(hipStreamCreate(&s.stream));
@@ -194,8 +246,10 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
         kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = s.device; o.shard_count = 1;
         for (uint32_t sh = (uint32_t)d; sh < n_shards; sh += D) {
             kmdb_db* db = nullptr;
-            if (n_shards == 1 ? kmdb_db_upload(view, &o, 0, &db) : kmdb_db_upload_shard(view, &o, 0, sh, n_shards, &db)) return 1;
+            if (n_shards == 1 ? kmdb_db_upload(view, &o, 0, &db) : kmdb_db_upload_planned(view, &o, 0, sh, n_shards, &plan, &db)) return 1;
             s.shards.push_back(db);
+            kmdb_stats st{};
+            if (!kmdb_db_stats(db, &st)) { s.h2d_bytes += st.h2d_bytes; s.n_patterns += st.n_patterns; }
         }
         NODE_TRY(hipMalloc((void**)&s.acc, std::max<uint64_t>(nd->per * D, 1) * 4));
         if (s.shards.size() > 1) NODE_TRY(hipMalloc((void**)&s.tmp, std::max<uint64_t>(nd->cells, 1) * 4));
@@ -242,17 +296,28 @@ extern "C" int kmdb_node_stats_get(const kmdb_node* nd, kmdb_node_stats* out) {
     return 0;
 }
 
+extern "C" int kmdb_node_device_stats_get(const kmdb_node* nd, uint32_t slot, kmdb_node_device_stats* out) {
+    if (!nd || !out) return kmdb_set_error("kmdb_node_device_stats_get: null argument");
+    if (slot >= nd->dev.size()) return kmdb_set_error("kmdb_node_device_stats_get: the node has " + std::to_string(nd->dev.size()) + " device slots");
+    const DevSlot& s = nd->dev[slot];
+    out->device = s.device; out->n_shards = (uint32_t)s.shards.size();
+    out->upload_s = s.upload_s; out->call_ms = s.call_ms; out->collective_ms = s.collective_ms; out->d2h_ms = s.d2h_ms;
+    out->h2d_bytes = s.h2d_bytes; out->n_patterns = s.n_patterns; out->n_records = s.n_records;
+    return 0;
+}
+
 extern "C" int kmdb_node_all2all_dense(kmdb_node* nd, uint32_t* out_lower_tri, const kmdb_opts* opts) {
     if (!nd || (!out_lower_tri && nd->cells)) return kmdb_set_error("kmdb_node_all2all_dense: null argument");
-    const int rc = on_devices(nd, [&](size_t d) -> int {
-        if (node_accumulate(nd, d, opts)) return 1;
+    const int rc = on_devices(nd, [&](size_t d, bool dev_ok) -> int {
+        if (node_accumulate(nd, d, dev_ok, opts)) return 1;
         DevSlot& s = nd->dev[d];
         const uint32_t* p; uint64_t lo, hi;
         node_chunk(nd, d, p, lo, hi);
-        const auto t0 = std::chrono::steady_clock::now();
-        if (hi > lo) NODE_TRY(hipMemcpy(out_lower_tri + lo, p, (hi - lo) * 4, hipMemcpyDeviceToHost));     // every device its own chunk, side by side over PCIe
-        s.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return 0;
+        // every device its own chunk, side by side over PCIe, queued behind its collective: the chunk leaves as soon as it has landed
+        if (hi > lo) NODE_TRY(hipMemcpyAsync(out_lower_tri + lo, p, (hi - lo) * 4, hipMemcpyDeviceToHost, s.stream));
+        NODE_TRY(hipEventRecord(s.ev[3], s.stream));
+        NODE_TRY(hipStreamSynchronize(s.stream));
+        return node_times(nd, d);
     });
     node_fill_stats(nd);
     return rc;
@@ -265,18 +330,19 @@ extern "C" int kmdb_node_all2all_sparse(kmdb_node* nd, const kmdb_cell_filter* f
     const size_t D = nd->dev.size();
     std::vector<kmdb_sparse_rows> part(D);
     for (auto& p : part) std::memset(&p, 0, sizeof p);
-    int rc = on_devices(nd, [&](size_t d) -> int {
-        if (node_accumulate(nd, d, opts)) return 1;
+    int rc = on_devices(nd, [&](size_t d, bool dev_ok) -> int {
+        if (node_accumulate(nd, d, dev_ok, opts)) return 1;
         DevSlot& s = nd->dev[d];
         if (s.shards.empty()) return kmdb_set_error("kmdb_node_all2all_sparse: a device without a shard");
         const uint32_t* p; uint64_t lo, hi;
         node_chunk(nd, d, p, lo, hi);
         kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = s.device; o.shard_count = 1; o.stream = s.stream;
-        const auto t0 = std::chrono::steady_clock::now();
-        // the cells are complete sums here (all shards, all devices): bounds and measures apply (kmdb_sparse_from_dense_device)
-        const int r = kmdb_sparse_from_dense_device(s.shards[0], p, lo, hi, filters, n_filters, sample_kmers, measure, &part[d], &o);
-        s.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return r;
+        // the cells are complete sums here (all shards, all devices): bounds and measures apply (kmdb_sparse_from_dense_device, on the
+        // same stream behind the collective)
+        if (kmdb_sparse_from_dense_device(s.shards[0], p, lo, hi, filters, n_filters, sample_kmers, measure, &part[d], &o)) return 1;
+        NODE_TRY(hipEventRecord(s.ev[3], s.stream));
+        NODE_TRY(hipStreamSynchronize(s.stream));
+        return node_times(nd, d);
     });
     node_fill_stats(nd);
     if (!rc) {

@@ -152,6 +152,14 @@ void node_report(const Db& db) {
     std::cerr << "  per device: compute " << st.call_ms << " ms, RCCL reduce-scatter " << st.collective_ms << " ms";
     if (st.rccl_version) std::cerr << " (RCCL " << st.rccl_version << ")";
     std::cerr << ", result to host " << st.d2h_ms << " ms" << std::endl;
+    // every device by itself (an imbalanced shard shows here, not in the maxima above)
+    for (uint32_t slot = 0; slot < st.n_devices; ++slot) {
+        kmdb_node_device_stats ds{};
+        if (kmdb_node_device_stats_get(db.node, slot, &ds)) break;
+        std::cerr << "  GPU " << ds.device << ": " << ds.n_shards << " shard(s), " << ds.n_patterns << " nodes, " << ds.h2d_bytes / 1000000 << " MB over PCIe in " << ds.upload_s
+                  << " s; " << ds.n_records << " block records, compute " << ds.call_ms << " ms, reduce-scatter " << ds.collective_ms << " ms, result " << ds.d2h_ms << " ms"
+                  << std::endl;
+    }
 }
 
 // seconds since the kernel started this process (exec, dynamic loading and static initialisers included; 10 ms resolution)

@@ -22,6 +22,32 @@ def test_library_exports_every_declared_symbol(K):
     assert K.lib().kmdb_abi_version() == K.ABI_VERSION
 
 
+def test_shard_plan_on_the_host(K, golden_dir):
+    """host_shards.cpp: the plan kmdb_node_upload works from — per prefix shard the k-mers it owns (hashtable items of the buckets
+    b % S == s, reference src/hashmap_lp.h:71-78, bucket = kmer >> 32 src/types.h:25-27) and the nodes it keeps (a node whose subtree
+    holds one of them) — against the same computed with numpy from the view."""
+    for stem in ("virus_k18", "clade64", "clade64_k25_f01", "synth_k21"):
+        h = K.HostDB(os.path.join(golden_dir, stem + ".db"))
+        a = h.view_arrays()
+        par, bo, sl = a["parent_id"], a["bucket_offset"], a["slots"]
+        P = len(par)
+        val = (sl >> np.uint64(32)).astype(np.int64)
+        bucket = np.repeat(np.arange(len(bo) - 1), np.diff(bo).astype(np.int64))
+        ok = val != 0x7FFFFFFF
+        for S in (1, 2, 3, 8, 11):
+            kept, kmers = h.shard_plan_counts(S)
+            for s in range(S):
+                w = np.bincount(val[ok & (bucket % S == s)], minlength=P)
+                keep = w > 0
+                for q in range(P - 1, 0, -1):
+                    if keep[q] and par[q] >= 0:
+                        keep[par[q]] = True
+                assert int(kept[s]) == int(keep.sum()) and int(kmers[s]) == int(w.sum()), (stem, S, s)
+            assert int(kmers.sum()) == int(ok.sum())
+    with pytest.raises(K.KmdbError, match="no hashtables"):
+        K.HostDB(os.path.join(golden_dir, "clade64.db"), skip_hashtables=True).shard_plan_counts(2)
+
+
 def test_product_does_not_touch_the_oracle():
     # the product path must never import / link / call anything under oracle/
     for base, _, files in os.walk(os.path.join(ROOT, "kmer-db_amd")):
