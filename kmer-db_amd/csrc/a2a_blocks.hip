@@ -96,7 +96,6 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
-    uint32_t nostore;              // timing experiment (K1W_DEBUG == 1, compile time): the wide kernel's records are placed but not written
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
@@ -234,7 +233,7 @@ __device__ __forceinline__ void wide_emit(WaveArena& A, const PoolView& pv, bool
         const unsigned long long grp = __ballot(on);
         if (!grp) break;
         const Resv r = arena_reserve_wide(A, pv, (uint32_t)__popcll(grp), lane);
-        if (on && !pv.nostore) {
+        if (on) {
             const uint32_t slot = resv_slot(r, (uint32_t)__popcll(grp & lt_mask));
             pv.wrec[slot] = WideRec{rows, cols};
             pv.wkey[slot] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
@@ -306,7 +305,7 @@ __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const
             ovf = ovf && !mine;
             pend = __ballot(ovf);
         }
-        if (on && !pv.nostore) {
+        if (on) {
             ((WideRec*)pv.rec)[p] = WideRec{rows, cols};
             pv.recw[p] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
         }
@@ -908,7 +907,6 @@ struct WParams {
 constexpr int K1W_WAVES = 2;
 constexpr uint32_t L2_MIN_BLOCKS = 24;     // nodes with that many blocks take the second level (measured at 10 000 samples: 11 -> 21.9 ms, 24 -> 20.0; KMDB_L2_MIN moves it)
 constexpr uint32_t L2_NODE_GRAB = 16, L2_ENT_GRAB = 1024, L2_SUB = 16;   // node indices / entries a wave takes per device atomic, from one of L2_SUB cursors each
-constexpr uint32_t K1W_DEBUG = 0;          // timing experiments at compile time (results wrong): 1 = no record stores, 2 = no emission at all, 3 = no owner search
 constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
 constexpr uint32_t K1W_HEAVY = 11;         // a node with that many blocks (66 records and more) is emitted by the whole wave
 constexpr uint32_t K1W_OXCAP = 128;        // further own pairs of a batch's nodes kept in LDS
@@ -1003,7 +1001,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     // record-parallel emission of the lanes in `on` (list of lane j: m entries from st_start[j]): a node with m blocks owns
     // m (m + 1) / 2 records (block pairs a >= b), one record per lane and step
     auto emit = [&](bool on, uint32_t m, uint32_t wv) {
-        if (K1W_DEBUG == 2u) return;
         // a node with many blocks is taken by the whole wave: lane t builds pair t of the node
         {
             unsigned long long hb = __ballot(on && m >= K1W_HEAVY);
@@ -1090,18 +1087,9 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             unsigned long long FX = 0, FY = 0;
             if (t < T) {
                 uint32_t own = 0;                               // the first lane whose inclusive sum exceeds t
-                uint32_t r0;
-                if (K1W_DEBUG == 3u) {                            // (timing experiment: no search — a record of the lane's own node, or none)
-                    own = lane;
-                    const uint32_t c0 = L.queue[own] - (own ? L.queue[own - 1u] : 0u);
-                    r0 = c0 ? t % c0 : 0u;
-                    if (!c0) own = 64u;
-                } else {
 #pragma unroll
-                    for (uint32_t sft = 32; sft >= 1u; sft >>= 1) if (L.queue[own + sft - 1u] <= t) own += sft;
-                    r0 = t - (own ? L.queue[own - 1u] : 0u);
-                }
-                if (own < 64u) {
+                for (uint32_t sft = 32; sft >= 1u; sft >>= 1) if (L.queue[own + sft - 1u] <= t) own += sft;
+                const uint32_t r0 = t - (own ? L.queue[own - 1u] : 0u);
                 uint32_t a = (uint32_t)((__fsqrt_rn(8.0f * (float)r0 + 1.0f) - 1.0f) * 0.5f);
                 while (tri32(a) > r0) --a;
                 while (tri32(a + 1u) <= r0) ++a;
@@ -1114,7 +1102,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 diag = a == b;
                 rec_on = !diag || __popcll(FX) >= 2;               // a diagonal record needs two ids to have a pair
                 stream = tri32(X) + Y;
-                }
             }
             // few streams: the step's records go to the wide pool in arrival order (one reservation for all lanes); many: to
             // the chunks of their block rows
@@ -1339,11 +1326,10 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
 // 32 is one v_permlane32_swap over the two words.  Every stage below works on the 32-bit words separately: fetch the partner lane's
 // word (lane ^ s), rotate it by s towards this lane's side (v_alignbit_b32: right for the upper lane of a pair, left for the lower one)
 // and splice it in under a per-lane mask (v_bfi_b32) — three instructions per word and stage, with the rotate amounts and masks of
-// the five stages in ten registers that are computed once per run (TrConst).  The fetches of the stages 16 / 8 / 4 go over the LDS
-// crossbar (ds_swizzle_b32, swap mode: no LDS memory involved) — the apply kernels are bound by VALU issue, the LDS pipe has room —
-// and the stages 2 / 1 are DPP quad permutes.  29 VALU + 6 LDS-pipe instructions per transpose; round 3's version (v_permlane16_swap +
-// v_perm for stage 16, ds_bpermute shuffles and 64-bit mask arithmetic below) took 72 VALU.  profiles/r04_transpose_probe.hip checks both
-// against the definition and times them.
+// the five stages in ten registers that are computed once per run (TrConst).  The fetches are v_permlane16_swap (stage 16) and DPP row /
+// quad permutes: 35 VALU instructions per transpose, no LDS (fetching the stages 16 / 8 / 4 over the LDS crossbar with ds_swizzle_b32
+// was measured slower — profiles/r05_experiment_switches.diff; round 3's version, v_perm + ds_bpermute shuffles and 64-bit mask
+// arithmetic, took 72 VALU).  profiles/r04_transpose_probe.hip checks the variants against the definition and times them.
 struct TrConst { uint32_t amt[5], msk[5]; };
 __device__ __forceinline__ TrConst tr_const(uint32_t lane) {
     TrConst c;
@@ -1357,17 +1343,14 @@ __device__ __forceinline__ TrConst tr_const(uint32_t lane) {
     }
     return c;
 }
-constexpr int K2_TR_SWIZZLE = 0;              // 1: stages 16 / 8 / 4 fetch over the LDS crossbar (ds_swizzle); 0: v_permlane16_swap / DPP: VALU only (A/B)
 __device__ __forceinline__ uint32_t tr_fetch(uint32_t v, int k, bool up16) {
     // the word of lane ^ (16 >> k)
     if (k == 0) {
-        if (K2_TR_SWIZZLE) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
         const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // [0]: odd rows <- the even rows below them, [1]: even rows <- the odd rows above
         return up16 ? a[0] : a[1];
     }
-    if (k == 1) return K2_TR_SWIZZLE ? (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x201F) : (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    if (k == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
     if (k == 2) {
-        if (K2_TR_SWIZZLE) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);
         const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);      // row_shl:4 into the banks 0 and 2: lane i <- i + 4
         return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);        // row_shr:4 into the banks 1 and 3: lane i <- i - 4
     }
@@ -1439,14 +1422,11 @@ __device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t s
 // weight is split into base-128 digits, the run is accumulated once per digit that occurs (`digit`), and the digit's tile is
 // merged shifted left by 7 * digit — exact in the matrix's uint32 wrap-around arithmetic.  Almost every weight is below 128
 // (99.98 % at the benchmark database), so nearly every run takes one pass.  Returns (to every thread) the OR of the weights.
-constexpr int K2_SPREAD_LUT = 1;           // 1: bits -> operand bytes through the 256-entry table in LDS; 0: in the ALU (A/B)
-constexpr int K2_DEBUG = 0;                // timing experiments (results wrong): 1 no MFMA, 2 no byte spreading, 3 no transposes, 4 records fetched once per run,
-                                           // 5 no merge of the waves' tiles / no flush
 typedef int k2_v4i __attribute__((ext_vector_type(4)));
 typedef int k2_v16i __attribute__((ext_vector_type(16)));
 
 template <bool DIAG, bool SORTED>
-__device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t digit, uint32_t* acc, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
+__device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t digit, uint32_t* acc,
                                                   unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t half = lane >> 5, l31 = lane & 31u;
@@ -1454,20 +1434,8 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
     auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> k2_v4i {
         const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
         k2_v4i r;
-        if (K2_SPREAD_LUT) {
-            const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
-            r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
-        } else {
-            // four bits -> four bytes in the ALU: n * 0x204081 puts bit i of the nibble at bit 8 i (24-bit multiply), and a packed
-            // 16-bit multiply by 255 turns the 0x01 bytes into 0xFF where the operand wants a mask for the weights
-            const bool ff = lut == lut_ff;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t v = __umul24((f >> (4 * j)) & 0xFu, 0x204081u) & 0x01010101u;
-                if (ff) v = (v << 8) - v;
-                r[j] = (int)v;
-            }
-        }
+        const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
+        r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
         return r;
     };
     unsigned long long nR = 0, nC = 0;
@@ -1484,15 +1452,15 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
         const unsigned long long R = nR, C = nC;
         const uint32_t W = nW;
         cur = next_step(cur + 4);
-        if (K2_DEBUG != 4) k2_fetch<SORTED>(it, DIAG, cur, lane, true, nR, nC, nW);
+        k2_fetch<SORTED>(it, DIAG, cur, lane, true, nR, nC, nW);
         wor |= W;
         // lane r now holds row r of the step's bit matrices R^T / C^T (bit k <=> record k has row / column r).  The operand layout wants
         // in every lane the rows l31 and 32 + l31: the lower half of the wave keeps its own word and fetches the upper half's, and
         // the other way round — one v_permlane32_swap per 32-bit word, nothing parked in LDS (round 3 wrote the 64 words to LDS and read
         // four back per lane; with the byte-spreading table that made 25 LDS instructions per step and a third of the LDS cycles lost to
         // bank conflicts).
-        const unsigned long long Ct = K2_DEBUG == 3 ? C : transpose64(C, trc);
-        const unsigned long long Rt = DIAG ? Ct : (K2_DEBUG == 3 ? R : transpose64(R, trc));           // on the diagonal rows == cols
+        const unsigned long long Ct = transpose64(C, trc);
+        const unsigned long long Rt = DIAG ? Ct : transpose64(R, trc);           // on the diagonal rows == cols
         auto halves = [&](unsigned long long w, unsigned long long& w0, unsigned long long& w1) {
             const auto a = __builtin_amdgcn_permlane32_swap((uint32_t)w, (uint32_t)w, false, false);                 // [0]: the lower half's words everywhere, [1]: the upper half's
             const auto b = __builtin_amdgcn_permlane32_swap((uint32_t)(w >> 32), (uint32_t)(w >> 32), false, false);
@@ -1507,30 +1475,19 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
 #pragma unroll
         for (uint32_t kh = 0; kh < 2; ++kh) {
             const uint32_t shift = 32u * kh + 16u * half;            // records 32 kh + 16 half .. + 15 of the step
-            k2_v4i a0, a1, b0, b1;
-            if (K2_DEBUG == 2) {
-                const k2_v4i x = {(int)(uint32_t)(ra0 >> shift), (int)(uint32_t)(ra1 >> shift), (int)(uint32_t)(cb0 >> shift), (int)(uint32_t)(cb1 >> shift)};
-                a0 = x; a1 = x; b0 = x; b1 = x;
-            } else {
-                a0 = spread(ra0, shift, lut_ff); a1 = spread(ra1, shift, lut_ff);
-                b0 = spread(cb0, shift, lut_01); b1 = spread(cb1, shift, lut_01);
-            }
+            k2_v4i a0 = spread(ra0, shift, lut_ff), a1 = spread(ra1, shift, lut_ff);
+            const k2_v4i b0 = spread(cb0, shift, lut_01), b1 = spread(cb1, shift, lut_01);
             const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
             a0 &= wv; a1 &= wv;
-            if (K2_DEBUG == 1) { c00[0] += a0[0] ^ b0[1]; c01[0] += a0[1] ^ b1[2]; c10[0] += a1[2] ^ b0[3]; c11[0] += a1[3] ^ b1[0]; c00[1] += a0[2] + a0[3] + a1[0] + a1[1] + b0[0] + b0[2] + b1[1] + b1[3]; }
-            else {
             c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
             c01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, c01, 0, 0, 0);
             c10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, c10, 0, 0, 0);
             c11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c11, 0, 0, 0);
-            }
         }
         lds_sync();
     }
     // merge the four waves' tiles through the LDS block (on the diagonal only c < r)
     const uint32_t sh = 7u * digit;
-    if (K2_DEBUG == 5) { if ((c00[0] ^ c01[1] ^ c10[2] ^ c11[3]) == 0x12345u) acc[lane] = 1u; }
-    else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half;
@@ -1547,15 +1504,15 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
 
 // one run (the records of one block pair inside a window): accumulate, once per weight digit that occurs, and flush the tile
 template <bool SORTED>
-__device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t* wor_sh, unsigned long long (*rtbuf)[64], unsigned long long (*ctbuf)[64],
+__device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t* wor_sh,
                                        unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01,
                                        uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
     if (threadIdx.x == 0) *wor_sh = 0;
     __syncthreads();
     for (uint32_t digit = 0; digit < 5; ++digit) {
-        const uint32_t wor = (it.X == it.Y && !it.rect_cols) ? k2_apply_mfma<true, SORTED>(it, digit, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01)
-                                          : k2_apply_mfma<false, SORTED>(it, digit, acc, rtbuf, ctbuf, wbuf, lut_ff, lut_01);
+        const uint32_t wor = (it.X == it.Y && !it.rect_cols) ? k2_apply_mfma<true, SORTED>(it, digit, acc, wbuf, lut_ff, lut_01)
+                                          : k2_apply_mfma<false, SORTED>(it, digit, acc, wbuf, lut_ff, lut_01);
         if ((threadIdx.x & 63u) == 0 && wor) atomicOr(wor_sh, wor);
         __syncthreads();
         if ((*wor_sh >> (7u * (digit + 1u))) == 0) break;           // no weight has a higher digit
@@ -1796,8 +1753,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAV
                                                        const uint32_t* __restrict__ chunk_fill, uint32_t n_states, const uint32_t* __restrict__ n_chunks_ptr,
                                                        uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, uint32_t win) {
     __shared__ uint32_t acc[64 * 64];
-    __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
-    __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
     __shared__ uint32_t s_key[K2_WIN], s_id[K2_WIN], s_fill[K2_WIN];
@@ -1832,7 +1787,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAV
             it.X = X; it.Y = bucket - tri32(X);
             it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw; it.rect_cols = 0;
         }
-        k2_run<false>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
+        k2_run<false>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth);
         a = b;
     }
 }
@@ -2120,15 +2075,6 @@ __global__ void rs_rows_kernel(const uint32_t* __restrict__ O, uint32_t G, uint3
     }
     if (threadIdx.x == 0) { row_job[NB] = cj; row_tab[NB] = ct; counters[KCTR_ROWJOBS] = cj; counters[KCTR_RAW] = O[(size_t)NB * G]; }
 }
-// bands of block rows: first job and first sorted record of every band (+ the ends)
-struct RsBandRows { uint32_t n; uint32_t x[9]; };
-__global__ void rs_bands_kernel(const uint32_t* __restrict__ row_job, const uint32_t* __restrict__ row_tab, const uint32_t* __restrict__ O, const RsBandRows B,
-                                uint32_t* __restrict__ band_job, uint32_t* __restrict__ band_rec) {
-    const uint32_t b = threadIdx.x;
-    if (b > B.n) return;
-    band_job[b] = row_job[B.x[b]];
-    band_rec[b] = O[row_tab[B.x[b]]];
-}
 struct RsJob { uint32_t X, nj, cb, ce, tab; const uint32_t* ids; };
 
 __device__ __forceinline__ bool rs_job(const RsRows& R, uint32_t job, uint32_t job_end, RsJob& j) {
@@ -2172,11 +2118,10 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const RsRows R, const uint
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) H[(size_t)j.tab + (size_t)k * j.nj] = cs_lds[k];
 }
-// (the jobs [band[0], band[1]) of one band of block rows per launch)
 // Per tile of CS_TILE records (four chunks): keys and records are fetched TOGETHER (the records wait in registers) and the next
 // tile's are requested before this one is staged — the kernel used to pay four dependent round trips per tile (chunk id, fill, key,
 // record), one workgroup-wide phase after the other.
-__global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, const uint32_t* __restrict__ band, const uint32_t* __restrict__ chunk_fill,
+__global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, const uint32_t* __restrict__ chunk_fill,
                                                          const uint32_t* __restrict__ recw, const WideRec* __restrict__ rec, uint32_t kmask,
                                                          const uint32_t* __restrict__ O, uint32_t cap, uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec,
                                                          uint32_t* __restrict__ counters) {
@@ -2185,7 +2130,7 @@ __global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, 
     RsJob job;
     // consecutive jobs write neighbouring stretches of every stream of their row (the lines at the seams are shared): workgroups are dealt
     // to the eight XCDs round-robin, so job = f(blockIdx) keeps every XCD on ONE contiguous range of jobs and the seams in one L2
-    if (!rs_job(R, band[0] + xcd_contiguous(blockIdx.x, gridDim.x), band[1], job)) return;
+    if (!rs_job(R, xcd_contiguous(blockIdx.x, gridDim.x), 0xFFFFFFFFu, job)) return;
     const uint32_t NB = R.NB;
     const uint32_t nb = job.X + 1u, sub = tri32(job.X), nch = job.ce - job.cb;
     WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
@@ -2267,8 +2212,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAV
                                                         uint32_t n_states, uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N,
                                                         uint32_t bwidth, uint32_t rect_nbc, uint32_t rect_cols) {
     __shared__ uint32_t acc[64 * 64];
-    __shared__ __attribute__((aligned(16))) unsigned long long rtbuf[4][64];
-    __shared__ __attribute__((aligned(16))) unsigned long long ctbuf[4][64];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];
     __shared__ uint16_t bnd[K2S_WIN + 2];          // run starts inside the window, then the end
@@ -2330,8 +2273,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAV
             it.rect_cols = rect_cols;
             it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.skey = swkey + p0 + a; it.kbits = kbits; it.dbits = dbits; it.rec = nullptr; it.recw = nullptr;
         }
-        k2_run<true>(it, acc, &wor_sh, rtbuf, ctbuf, wbuf, lut_ff, lut_01, M, N, bwidth);
+        k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth);
     }
+}
+
+// Many streams (row mode): the apply step over the sorted records takes a stream — or a part of K2J_REC records of a long one — per
+// workgroup instead of a window of sorted positions: a tile is written back ONCE per K2J_REC records of its stream (north_star: "a single
+// HBM write-back per tile"), where the windows of 4096 positions wrote every tile they met — 1.49 GB of atomics for the 0.2 GB matrix of
+// 10 000 samples.  Where a stream starts is known from the counting sort's offsets: no run boundaries are searched.
+constexpr uint32_t K2J_REC = 16384;
+__global__ void k2j_starts_kernel(const RsRows R, uint32_t n_states, uint32_t* __restrict__ start) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_states) return;
+    if (s == n_states) { start[s] = R.O[R.row_tab[R.NB]]; return; }                       // all sorted records
+    const uint32_t X = stream_row(s), Y = s - tri32(X);
+    const uint32_t nj = R.row_job[X + 1] - R.row_job[X];                                   // a row without records has no jobs: its streams start where the next row does
+    start[s] = R.O[(size_t)R.row_tab[X] + (size_t)Y * nj];
+}
+// the jobs in any order: one reservation per workgroup of streams
+__global__ __launch_bounds__(1024) void k2j_build_kernel(const uint32_t* __restrict__ start, uint32_t n_states, uint2* __restrict__ jobs, uint32_t cap,
+                                                         uint32_t* __restrict__ counters) {
+    __shared__ uint32_t wsum[16], base_sh;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t len = s < n_states ? start[s + 1] - start[s] : 0u;
+    const uint32_t nj = (len + K2J_REC - 1u) / K2J_REC;
+    const uint32_t incl = wave_incl_scan(nj, lane);
+    if (lane == 63u) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < 16; ++k) { const uint32_t v = wsum[k]; wsum[k] = run; run += v; }
+        base_sh = run ? atomicAdd(&counters[KCTR_K2JOBS], run) : 0u;
+    }
+    __syncthreads();
+    uint32_t o = base_sh + wsum[wave] + incl - nj;
+    for (uint32_t part = 0; part < nj; ++part, ++o) if (o < cap) jobs[o] = make_uint2(s, part);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAVES, 8))) void k2_jobs_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
+                                                        const uint32_t* __restrict__ start, const uint2* __restrict__ jobs, const uint32_t* __restrict__ n_jobs, uint32_t cap,
+                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+    __shared__ uint32_t acc[64 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
+    __shared__ unsigned long long lut_ff[256], lut_01[256];
+    __shared__ uint32_t wor_sh;
+    const uint32_t nj = *n_jobs < cap ? *n_jobs : cap;
+    if (blockIdx.x >= nj) return;
+    const uint2 job = jobs[blockIdx.x];
+    {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= ((threadIdx.x >> i) & 1u) ? 0xFFull << (8 * i) : 0ull;
+        lut_ff[threadIdx.x] = v;
+        lut_01[threadIdx.x] = v & 0x0101010101010101ull;
+    }
+    const uint32_t a = start[job.x] + job.y * K2J_REC, e = start[job.x + 1];
+    const uint32_t b = e - a > K2J_REC ? a + K2J_REC : e;
+    K2Item it;
+    it.X = stream_row(job.x); it.Y = job.x - tri32(it.X); it.rect_cols = 0;
+    it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + a; it.skey = swkey + a; it.kbits = kbits; it.dbits = dbits;
+    it.rec = nullptr; it.recw = nullptr;
+    k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2441,7 +2442,7 @@ inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, 0u};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -2506,7 +2507,14 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipMalloc((void**)&db->swkey, slots * 4));
     HIP_TRY(hipMalloc(&db->swrec, slots * sizeof(WideRec)));
     db->sorted_cap = slots;
-    if (db->row_mode) { db->wide_pool_cap = chunks; return 0; }
+    if (db->row_mode) {
+        // jobs of the apply kernel: every stream at least one, a long one a job per K2J_REC records
+        FREE_NULL(db->k2j_jobs);
+        db->k2j_cap = slots / K2J_REC + db->n_states + 1;
+        HIP_TRY(hipMalloc((void**)&db->k2j_jobs, db->k2j_cap * sizeof(uint2)));
+        db->wide_pool_cap = chunks;
+        return 0;
+    }
     HIP_TRY(hipMalloc((void**)&db->wkey, slots * 4));
     HIP_TRY(hipMalloc(&db->wrec, slots * sizeof(WideRec)));
     if (!db->cs_hist) {
@@ -2725,6 +2733,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     db->NB = (uint32_t)((N + db->width - 1) / db->width);
     const uint64_t n_states = (uint64_t)db->NB * (db->NB + 1) / 2;          // streams = block pairs
     if (n_states + 1 >= (1ull << 22)) { db->fallback_reason = "too many block pairs"; return 0; }          // 22 stream bits + 8-bit weight digits in a key word
+    static_assert((1ull << 22) < (uint64_t)BNONE * (BNONE + 1ull) / 2ull, "fewer than 2^22 block pairs keep the block index (< 2897) below BNONE and inside pair_blk's 16 bits");
     db->n_states = (uint32_t)n_states;
     if (k1w_wave_bytes(std::max<uint32_t>(K1W_ARENA_MIN, (db->NB + 2u + 63u) & ~63u), (db->NB + 2u + 3u) & ~3u, db->chain_cap, db->NB) > (size_t)(152u << 10)) {
         db->fallback_reason = "the lists of the wide-node kernel do not fit the LDS (" + std::to_string(db->NB) + " blocks, root paths of up to " +
@@ -2823,7 +2832,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     if (db->row_mode) {
         db->k1w_waves = std::min<uint32_t>(db->k1w_waves, std::max<uint32_t>(256u, std::min<uint32_t>(4096u, (1u << 21) / std::max<uint32_t>(db->NB, 1u))));
         HIP_TRY(hipMalloc((void**)&db->rs_rows, (size_t)2 * (db->NB + 1) * 4));
-        HIP_TRY(hipMalloc((void**)&db->rs_bands, 18 * 4));
+        HIP_TRY(hipMalloc((void**)&db->k2j_start, ((size_t)db->n_states + 2) * 4));
     }
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide records: the wide estimate at two thirds (+ a grab / the open row chunks per wave)
@@ -2847,7 +2856,7 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_rows); FREE_NULL(db->cs_tmp);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     FREE_NULL(db->ct_hist); FREE_NULL(db->ct_offs); FREE_NULL(db->ct_cursor); FREE_NULL(db->ct_tmp); FREE_NULL(db->rs_rows); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs);
-    FREE_NULL(db->run_ctr); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->rs_bands);
+    FREE_NULL(db->run_ctr); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->k2j_start); FREE_NULL(db->k2j_jobs);
     FREE_NULL(db->l2_cursors); FREE_NULL(db->l2_bitmap); FREE_NULL(db->l2_rank); FREE_NULL(db->l2_len); FREE_NULL(db->l2_loff); FREE_NULL(db->l2_ent_g);
     FREE_NULL(db->l2_node_w); FREE_NULL(db->l2_list_w); FREE_NULL(db->l2_ent_blk); FREE_NULL(db->l2_ent_mask); FREE_NULL(db->l2_list_mask);
     db->l2_node_cap = 0; db->l2_ent_cap = 0;
@@ -3024,8 +3033,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.dflag = db->dflag; q.wide_base = db->wide_base;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         q.fn_mask = db->fn_mask; q.fn_blk = db->fn_blk; q.emit_lo = emit_lo; q.emit_hi = emit_hi; q.pool = pool_view(db, db->dense_wide);
-        q.pool.nostore = K1W_DEBUG == 1u ? 1u : 0u;
-        // ---- second level: many streams, few enough blocks that a tile job's bitmap scan stays small (tiles x nodes: quadratic in the
+            // ---- second level: many streams, few enough blocks that a tile job's bitmap scan stays small (tiles x nodes: quadratic in the
         // blocks), KMDB_L2=0 switches it off, KMDB_L2_MIN=c moves the threshold
         {
             const char* l2_env = getenv("KMDB_L2");
@@ -3092,7 +3100,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     if (stage("wide emit")) return 1;
     HIP_TRY(hipEventRecord(db->ev_k[2], st));
     const uint32_t kmask = (1u << db->key_bits) - 1u;
-    uint32_t jobs_launched = 0;
+    uint32_t jobs_launched = 0, k2jobs_launched = 0;
     if (row_mode) {
         // ---- many streams: chunk table grouped (stream chunks -> side stream), then the sort inside the block rows and its apply
         if (group_and_apply_chunks(st)) return 1;
@@ -3119,29 +3127,18 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         HIP_TRY(prim::exclusive_sum(db->rs_tmp, tb, db->rs_hist, db->rs_offs, (int)ne, st));
         const uint32_t* total_ptr = db->rs_offs + (ne - 1);
         HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
-        // Bands of block rows with about equal record counts (a row's share grows with its index): band b is sorted on this stream,
-        // then applied on a third one while band b + 1 is sorted — the sort waits for memory, the apply kernel for the VALU.
-        uint32_t n_bands = 1u;                                   // (measured at 10 000 samples: 2 / 4 / 8 bands 18.4 / 17.0 / 18.7 ms against 16.5 for one — the two kernels do not complement each other)
-        if (const char* e = getenv("KMDB_RS_BANDS")) n_bands = std::max(1, std::min(8, atoi(e)));
-        n_bands = std::min<uint32_t>(n_bands, NB);
-        RsBandRows bands{};
-        bands.n = n_bands;
-        for (uint32_t b = 0; b <= n_bands; ++b) bands.x[b] = b == n_bands ? NB : (uint32_t)std::min<double>(NB - 1.0, std::floor(NB * std::sqrt((double)b / n_bands)));
-        for (uint32_t b = 1; b <= n_bands; ++b) bands.x[b] = std::max(bands.x[b], bands.x[b - 1]);
-        uint32_t* band_job = db->rs_bands, *band_rec = db->rs_bands + 9;
-        hipLaunchKernelGGL(rs_bands_kernel, dim3(1), dim3(16), 0, st, row_job, row_tab, db->rs_offs, bands, band_job, band_rec);
+        // (Sorting and applying bands of block rows side by side on two streams was measured at 10 000 samples: 2 / 4 / 8 bands 18.4 / 17.0 /
+        // 18.7 ms against 16.5 for one — the two kernels do not complement each other.)
         HIP_TRY(hipFuncSetAttribute((const void*)rs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds(NB)));
-        const uint32_t nsorted = db->have_counts ? db->last_n_sorted : (uint32_t)db->sorted_cap;
-        const uint32_t g2 = (nsorted + K2S_WIN - 1) / K2S_WIN + 1;
-        hipStream_t s3 = n_bands > 1 ? db->stream3 : st;
-        for (uint32_t b = 0; b < n_bands; ++b) {
-            hipLaunchKernelGGL(rs_scatter_kernel, dim3((jobs + 7u) & ~7u), dim3(CS_THREADS), rs_scatter_lds(NB), st, R, band_job + b, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
-                               db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters);
-            if (s3 != st) { HIP_TRY(hipEventRecord(db->ev_band[b], st)); HIP_TRY(hipStreamWaitEvent(s3, db->ev_band[b], 0)); }
-            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, s3, db->swkey, (const WideRec*)db->swrec, (uint32_t)db->sorted_cap, band_rec + b + 1, band_rec + b,
-                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u);
-        }
-        if (s3 != st) { HIP_TRY(hipEventRecord(db->ev_band[8], s3)); HIP_TRY(hipStreamWaitEvent(st, db->ev_band[8], 0)); }
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((jobs + 7u) & ~7u), dim3(CS_THREADS), rs_scatter_lds(NB), st, R, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
+                           db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters);
+        // the sorted records applied stream by stream (a long stream in parts of K2J_REC records): one write-back of a tile per job
+        hipLaunchKernelGGL(k2j_starts_kernel, dim3((db->n_states + 1u + 255u) / 256u), dim3(256), 0, st, R, db->n_states, db->k2j_start);
+        hipLaunchKernelGGL(k2j_build_kernel, dim3((db->n_states + 1023u) / 1024u), dim3(1024), 0, st, db->k2j_start, db->n_states, db->k2j_jobs, (uint32_t)db->k2j_cap, db->counters);
+        k2jobs_launched = db->have_counts ? db->last_n_k2jobs : (uint32_t)db->k2j_cap;       // (the streams' lengths repeat exactly from call to call)
+        if (k2jobs_launched)
+            hipLaunchKernelGGL(k2_jobs_kernel, dim3(k2jobs_launched), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, db->k2j_start, db->k2j_jobs, db->counters + KCTR_K2JOBS,
+                               (uint32_t)db->k2j_cap, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width);
         HIP_TRY(hipGetLastError());
         if (stage("row sort+apply")) return 1;
     } else {
@@ -3241,14 +3238,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         return 0;
     }
     if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks ||
-                            (row_mode ? (c[KCTR_ROWJOBS] > jobs_launched || c[KCTR_WIDE_RECORDS] != db->last_n_sorted) : c[KCTR_RAW] > raw_launch))) {
+                            (row_mode ? (c[KCTR_ROWJOBS] > jobs_launched || c[KCTR_WIDE_RECORDS] != db->last_n_sorted || c[KCTR_K2JOBS] > k2jobs_launched) : c[KCTR_RAW] > raw_launch))) {
         // the exact counts cannot differ for an unchanged database and emit range, and the varying ones stay inside their slack in
         // practice; if not: redo the call with upper bounds
         db->have_counts = false; *retry = true;
         return 0;
     }
     db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW]; db->last_n_slow = c[KCTR_SLOW];
-    db->last_n_rowjobs = c[KCTR_ROWJOBS]; db->last_n_sorted = c[KCTR_WIDE_RECORDS]; db->last_l2_nodes = c[KCTR_L2_NODES];
+    db->last_n_rowjobs = c[KCTR_ROWJOBS]; db->last_n_sorted = c[KCTR_WIDE_RECORDS]; db->last_l2_nodes = c[KCTR_L2_NODES]; db->last_n_k2jobs = c[KCTR_K2JOBS];
     if (db->l2_on && !db->have_counts && getenv("KMDB_VERBOSE"))
         fprintf(stderr, "[kmdb] second level: %u nodes with %u blocks or more joined per tile (indices for %u, entries for %u)\n", c[KCTR_L2_NODES], db->l2_min_blocks,
                 db->l2_node_cap, db->l2_ent_cap);
@@ -3261,7 +3258,6 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
 // an attempt that fails half way may have work under way on the side streams: nothing of it may outlive the call (the caller frees M)
 static void blocks_join_side_streams(kmdb_db* db) {
     if (db->stream2) (void)hipStreamSynchronize(db->stream2);
-    if (db->stream3) (void)hipStreamSynchronize(db->stream3);
 }
 
 int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, hipStream_t st) {
@@ -3281,7 +3277,7 @@ int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi
             if (lo == hi) continue;
             kmdb_db::SliceCounts& sc = db->slice_counts[k];
             db->have_counts = sc.valid && sc.lo == lo && sc.hi == hi;
-            if (db->have_counts) { db->last_n_wide = sc.n_wide; db->last_n_chunks = sc.n_chunks; db->last_n_raw = sc.n_raw; db->last_n_rowjobs = sc.n_rowjobs; db->last_n_sorted = sc.n_sorted; }
+            if (db->have_counts) { db->last_n_wide = sc.n_wide; db->last_n_chunks = sc.n_chunks; db->last_n_raw = sc.n_raw; db->last_n_rowjobs = sc.n_rowjobs; db->last_n_sorted = sc.n_sorted; db->last_n_k2jobs = sc.n_k2jobs; }
             db->last_emit_lo = lo; db->last_emit_hi = hi;
             if (!db->have_counts) db->last_call_sized = true;
             bool retry = false;
@@ -3290,7 +3286,7 @@ int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi
             if (!db->fallback_reason.empty()) return 0;
             if (retry) { again = true; for (auto& c : db->slice_counts) c.valid = false; }
             else {
-                sc = kmdb_db::SliceCounts{true, lo, hi, db->last_n_wide, db->last_n_chunks, db->last_n_raw, db->last_n_rowjobs, db->last_n_sorted};
+                sc = kmdb_db::SliceCounts{true, lo, hi, db->last_n_wide, db->last_n_chunks, db->last_n_raw, db->last_n_rowjobs, db->last_n_sorted, db->last_n_k2jobs};
                 records += db->last_records;
             }
         }

@@ -267,7 +267,8 @@ __device__ __forceinline__ void decode_node(const uint64_t* __restrict__ bits, u
 // Sample ids are grouped into blocks of `width` (<= 64) consecutive ids; the width is chosen per database
 // at upload (a narrower block that matches the cluster structure of the samples means fewer block records).
 struct BlockMap {
-    uint32_t width, magic;                          // magic = floor(2^32 / width) + 1: exact division for ids < 2^16
+    uint32_t width, magic;                          // magic = floor(2^32 / width) + 1: __umulhi(id, magic) == id / width for every id < 2^32 / width,
+                                                    // i.e. below 2^26 at width <= 64 — far above KMDB_MAX_SAMPLES = 2^20 (static_assert below)
     __host__ __device__ __forceinline__ uint32_t blk(uint32_t id) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         return __umulhi(id, magic);
@@ -277,6 +278,8 @@ struct BlockMap {
     }
     __host__ __device__ __forceinline__ uint32_t bit(uint32_t id, uint32_t b) const { return id - b * width; }
 };
+
+static_assert((uint64_t)KMDB_MAX_SAMPLES * 64u <= (1ull << 32), "BlockMap::blk: the magic division is exact only for ids below 2^32 / width");
 
 // decode_node plus, per id, the running bit mask of the ids of the same block seen so far
 // in this node ("cum"): the block-record kernel needs it per stack position.

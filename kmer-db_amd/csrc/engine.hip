@@ -11,6 +11,7 @@
 
 #include "prim.h"
 
+#include <sys/mman.h>
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -185,8 +186,6 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     for (auto& e : db->ev_k) if (hipEventCreate(&e) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
     if (hipStreamCreate(&db->stream2) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
     for (auto& e : db->ev_side) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
-    if (hipStreamCreate(&db->stream3) != hipSuccess) { kmdb_set_error("hipStreamCreate failed"); return fail(); }
-    for (auto& e : db->ev_band) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { kmdb_set_error("hipEventCreate failed"); return fail(); }
     // KMDB_VERBOSE: the four parts of the upload as wholes (the layout and the preparation print their own phases; what those
     // leave out — the release of their temporaries, the first use of the device by the process — shows up here)
     const bool verbose = getenv("KMDB_VERBOSE") != nullptr;
@@ -239,6 +238,8 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     db->one_shot = false;
     kmdb_release_staging(db);
     if (db->staging_thread.joinable()) db->staging_thread.join();
+    for (const auto& r : db->staging_kept) (void)munmap(r.first, r.second);      // a one-shot handle's regions: pages long dropped, the mappings go now
+    db->staging_kept.clear();
     kmdb_blocks_release(db);
     void* ptrs[] = {db->k0in, db->bitrel, db->blkbase, db->bits, db->nl, db->parent, db->w, db->dflag, db->sub_end, db->long_nodes, db->nseg_anc,
                     db->nseg_anc_n, db->meta, db->bitpos, db->ck_ofs, db->ck_bit, db->ck_id, db->wprefix, db->segs, db->v1_scan_tmp, db->stack_scratch, db->v1_counters,
@@ -247,8 +248,6 @@ extern "C" void kmdb_db_free(kmdb_db* db) {
     for (auto& e : db->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_k) if (e) (void)hipEventDestroy(e);
     for (auto& e : db->ev_side) if (e) (void)hipEventDestroy(e);
-    for (auto& e : db->ev_band) if (e) (void)hipEventDestroy(e);
-    if (db->stream3) (void)hipStreamDestroy(db->stream3);
     if (db->stream2) (void)hipStreamDestroy(db->stream2);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;

@@ -39,6 +39,7 @@ enum : uint32_t {
     KCTR_ROWJOBS = 11,      // row mode: workgroups of the sort inside the block rows
     KCTR_L2_OVERFLOW = 12,  // != 0: the second level's node indices or entries ran out (results invalid; repeated with larger arrays)
     KCTR_L2_NODES = 13,     // nodes that went to the second level
+    KCTR_K2JOBS = 14,       // row mode: jobs of the apply kernel over the sorted records (one stream, or one part of a long stream, each)
     KCTR_COUNT = 16
 };
 constexpr uint32_t KMDB_PAIR_REGIONS = 4096;
@@ -136,7 +137,7 @@ struct kmdb_db {
     void* rs_tmp = nullptr;
     size_t rs_tmp_bytes = 0;
     uint64_t sorted_cap = 0;                           // records the sorted arrays (swkey / swrec) hold
-    uint32_t last_n_rowjobs = 0, last_n_sorted = 0, k1w_waves = 0, k1w_slots = 0;   // (k1w_waves: most the pools are sized for; k1w_slots: waves the chip holds at once)
+    uint32_t last_n_rowjobs = 0, last_n_sorted = 0, last_n_k2jobs = 0, k1w_waves = 0, k1w_slots = 0;   // (k1w_waves: most the pools are sized for; k1w_slots: waves the chip holds at once)
     uint32_t* cs_rows = nullptr;                       // two-pass sort: row starts / first workgroup / first table entry, [3][NB + 1]
     uint32_t *cs_hist = nullptr, *cs_offs = nullptr;   // counting sort of the wide pool: [stream][block] counts / offsets (+ total)
     void* cs_tmp = nullptr;
@@ -163,7 +164,7 @@ struct kmdb_db {
     uint64_t last_records = 0;
     uint32_t last_emit_lo = 0, last_emit_hi = 0;
     uint32_t n_slices = 1;          // passes over the pattern stream per call (a database whose records do not fit one)
-    struct SliceCounts { bool valid = false; uint32_t lo = 0, hi = 0, n_wide = 0, n_chunks = 0, n_raw = 0, n_rowjobs = 0, n_sorted = 0; };
+    struct SliceCounts { bool valid = false; uint32_t lo = 0, hi = 0, n_wide = 0, n_chunks = 0, n_raw = 0, n_rowjobs = 0, n_sorted = 0, n_k2jobs = 0; };
     std::vector<SliceCounts> slice_counts;   // what the previous call found, per slice of the pattern stream
     void* scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
@@ -171,6 +172,7 @@ struct kmdb_db {
     // host staging buffers of the upload, given back by a helper thread after the first call (or when the handle is freed):
     // unmapping them costs 0.3 s (the HIP runtime had them registered for the copies) and blocks every hipMalloc meanwhile
     std::vector<std::pair<void*, size_t>> staging;
+    std::vector<std::pair<void*, size_t>> staging_kept;   // one-shot handle: regions whose pages were dropped but that stay mapped until kmdb_db_free
     std::thread staging_thread;    // gives the staging buffers back (kmdb_release_staging); joined by kmdb_db_settle / kmdb_db_free
     bool one_shot = false;         // KMDB_FLAG_ONE_SHOT at upload: the staging buffers stay until the handle is freed
     bool v1_ready = false;          // the arrays below exist (all of them)
@@ -197,9 +199,9 @@ struct kmdb_db {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the stream chunks are sorted and applied next to the wide kernel
     hipEvent_t ev_side[2] = {nullptr, nullptr};
-    hipStream_t stream3 = nullptr;  // many streams: the sorted bands of block rows applied next to the sort of the following band
-    hipEvent_t ev_band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // band b sorted (0..7), stream3 done (8)
-    uint32_t* rs_bands = nullptr;   // [2][9] first job / first sorted record of every band (+ end)
+    uint32_t* k2j_start = nullptr;  // [n_states + 1] many streams: where every stream starts in the sorted arrays
+    uint2* k2j_jobs = nullptr;      // [k2j_cap] jobs of the apply kernel: {stream, part of K2J_REC records}
+    uint64_t k2j_cap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // after decode / narrow / wide / apply
     kmdb_stats stats{};

@@ -18,7 +18,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -96,7 +99,11 @@ void parallel_items(size_t n, unsigned threads, F&& fn) {
     std::atomic<size_t> next{0};
     auto work = [&]() { for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i); };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+    pool.reserve(threads);
+    for (unsigned t = 1; t < threads; ++t) {
+        try { pool.emplace_back(work); }
+        catch (const std::system_error&) { break; }          // no more threads to be had: the ones there are (this one at least) do the items
+    }
     work();
     for (auto& th : pool) th.join();
 }
@@ -113,8 +120,31 @@ constexpr size_t PAT_HEADER = 40;     // num_kmers, parent_id (8 + 8), num_sampl
 
 }  // namespace
 
+// what a load holds until it has succeeded: freed by whichever way the function is left, an exception included (a damaged count that
+// passes the plausibility checks can still make a container throw std::bad_alloc — nothing may cross the extern "C" boundary)
+namespace {
+struct LoadHold {
+    void* map = nullptr;
+    size_t len = 0;
+    kmdbh_db* db = nullptr;
+    ~LoadHold() { if (map) munmap(map, len); delete db; }
+};
+}  // namespace
+static int db_load_impl(const char* path, int mode, kmdbh_db** out);
 extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
+    if (!path || !out) return kmdb_set_error("kmdbh_db_load: null argument");
     *out = nullptr;
+    try {
+        return db_load_impl(path, mode, out);
+    } catch (const std::bad_alloc&) {
+        *out = nullptr;
+        return kmdb_set_error(std::string("Cannot open k-mer database ") + path + " (out of memory)");
+    } catch (const std::exception& e) {
+        *out = nullptr;
+        return kmdb_set_error(std::string("Cannot open k-mer database ") + path + " (" + e.what() + ")");
+    }
+}
+static int db_load_impl(const char* path, int mode, kmdbh_db** out) {
     int fd = ::open(path, O_RDONLY);
     if (fd < 0) return kmdb_set_error(std::string("Cannot open k-mer database ") + path);
     struct stat st{};
@@ -123,11 +153,12 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
     ::close(fd);
     if (map == MAP_FAILED) return kmdb_set_error(std::string("Cannot map k-mer database ") + path);
 
+    LoadHold hold;
+    hold.map = map; hold.len = (size_t)st.st_size;
     auto* db = new kmdbh_db();
+    hold.db = db;
     Cursor c{(const uint8_t*)map, (const uint8_t*)map + st.st_size};
     auto fail = [&](const char* what) {
-        munmap(map, (size_t)st.st_size);
-        delete db;
         return kmdb_set_error(std::string("Cannot open k-mer database ") + path + " (" + what + ")");
     };
     const unsigned T = loader_threads();
@@ -159,7 +190,7 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
         db->names[i].assign((const char*)s, len);
     }
     uint64_t nb = c.get<uint64_t>();
-    if (!c.ok || nb > (uint64_t)st.st_size) return fail("bad bucket count");
+    if (!c.ok || nb > (uint64_t)st.st_size / 64) return fail("bad bucket count");          // every serialised table takes 64 header bytes at least
     if (!(db->format_word & 1ull)) return fail("compressed hashtable serialisation is not supported");
     const bool want_ht = (mode == 0);
     // ---- hashtables, pass 1 (one thread: header to header): where every table's fill vector and items are, and the slot offsets
@@ -306,6 +337,7 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
     phase("pattern blocks parsed");
     db->pattern_section_bytes = PAT_HEADER * P + 8 * n_words;
     munmap(map, (size_t)st.st_size);
+    hold.map = nullptr;
     phase("file unmapped");
     db->data[n_words] = 0;                            // one padding pair for 2-word decode windows
     db->data[n_words + 1] = 0;
@@ -327,6 +359,7 @@ extern "C" int kmdbh_db_load(const char* path, int mode, kmdbh_db** out) {
     v.n_buckets = want_ht ? nb : 0;
     v.bucket_offset = want_ht ? db->bucket_offset.data() : nullptr;
     v.slots = want_ht ? db->slots.data() : nullptr;
+    hold.db = nullptr;
     *out = db;
     return 0;
 }

@@ -235,6 +235,7 @@ void kmdb_release_staging(kmdb_db* db) {
     regions.swap(db->staging);
     const bool unmap = !db->one_shot;
     if (db->staging_thread.joinable()) db->staging_thread.join();
+    if (!unmap) db->staging_kept.insert(db->staging_kept.end(), regions.begin(), regions.end());      // unmapped by kmdb_db_free (they used to leak)
     db->staging_thread = std::thread([regions, unmap]() {
         // the pages first, on several threads under the shared address-space lock (kmdb_drop_pages); what munmap then holds the lock
         // exclusively for is the bookkeeping of empty ranges.  A one-shot handle (the front-end's) leaves even that to the end of the process.

@@ -440,6 +440,7 @@ struct DevBuf {
             return kmdb_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+struct N2aU32toU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
 // the handle's run index (false: this handle does without one — no memory for it — and the walk decodes the gamma streams as before)
 static bool n2a_run_index(const kmdb_engine_view& e, hipStream_t st) {
     if (*e.rl_ofs && *e.rl_runs && *e.rl_node) return true;
@@ -454,9 +455,24 @@ static bool n2a_run_index(const kmdb_engine_view& e, hipStream_t st) {
     size_t tb = 0;
     if (prim::exclusive_sum(nullptr, tb, cnt, ofs, (int)(P + 1), st) != hipSuccess || hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess) return fail();
     if (prim::exclusive_sum(tmp, tb, cnt, ofs, (int)(P + 1), st) != hipSuccess) return fail();
+    // the offsets are 32 bits wide, and the number of runs is bounded by the sum of the local lists' lengths over up to 2^31 patterns, not
+    // by the sample count: the counts are summed in 64 bits first, and a database with 2^32 runs or more does without the index
+    // (a wrapped total would have under-allocated `runs`)
+    {
+        unsigned long long* d_sum = nullptr;
+        void* tmp2 = nullptr;
+        size_t tb2 = 0;
+        rocprim::transform_iterator<uint32_t*, N2aU32toU64, unsigned long long> it(cnt, N2aU32toU64());
+        unsigned long long h_sum = 0;
+        bool ok = hipMalloc((void**)&d_sum, 8) == hipSuccess && prim::sum(nullptr, tb2, it, d_sum, (int)(P + 1), st) == hipSuccess &&
+                  hipMalloc(&tmp2, std::max<size_t>(tb2, 16)) == hipSuccess && prim::sum(tmp2, tb2, it, d_sum, (int)(P + 1), st) == hipSuccess &&
+                  hipMemcpyAsync(&h_sum, d_sum, 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        if (d_sum) (void)hipFree(d_sum);
+        if (tmp2) (void)hipFree(tmp2);
+        if (!ok || h_sum >= (1ull << 32)) return fail();
+    }
     uint32_t total = 0;
     if (hipMemcpyAsync(&total, ofs + P, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
-    // (the running sum is 32 bits wide: a database with 2^32 runs or more would need far more than the sample limit allows)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)total * 4 + (size_t)P * sizeof(uint4) + (1ull << 30) > free_b / 2) return fail();
     if (hipMalloc((void**)&runs, std::max<size_t>((size_t)total, 1) * 4) != hipSuccess) return fail();

@@ -57,18 +57,15 @@ bool take_option(std::vector<std::string>& a, const std::string& name, std::stri
 // ---- -min / -max filters (params.cpp:14-42, 418-455; sparse_filters.h) ---------------------------
 using metric_fn = std::function<double(uint32_t, uint32_t, uint32_t, int)>;
 
+// the nine measures by name: ONE implementation, the library's kmdbh_metric (csrc/host_metrics.cpp: the reference's arithmetic,
+// params.cpp:14-42) — the front-end's filters and its `distance` mode must agree with it bit for bit
 std::map<std::string, metric_fn> metrics() {
     std::map<std::string, metric_fn> m;
-    auto mash_of = [](double j, int k) { return j == 0 ? 1.0 : (-1.0 / k) * std::log((2 * j) / (j + 1)); };
-    m["jaccard"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / (uint32_t)(a + b - c); };
-    m["min"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / std::min(a, b); };
-    m["max"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / std::max(a, b); };
-    m["cosine"] = [](uint32_t c, uint32_t a, uint32_t b, int) { return (double)c / std::sqrt((uint32_t)(a * b)); };
-    m["mash"] = [mash_of](uint32_t c, uint32_t q, uint32_t d, int k) { return mash_of((double)c / (uint32_t)(q + d - c), k); };
-    m["ani"] = [mash_of](uint32_t c, uint32_t q, uint32_t d, int k) { return 1.0 - mash_of((double)c / (uint32_t)(q + d - c), k); };
-    m["ani-shorter"] = [mash_of](uint32_t c, uint32_t q, uint32_t d, int k) { return 1.0 - mash_of((double)c / std::min(q, d), k); };
-    m["mash-query"] = [mash_of](uint32_t c, uint32_t q, uint32_t, int k) { return mash_of((double)c / q, k); };
-    m["num-kmers"] = [](uint32_t c, uint32_t, uint32_t, int) { return (double)c; };
+    for (const char* name : {"jaccard", "min", "max", "cosine", "mash", "ani", "ani-shorter", "mash-query", "num-kmers"}) {
+        const int id = kmdbh_metric_id(name);
+        if (id < 0) throw std::runtime_error(std::string("internal: the library does not know the measure ") + name);
+        m[name] = [id](uint32_t c, uint32_t a, uint32_t b, int k) { return kmdbh_metric(id, c, a, b, k); };
+    }
     return m;
 }
 
