@@ -588,6 +588,174 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     if (npairs > 1) q.pair_ofs[i] = out;
 }
 
+// The short nodes (l <= 32 ids, stream <= 128 bits: 94 % of all) WITHOUT the in-block re-deal, NPT nodes per thread.  The re-dealing launch above
+// spends its time waiting, not computing (round 4 counters: VALU busy 12 % of the wave time, 71 % waiting): a wave runs four
+// dependent round trips — header, re-dealt header + stream position, stream words, pair reservation — with three barriers in between.
+// Here a thread takes node t of NPT consecutive 256-node windows: all headers in one round trip, all stream words in the next, one pair
+// reservation per wave for all of them; lanes of a wave run decode loops of different lengths (the re-deal evened them out), which costs
+// issue slots the kernel has to spare.
+struct K0Short {
+    uint32_t npairs, blk0, need, bit0, span;
+    unsigned long long mask0, m1, m2;
+    bool second_pass;
+};
+template <int NPT>
+__global__ __launch_bounds__(256) void k0_short_direct_kernel(const K0Params q) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const BlockMap bm = q.bm;
+    const unsigned long long wm = bm.width == 64 ? ~0ull : (1ull << bm.width) - 1ull;
+    using Cursor = RunCursor32<6, false>;
+    uint32_t idx[NPT], l[NPT], last[NPT];
+    uint64_t pos[NPT];
+    bool live[NPT];
+    uint2 km[NPT];
+    uint32_t rel[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        idx[j] = (blockIdx.x * NPT + j) * 256u + threadIdx.x;
+        live[j] = idx[j] < q.P;
+        km[j] = live[j] ? q.k0in[idx[j]] : make_uint2(0u, 0u);
+        rel[j] = live[j] ? q.bitrel[idx[j]] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        l[j] = kmdb_k0_l(km[j]); last[j] = kmdb_k0_last(km[j]);
+        if (kmdb_long_node(l[j], kmdb_k0_bits(km[j]))) live[j] = false;          // the long launch's
+        pos[j] = live[j] && l[j] > 1u ? q.blkbase[idx[j] >> 8] + rel[j] : 0ull;
+    }
+    // the stream words of all NPT nodes under way before the first decode loop
+    uint32_t cw[NPT][6];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const uint32_t* b32 = (const uint32_t*)q.bits;
+        const uint64_t u0 = pos[j] >> 5;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cw[j][k] = (live[j] && l[j] > 1u) ? b32[(u0 + k) ^ 1ull] : 0u;
+    }
+    K0Short r[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        K0Short s{0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, false};
+        if (live[j] && l[j] == 1u) {
+            s.blk0 = bm.blk(last[j]); s.mask0 = 1ull << bm.bit(last[j], s.blk0); s.npairs = 1;
+        } else if (live[j] && l[j]) {
+            // the list relative to its (still unknown) first id, as in k0_decode_kernel (pattern_t::decodeSamples, reference src/pattern.cpp:99-109)
+            unsigned long long R = 1ull;
+            uint32_t span = 0;
+            {
+                Cursor c(Cursor::Preloaded{}, pos[j]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c.c[k] = cw[j][k];
+                uint32_t rem = l[j] - 1u;
+                while (rem) {
+                    uint32_t z, v;
+                    c.step(rem, z, v);
+                    if (z) {
+                        if (span + z < 64u) R |= ((2ull << (z - 1)) - 1ull) << (span + 1);
+                        span += z; rem -= z;
+                    }
+                    if (v) {
+                        span += v; --rem;
+                        if (span < 64u) R |= 1ull << span;
+                    }
+                }
+            }
+            const uint32_t id0 = last[j] - span;
+            s.span = span;
+            s.blk0 = bm.blk(id0);
+            s.bit0 = bm.bit(id0, s.blk0);
+            if (span < 64u) {
+                const uint32_t bit0 = s.bit0;
+                const unsigned long long lo = R << bit0, hi = bit0 ? R >> (64u - bit0) : 0ull;
+                auto ext = [&](uint32_t sh) -> unsigned long long {
+                    return sh == 0 ? lo : sh < 64u ? ((lo >> sh) | (hi << (64u - sh))) : sh == 64u ? hi : sh < 128u ? (hi >> (sh - 64u)) : 0ull;
+                };
+                s.mask0 = lo & wm;
+                s.m1 = ext(bm.width) & wm; s.m2 = ext(2 * bm.width) & wm;
+                s.npairs = 1u + (s.m1 != 0) + (s.m2 != 0);
+                s.need = s.npairs - 1u;
+            } else {
+                s.second_pass = true;
+                s.need = bm.blk(last[j]) - s.blk0;
+                s.need = s.need < l[j] - 1u ? s.need : l[j] - 1u;
+            }
+        }
+        r[j] = s;
+    }
+    // one reservation per wave for the extra pairs of all its nodes
+    uint32_t need_all = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) need_all += r[j].need;
+    uint32_t out = 0;
+    bool lost = false;
+    {
+        const uint32_t incl = wave_incl_scan(need_all, lane);
+        const uint32_t total = bcast(incl, WAVE - 1);
+        if (total) {
+            const uint32_t region = (blockIdx.x * 4u + (threadIdx.x >> 6)) % q.n_regions;
+            uint32_t base = 0;
+            if (lane == WAVE - 1) base = atomicAdd(&q.pair_cursor[region * 16u], total);
+            base = bcast(base, WAVE - 1);
+            if (base + total <= q.region_cap) out = region * q.region_cap + base + (incl - need_all);
+            else {
+                uint32_t sb = 0;
+                if (lane == WAVE - 1) sb = atomicAdd(&q.pair_cursor[q.n_regions * 16u], total);
+                sb = bcast(sb, WAVE - 1);
+                if (sb + total <= q.spill_cap) out = q.n_regions * q.region_cap + sb + (incl - need_all);
+                else { if (lane == 0) atomicOr(&q.counters[KCTR_PAIR_OVERFLOW], 1u); lost = true; }     // results invalid; the call is repeated with a larger pool
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        if (!live[j]) continue;
+        K0Short s = r[j];
+        const uint32_t i = idx[j];
+        if (lost) { s.second_pass = false; s.npairs = s.npairs ? 1u : 0u; s.m1 = s.m2 = 0; }
+        if (!s.second_pass) {
+            if (s.m1) { q.pair_blk[out] = (uint16_t)(s.blk0 + 1); q.pair_mask[out] = s.m1; }
+            if (s.m2) { const uint32_t o2 = out + (s.m1 != 0); q.pair_blk[o2] = (uint16_t)(s.blk0 + 2); q.pair_mask[o2] = s.m2; }
+        } else {
+            // a list that spans 64 ids or more: second walk with absolute ids (the stream words again from the cache)
+            Cursor c(q.bits, pos[j]);
+            uint32_t o = out;
+            uint32_t curblk = s.blk0, bit = s.bit0, rem = l[j] - 1u;
+            unsigned long long acc = 1ull << s.bit0;
+            auto flush = [&]() {
+                if (s.npairs == 0) s.mask0 = acc;
+                else { q.pair_blk[o] = (uint16_t)curblk; q.pair_mask[o] = acc; ++o; }
+                ++s.npairs;
+            };
+            while (rem) {
+                uint32_t z, v;
+                c.step(rem, z, v);
+                if (z) {
+                    rem -= z;
+                    while (z) {
+                        const uint32_t room = bm.width - 1u - bit;
+                        const uint32_t tk = z < room ? z : room;
+                        if (tk) { acc |= ((2ull << (tk - 1)) - 1ull) << (bit + 1); bit += tk; z -= tk; }
+                        if (z) { flush(); ++curblk; acc = 1ull; bit = 0; --z; }
+                    }
+                }
+                if (v) {
+                    const uint32_t id = curblk * bm.width + bit + v;
+                    --rem;
+                    const uint32_t blk = bm.blk(id);
+                    if (blk != curblk) { flush(); curblk = blk; acc = 0; }
+                    bit = bm.bit(id, blk);
+                    acc |= 1ull << bit;
+                }
+            }
+            flush();
+        }
+        q.p0_mask[i] = s.mask0;
+        q.p0_info[i] = s.blk0 | (s.npairs << 16);
+        if (s.npairs > 1) q.pair_ofs[i] = out;
+        out += r[j].need;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1n: the DFS stream, nodes with at most two blocks
 // ------------------------------------------------------------------------------------------
@@ -643,6 +811,10 @@ __host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tb
     return (((size_t)chain_cap * 20 + 15) & ~(size_t)15) + arena_table_bytes(tbits, n_states) + rowtab_bytes(n_rows);          // n_rows: 0 unless row mode
 }
 
+// PIPE (experiment, round 5): 0 = the node records of the next batch are fetched while this one is processed, the second pair of a node
+// behind its p0_info and pair_ofs (three dependent round trips inside the fetch); 1 = two batches ahead for the records (pair_ofs read
+// unconditionally with them), one batch ahead for the second pairs — no load of the loop waits on another load of the same iteration.
+template <int PIPE>
 __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
@@ -694,10 +866,13 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         lds_sync();
     }
 
-    // node records of the NEXT batch are fetched while the current one is processed
-    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_df = 0, nx_e1b = BNONE;
+    // node records of the NEXT batch(es) are fetched while the current one is processed
+    uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_df = 0, nx_e1b = BNONE, nx_po = 0;
     int32_t nx_par = -1;
     unsigned long long nx_m0 = 0, nx_e1m = 0;
+    uint32_t n2_nl = 0, n2_w = 0, n2_info = 0, n2_df = 0x7FFFu, n2_po = 0;          // PIPE: two batches ahead
+    int32_t n2_par = -1;
+    unsigned long long n2_m0 = 0;
     auto fetch = [&](uint32_t b0) {
         const uint32_t ii = b0 + lane;
         const bool v = ii < end;
@@ -710,7 +885,26 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         nx_e1b = BNONE; nx_e1m = 0;
         if ((nx_info >> 16) > 1u) { const uint32_t po = q.pair_ofs[ii]; nx_e1b = q.pair_blk[po]; nx_e1m = q.pair_mask[po]; }
     };
-    fetch(first);
+    auto fetch2 = [&](uint32_t b0) {                                  // (pair_ofs of a node without further pairs is never written: whatever is read is not used)
+        const uint32_t ii = b0 + lane;
+        const bool v = ii < end;
+        n2_nl = v ? q.nl[ii] : 0u;
+        n2_w = v ? q.w[ii] : 0u;
+        n2_par = v ? q.parent[ii] : -1;
+        n2_df = v ? q.dflag[ii] : 0x7FFFu;
+        n2_info = v ? q.p0_info[ii] : 0u;
+        n2_m0 = v ? q.p0_mask[ii] : 0ull;
+        n2_po = v ? q.pair_ofs[ii] : 0u;
+    };
+    auto advance = [&]() {                                            // the batch two ahead becomes the next one; its second pairs are requested
+        nx_nl = n2_nl; nx_w = n2_w; nx_par = n2_par; nx_df = n2_df; nx_info = n2_info; nx_m0 = n2_m0; nx_po = n2_po;
+        nx_e1b = BNONE; nx_e1m = 0;
+        if ((nx_info >> 16) > 1u) { nx_e1b = q.pair_blk[nx_po]; nx_e1m = q.pair_mask[nx_po]; }
+    };
+    if (PIPE) {
+        fetch2(first); advance();
+        if (first + WAVE < end) fetch2(first + WAVE); else { n2_nl = 0; n2_w = 0; n2_par = -1; n2_df = 0x7FFFu; n2_info = 0; n2_m0 = 0; n2_po = 0; }
+    } else fetch(first);
     WaveArena A;
     arena_init(A, table, q.tbits, q.n_keys, seg, lane);
     for (uint32_t base = first; base < end; base += WAVE) {
@@ -719,7 +913,12 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         const uint32_t nl = nx_nl, w = nx_w, info = nx_info, df = nx_df, e1b = nx_e1b;
         const int32_t par = nx_par;
         const unsigned long long m0 = nx_m0, e1m = nx_e1m;
-        if (base + WAVE < end) fetch(base + WAVE);
+        if (PIPE) {
+            if (base + WAVE < end) {
+                advance();
+                if (base + 2 * WAVE < end) fetch2(base + 2 * WAVE); else { n2_nl = 0; n2_w = 0; n2_par = -1; n2_df = 0x7FFFu; n2_info = 0; n2_m0 = 0; n2_po = 0; }
+            }
+        } else if (base + WAVE < end) fetch(base + WAVE);
         const uint32_t dep = df & 0x7FFFu;
         NSum S = locals(info, m0, e1b, e1m);
         if (valid && par >= 0 && par < (int32_t)base) {
@@ -2945,7 +3144,12 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         // three quarters of the pool in sub-pools, the rest shared
         q.pair_cursor = db->pair_cursor; q.n_regions = nreg; q.region_cap = (uint32_t)(db->pair_cap * 3 / 4 / nreg);
         q.spill_cap = (uint32_t)(db->pair_cap - (uint64_t)q.region_cap * nreg); q.counters = db->counters;
-        hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
+        // KMDB_K0V (experiment, round 5): 0 the re-dealing launch, 1 / 2 / 4 the direct launch with that many nodes per thread
+        static const int k0v = getenv("KMDB_K0V") ? atoi(getenv("KMDB_K0V")) : 0;
+        if (k0v == 1) hipLaunchKernelGGL((k0_short_direct_kernel<1>), dim3((P + 255) / 256), dim3(256), 0, st, q);
+        else if (k0v == 2) hipLaunchKernelGGL((k0_short_direct_kernel<2>), dim3((P + 511) / 512), dim3(256), 0, st, q);
+        else if (k0v == 4) hipLaunchKernelGGL((k0_short_direct_kernel<4>), dim3((P + 1023) / 1024), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
         if (db->n_long) {
             q.perm = db->long_nodes; q.P = db->n_long;
             hipLaunchKernelGGL((k0_decode_kernel<true>), dim3((db->n_long + 255) / 256), dim3(256), 0, st, q);
@@ -2968,8 +3172,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         const size_t wave_lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys, row_mode ? db->NB : 0u);
         const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(K1N_WAVES, (144u << 10) / wave_lds));
         const size_t lds = wave_lds * waves;
-        HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
+        static const int k1nv = getenv("KMDB_K1NV") ? atoi(getenv("KMDB_K1NV")) : 0;       // (experiment, round 5)
+        if (k1nv) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k1n_kernel<1>, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k1n_kernel<0>, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (stage("narrow emit")) return 1;

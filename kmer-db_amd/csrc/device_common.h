@@ -206,6 +206,14 @@ struct RunCursor32 {
         c[NU] = 0;
         left = NU;
     }
+    // the units are already in registers (the caller fetched them with the units of other streams: c[0 .. NU) filled by it)
+    struct Preloaded {};
+    __device__ __forceinline__ RunCursor32(Preloaded, uint64_t pos) : b32(nullptr) {
+        u0 = pos >> 5;
+        s = (uint32_t)pos & 31u;
+        c[NU] = 0;
+        left = NU;
+    }
     __device__ __forceinline__ void shift_unit() {
 #pragma unroll
         for (int k = 0; k < NU; ++k) c[k] = c[k + 1];

@@ -20,11 +20,11 @@ def main():
     if not starts:
         starts = [i for i, t in enumerate(ev) if "k0_decode_kernel" in t[2]]
     i0 = starts[-1] if len(starts) < 2 else starts[-1]
-    while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 200_000 and not any(x in ev[i0 - 1][2] for x in ("k2_sorted", "k2_apply", "row_compact")):
+    while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 200_000 and not any(x in ev[i0 - 1][2] for x in ("k2_sorted", "k2_jobs", "k2_apply", "row_compact")):
         i0 -= 1
     call = ev[i0:]
     # the call ends with the copy of its counters after the last apply kernel: what follows (the caller's own kernels) is not part of it
-    last = max((i for i, t in enumerate(call) if any(x in t[2] for x in ("k2_sorted", "k2_apply", "row_compact"))), default=len(call) - 1)
+    last = max((i for i, t in enumerate(call) if any(x in t[2] for x in ("k2_sorted", "k2_jobs", "k2_apply", "row_compact"))), default=len(call) - 1)
     end = last
     while end + 1 < len(call) and "rocclr_copyBuffer" in call[end + 1][2] and call[end + 1][0] - call[end][1] < 100_000:
         end += 1

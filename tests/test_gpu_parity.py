@@ -1142,7 +1142,8 @@ def test_bench_one_gpu_share_of_configs2(dev):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
     assert d["config"]["samples"] == 10000 and d["config"]["genome_length_bp"] == 625000 and d["config"]["path"] == "block-record pipeline"
-    assert d["roofline"]["block_records_per_launch"] > 10 ** 9
+    # (round 4: 1.08 G block records; since round 5 the nodes with 24 blocks or more are joined per tile instead — 0.62 G records written)
+    assert d["roofline"]["block_records_per_launch"] > 5 * 10 ** 8 and d["roofline"]["nodes_joined_per_tile"] > 10 ** 5
     assert "slices of the pattern stream" not in r.stderr, "one GPU's share of configs[2] should be one pass"
 
 
