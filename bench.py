@@ -283,10 +283,38 @@ def frontend_run(K, db_path, td, ref_matrix, names, counts, k):
     return res
 
 
-def extra_workload(K, S, args, device, name):
-    """The default run also times the 10 000-sample workload (BASELINE configs[2]'s sample count on one GPU) and embeds it in the one
-    JSON line: warm calls (HIP events around the whole call), the checksum identity, and — unless --no-cpu-baseline — the whole matrix
-    compared with the real reference's (oracle/_ref) on the same database written in the reference's format."""
+def rows_from_definition(S, M, wl, k, seed, device, rows):
+    """Rows of the matrix M (device, lower triangle) recomputed straight from the definition — M[i][j] = |K_i ∩ K_j| over the samples'
+    k-mer SETS, no pattern, tree or record involved — for a database too large for the reference's host image: the genomes are
+    derived again from the seed, the k-mer sets of the checked rows kept sorted, every other sample's set looked up in them."""
+    N = wl["samples"]
+    g = S.CladeGenomes(N, wl["clade_size"], wl["length"], seed=seed, device=device)
+    rows = sorted(set(int(r) for r in rows if 0 < r < N))
+    sets = [S.kmers_of(g.sample(i), k) for i in rows]
+    want = [torch.zeros(i, dtype=torch.int64, device=device) for i in rows]
+    top = max(rows)
+    for j in range(top):
+        kj = S.kmers_of(g.sample(j), k)
+        for t, i in enumerate(rows):
+            if j >= i:
+                continue
+            si = sets[t]
+            pos = torch.searchsorted(si, kj).clamp_(max=si.numel() - 1)
+            want[t][j] = (si[pos] == kj).sum()
+    bad = []
+    for t, i in enumerate(rows):
+        o = i * (i - 1) // 2
+        if not torch.equal(M[o: o + i].to(torch.int64).bitwise_and(0xFFFFFFFF), want[t]):
+            bad.append(i)
+    return rows, bad
+
+
+def extra_workload(K, S, args, device, name, reference=True, definition_rows=0):
+    """The default run also times the 10 000-sample workloads and embeds them in the one JSON line: c3part (BASELINE configs[2]'s sample
+    count at a genome length whose database the reference can hold: the whole matrix compared with the real reference's, oracle/_ref, on
+    the same database written in the reference's format) and c3gpu (one GPU's share of configs[2] itself, 10 000 x 625 kbp: too large
+    for the reference's host image here, so `definition_rows` rows are recomputed from the samples' k-mer sets instead).  Warm calls
+    (HIP events around the whole call) and the checksum identity for both."""
     wl = WORKLOADS[name]
     dev_index = device.index or 0
     arr, names, counts, nk, _ = generate_in_child(dev_index, n_samples=wl["samples"], clade_size=wl["clade_size"], length=wl["length"], k=args.k, seed=args.seed,
@@ -325,12 +353,25 @@ def extra_workload(K, S, args, device, name):
            "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg},
            "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3])},
-           "patterns": db.P, "records": stl["n_records"], "wide_nodes": stl["n_wide"], "record_chunks": stl["n_chunks"], "block_width": stl["width"],
+           "patterns": db.P, "records": stl["n_records"], "wide_nodes": stl["n_wide"], "nodes_joined_per_tile": stl["n_joined"], "record_chunks": stl["n_chunks"], "block_width": stl["width"],
            "path": {1: "block-record pipeline", 2: "v1 tile kernel", 3: "v1 HBM-atomics kernel"}.get(stl["path"], "none"),
            "upload_s": upload_s, "cold_call_ms": cold_ms, "checks": "sum of the matrix == sum_p w_p C(n_p, 2); warm == cold", "reference_match": None}
     db.close()
+    out["rows_from_definition"] = False
+    if definition_rows:
+        N, cs = wl["samples"], wl["clade_size"]
+        cand = [1, 2, cs - 1, cs, cs + 1, N // 2, N // 2 + 1, N - cs, N - cs - 1, N - 2, N - 1, N // 3, 2 * N // 3][:max(8, definition_rows)]
+        t1 = time.time()
+        rows, bad = rows_from_definition(S, M, wl, args.k, args.seed, device, cand)
+        assert not bad, "%s: rows %s differ from |K_i ∩ K_j| over the samples' k-mer sets" % (name, bad)
+        out["rows_from_definition"] = True
+        out["definition_rows"] = rows
+        out["checks"] += "; rows %s == |K_i ∩ K_j| recomputed from the samples' k-mer sets (%.0f s)" % (rows, time.time() - t1)
     del M
-    if not args.no_cpu_baseline:
+    if not reference:
+        out["reference_note"] = ("the reference is not run on this database: its host image (patterns + hashtables of %d patterns) and its %d-thread buffers "
+                                 "need more host RAM than a shared GPU box guarantees; c3part carries the whole-matrix comparison at the same sample count" % (out["patterns"], 16))
+    if reference and not args.no_cpu_baseline:
         from oracle import oracle as O
         if O.have_ref():
             with tempfile.TemporaryDirectory(dir=args.tmp) as td:
@@ -923,6 +964,12 @@ def main():
             del arr
             torch.cuda.empty_cache()
             out["extra"] = {"c3part": extra_workload(K, S, args, device, "c3part")}
+            torch.cuda.empty_cache()
+            # one GPU's share of BASELINE configs[2] itself (10 000 x 625 kbp), under the same clock
+            out["extra"]["c3gpu"] = extra_workload(K, S, args, device, "c3gpu", reference=False, definition_rows=8)
+            log("c3gpu: %.2f ms per call, frac %.4f, %d block records, %d nodes joined per tile, rows_from_definition: %s" % (
+                out["extra"]["c3gpu"]["ms_per_step"], out["extra"]["c3gpu"]["roofline"]["frac"], out["extra"]["c3gpu"]["records"],
+                out["extra"]["c3gpu"]["nodes_joined_per_tile"], out["extra"]["c3gpu"]["rows_from_definition"]))
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The parity tests against the oracle, the reference's raw outputs and its golden files run FIRST; the long tests — tens of thousands of
+# samples (property checks: checksum identity, rows from the definition) and the bench.py contract tests (subprocesses) — run LAST, so that a
+# box slow enough to hit the driver's step limit loses the least informative tests, not the parity proper.
+LONG_LAST = ("test_baseline_sample_counts", "test_more_than_65535_samples", "test_db2db_large_parts", "test_new2all_thousand_queries",
+             "test_randomised_stress", "test_bench_")
+
+
+def pytest_collection_modifyitems(config, items):
+    rank = lambda it: next((k + 1 for k, name in enumerate(LONG_LAST) if it.name.startswith(name)), 0)      # noqa: E731
+    items.sort(key=rank)                                        # stable: file order inside every class
+
+
 @pytest.fixture(scope="session")
 def K():
     from _kmerdb_loader import import_kmerdb_amd
