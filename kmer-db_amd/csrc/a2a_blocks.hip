@@ -346,6 +346,7 @@ struct K0Params {
     const uint64_t* bits;
     const uint32_t* perm;          // nullptr: all nodes in DFS order, long ones skipped; else: the long nodes
     uint32_t P;                    // nodes of this launch
+    uint32_t short_ids;            // lists of more ids belong to the long launch (kmdb_db.short_max_ids)
     BlockMap bm;
     unsigned long long* p0_mask;   // first pair inline
     uint32_t* p0_info;             // block | npairs << 16
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
         const uint32_t tl = kmdb_k0_l(kt), tbits = kmdb_k0_bits(kt);
         // work of a node ~ number of codes that are not "0" ~ stream bits beyond one per delta
         uint32_t key = 0;                                                    // 0: nothing to decode here
-        if (t < q.P && tl > 1 && !kmdb_long_node(tl, tbits)) {
+        if (t < q.P && tl > 1 && !kmdb_long_node(tl, tbits, q.short_ids)) {
             key = 1u + (tbits - (tl - 1u));
             key = key > 63u ? 63u : key;
         }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     const BlockMap bm = q.bm;
     const uint2 km = live ? q.k0in[i] : make_uint2(0u, 0u);
     const uint32_t l = kmdb_k0_l(km), last = kmdb_k0_last(km), nbits = kmdb_k0_bits(km);
-    if (!q.perm && kmdb_long_node(l, nbits)) live = false;
+    if (!q.perm && kmdb_long_node(l, nbits, q.short_ids)) live = false;
     using Cursor = RunCursor32<LONG ? 16 : 6, LONG>;
     uint32_t npairs = 0, blk0 = 0, need = 0, span = 0, bit0 = 0;
     unsigned long long mask0 = 0, m1 = 0, m2 = 0;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256) void k0_short_direct_kernel(const K0Params q) 
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         l[j] = kmdb_k0_l(km[j]); last[j] = kmdb_k0_last(km[j]);
-        if (kmdb_long_node(l[j], kmdb_k0_bits(km[j]))) live[j] = false;          // the long launch's
+        if (kmdb_long_node(l[j], kmdb_k0_bits(km[j]), q.short_ids)) live[j] = false;          // the long launch's
         pos[j] = live[j] && l[j] > 1u ? q.blkbase[idx[j] >> 8] + rel[j] : 0ull;
     }
     // the stream words of all NPT nodes under way before the first decode loop
@@ -1102,8 +1103,10 @@ struct WParams {
     uint32_t emit_lo, emit_hi;
     PoolView pool;
     L2View l2;
+    unsigned long long* prof;      // (profiling build of the kernel only: per wave K1W_NPH phase times in 10 ns ticks)
 };
 constexpr int K1W_WAVES = 2;
+constexpr int K1W_NPH = 8;
 constexpr uint32_t L2_MIN_BLOCKS = 24;     // nodes with that many blocks take the second level (measured at 10 000 samples: 11 -> 21.9 ms, 24 -> 20.0; KMDB_L2_MIN moves it)
 constexpr uint32_t L2_NODE_GRAB = 16, L2_ENT_GRAB = 1024, L2_SUB = 16;   // node indices / entries a wave takes per device atomic, from one of L2_SUB cursors each
 constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
@@ -1179,12 +1182,24 @@ __global__ void wrun_anc_kernel(const uint32_t* __restrict__ widx, uint32_t n_wi
 //   number of entries and the mask of the node's own last entry.  At the start of a run the chain is built from the root path of
 //   the slice's first node (a table made at upload): the lists of all its wide ancestors in one scan.
 // No node climbs parent links, and a list may have as many entries as there are blocks.
+template <bool PROF>
 __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + wave;         // 1 or K1W_WAVES waves per workgroup, by the LDS a wave needs
     if (wid >= q.n_waves) return;
+    // (PROF: where a wave's time goes — 0 run start + chain, 1 batch loads + list lengths, 2 rows, 3 second-level entries, 4 whole-wave records,
+    // 5 record-parallel emission, 6 chain hand-over, 7 end)
+    unsigned long long ph[K1W_NPH] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto PT = [&](int k) {
+        if (!PROF) return;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int j = 0; j < K1W_NPH; ++j) if (j == k) ph[j] += now - t_last;
+        t_last = now;
+    };
     unsigned char* wbase = lds_raw + k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap, q.n_rows) * wave;
     const K1WLds L = k1w_carve(wbase, q.arena_cap, q.e_cap, q.chain_cap);
     RowTab RT{nullptr, nullptr, 0u};
@@ -1243,6 +1258,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     l2_enext += mj; l2_estock -= mj;
                     if (lane == 0) q.l2.node_w[g] = wj;
                     ++l2_nodes;
+                    PT(3);
                     continue;
                 }
                 const uint32_t Tj = mj * (mj + 1u) / 2u;
@@ -1266,6 +1282,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     if (q.n_rows) row_emit(A, q.pool, RT, rec_on, X, FX, FY, wj, stream, lane, lt_mask);
                     else wide_emit(A, q.pool, rec_on, FX, FY, wj, stream, lane, lt_mask);
                 }
+                PT(4);
             }
             on = on && m < K1W_HEAVY;
         }
@@ -1308,6 +1325,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             else wide_emit(A, q.pool, rec_on, FX, diag ? FX : FY, ww, stream, lane, lt_mask);
         }
         lds_sync();
+        PT(5);
     };
 
     // The records per node differ by orders of magnitude (3 blocks: 6 records, 200 blocks: 20 100) and heavy nodes sit together
@@ -1380,6 +1398,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             }
             lds_sync();
         }
+        PT(0);
         // ---- the batches of the run
         for (uint32_t k0 = kb; k0 < ke; k0 += WAVE) {
             const uint32_t nv = ke - k0 < (uint32_t)WAVE ? ke - k0 : (uint32_t)WAVE;
@@ -1442,6 +1461,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 if (fits) for (uint32_t t = 0; t < nx; ++t) { L.ox_blk[x0 + t] = q.pair_blk[po + t]; L.ox_mask[x0 + t] = q.pair_mask[po + t]; }
             }
             lds_sync();
+            PT(1);
             // ---- rows, as many lanes at a time as the arena holds, and their records.  Only the lanes that emit need a row, and
             // the last one (its list becomes the chain list).
             const bool need = valid && (act || lane == nv - 1u);
@@ -1492,6 +1512,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 L.st_start[lane] = (uint16_t)start;
                 if (lane == nv - 1u && on) last_start = start;
                 lds_sync();
+                PT(2);
                 emit(on && act, len, wv);
                 fin = hi;
             }
@@ -1509,11 +1530,14 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 const uint32_t ll = bcast(len, nv - 1u), ls = bcast(last_start, nv - 1u);
                 for (uint32_t e = lane; e < ll; e += WAVE) { L.e_blk[e] = L.ent_blk[ls + e]; L.e_mask[e] = L.ent_mask[ls + e]; }
                 lds_sync();
+                PT(6);
             }
         }
     }
     arena_finish(A, q.pool, lane);
     if (q.n_rows) rowtab_finish(RT, q.pool, lane);
+    PT(7);
+    if (PROF && lane == 0) for (int j = 0; j < K1W_NPH; ++j) q.prof[(size_t)wid * K1W_NPH + j] = ph[j];
     if (lane == 0 && n_miss) atomicAdd(&q.pool.counters[KCTR_SLOW], n_miss);
     if (lane == 0 && l2_nodes) atomicAdd(&q.pool.counters[KCTR_L2_NODES], l2_nodes);
 }
@@ -2481,13 +2505,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAV
 // HBM write-back per tile"), where the windows of 4096 positions wrote every tile they met — 1.49 GB of atomics for the 0.2 GB matrix of
 // 10 000 samples.  Where a stream starts is known from the counting sort's offsets: no run boundaries are searched.
 constexpr uint32_t K2J_REC = 16384;
-__global__ void k2j_starts_kernel(const RsRows R, uint32_t n_states, uint32_t* __restrict__ start) {
+// (O = the sort's offsets [row][stream of the row][job of the row], exclusive sums: entry (X, Y, job 0) is where stream (X, Y) starts)
+__global__ void k2j_starts_kernel(const RsRows R, const uint32_t* __restrict__ O, uint32_t n_states, uint32_t* __restrict__ start) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_states) return;
-    if (s == n_states) { start[s] = R.O[R.row_tab[R.NB]]; return; }                       // all sorted records
+    if (s == n_states) { start[s] = O[R.row_tab[R.NB]]; return; }                         // all sorted records
     const uint32_t X = stream_row(s), Y = s - tri32(X);
     const uint32_t nj = R.row_job[X + 1] - R.row_job[X];                                   // a row without records has no jobs: its streams start where the next row does
-    start[s] = R.O[(size_t)R.row_tab[X] + (size_t)Y * nj];
+    start[s] = O[(size_t)R.row_tab[X] + (size_t)Y * nj];
 }
 // the jobs in any order: one reservation per workgroup of streams
 __global__ __launch_bounds__(1024) void k2j_build_kernel(const uint32_t* __restrict__ start, uint32_t n_states, uint2* __restrict__ jobs, uint32_t cap,
@@ -3136,7 +3161,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     // exactly as long — measured, profiles/r03_k0side_ab.sh)
     if (decode) {
         K0Params q{};
-        q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.perm = nullptr; q.P = P; q.bm = bm;
+        q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.perm = nullptr; q.P = P; q.short_ids = db->short_max_ids; q.bm = bm;
         q.p0_mask = db->p0_mask; q.p0_info = db->p0_info; q.pair_ofs = db->pair_ofs; q.pair_blk = db->pair_blk; q.pair_mask = db->pair_mask;
         // sub-pools of the pair pool: enough of them that their cursors are not hot, few enough that one wave's need fits a share
         uint32_t nreg = 1;
@@ -3279,14 +3304,16 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.n_rows = row_mode ? db->NB : 0u;
         const size_t wave_lds = k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap, q.n_rows);
         const uint32_t waves = wave_lds * K1W_WAVES <= (size_t)(64u << 10) ? (uint32_t)K1W_WAVES : 1u;
-        HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
+        static const bool k1w_prof = getenv("KMDB_K1W_PROF") != nullptr;              // (experiment, round 5: phase times of the wide kernel on stderr)
+        HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
+        if (k1w_prof) HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
         // As many waves as the chip holds at once, each with an equal share of the runs (dealt round-robin): with more, the waves
         // beyond the first round start when the first ones end, and all take equally long — 1.6 rounds cost 2 (measured at 10 000
         // samples: 4096 waves at 10 per CU took 8.8 ms, of which every wave ran 4.4).
         if (!db->k1w_slots) {
             int per_cu = 0, dev = 0;
             hipDeviceProp_t prop;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k1w_kernel, (int)(WAVE * waves), wave_lds * waves));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k1w_kernel<false>, (int)(WAVE * waves), wave_lds * waves));
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipGetDeviceProperties(&prop, dev));
             db->k1w_slots = (uint32_t)std::max(1, per_cu) * waves * (uint32_t)std::max(1, prop.multiProcessorCount);
@@ -3294,7 +3321,22 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.n_waves = std::min<uint32_t>(std::min<uint32_t>(db->k1w_slots, db->k1w_waves), q.n_runs);
         q.run_ctr = db->run_ctr;
         if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(db->k1w_waves, q.n_runs), (uint32_t)atoi(e)));
-        hipLaunchKernelGGL(k1w_kernel, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
+        if (k1w_prof) {
+            static unsigned long long* d_prof = nullptr;
+            if (!d_prof) HIP_TRY(hipMalloc((void**)&d_prof, (size_t)K1W_MAX_WAVES * K1W_NPH * 8));
+            q.prof = d_prof;
+            hipLaunchKernelGGL(k1w_kernel<true>, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
+            std::vector<unsigned long long> h((size_t)q.n_waves * K1W_NPH);
+            HIP_TRY(hipMemcpyAsync(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            double sum[K1W_NPH] = {0}, mx = 0;
+            for (uint32_t w = 0; w < q.n_waves; ++w) { double t = 0; for (int j = 0; j < K1W_NPH; ++j) { sum[j] += (double)h[(size_t)w * K1W_NPH + j]; t += (double)h[(size_t)w * K1W_NPH + j]; } mx = std::max(mx, t); }
+            fprintf(stderr, "[kmdb] k1w phases, mean per wave in us (%u waves, %u wide nodes; slowest wave %.1f us):", q.n_waves, n_wide, mx * 0.01);
+            const char* nm[K1W_NPH] = {"run+chain", "loads+lengths", "rows", "l2 entries", "heavy records", "light records", "hand-over", "end"};
+            for (int j = 0; j < K1W_NPH; ++j) fprintf(stderr, " %s %.1f", nm[j], sum[j] / q.n_waves * 0.01);
+            fprintf(stderr, "\n");
+        } else
+        hipLaunchKernelGGL(k1w_kernel<false>, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
         if (db->l2_on) {
             // rank directories, list offsets, lists, and the tile joins adding into M (a tile whose blocks have no list leaves at once)
             const uint32_t NB = db->NB, W = db->l2_node_cap / 64u;
@@ -3343,7 +3385,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         hipLaunchKernelGGL(rs_scatter_kernel, dim3((jobs + 7u) & ~7u), dim3(CS_THREADS), rs_scatter_lds(NB), st, R, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
                            db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters);
         // the sorted records applied stream by stream (a long stream in parts of K2J_REC records): one write-back of a tile per job
-        hipLaunchKernelGGL(k2j_starts_kernel, dim3((db->n_states + 1u + 255u) / 256u), dim3(256), 0, st, R, db->n_states, db->k2j_start);
+        hipLaunchKernelGGL(k2j_starts_kernel, dim3((db->n_states + 1u + 255u) / 256u), dim3(256), 0, st, R, db->rs_offs, db->n_states, db->k2j_start);
         hipLaunchKernelGGL(k2j_build_kernel, dim3((db->n_states + 1023u) / 1024u), dim3(1024), 0, st, db->k2j_start, db->n_states, db->k2j_jobs, (uint32_t)db->k2j_cap, db->counters);
         k2jobs_launched = db->have_counts ? db->last_n_k2jobs : (uint32_t)db->k2j_cap;       // (the streams' lengths repeat exactly from call to call)
         if (k2jobs_launched)

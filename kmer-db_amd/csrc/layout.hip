@@ -98,7 +98,7 @@ struct LayStats { unsigned long long alg, upd, pairs; uint32_t max_n, max_depth,
 __global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ acc, const uint32_t* __restrict__ dep,
                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ size, const int32_t* __restrict__ parent,
                                   const uint32_t* __restrict__ h_l, const uint32_t* __restrict__ h_last, const uint32_t* __restrict__ h_n, const uint32_t* __restrict__ h_nbits,
-                                  const uint32_t* __restrict__ h_w, const unsigned long long* __restrict__ h_wfull, uint32_t P,
+                                  const uint32_t* __restrict__ h_w, const unsigned long long* __restrict__ h_wfull, uint32_t P, uint32_t short_ids,
                                   uint2* __restrict__ k0in, uint32_t* __restrict__ nl, int32_t* __restrict__ dparent, uint32_t* __restrict__ w,
                                   uint16_t* __restrict__ dflag, uint32_t* __restrict__ sub_end, LayStats* __restrict__ st) {
     unsigned long long alg = 0, upd = 0, pairs = 0;
@@ -119,7 +119,7 @@ __global__ void lay_gather_kernel(const uint32_t* __restrict__ order, const uint
         alg += 40ull + (unsigned long long)((nb + 127u) / 128u) * 16ull;
         upd += (unsigned long long)(n - l) * l + (unsigned long long)l * (l ? l - 1 : 0) / 2;
         pairs += (h_wfull ? h_wfull[pid] : (unsigned long long)h_w[pid]) * ((unsigned long long)n * (n ? n - 1 : 0) / 2);
-        mn = max(mn, n); md = max(md, d); nlong += kmdb_long_node(l, nb) ? 1u : 0u;
+        mn = max(mn, n); md = max(md, d); nlong += kmdb_long_node(l, nb, short_ids) ? 1u : 0u;
     }
     // block reduction of the statistics
     __shared__ unsigned long long s_alg[256], s_upd[256], s_pairs[256];
@@ -174,7 +174,8 @@ __global__ void lay_copy_bits_kernel(const uint32_t* __restrict__ order, const u
 // long nodes: selected in DFS order (stable partition), then ordered by work
 struct LongNodePred {
     const uint2* k0in;
-    __host__ __device__ bool operator()(uint32_t i) const { const uint2 km = k0in[i]; return kmdb_long_node(kmdb_k0_l(km), kmdb_k0_bits(km)); }
+    uint32_t short_ids;
+    __host__ __device__ bool operator()(uint32_t i) const { const uint2 km = k0in[i]; return kmdb_long_node(kmdb_k0_l(km), kmdb_k0_bits(km), short_ids); }
 };
 __global__ void lay_long_keys_kernel(const uint2* __restrict__ k0in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ keys) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,6 +266,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         tphase0 = now;
     };
     hipStream_t st = db->stream;
+    if (const char* e = getenv("KMDB_SHORT_IDS")) if (*e) db->short_max_ids = (uint32_t)std::max(1, std::min(64, atoi(e)));     // (experiment, round 5)
     const unsigned B = 256;
     unsigned G = (unsigned)((P + B - 1) / B), G1 = (unsigned)((P + 1 + B - 1) / B);
 
@@ -494,7 +496,7 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         h2d_bytes += P * 8;
     }
     hipLaunchKernelGGL(lay_gather_kernel, dim3(std::min<unsigned>(G1, 2048u)), dim3(B), 0, st, order.p, acc[cur].p, dep[dcur].p, cnt.p, size.p, d_parent.p, d_ll.p, d_last.p, d_n.p, d_nbits.p, d_w.p,
-                       d_wfull.p, (uint32_t)P, db->k0in, db->nl, db->parent, db->w, db->dflag, db->sub_end, d_stats.p);
+                       d_wfull.p, (uint32_t)P, db->short_max_ids, db->k0in, db->nl, db->parent, db->w, db->dflag, db->sub_end, d_stats.p);
     HIP_TRY(hipGetLastError());
     LayStats hs{};
     uint32_t hflags[4] = {0, 0, 0, 0};
@@ -561,10 +563,10 @@ int kmdb_layout_upload(kmdb_db* db, const kmdb_db_view* v, int with_hashtables, 
         HIP_TRY(hipMalloc((void**)&db->long_nodes, (size_t)hs.n_long * 4));
         rocprim::counting_iterator<uint32_t> first(0u);
         size_t tb = 0;
-        HIP_TRY(prim::select_if(nullptr, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
+        HIP_TRY(prim::select_if(nullptr, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in, db->short_max_ids}, st));
         DevTmp<unsigned char> tmp;
         if (tmp.alloc(tb)) return 1;
-        HIP_TRY(prim::select_if(tmp.p, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in}, st));
+        HIP_TRY(prim::select_if(tmp.p, tb, first, sel.p, nsel.p, (int)P, LongNodePred{db->k0in, db->short_max_ids}, st));
         hipLaunchKernelGGL(lay_long_keys_kernel, dim3((hs.n_long + 255) / 256), dim3(256), 0, st, db->k0in, sel.p, hs.n_long, lk.p);
         // most work first; the sort is stable, so equal work keeps ascending DFS order
         size_t tb2 = 0;
