@@ -42,6 +42,9 @@ WORKLOADS = {
     "c3gpu": dict(samples=10000, clade_size=50, length=625_000),           # configs[2] / 8 GPUs
     # secondary modes (--mode), sized so that the synthetic generator and the reference finish in minutes
     "c4part": dict(samples=20000, clade_size=50, length=100_000, k=25, fraction=0.1),      # configs[3] is 50 000 samples: --samples 50000
+    # all2all-sp on data that IS sparse: the clades descend from independent roots (r1 = 0.75: a clade ancestor shares no 25-mer with another),
+    # so only the 50 x 50 blocks on the diagonal are non-zero — configs[3]'s sample count, nnz = 1.2 M of 1.25 G cells
+    "c4sparse": dict(samples=50000, clade_size=50, length=50_000, k=25, fraction=0.1, r1=0.75),
     "c5part": dict(samples=10000, clade_size=50, length=100_000, queries=1000),            # configs[4]: 1000 queries vs a 10 000-sample database
     "parts": dict(samples=2000, clade_size=50, length=300_000),                            # all2all-parts cell: two halves of one collection
 }
@@ -416,7 +419,7 @@ def secondary_mode(args, K, S, device):
     from oracle import oracle as O
     dev_index = device.index or 0
     N, cs, L, k, f = args.samples, args.clade_size, args.length, args.k, args.fraction
-    g = S.CladeGenomes(N, cs, L, seed=args.seed, device=device)
+    g = S.CladeGenomes(N, cs, L, r1=args.r1, seed=args.seed, device=device)
     t0 = time.time()
 
     def make(ids, with_tables):
@@ -479,8 +482,9 @@ def secondary_mode(args, K, S, device):
             assert spf.nnz == int(keep.sum()) and np.array_equal(spf.col, sp.col[keep]) and np.array_equal(spf.val, sp.val[keep]) \
                 and np.array_equal(spf.measure, jac[keep]), "filtered sparse output differs"
             extra_wall = {"filtered_call_ms": filt_ms, "filtered_nnz": int(spf.nnz), "filter": "jaccard >= %.6g (the 99th percentile), measure = jaccard" % thr}
-            cfg = {"workload": "%s: %s, all2all-sp" % (args.workload, desc), "nnz": int(sp.nnz), "patterns": int(d.P)}
-            kernel = "kmdb_all2all_sparse: block-record pipeline into the dense triangle + row_nnz / row_compact (CSR)"
+            cfg = {"workload": "%s: %s, all2all-sp" % (args.workload, desc), "nnz": int(sp.nnz), "cells": int(N) * (int(N) - 1) // 2, "patterns": int(d.P),
+                   "r1": args.r1}
+            kernel = "kmdb_all2all_sparse: block-record pipeline into the dense triangle + compaction of the tiles it added to (row_tiles_kernel; CSR)"
         elif args.mode == "new2all":
             NQ = args.queries
             pat, arr, tables = make(list(range(N)), True)
@@ -704,6 +708,7 @@ def main():
                     help="all2all (default, the headline line) or one of the secondary rows: all2all-sp, new2all, db2db (1 GPU)")
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--fraction", type=float, default=None)
+    ap.add_argument("--r1", type=float, default=None, help="secondary modes: mutation rate between the root genome and a clade ancestor (0.75: independent roots)")
     ap.add_argument("--queries", type=int, default=None)
     ap.add_argument("--seed", type=int, default=20260928 + 1)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -729,8 +734,8 @@ def main():
         # one GPU: BASELINE configs[1]; several: configs[2] — 10 000 samples, every rank one GPU's share of the 5 Mbp genomes (c3gpu =
         # 5 Mbp / 8: at --gpus 8 with the default --scaling weak the job IS configs[2])
         args.workload = "c3gpu" if (args.mode == "all2all" and args.gpus > 1) else MODE_WORKLOAD[args.mode]
-    for key, val in dict(dict(k=18, fraction=1.0, queries=0), **WORKLOADS[args.workload]).items():
-        if getattr(args, key) is None:
+    for key, val in dict(dict(k=18, fraction=1.0, queries=0, r1=0.10), **WORKLOADS[args.workload]).items():
+        if getattr(args, key, None) is None:
             setattr(args, key, val)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

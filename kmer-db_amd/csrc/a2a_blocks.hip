@@ -1729,9 +1729,9 @@ __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t dig
 template <bool SORTED>
 __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t* wor_sh,
                                        unsigned char (*wbuf)[64], const unsigned long long* lut_ff, const unsigned long long* lut_01,
-                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, unsigned char* __restrict__ touched) {
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 256) acc[k] = 0;
-    if (threadIdx.x == 0) *wor_sh = 0;
+    if (threadIdx.x == 0) { *wor_sh = 0; if (touched && !it.rect_cols) touched[tri32(it.X) + it.Y] = 1; }      // (the tile gets something: all2all-sp scans only such tiles)
     __syncthreads();
     for (uint32_t digit = 0; digit < 5; ++digit) {
         const uint32_t wor = (it.X == it.Y && !it.rect_cols) ? k2_apply_mfma<true, SORTED>(it, digit, acc, wbuf, lut_ff, lut_01)
@@ -1809,7 +1809,8 @@ __global__ void l2_lists_kernel(const uint32_t* __restrict__ ent_g, const uint16
 constexpr uint32_t L2_WAVES = 4, L2_QCAP = 576;
 __global__ __launch_bounds__(64 * L2_WAVES) __attribute__((amdgpu_waves_per_eu(3, 8)))
 void l2_join_apply_kernel(const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R, const unsigned long long* __restrict__ L, const uint32_t* __restrict__ Wt,
-                          const uint32_t* __restrict__ loff, uint32_t w_stride, uint32_t nb_blocks, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+                          const uint32_t* __restrict__ loff, uint32_t w_stride, uint32_t nb_blocks, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth,
+                          unsigned char* __restrict__ touched) {
     uint32_t W;
     __shared__ uint32_t q[L2_WAVES][L2_QCAP];
     __shared__ uint32_t q2[L2_WAVES][L2_QCAP];
@@ -1961,6 +1962,7 @@ void l2_join_apply_kernel(const unsigned long long* __restrict__ B, const uint32
         __syncthreads();
     }
     // one HBM atomic per non-zero cell of the tile (the apply kernels add into the same matrix)
+    if (threadIdx.x == 0 && touched) touched[t] = 1;
     for (uint32_t k = threadIdx.x; k < 64 * 64; k += 64 * L2_WAVES) {
         const uint32_t v = acc[k];
         if (!v) continue;
@@ -1974,7 +1976,7 @@ constexpr int K2A_MIN_WAVES = 3;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAVES, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
                                                        const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
                                                        const uint32_t* __restrict__ chunk_fill, uint32_t n_states, const uint32_t* __restrict__ n_chunks_ptr,
-                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, uint32_t win) {
+                                                       uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, uint32_t win, unsigned char* __restrict__ touched) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
@@ -2010,7 +2012,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAV
             it.X = X; it.Y = bucket - tri32(X);
             it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw; it.rect_cols = 0;
         }
-        k2_run<false>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth);
+        k2_run<false>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth, touched);
         a = b;
     }
 }
@@ -2433,7 +2435,7 @@ constexpr int K2S_MIN_WAVES = 3;           // waves per SIMD the compiler must l
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAVES, 8))) void k2_sorted_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
                                                         uint32_t limit, const uint32_t* __restrict__ total_ptr, const uint32_t* __restrict__ lo_ptr,
                                                         uint32_t n_states, uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N,
-                                                        uint32_t bwidth, uint32_t rect_nbc, uint32_t rect_cols) {
+                                                        uint32_t bwidth, uint32_t rect_nbc, uint32_t rect_cols, unsigned char* __restrict__ touched) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];
@@ -2496,7 +2498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAV
             it.rect_cols = rect_cols;
             it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.skey = swkey + p0 + a; it.kbits = kbits; it.dbits = dbits; it.rec = nullptr; it.recw = nullptr;
         }
-        k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth);
+        k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth, touched);
     }
 }
 
@@ -2535,7 +2537,7 @@ __global__ __launch_bounds__(1024) void k2j_build_kernel(const uint32_t* __restr
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAVES, 8))) void k2_jobs_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
                                                         const uint32_t* __restrict__ start, const uint2* __restrict__ jobs, const uint32_t* __restrict__ n_jobs, uint32_t cap,
-                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth) {
+                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, unsigned char* __restrict__ touched) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];
@@ -2556,7 +2558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAV
     it.X = stream_row(job.x); it.Y = job.x - tri32(it.X); it.rect_cols = 0;
     it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + a; it.skey = swkey + a; it.kbits = kbits; it.dbits = dbits;
     it.rec = nullptr; it.recw = nullptr;
-    k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth);
+    k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth, touched);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2885,7 +2887,7 @@ int kmdb_rect_sort_apply(hipStream_t st, uint32_t* wkey, void* wrec, uint32_t ns
         RS_TRY(prim::sort_pairs(tmp, tb, wkey, swkey, (WideRec*)wrec, swrec, (int)nslots, 0, key_bits, st));
     }
     hipLaunchKernelGGL(k2_sorted_kernel, dim3((nslots + K2S_WIN - 1) / K2S_WIN), dim3(256), 0, st, swkey, (const WideRec*)swrec, nslots, total_ptr, (const uint32_t*)nullptr,
-                       n_states, (uint32_t)key_bits, wide_digit_bits(key_bits), M, n_rows, 64u, nbc, n_cols);
+                       n_states, (uint32_t)key_bits, wide_digit_bits(key_bits), M, n_rows, 64u, nbc, n_cols, (unsigned char*)nullptr);
     RS_TRY(hipGetLastError());
     RS_TRY(hipStreamSynchronize(st));
 #undef RS_TRY
@@ -3024,6 +3026,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
         while ((1ull << key_bits) <= (uint64_t)db->n_states + 1) ++key_bits;          // streams; all-ones = never written
         db->key_bits = key_bits;
     }
+    HIP_TRY(hipMalloc((void**)&db->tile_touched, (size_t)db->n_states + 1));
     HIP_TRY(hipMalloc((void**)&db->ct_hist, ((size_t)db->n_ckeys + 2) * 4));
     HIP_TRY(hipMalloc((void**)&db->ct_offs, ((size_t)db->n_ckeys + 2) * 4));
     HIP_TRY(hipMalloc((void**)&db->ct_cursor, ((size_t)db->n_ckeys + 2) * 4));
@@ -3080,7 +3083,7 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_rows); FREE_NULL(db->cs_tmp);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     FREE_NULL(db->ct_hist); FREE_NULL(db->ct_offs); FREE_NULL(db->ct_cursor); FREE_NULL(db->ct_tmp); FREE_NULL(db->rs_rows); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs);
-    FREE_NULL(db->run_ctr); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->k2j_start); FREE_NULL(db->k2j_jobs);
+    FREE_NULL(db->run_ctr); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->k2j_start); FREE_NULL(db->k2j_jobs); FREE_NULL(db->tile_touched);
     FREE_NULL(db->l2_cursors); FREE_NULL(db->l2_bitmap); FREE_NULL(db->l2_rank); FREE_NULL(db->l2_len); FREE_NULL(db->l2_loff); FREE_NULL(db->l2_ent_g);
     FREE_NULL(db->l2_node_w); FREE_NULL(db->l2_list_w); FREE_NULL(db->l2_ent_blk); FREE_NULL(db->l2_ent_mask); FREE_NULL(db->l2_list_mask);
     db->l2_node_cap = 0; db->l2_ent_cap = 0;
@@ -3230,7 +3233,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + win - 1) / win);
         if (grid)
             hipLaunchKernelGGL(k2_apply_kernel, dim3(grid), dim3(256), 0, s2, db->rec, db->recw, db->sorted_key, db->sorted_id, db->chunk_fill, db->n_states,
-                               db->ct_offs + db->n_states, M, (uint32_t)db->N, db->width, win);
+                               db->ct_offs + db->n_states, M, (uint32_t)db->N, db->width, win, db->tile_touched);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(db->ev_side[1], s2));
         if (sync_debug) { const hipError_t e = hipStreamSynchronize(s2); fprintf(stderr, "[kmdb] stage %-14s %s\n", "chunk apply", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
@@ -3345,7 +3348,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             hipLaunchKernelGGL(l2_lists_kernel, dim3((db->l2_ent_cap + 255u) / 256u), dim3(256), 0, st, db->l2_ent_g, db->l2_ent_blk, db->l2_ent_mask, db->l2_node_w,
                                db->l2_ent_cap, W, db->l2_bitmap, db->l2_rank, db->l2_loff, db->l2_list_mask, db->l2_list_w);
             hipLaunchKernelGGL(l2_join_apply_kernel, dim3(NB * (NB + 1u) / 2u), dim3(64 * L2_WAVES), 0, st, db->l2_bitmap, db->l2_rank, db->l2_list_mask, db->l2_list_w,
-                               db->l2_loff, W, NB, M, (uint32_t)db->N, db->width);
+                               db->l2_loff, W, NB, M, (uint32_t)db->N, db->width, db->tile_touched);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -3390,7 +3393,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         k2jobs_launched = db->have_counts ? db->last_n_k2jobs : (uint32_t)db->k2j_cap;       // (the streams' lengths repeat exactly from call to call)
         if (k2jobs_launched)
             hipLaunchKernelGGL(k2_jobs_kernel, dim3(k2jobs_launched), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, db->k2j_start, db->k2j_jobs, db->counters + KCTR_K2JOBS,
-                               (uint32_t)db->k2j_cap, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width);
+                               (uint32_t)db->k2j_cap, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, db->tile_touched);
         HIP_TRY(hipGetLastError());
         if (stage("row sort+apply")) return 1;
     } else {
@@ -3418,7 +3421,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
             const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
             hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, nslots, total_ptr, (const uint32_t*)nullptr,
-                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u);
+                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u, db->tile_touched);
             HIP_TRY(hipGetLastError());
         }
         if (stage("sorted apply")) return 1;
@@ -3515,6 +3518,7 @@ static void blocks_join_side_streams(kmdb_db* db) {
 int kmdb_blocks_run(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi, hipStream_t st) {
     const uint64_t cells = db->N * (db->N - 1) / 2;
     for (int round = 0; round < 64; ++round) {
+        if (db->tile_touched) HIP_TRY(hipMemsetAsync(db->tile_touched, 0, (size_t)db->n_states + 1, st));      // the tiles this call adds to (all its slices)
         // the slices of [emit_lo, emit_hi) one after the other, adding into the same matrix; a pass that had to enlarge a pool (or
         // asked for more slices) leaves a partial sum behind: everything again from a zeroed matrix
         const uint32_t S = std::max<uint32_t>(1u, db->n_slices);

@@ -148,6 +148,43 @@ __global__ void row_compact_kernel(const uint32_t* __restrict__ M, uint64_t row_
     }
 }
 
+
+// The same two passes over the TOUCHED tiles only (reference: all2all_sp is O(nnz), src/similarity_calculator.cpp:596-638, compact2
+// src/array.h:391-446): the apply kernels of the block-record pipeline flag every block pair (X, Y) they add to (kmdb_db.tile_touched);
+// a row of block row X looks at the flags of its X + 1 column blocks, 64 at a time, and reads only the cells of flagged tiles.  One
+// wave per row (a tile holds at most 64 columns: a lane each); the row's entries come out in ascending column order.
+struct TileSkip { const unsigned char* touched; uint32_t width; };
+template <bool COMPACT>
+__global__ __launch_bounds__(64) void row_tiles_kernel(const uint32_t* __restrict__ M, uint64_t n_rows, const TileSkip ts, unsigned long long* __restrict__ row_nnz,
+                                                       const unsigned long long* __restrict__ row_ptr, uint32_t* __restrict__ col, uint32_t* __restrict__ val,
+                                                       const DevFilter f) {
+    const uint64_t row = blockIdx.x;
+    if (row >= n_rows) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t X = (uint32_t)(row / ts.width);
+    const uint32_t* r = M + tri64(row);
+    const unsigned char* flags = ts.touched + (size_t)X * (X + 1) / 2;
+    unsigned long long out = COMPACT ? row_ptr[row] : 0ull;
+    uint32_t count = 0;
+    for (uint32_t Y0 = 0; Y0 <= X; Y0 += 64) {
+        const uint32_t Yl = Y0 + lane;
+        unsigned long long m = __ballot(Yl <= X && flags[Yl] != 0);
+        while (m) {
+            const uint32_t Y = Y0 + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const uint64_t j = (uint64_t)Y * ts.width + lane;
+            uint32_t v = (lane < ts.width && j < row) ? r[j] : 0u;
+            if (!dev_keep(f, v, (uint32_t)row, (uint32_t)j)) v = 0u;
+            const unsigned long long bal = __ballot(v != 0);
+            if (COMPACT) {
+                if (v) { const unsigned long long o = out + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)); col[o] = (uint32_t)j; val[o] = v; }
+                out += (uint32_t)__popcll(bal);
+            } else count += (uint32_t)__popcll(bal);
+        }
+    }
+    if (!COMPACT && lane == 0) row_nnz[row] = count;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -528,6 +565,12 @@ static int sparse_impl(kmdb_db* db, bool from_cells, const void* dense_dev, uint
         row_lo = row_of(cell_lo); row_hi = row_of(cell_hi - 1) + 1;
     }
     SP_TRY(hipMemsetAsync(row_nnz, 0, (N + 1) * 8, st));
+    // the block-record pipeline just told which tiles it added to: only those are scanned (KMDB_SP_ALL_TILES=1: every cell, as before — A/B)
+    const bool skip = !from_cells && db->stats.path == KMDB_PATH_RECORDS && db->tile_touched && N > 1 && !getenv("KMDB_SP_ALL_TILES");
+    const TileSkip ts{db->tile_touched, db->width};
+    if (skip) hipLaunchKernelGGL((row_tiles_kernel<false>), dim3((unsigned)N), dim3(64), 0, st, cellsp, N, ts, row_nnz, (const unsigned long long*)nullptr, (uint32_t*)nullptr,
+                                 (uint32_t*)nullptr, df);
+    else
     if (row_hi > row_lo) hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)(row_hi - row_lo)), dim3(256), 0, st, cellsp, row_lo, cell_lo, cell_hi, row_nnz, df);
     size_t tmp_bytes = 0;
     SP_TRY(prim::exclusive_sum(nullptr, tmp_bytes, row_nnz, row_ptr, (int)(N + 1), st));
@@ -539,6 +582,8 @@ static int sparse_impl(kmdb_db* db, bool from_cells, const void* dense_dev, uint
     const uint64_t nnz = h_ptr[N];
     SP_TRY(hipMalloc((void**)&col, std::max<uint64_t>(nnz, 1) * 4));
     SP_TRY(hipMalloc((void**)&val, std::max<uint64_t>(nnz, 1) * 4));
+    if (skip) hipLaunchKernelGGL((row_tiles_kernel<true>), dim3((unsigned)N), dim3(64), 0, st, cellsp, N, ts, (unsigned long long*)nullptr, row_ptr, col, val, df);
+    else
     if (row_hi > row_lo) hipLaunchKernelGGL(row_compact_kernel, dim3((unsigned)(row_hi - row_lo)), dim3(256), 0, st, cellsp, row_lo, cell_lo, cell_hi, row_ptr, col, val, df);
     rc = finish_stats(db, st);
     if (rc) { cleanup(); return rc; }

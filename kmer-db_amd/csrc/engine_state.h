@@ -200,6 +200,8 @@ struct kmdb_db {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the stream chunks are sorted and applied next to the wide kernel
     hipEvent_t ev_side[2] = {nullptr, nullptr};
+    unsigned char* tile_touched = nullptr;   // [n_states] != 0: the last call's apply kernels added something to the tile of that block pair (the sparse
+                                             // entry point scans only those tiles)
     uint32_t* k2j_start = nullptr;  // [n_states + 1] many streams: where every stream starts in the sorted arrays
     uint2* k2j_jobs = nullptr;      // [k2j_cap] jobs of the apply kernel: {stream, part of K2J_REC records}
     uint64_t k2j_cap = 0;

@@ -150,6 +150,56 @@ def test_all2all_sparse_bit_exact(K, O, golden_dir, dev, stem):
         assert "".join("%d:%d," % (a + 1, b) for a, b in zip(c, v)).encode() == lines[i]
 
 
+@pytest.mark.parametrize("N,cs,L,r1,width", [(3000, 50, 1500, 0.75, 0), (2500, 40, 1200, 0.75, 64), (1200, 50, 3000, 0.10, 0)])
+def test_all2all_sparse_scans_the_tiles_the_call_added_to(K, O, dev, tmp_path, N, cs, L, r1, width):
+    """all2all-sp on data that is sparse (reference all2all_sp is O(nnz): src/similarity_calculator.cpp:596-638, src/array.h:391-446): clades
+    from independent roots (r1 = 0.75) share nothing, only the blocks on the diagonal are non-zero.  The compaction scans the tiles the
+    apply kernels flagged (kmdb_db.tile_touched) instead of all N (N - 1) / 2 cells: rows == the reference's all2all_sp text (or the
+    oracle's matrix), == the scan of every cell (KMDB_SP_ALL_TILES=1), with bounds too, and with a block width that cuts the clades."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    device = torch.device("cuda", dev)
+    g, pat = S.synth_database(N, cs, L, k=25, fraction=0.2, seed=41, r1=r1, device=device)
+    arr = S.to_view_arrays(pat)
+    path = str(tmp_path / "s.db")
+    S.write_db_fast(path, 25, 0.2, [g.name(i) for i in range(N)], pat["sample_counts"], arr, device=device)
+    exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+    view = K.make_view(25, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                       arr["data_offset"], arr["data"])
+    try:
+        if width:
+            os.environ["KMDB_BLOCK_WIDTH"] = str(width)
+        d = K.DeviceDB(view, device=dev)
+        sp = d.all2all_sparse()
+        assert d.stats()["path"] == K.capi.PATH_RECORDS
+        nz = np.nonzero(exp)[0]
+        assert sp.nnz == nz.size and np.array_equal(sp.val, exp[nz])
+        rr = np.repeat(np.arange(N, dtype=np.int64), np.diff(sp.row_ptr).astype(np.int64))
+        assert np.array_equal(rr * (rr - 1) // 2 + sp.col.astype(np.int64), nz)
+        if r1 > 0.5:
+            assert sp.nnz < N * cs            # nothing outside the clades' own blocks
+        if O.have_ref():
+            txt, _ = O.ref_all2all_sp(path, str(tmp_path / "sp.txt"), threads=8)
+            lines = txt.split(b"\n")
+            for i in range(0, N, 7):
+                c, v = sp.row(i)
+                assert "".join("%d:%d," % (a + 1, b) for a, b in zip(c, v)).encode() == lines[i], i
+        cnt = np.asarray(pat["sample_counts"], dtype=np.uint32)
+        flt = [("jaccard", 0.3, None), ("num-kmers", 3.0, None)]
+        a = d.all2all_sparse_filtered(flt, cnt, measure="ani")
+        os.environ["KMDB_SP_ALL_TILES"] = "1"
+        sp2 = d.all2all_sparse()
+        b = d.all2all_sparse_filtered(flt, cnt, measure="ani")
+        assert sp2.nnz == sp.nnz and np.array_equal(sp2.row_ptr, sp.row_ptr) and np.array_equal(sp2.col, sp.col) and np.array_equal(sp2.val, sp.val)
+        assert a.nnz == b.nnz and np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.col, b.col) and np.array_equal(a.val, b.val)
+        assert np.array_equal(a.measure, b.measure, equal_nan=True) and 0 < a.nnz < sp.nnz
+        d.close()
+    finally:
+        os.environ.pop("KMDB_BLOCK_WIDTH", None)
+        os.environ.pop("KMDB_SP_ALL_TILES", None)
+
+
 def test_new2all_bit_exact(K, O, golden_dir, dev):
     path = os.path.join(golden_dir, "clade64.db")
     d = K.DeviceDB(K.HostDB(path), device=dev, with_hashtables=True)
