@@ -96,6 +96,8 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
+    uint32_t pshift;               // row mode, != 0: packed records — the weight digit (and its index) sit in the column mask word from bit `pshift` (= the
+                                   // block width) on, 64 - pshift - 2 bits of digit; the key word beside the record holds the stream only and stays behind in the sort
 };
 struct Resv { uint32_t base1, n1, base2; };   // slots [base1, base1 + n1) and [base2, ...) for the rest
 __device__ __forceinline__ uint32_t resv_slot(const Resv& r, uint32_t rank) { return rank < r.n1 ? r.base1 + rank : r.base2 + (rank - r.n1); }
@@ -262,7 +264,8 @@ __device__ __forceinline__ void rowtab_init(RowTab& R, uint32_t* lds, uint32_t n
 }
 __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const RowTab& R, bool on, uint32_t X, unsigned long long rows, unsigned long long cols,
                                          uint32_t w, uint32_t stream, uint32_t lane, unsigned long long lt_mask) {
-    const uint32_t dmask = (1u << pv.dbits) - 1u;
+    const uint32_t dbits = pv.pshift ? (64u - pv.pshift - 2u < 16u ? 64u - pv.pshift - 2u : 16u) : pv.dbits;
+    const uint32_t dmask = (1u << dbits) - 1u;
     uint32_t j = 0;
     for (;;) {
         const unsigned long long onm = __ballot(on);
@@ -306,10 +309,15 @@ __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const
             pend = __ballot(ovf);
         }
         if (on) {
-            ((WideRec*)pv.rec)[p] = WideRec{rows, cols};
-            pv.recw[p] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
+            if (pv.pshift) {
+                ((WideRec*)pv.rec)[p] = WideRec{rows, cols | ((unsigned long long)((w & dmask) | (j << dbits)) << pv.pshift)};
+                pv.recw[p] = stream;
+            } else {
+                ((WideRec*)pv.rec)[p] = WideRec{rows, cols};
+                pv.recw[p] = stream | (((w & dmask) | (j << dbits)) << pv.kbits);
+            }
         }
-        w >>= pv.dbits; ++j;
+        w >>= dbits; ++j;
         on = on && w != 0;
     }
 }
@@ -1604,6 +1612,7 @@ struct K2Item {
     const WideRec* srec;                   // sorted mode: the run's records, n_rec of them, contiguous
     const uint32_t* skey;                  //              their key words (weight digits)
     uint32_t kbits, dbits;
+    uint32_t pshift;                       // sorted mode, != 0: packed records (PoolView::pshift): weight digit in the column word, no key words
     uint32_t rect_cols;                    // 0: lower-triangular matrix of N samples; else a dense n_rows x rect_cols matrix (db2db), N = n_rows
     uint32_t n_rec;
     const unsigned char* rec;              // record pool
@@ -1621,6 +1630,12 @@ __device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t s
         if (p < it.n_rec) {
             const WideRec r = it.srec[p];
             R = r.rows; Cc = r.cols;
+            if (it.pshift) {
+                const uint32_t f = (uint32_t)(r.cols >> it.pshift), pd = 64u - it.pshift - 2u < 16u ? 64u - it.pshift - 2u : 16u;
+                const uint32_t sh = (f >> pd) * pd;
+                Cc = r.cols & ((1ull << it.pshift) - 1ull);
+                W = sh < 32u ? (f & ((1u << pd) - 1u)) << sh : 0u;
+            } else
             W = weighted ? wide_weight(it.skey[p], it.kbits, it.dbits) : 1u;
         }
     } else {
@@ -2010,7 +2025,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAV
             while (tri32(X) > bucket) --X;
             while (tri32(X + 1u) <= bucket) ++X;
             it.X = X; it.Y = bucket - tri32(X);
-            it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw; it.rect_cols = 0;
+            it.count = (b - a) * CH_STEPS; it.ids = s_id + a; it.fills = s_fill + a; it.srec = nullptr; it.n_rec = 0; it.rec = rec; it.recw = recw; it.rect_cols = 0; it.pshift = 0;
         }
         k2_run<false>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth, touched);
         a = b;
@@ -2349,7 +2364,7 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const RsRows R, const uint
 __global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, const uint32_t* __restrict__ chunk_fill,
                                                          const uint32_t* __restrict__ recw, const WideRec* __restrict__ rec, uint32_t kmask,
                                                          const uint32_t* __restrict__ O, uint32_t cap, uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec,
-                                                         uint32_t* __restrict__ counters) {
+                                                         uint32_t* __restrict__ counters, uint32_t packed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
     __shared__ uint32_t s_id[RS_JOB_CHUNKS], s_fill[RS_JOB_CHUNKS];
     RsJob job;
@@ -2421,7 +2436,7 @@ __global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, 
         for (uint32_t k = threadIdx.x; k < nb; k += CS_THREADS) cursor[k] += hist[k];
         for (uint32_t pp = threadIdx.x; pp < tile_n; pp += CS_THREADS) {
             const uint32_t d = st_dst[pp];
-            if (d < cap) { swrec[d] = st_rec[pp]; swkey[d] = st_key[pp]; }
+            if (d < cap) { swrec[d] = st_rec[pp]; if (!packed) swkey[d] = st_key[pp]; }      // (packed records carry their weight themselves)
             else atomicOr(&counters[KCTR_WIDE_OVERFLOW], 1u);            // the sorted arrays are too small: the call is repeated with larger ones
         }
         __syncthreads();
@@ -2495,7 +2510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAV
             const uint32_t bucket = key;
             if (rect_nbc) { it.X = bucket / rect_nbc; it.Y = bucket - it.X * rect_nbc; }      // db2db: stream = row block x column blocks + column block
             else { it.X = stream_row(bucket); it.Y = bucket - tri32(it.X); }
-            it.rect_cols = rect_cols;
+            it.rect_cols = rect_cols; it.pshift = 0;
             it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + p0 + a; it.skey = swkey + p0 + a; it.kbits = kbits; it.dbits = dbits; it.rec = nullptr; it.recw = nullptr;
         }
         k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth, touched);
@@ -2537,7 +2552,7 @@ __global__ __launch_bounds__(1024) void k2j_build_kernel(const uint32_t* __restr
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAVES, 8))) void k2_jobs_kernel(const uint32_t* __restrict__ swkey, const WideRec* __restrict__ swrec,
                                                         const uint32_t* __restrict__ start, const uint2* __restrict__ jobs, const uint32_t* __restrict__ n_jobs, uint32_t cap,
-                                                        uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, unsigned char* __restrict__ touched) {
+                                                        uint32_t limit, uint32_t pshift, uint32_t kbits, uint32_t dbits, uint32_t* __restrict__ M, uint32_t N, uint32_t bwidth, unsigned char* __restrict__ touched) {
     __shared__ uint32_t acc[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
     __shared__ unsigned long long lut_ff[256], lut_01[256];
@@ -2552,10 +2567,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2S_MIN_WAV
         lut_ff[threadIdx.x] = v;
         lut_01[threadIdx.x] = v & 0x0101010101010101ull;
     }
-    const uint32_t a = start[job.x] + job.y * K2J_REC, e = start[job.x + 1];
+    // (limit = slots of the sorted arrays: a call whose pools were too small sorted only what fitted — it is repeated with larger pools, and
+    // until then nothing beyond the arrays may be read)
+    const uint32_t e = start[job.x + 1] < limit ? start[job.x + 1] : limit;
+    uint32_t a = start[job.x] + job.y * K2J_REC;
+    a = a < e ? a : e;
     const uint32_t b = e - a > K2J_REC ? a + K2J_REC : e;
+    if (a == b) return;
     K2Item it;
-    it.X = stream_row(job.x); it.Y = job.x - tri32(it.X); it.rect_cols = 0;
+    it.X = stream_row(job.x); it.Y = job.x - tri32(it.X); it.rect_cols = 0; it.pshift = pshift;
     it.n_rec = b - a; it.count = (it.n_rec + 63u) / 64u; it.ids = nullptr; it.fills = nullptr; it.srec = swrec + a; it.skey = swkey + a; it.kbits = kbits; it.dbits = dbits;
     it.rec = nullptr; it.recw = nullptr;
     k2_run<true>(it, acc, &wor_sh, wbuf, lut_ff, lut_01, M, N, bwidth, touched);
@@ -2668,7 +2688,7 @@ inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, db->row_mode ? db->rec_pshift : 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -3020,6 +3040,9 @@ static int blocks_prepare_impl(kmdb_db* db) {
     if (const char* e = getenv("KMDB_DENSE")) db->dense_narrow = atoi(e) >= 2;
     db->row_mode = db->n_states > CS_MAX_KEYS;
     if (const char* e = getenv("KMDB_ROW_MODE")) if (*e) db->row_mode = atoi(e) != 0;          // (tests: small databases through the many-streams path)
+    // packed records: a block width of at most 54 leaves the column mask 10 spare bits and more — an 8-bit weight digit at least and the digit's
+    // index — so the records of the many-streams path travel as 16 bytes through the sort and the apply step (KMDB_REC_PACKED=0: 16 + 4, A/B)
+    db->rec_pshift = (db->row_mode && db->width <= 54u && !(getenv("KMDB_REC_PACKED") && getenv("KMDB_REC_PACKED")[0] == '0')) ? db->width : 0u;
     db->n_ckeys = db->n_states;                                  // keys of the grouped chunk table = the streams (row chunks sit in their rows' lists)
     {
         int key_bits = 1;
@@ -3386,14 +3409,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         // 18.7 ms against 16.5 for one — the two kernels do not complement each other.)
         HIP_TRY(hipFuncSetAttribute((const void*)rs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds(NB)));
         hipLaunchKernelGGL(rs_scatter_kernel, dim3((jobs + 7u) & ~7u), dim3(CS_THREADS), rs_scatter_lds(NB), st, R, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
-                           db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters);
+                           db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters, db->rec_pshift ? 1u : 0u);
         // the sorted records applied stream by stream (a long stream in parts of K2J_REC records): one write-back of a tile per job
         hipLaunchKernelGGL(k2j_starts_kernel, dim3((db->n_states + 1u + 255u) / 256u), dim3(256), 0, st, R, db->rs_offs, db->n_states, db->k2j_start);
         hipLaunchKernelGGL(k2j_build_kernel, dim3((db->n_states + 1023u) / 1024u), dim3(1024), 0, st, db->k2j_start, db->n_states, db->k2j_jobs, (uint32_t)db->k2j_cap, db->counters);
         k2jobs_launched = db->have_counts ? db->last_n_k2jobs : (uint32_t)db->k2j_cap;       // (the streams' lengths repeat exactly from call to call)
         if (k2jobs_launched)
             hipLaunchKernelGGL(k2_jobs_kernel, dim3(k2jobs_launched), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, db->k2j_start, db->k2j_jobs, db->counters + KCTR_K2JOBS,
-                               (uint32_t)db->k2j_cap, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, db->tile_touched);
+                               (uint32_t)db->k2j_cap, (uint32_t)db->sorted_cap, db->rec_pshift, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, db->tile_touched);
         HIP_TRY(hipGetLastError());
         if (stage("row sort+apply")) return 1;
     } else {

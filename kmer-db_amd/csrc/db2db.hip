@@ -175,23 +175,24 @@ __global__ __launch_bounds__(256) void d2_sets_round_kernel(D2Db db, uint32_t P,
 // One wave per pair, persistent waves.  COUNT: only the number of records (sizes the pool); else: records into the pool in
 // arrival order, slots taken GRAB at a time from one of 256 cursors (a shared cursor would serialise: same-address atomics).
 constexpr uint32_t D2_GRAB = 512, D2_CURSORS = 256;
+// 64-bit words of LDS one wave of the pair kernel needs: both bit sets, both compacted mask lists, both 16-bit index lists
+__host__ __device__ inline size_t d2_wave_words(uint32_t nbr, uint32_t nbc) { return (size_t)2 * (nbr + nbc) + ((size_t)(nbr + nbc) * 2 + 7) / 8; }
 struct D2Pool { uint32_t* wkey; ulonglong2* wrec; uint32_t* cursor; uint32_t region; uint32_t kbits, dbits; uint32_t* overflow; };
 template <bool COUNT, bool STORE>
 __global__ __launch_bounds__(256) void d2_emit_kernel(D2Db row, D2Db col, const unsigned long long* __restrict__ rsets, const unsigned long long* __restrict__ csets,
                                                       const unsigned long long* __restrict__ pairs, const uint32_t* __restrict__ counts,
                                                       uint32_t npairs, uint32_t nbr, uint32_t nbc, uint32_t cbits, D2Pool pool,
                                                       unsigned long long* __restrict__ n_records) {
-    extern __shared__ unsigned long long d2_lds[];          // per wave: row set [nbr], column set [nbc], then the non-empty blocks of each
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t per_wave = 2u * (nbr + nbc);
+    extern __shared__ unsigned long long d2_lds[];          // per wave: row set [nbr], column set [nbc], the non-empty blocks of each, their block indices
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;       // 1 .. 4 waves per workgroup, by the LDS a wave needs
+    const size_t per_wave = d2_wave_words(nbr, nbc);
     unsigned long long* rset = d2_lds + (size_t)wave * per_wave;
     unsigned long long* cset = rset + nbr;
     unsigned long long* rmask = cset + nbc;                   // compacted: mask of the a-th non-empty row block
     unsigned long long* cmask = rmask + nbr;
-    __shared__ uint16_t blkidx[4][2][1024];                   // ... and its block index (N <= 65535: at most 1024 blocks)
-    uint16_t* ridx = blkidx[wave][0];
-    uint16_t* cidx = blkidx[wave][1];
-    const uint32_t wid = blockIdx.x * 4u + wave, nwaves = gridDim.x * 4u;
+    uint16_t* ridx = (uint16_t*)(cmask + nbc);                // ... and its block index (a block index fits 16 bits up to 4 M samples)
+    uint16_t* cidx = ridx + nbr;
+    const uint32_t wid = blockIdx.x * wpb + wave, nwaves = gridDim.x * wpb;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long mine = 0;
     uint32_t next = 0, left = 0, sub = wid % D2_CURSORS;      // the wave's current grab of pool slots
@@ -360,7 +361,8 @@ static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmd
         return kmdb_set_error("kmdb_db2db_dense: both databases must be uploaded with hashtables");
     if (er.kmer_length != ec.kmer_length) return kmdb_set_error("kmdb_db2db_dense: the databases have different k-mer lengths");
     if (er.device != ec.device) return kmdb_set_error("kmdb_db2db_dense: the databases live on different devices");
-    if (er.N > KMDB_V1_MAX_SAMPLES || ec.N > KMDB_V1_MAX_SAMPLES) return kmdb_set_error("kmdb_db2db_dense: more than 65535 samples per database is not supported (16-bit block index of the pair kernel)");
+    // (sample ids take 20 bits here as everywhere: round 4's limit of 65 535 samples per part — a 16-bit block index array of fixed size in the
+    // pair kernel — is gone; what bounds a part now is the pair kernel's LDS and the 2^22 block pairs of the stream keys, checked below)
     D2_TRY(hipSetDevice(er.device));
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : (hipStream_t)er.stream;
     const uint64_t nr = er.N, nc = ec.N;
@@ -414,8 +416,12 @@ static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmd
             int key_bits = 1;
             while ((1ull << key_bits) <= (uint64_t)nbr * nbc + 1) ++key_bits;
             const uint32_t dbits = (uint32_t)(32 - key_bits - 2);
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nruns + 3) / 4, 256 * 8);
-            const size_t lds = (size_t)4 * 2 * (nbr + nbc) * 8;
+            if ((uint64_t)nbr * nbc + 1 >= (1ull << 22)) return kmdb_set_error("kmdb_db2db_dense: more than 2^22 block pairs (parts of " + std::to_string(nr) + " x " + std::to_string(nc) + " samples)");
+            const size_t wave_lds = d2_wave_words(nbr, nbc) * 8;
+            if (wave_lds > (size_t)(150u << 10)) return kmdb_set_error("kmdb_db2db_dense: the sample lists of a pattern pair do not fit the LDS (parts of " + std::to_string(nr) + " + " + std::to_string(nc) + " samples; about 540 000 in all is the limit)");
+            const uint32_t wpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150u << 10) / wave_lds));
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nruns + wpb - 1) / wpb, 256 * 8);
+            const size_t lds = wave_lds * wpb;
             // both parts' list stores, or neither (a wave that climbs one side's root paths gains nothing from the other's store)
             // (what the call allocates after the stores: six records of 20 bytes per pair, twice — the pool and the sort's copy — and slack)
             const uint64_t reserve = (uint64_t)nruns * 6 * 20 * 2 + (1ull << 30);
@@ -441,10 +447,10 @@ static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmd
                 if (attempt) {
                     D2_TRY(hipMemsetAsync(d_nrec.p, 0, 64 * 8 * 8, st));
                     if (store)
-                        hipLaunchKernelGGL((d2_emit_kernel<true, true>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                        hipLaunchKernelGGL((d2_emit_kernel<true, true>), dim3(grid), dim3(64 * wpb), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
                                            nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                     else
-                        hipLaunchKernelGGL((d2_emit_kernel<true, false>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                        hipLaunchKernelGGL((d2_emit_kernel<true, false>), dim3(grid), dim3(64 * wpb), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
                                            nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                     D2_TRY(hipGetLastError());
                     unsigned long long h_nrec[64 * 8];
@@ -455,7 +461,7 @@ static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmd
                 }
                 // per cursor: its share of the records and of the grab tails (up to 63 slots per grab), one unfinished grab per wave
                 // that ends there, and room for the uneven ends of the waves' round-robin over the cursors
-                const uint64_t grabs = (total + total / 8) / D2_GRAB / D2_CURSORS + (uint64_t)grid * 4 / D2_CURSORS + 130;
+                const uint64_t grabs = (total + total / 8) / D2_GRAB / D2_CURSORS + (uint64_t)grid * wpb / D2_CURSORS + 130;
                 const uint64_t region = grabs * D2_GRAB;
                 slots = region * D2_CURSORS;
                 if (slots >= (1ull << 31)) return kmdb_set_error("kmdb_db2db_dense: more than 2^31 block records");
@@ -466,10 +472,10 @@ static int db2db_impl(kmdb_db* db_row, kmdb_db* db_col, uint32_t* out, const kmd
                 D2_TRY(hipMemsetAsync(d_flag.as<uint32_t>() + 1, 0, 4, st));
                 pool.wkey = d_wkey.as<uint32_t>(); pool.wrec = d_wrec.as<ulonglong2>(); pool.region = (uint32_t)region;
                 if (store)
-                    hipLaunchKernelGGL((d2_emit_kernel<false, true>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                    hipLaunchKernelGGL((d2_emit_kernel<false, true>), dim3(grid), dim3(64 * wpb), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
                                        nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                 else
-                    hipLaunchKernelGGL((d2_emit_kernel<false, false>), dim3(grid), dim3(256), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
+                    hipLaunchKernelGGL((d2_emit_kernel<false, false>), dim3(grid), dim3(64 * wpb), lds, st, vr, vc, rsets, csets, d_uniq.as<unsigned long long>(), d_cnt.as<uint32_t>(),
                                        nruns, nbr, nbc, cbits, pool, d_nrec.as<unsigned long long>());
                 D2_TRY(hipGetLastError());
                 uint32_t ovf = 0;

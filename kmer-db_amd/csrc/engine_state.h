@@ -123,6 +123,8 @@ struct kmdb_db {
     // many streams ("row mode"): the wide records go to per-block-row chunks of the chunk pool; the chunk table grouped by key, then a
     // counting sort inside every row
     bool row_mode = false;
+    uint32_t rec_pshift = 0;        // many streams, block width <= 54: the weight digit of a block record lives in the spare bits of its column mask (from
+                                    // this bit on) and the record travels as 16 bytes; 0: 16 bytes of masks + the 4-byte key word
     uint32_t n_ckeys = 0;                              // keys of the chunk table: streams (+ block rows in row mode); n_ckeys = never opened
     uint32_t *ct_hist = nullptr, *ct_offs = nullptr, *ct_cursor = nullptr;   // [n_ckeys + 2]
     void* ct_tmp = nullptr;
