@@ -46,6 +46,8 @@ WORKLOADS = {
     # so only the 50 x 50 blocks on the diagonal are non-zero — configs[3]'s sample count, nnz = 1.2 M of 1.25 G cells
     "c4sparse": dict(samples=50000, clade_size=50, length=50_000, k=25, fraction=0.1, r1=0.75),
     "c5part": dict(samples=10000, clade_size=50, length=100_000, queries=1000),            # configs[4]: 1000 queries vs a 10 000-sample database
+    # configs[4] at one GPU's share of configs[2]'s database: 1000 queries vs 10 000 x 625 kbp (hashtables of 140 M k-mers: beyond the caches)
+    "c5gpu": dict(samples=10000, clade_size=50, length=625_000, queries=1000),
     "parts": dict(samples=2000, clade_size=50, length=300_000),                            # all2all-parts cell: two halves of one collection
 }
 MODE_WORKLOAD = {"all2all": "c2", "all2all-sp": "c4part", "new2all": "c5part", "db2db": "parts"}
@@ -538,7 +540,22 @@ def secondary_mode(args, K, S, device):
                 assert int(ns[kp[idx[hit]].to(torch.int64)].sum()) == int(got[i].astype(np.uint64).sum()), "row %d checksum mismatch" % i
             units, metric, unit = float(NQ), "new2all queries/sec (k-mer sets resident on the host, %d-sample database)" % N, "queries/s"
             cpu = None
-            if not args.no_cpu_baseline and O.have_ref():
+            # rows straight from the definition — |Q ∩ K_j| over the k-mer SETS, no pattern, table or tree involved — for 16 queries, on the
+            # queries' own clades and a spread over all samples
+            t1 = time.time()
+            spread = sorted(set(range(0, N, max(1, N // 400))))
+            checked = []
+            for qi in range(0, NQ, max(1, NQ // 16)):
+                c0 = chosen[qi * len(chosen) // NQ] * cs
+                cols = sorted(set(spread) | set(range(c0, min(N, c0 + cs))))
+                want = np.array([int(torch.isin(S.kmers_of(g.sample(j), k, f), qs_dev[qi]).sum()) for j in cols], dtype=np.uint32)
+                assert np.array_equal(got[qi][cols], want), "new2all row %d differs from the definition" % qi
+                checked.append(qi)
+            log("  rows of queries %s == |Q ∩ K_j| on %d samples each (%.0f s)" % (checked, len(cols), time.time() - t1))
+            big = int(d.P) > 40_000_000
+            if big:
+                log("  reference not run: writing its .db (patterns + hashtables of %d patterns) and its host image are beyond this run" % int(d.P))
+            if not args.no_cpu_baseline and O.have_ref() and not big:
                 path = os.path.join(td, "db.db")
                 S.write_db(path, k, f, [g.name(i) for i in range(N)], pat["sample_counts"], arr, kmers_count=int(pat["dictionary"].numel()), tables=tables)
                 # the reference's new2all the way its console runs it (console_new2all.cpp:64-95): T worker threads over ALL the queries, one
@@ -556,7 +573,8 @@ def secondary_mode(args, K, S, device):
                        "sample": "the same database, ALL %d queries through the reference's new2all compute (T worker threads, one one2all<false> per "
                                  "query, src/console_new2all.cpp:64-95; best of T in %s); all rows compared equal" % (NQ, [t for t, _ in tried])}
             cfg = {"workload": "%s: %d fresh strains (%d k-mers each) against %s, new2all dense" % (args.workload, NQ, int(np.mean([q.size for q in qs])), desc),
-                   "queries": NQ, "kmers_found": hits_total, "patterns": int(d.P)}
+                   "queries": NQ, "kmers_found": hits_total, "patterns": int(d.P), "rows_from_definition": checked,
+                   "hashtable_slots": int(tables[1].size)}
             kernel = "kmdb_new2all_batch: n2a_probe_kernel + pattern climb + row accumulation"
         else:
             ids_a, ids_b = list(range(0, N, 2)), list(range(1, N, 2))

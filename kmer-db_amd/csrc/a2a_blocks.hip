@@ -96,6 +96,7 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
+    uint32_t lane_atomics;         // (experiment) row mode: one LDS atomic per lane instead of one per run of lanes with the same row
     uint32_t pshift;               // row mode, != 0: packed records — the weight digit (and its index) sit in the column mask word from bit `pshift` (= the
                                    // block width) on, 64 - pshift - 2 bits of digit; the key word beside the record holds the stream only and stays behind in the sort
 };
@@ -270,6 +271,13 @@ __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const
     for (;;) {
         const unsigned long long onm = __ballot(on);
         if (!onm) break;
+        uint32_t p, e;
+        if (pv.lane_atomics) {
+            // (experiment, round 5) every lane its own LDS atomic: lanes of the same row collide in the LDS unit instead of being grouped by
+            // the ~50 VALU instructions below
+            e = on ? R.end[X] : 0u;
+            p = on ? atomicAdd(&R.pos[X], 1u) : 0u;
+        } else {
         // runs of consecutive lanes with the same row: the first lane of a run reserves for all of it
         const uint32_t pX = (uint32_t)__shfl_up((int)X, 1, WAVE);
         const bool lead = on && (lane == 0u || !((onm >> (lane - 1u)) & 1ull) || pX != X);
@@ -283,8 +291,9 @@ __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const
         }
         uint32_t old = 0, end = 0;
         if (lead) { end = R.end[X]; old = atomicAdd(&R.pos[X], cnt); }
-        uint32_t p = (uint32_t)__shfl((int)old, (int)ll, WAVE) + (lane - ll);
-        const uint32_t e = (uint32_t)__shfl((int)end, (int)ll, WAVE);
+        p = (uint32_t)__shfl((int)old, (int)ll, WAVE) + (lane - ll);
+        e = (uint32_t)__shfl((int)end, (int)ll, WAVE);
+        }
         bool ovf = on && p >= e;
         unsigned long long pend = __ballot(ovf);
         while (pend) {
@@ -597,174 +606,6 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     if (npairs > 1) q.pair_ofs[i] = out;
 }
 
-// The short nodes (l <= 32 ids, stream <= 128 bits: 94 % of all) WITHOUT the in-block re-deal, NPT nodes per thread.  The re-dealing launch above
-// spends its time waiting, not computing (round 4 counters: VALU busy 12 % of the wave time, 71 % waiting): a wave runs four
-// dependent round trips — header, re-dealt header + stream position, stream words, pair reservation — with three barriers in between.
-// Here a thread takes node t of NPT consecutive 256-node windows: all headers in one round trip, all stream words in the next, one pair
-// reservation per wave for all of them; lanes of a wave run decode loops of different lengths (the re-deal evened them out), which costs
-// issue slots the kernel has to spare.
-struct K0Short {
-    uint32_t npairs, blk0, need, bit0, span;
-    unsigned long long mask0, m1, m2;
-    bool second_pass;
-};
-template <int NPT>
-__global__ __launch_bounds__(256) void k0_short_direct_kernel(const K0Params q) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const BlockMap bm = q.bm;
-    const unsigned long long wm = bm.width == 64 ? ~0ull : (1ull << bm.width) - 1ull;
-    using Cursor = RunCursor32<6, false>;
-    uint32_t idx[NPT], l[NPT], last[NPT];
-    uint64_t pos[NPT];
-    bool live[NPT];
-    uint2 km[NPT];
-    uint32_t rel[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        idx[j] = (blockIdx.x * NPT + j) * 256u + threadIdx.x;
-        live[j] = idx[j] < q.P;
-        km[j] = live[j] ? q.k0in[idx[j]] : make_uint2(0u, 0u);
-        rel[j] = live[j] ? q.bitrel[idx[j]] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        l[j] = kmdb_k0_l(km[j]); last[j] = kmdb_k0_last(km[j]);
-        if (kmdb_long_node(l[j], kmdb_k0_bits(km[j]), q.short_ids)) live[j] = false;          // the long launch's
-        pos[j] = live[j] && l[j] > 1u ? q.blkbase[idx[j] >> 8] + rel[j] : 0ull;
-    }
-    // the stream words of all NPT nodes under way before the first decode loop
-    uint32_t cw[NPT][6];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const uint32_t* b32 = (const uint32_t*)q.bits;
-        const uint64_t u0 = pos[j] >> 5;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cw[j][k] = (live[j] && l[j] > 1u) ? b32[(u0 + k) ^ 1ull] : 0u;
-    }
-    K0Short r[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        K0Short s{0u, 0u, 0u, 0u, 0u, 0ull, 0ull, 0ull, false};
-        if (live[j] && l[j] == 1u) {
-            s.blk0 = bm.blk(last[j]); s.mask0 = 1ull << bm.bit(last[j], s.blk0); s.npairs = 1;
-        } else if (live[j] && l[j]) {
-            // the list relative to its (still unknown) first id, as in k0_decode_kernel (pattern_t::decodeSamples, reference src/pattern.cpp:99-109)
-            unsigned long long R = 1ull;
-            uint32_t span = 0;
-            {
-                Cursor c(Cursor::Preloaded{}, pos[j]);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) c.c[k] = cw[j][k];
-                uint32_t rem = l[j] - 1u;
-                while (rem) {
-                    uint32_t z, v;
-                    c.step(rem, z, v);
-                    if (z) {
-                        if (span + z < 64u) R |= ((2ull << (z - 1)) - 1ull) << (span + 1);
-                        span += z; rem -= z;
-                    }
-                    if (v) {
-                        span += v; --rem;
-                        if (span < 64u) R |= 1ull << span;
-                    }
-                }
-            }
-            const uint32_t id0 = last[j] - span;
-            s.span = span;
-            s.blk0 = bm.blk(id0);
-            s.bit0 = bm.bit(id0, s.blk0);
-            if (span < 64u) {
-                const uint32_t bit0 = s.bit0;
-                const unsigned long long lo = R << bit0, hi = bit0 ? R >> (64u - bit0) : 0ull;
-                auto ext = [&](uint32_t sh) -> unsigned long long {
-                    return sh == 0 ? lo : sh < 64u ? ((lo >> sh) | (hi << (64u - sh))) : sh == 64u ? hi : sh < 128u ? (hi >> (sh - 64u)) : 0ull;
-                };
-                s.mask0 = lo & wm;
-                s.m1 = ext(bm.width) & wm; s.m2 = ext(2 * bm.width) & wm;
-                s.npairs = 1u + (s.m1 != 0) + (s.m2 != 0);
-                s.need = s.npairs - 1u;
-            } else {
-                s.second_pass = true;
-                s.need = bm.blk(last[j]) - s.blk0;
-                s.need = s.need < l[j] - 1u ? s.need : l[j] - 1u;
-            }
-        }
-        r[j] = s;
-    }
-    // one reservation per wave for the extra pairs of all its nodes
-    uint32_t need_all = 0;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) need_all += r[j].need;
-    uint32_t out = 0;
-    bool lost = false;
-    {
-        const uint32_t incl = wave_incl_scan(need_all, lane);
-        const uint32_t total = bcast(incl, WAVE - 1);
-        if (total) {
-            const uint32_t region = (blockIdx.x * 4u + (threadIdx.x >> 6)) % q.n_regions;
-            uint32_t base = 0;
-            if (lane == WAVE - 1) base = atomicAdd(&q.pair_cursor[region * 16u], total);
-            base = bcast(base, WAVE - 1);
-            if (base + total <= q.region_cap) out = region * q.region_cap + base + (incl - need_all);
-            else {
-                uint32_t sb = 0;
-                if (lane == WAVE - 1) sb = atomicAdd(&q.pair_cursor[q.n_regions * 16u], total);
-                sb = bcast(sb, WAVE - 1);
-                if (sb + total <= q.spill_cap) out = q.n_regions * q.region_cap + sb + (incl - need_all);
-                else { if (lane == 0) atomicOr(&q.counters[KCTR_PAIR_OVERFLOW], 1u); lost = true; }     // results invalid; the call is repeated with a larger pool
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        if (!live[j]) continue;
-        K0Short s = r[j];
-        const uint32_t i = idx[j];
-        if (lost) { s.second_pass = false; s.npairs = s.npairs ? 1u : 0u; s.m1 = s.m2 = 0; }
-        if (!s.second_pass) {
-            if (s.m1) { q.pair_blk[out] = (uint16_t)(s.blk0 + 1); q.pair_mask[out] = s.m1; }
-            if (s.m2) { const uint32_t o2 = out + (s.m1 != 0); q.pair_blk[o2] = (uint16_t)(s.blk0 + 2); q.pair_mask[o2] = s.m2; }
-        } else {
-            // a list that spans 64 ids or more: second walk with absolute ids (the stream words again from the cache)
-            Cursor c(q.bits, pos[j]);
-            uint32_t o = out;
-            uint32_t curblk = s.blk0, bit = s.bit0, rem = l[j] - 1u;
-            unsigned long long acc = 1ull << s.bit0;
-            auto flush = [&]() {
-                if (s.npairs == 0) s.mask0 = acc;
-                else { q.pair_blk[o] = (uint16_t)curblk; q.pair_mask[o] = acc; ++o; }
-                ++s.npairs;
-            };
-            while (rem) {
-                uint32_t z, v;
-                c.step(rem, z, v);
-                if (z) {
-                    rem -= z;
-                    while (z) {
-                        const uint32_t room = bm.width - 1u - bit;
-                        const uint32_t tk = z < room ? z : room;
-                        if (tk) { acc |= ((2ull << (tk - 1)) - 1ull) << (bit + 1); bit += tk; z -= tk; }
-                        if (z) { flush(); ++curblk; acc = 1ull; bit = 0; --z; }
-                    }
-                }
-                if (v) {
-                    const uint32_t id = curblk * bm.width + bit + v;
-                    --rem;
-                    const uint32_t blk = bm.blk(id);
-                    if (blk != curblk) { flush(); curblk = blk; acc = 0; }
-                    bit = bm.bit(id, blk);
-                    acc |= 1ull << bit;
-                }
-            }
-            flush();
-        }
-        q.p0_mask[i] = s.mask0;
-        q.p0_info[i] = s.blk0 | (s.npairs << 16);
-        if (s.npairs > 1) q.pair_ofs[i] = out;
-        out += r[j].need;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // K1n: the DFS stream, nodes with at most two blocks
 // ------------------------------------------------------------------------------------------
@@ -820,10 +661,9 @@ __host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tb
     return (((size_t)chain_cap * 20 + 15) & ~(size_t)15) + arena_table_bytes(tbits, n_states) + rowtab_bytes(n_rows);          // n_rows: 0 unless row mode
 }
 
-// PIPE (experiment, round 5): 0 = the node records of the next batch are fetched while this one is processed, the second pair of a node
-// behind its p0_info and pair_ofs (three dependent round trips inside the fetch); 1 = two batches ahead for the records (pair_ofs read
-// unconditionally with them), one batch ahead for the second pairs — no load of the loop waits on another load of the same iteration.
-template <int PIPE>
+// The node records are fetched TWO batches ahead (pair_ofs read unconditionally with them), the second pairs one batch ahead: no load of
+// the loop waits on another load of the same iteration.  (Round 4 fetched one batch ahead, the second pair of a node behind its p0_info and
+// pair_ofs — three dependent round trips inside the fetch: 0.07 - 0.2 ms slower, profiles/r05_j3 / r05_j4.)
 __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
@@ -879,21 +719,9 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     uint32_t nx_nl = 0, nx_w = 0, nx_info = 0, nx_df = 0, nx_e1b = BNONE, nx_po = 0;
     int32_t nx_par = -1;
     unsigned long long nx_m0 = 0, nx_e1m = 0;
-    uint32_t n2_nl = 0, n2_w = 0, n2_info = 0, n2_df = 0x7FFFu, n2_po = 0;          // PIPE: two batches ahead
+    uint32_t n2_nl = 0, n2_w = 0, n2_info = 0, n2_df = 0x7FFFu, n2_po = 0;          // two batches ahead
     int32_t n2_par = -1;
     unsigned long long n2_m0 = 0;
-    auto fetch = [&](uint32_t b0) {
-        const uint32_t ii = b0 + lane;
-        const bool v = ii < end;
-        nx_nl = v ? q.nl[ii] : 0u;
-        nx_w = v ? q.w[ii] : 0u;
-        nx_par = v ? q.parent[ii] : -1;
-        nx_df = v ? q.dflag[ii] : 0x7FFFu;
-        nx_info = v ? q.p0_info[ii] : 0u;
-        nx_m0 = v ? q.p0_mask[ii] : 0ull;
-        nx_e1b = BNONE; nx_e1m = 0;
-        if ((nx_info >> 16) > 1u) { const uint32_t po = q.pair_ofs[ii]; nx_e1b = q.pair_blk[po]; nx_e1m = q.pair_mask[po]; }
-    };
     auto fetch2 = [&](uint32_t b0) {                                  // (pair_ofs of a node without further pairs is never written: whatever is read is not used)
         const uint32_t ii = b0 + lane;
         const bool v = ii < end;
@@ -910,10 +738,8 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         nx_e1b = BNONE; nx_e1m = 0;
         if ((nx_info >> 16) > 1u) { nx_e1b = q.pair_blk[nx_po]; nx_e1m = q.pair_mask[nx_po]; }
     };
-    if (PIPE) {
-        fetch2(first); advance();
-        if (first + WAVE < end) fetch2(first + WAVE); else { n2_nl = 0; n2_w = 0; n2_par = -1; n2_df = 0x7FFFu; n2_info = 0; n2_m0 = 0; n2_po = 0; }
-    } else fetch(first);
+    fetch2(first); advance();
+    if (first + WAVE < end) fetch2(first + WAVE); else { n2_nl = 0; n2_w = 0; n2_par = -1; n2_df = 0x7FFFu; n2_info = 0; n2_m0 = 0; n2_po = 0; }
     WaveArena A;
     arena_init(A, table, q.tbits, q.n_keys, seg, lane);
     for (uint32_t base = first; base < end; base += WAVE) {
@@ -922,12 +748,10 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         const uint32_t nl = nx_nl, w = nx_w, info = nx_info, df = nx_df, e1b = nx_e1b;
         const int32_t par = nx_par;
         const unsigned long long m0 = nx_m0, e1m = nx_e1m;
-        if (PIPE) {
-            if (base + WAVE < end) {
-                advance();
-                if (base + 2 * WAVE < end) fetch2(base + 2 * WAVE); else { n2_nl = 0; n2_w = 0; n2_par = -1; n2_df = 0x7FFFu; n2_info = 0; n2_m0 = 0; n2_po = 0; }
-            }
-        } else if (base + WAVE < end) fetch(base + WAVE);
+        if (base + WAVE < end) {
+            advance();
+            if (base + 2 * WAVE < end) fetch2(base + 2 * WAVE); else { n2_nl = 0; n2_w = 0; n2_par = -1; n2_df = 0x7FFFu; n2_info = 0; n2_m0 = 0; n2_po = 0; }
+        }
         const uint32_t dep = df & 0x7FFFu;
         NSum S = locals(info, m0, e1b, e1m);
         if (valid && par >= 0 && par < (int32_t)base) {
@@ -1144,11 +968,12 @@ struct K1WLds {
     uint16_t* own_ox;              // [64] first copy of the lane's further own pairs in ox_*, 0xFFFF: not copied (read from the pair pool)
     uint16_t* ox_blk;              // [K1W_OXCAP]
     uint16_t* st_start;            // [64] first arena entry of the lane's row
+    uint16_t* st_pre;              // [64] entries of the lane's list that are NOT in its row: they are the first st_pre entries of the chain list
     unsigned char* own_base;       // [64] WB_*
 };
 __host__ __device__ inline size_t k1w_core_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
     const size_t b = (size_t)8 * (arena_cap + e_cap + chain_cap + 64 + K1W_OXCAP) + (size_t)4 * (chain_cap + 3 * 64 + K1W_QCAP) +
-                     (size_t)2 * (arena_cap + e_cap + chain_cap + 6 * 64 + K1W_OXCAP) + 64;
+                     (size_t)2 * (arena_cap + e_cap + chain_cap + 7 * 64 + K1W_OXCAP) + 64;
     return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t k1w_wave_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap, uint32_t n_rows) {
@@ -1160,7 +985,7 @@ __device__ __forceinline__ K1WLds k1w_carve(unsigned char* p, uint32_t arena_cap
     L.ox_mask = L.own_m0 + 64;
     L.ch_node = (uint32_t*)(L.ox_mask + K1W_OXCAP);  L.own_po = L.ch_node + chain_cap;  L.own_node = L.own_po + 64;  L.st_w = L.own_node + 64;  L.queue = L.st_w + 64;
     L.ent_blk = (uint16_t*)(L.queue + K1W_QCAP);  L.e_blk = L.ent_blk + arena_cap;  L.ch_len = L.e_blk + e_cap;  L.own_b0 = L.ch_len + chain_cap;
-    L.own_np = L.own_b0 + 64;  L.own_link = L.own_np + 64;  L.st_start = L.own_link + 64;  L.own_ox = L.st_start + 64;  L.ox_blk = L.own_ox + 64;
+    L.own_np = L.own_b0 + 64;  L.own_link = L.own_np + 64;  L.st_start = L.own_link + 64;  L.st_pre = L.st_start + 64;  L.own_ox = L.st_pre + 64;  L.ox_blk = L.own_ox + 64;
     L.own_base = (unsigned char*)(L.ox_blk + K1W_OXCAP);
     return L;
 }
@@ -1230,9 +1055,10 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 const uint32_t j = (uint32_t)__builtin_ctzll(hb);
                 hb &= hb - 1ull;
                 const uint32_t mj = bcast(m, j), wj = bcast(wv, j);
-                const uint32_t stj = L.st_start[j];
-                const unsigned long long* cmask = L.ent_mask + stj;
-                const uint16_t* cblk = L.ent_blk + stj;
+                const uint32_t stj = L.st_start[j], prej = L.st_pre[j];
+                // entry e of the node's list: the first prej from the chain list, the others from its row
+                auto cmask = [&](uint32_t e) -> unsigned long long { return e < prej ? L.e_mask[e] : L.ent_mask[stj + e - prej]; };
+                auto cblk = [&](uint32_t e) -> uint32_t { return e < prej ? (uint32_t)L.e_blk[e] : (uint32_t)L.ent_blk[stj + e - prej]; };
                 if (q.l2.on && mj >= q.l2.min_blocks) {
                     // second level: the node's entries instead of its records
                     const uint32_t sub = wid % L2_SUB;
@@ -1259,8 +1085,8 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     const uint32_t g = l2_gnext;
                     ++l2_gnext; --l2_gstock;
                     for (uint32_t e = lane; e < mj; e += WAVE) {
-                        const uint32_t idx = l2_enext + e, blk = cblk[e];
-                        q.l2.ent_g[idx] = g; q.l2.ent_blk[idx] = (uint16_t)blk; q.l2.ent_mask[idx] = cmask[e];
+                        const uint32_t idx = l2_enext + e, blk = cblk(e);
+                        q.l2.ent_g[idx] = g; q.l2.ent_blk[idx] = (uint16_t)blk; q.l2.ent_mask[idx] = cmask(e);
                         atomicOr(&q.l2.bitmap[(size_t)blk * q.l2.W + (g >> 6)], 1ull << (g & 63u));
                     }
                     l2_enext += mj; l2_estock -= mj;
@@ -1280,9 +1106,9 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                         while (tri32(a) > t) --a;
                         while (tri32(a + 1u) <= t) ++a;
                         const uint32_t b = t - tri32(a);
-                        FX = cmask[a]; FY = cmask[b];
-                        X = cblk[a];
-                        const uint32_t Y = cblk[b];
+                        FX = cmask(a); FY = cmask(b);
+                        X = cblk(a);
+                        const uint32_t Y = cblk(b);
                         rec_on = a != b || __popcll(FX) >= 2;
                         if (a == b) FY = FX;
                         stream = tri32(X) + Y;
@@ -1318,10 +1144,10 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 while (tri32(a) > r0) --a;
                 while (tri32(a + 1u) <= r0) ++a;
                 const uint32_t b = r0 - tri32(a);
-                const uint32_t st = L.st_start[own];
-                FX = L.ent_mask[st + a]; FY = L.ent_mask[st + b];
-                X = L.ent_blk[st + a];
-                const uint32_t Y = L.ent_blk[st + b];
+                const uint32_t st = L.st_start[own], pre = L.st_pre[own];
+                FX = a < pre ? L.e_mask[a] : L.ent_mask[st + a - pre]; FY = b < pre ? L.e_mask[b] : L.ent_mask[st + b - pre];
+                X = a < pre ? (uint32_t)L.e_blk[a] : (uint32_t)L.ent_blk[st + a - pre];
+                const uint32_t Y = b < pre ? (uint32_t)L.e_blk[b] : (uint32_t)L.ent_blk[st + b - pre];
                 ww = L.st_w[own];
                 diag = a == b;
                 rec_on = !diag || __popcll(FX) >= 2;               // a diagonal record needs two ids to have a pair
@@ -1425,7 +1251,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             unsigned long long lm = m0;
             if (np > 1u) { lb = q.pair_blk[po + np - 2u]; lm = q.pair_mask[po + np - 2u]; }
             // ---- where the parent's list comes from
-            uint32_t base = WB_NONE, link = 0;
+            uint32_t base = WB_NONE, link = 0, pre0 = 0;
             LSum Pb = lsum_none();
             if (valid && par >= 0) {
                 if (!iswide((uint32_t)par)) {
@@ -1440,6 +1266,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                         if (link < q.chain_cap && L.ch_node[link] == (uint32_t)par) {
                             const uint32_t cl = L.ch_len[link];
                             Pb = LSum{L.ch_last[link], cl, 0u, cl ? (uint32_t)L.e_blk[cl - 1u] : BLK_NONE};
+                            pre0 = cl ? cl - 1u : 0u;              // all but the last entry of the chain node's list are taken from the chain list where they are
                         } else { base = WB_NONE; ++n_miss; }         // cannot happen (the engine treats it as an internal error)
                     }
                 }
@@ -1447,16 +1274,21 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             // ---- entries of every node's list: own stretch below the base, in-batch parents by pointer doubling
             LSum S = np ? LSum{lm, np, b0, lb} : lsum_none();
             if (base != WB_LANE) S = lsum_merge(Pb, S);
+            // (pre: the shared prefix of the lane's TOPMOST in-batch ancestor — the lane whose base is not another lane)
+            uint32_t pre = pre0;
             {
                 int pl = base == WB_LANE ? (int)link : -1;
                 while (__ballot(pl >= 0)) {
                     const int src = pl >= 0 ? pl : (int)lane;
                     const LSum o = lsum_shfl(S, src);
                     const int opl = __shfl(pl, src, WAVE);                // -1 once that lane's stretch reaches its base
-                    if (pl >= 0) { S = lsum_merge(o, S); pl = opl; }
+                    const uint32_t opre = (uint32_t)__shfl((int)pre, src, WAVE);
+                    if (pl >= 0) { S = lsum_merge(o, S); pl = opl; pre = opre; }
                 }
             }
             const uint32_t len = valid ? S.c : 0u;
+            pre = valid ? pre : 0u;
+            const uint32_t slen = len - pre;                               // entries of the lane's row
             L.own_np[lane] = (uint16_t)np; L.own_b0[lane] = (uint16_t)b0; L.own_m0[lane] = m0; L.own_po[lane] = po;
             L.own_base[lane] = (unsigned char)base; L.own_link[lane] = (uint16_t)link; L.own_node[lane] = node;
             {
@@ -1475,7 +1307,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             const bool need = valid && (act || lane == nv - 1u);
             uint32_t fin = 0, last_start = 0;
             while (fin < nv) {
-                const uint32_t c = (lane >= fin && need) ? len : 0u;
+                const uint32_t c = (lane >= fin && need) ? slen : 0u;
                 const uint32_t incl = wave_incl_scan(c, lane);
                 const unsigned long long over = __ballot(incl > q.arena_cap);
                 uint32_t hi = over ? (uint32_t)__builtin_ctzll(over) : (uint32_t)WAVE;
@@ -1484,7 +1316,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 const uint32_t start = incl - c;
                 if (on) {
                     // fill the row right to left: own pairs, the in-batch parents' pairs, then the base
-                    uint32_t pos = start + len, cur = 0xFFFFFFFFu;
+                    uint32_t pos = start + slen, cur = 0xFFFFFFFFu;
                     auto rpush = [&](uint32_t blk, unsigned long long mask) {
                         if (blk == cur) L.ent_mask[pos] |= mask;
                         else { --pos; L.ent_blk[pos] = (uint16_t)blk; L.ent_mask[pos] = mask; cur = blk; }
@@ -1510,14 +1342,16 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                             if ((fb >> 16) != BLK_NONE) rpush(fb >> 16, fm.y);
                             if ((fb & 0xFFFFu) != BLK_NONE) rpush(fb & 0xFFFFu, fm.x);
                         } else if (yb == WB_CHAIN) {
+                            // the chain node's last entry (its mask may be the node's own: a deeper chain node can have more ids in that
+                            // block); the entries before it stay in the chain list, shared by every lane that hangs below this node
                             const uint32_t cs = L.own_link[y];
                             const uint32_t cl = L.ch_len[cs];
-                            for (uint32_t e = cl; e-- > 0u;) rpush(L.e_blk[e], e + 1u == cl ? L.ch_last[cs] : L.e_mask[e]);
+                            if (cl) rpush(L.e_blk[cl - 1u], L.ch_last[cs]);
                         }
                         break;
                     }
                 }
-                L.st_start[lane] = (uint16_t)start;
+                L.st_start[lane] = (uint16_t)start; L.st_pre[lane] = (uint16_t)pre;
                 if (lane == nv - 1u && on) last_start = start;
                 lds_sync();
                 PT(2);
@@ -1535,8 +1369,9 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 uint32_t later = (uint32_t)__shfl_down((int)mdep, 1, WAVE);
                 if (lane == (uint32_t)WAVE - 1u) later = 0xFFFFFFFFu;
                 if (valid && dep < later && dep - 1u < q.chain_cap) { L.ch_node[dep - 1u] = node; L.ch_len[dep - 1u] = (uint16_t)len; L.ch_last[dep - 1u] = S.lm; }
-                const uint32_t ll = bcast(len, nv - 1u), ls = bcast(last_start, nv - 1u);
-                for (uint32_t e = lane; e < ll; e += WAVE) { L.e_blk[e] = L.ent_blk[ls + e]; L.e_mask[e] = L.ent_mask[ls + e]; }
+                // the last node's list becomes the chain list: its first entries are there already, its row follows them
+                const uint32_t ll = bcast(slen, nv - 1u), ls = bcast(last_start, nv - 1u), lp = bcast(pre, nv - 1u);
+                for (uint32_t e = lane; e < ll; e += WAVE) { L.e_blk[lp + e] = L.ent_blk[ls + e]; L.e_mask[lp + e] = L.ent_mask[ls + e]; }
                 lds_sync();
                 PT(6);
             }
@@ -1986,7 +1821,7 @@ void l2_join_apply_kernel(const unsigned long long* __restrict__ B, const uint32
     }
 }
 
-constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup at most; the launch picks 16 (few streams: measured better) or 32
+constexpr uint32_t K2_WIN = 64;            // sorted chunks per workgroup at most; the launch picks 16 (few streams: measured better) or 32
 constexpr int K2A_MIN_WAVES = 3;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAVES, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
                                                        const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
@@ -2688,7 +2523,7 @@ inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, db->row_mode ? db->rec_pshift : 0u};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, getenv("KMDB_ROW_LANE_ATOMICS") ? 1u : 0u, db->row_mode ? db->rec_pshift : 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -3195,12 +3030,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         // three quarters of the pool in sub-pools, the rest shared
         q.pair_cursor = db->pair_cursor; q.n_regions = nreg; q.region_cap = (uint32_t)(db->pair_cap * 3 / 4 / nreg);
         q.spill_cap = (uint32_t)(db->pair_cap - (uint64_t)q.region_cap * nreg); q.counters = db->counters;
-        // KMDB_K0V (experiment, round 5): 0 the re-dealing launch, 1 / 2 / 4 the direct launch with that many nodes per thread
-        static const int k0v = getenv("KMDB_K0V") ? atoi(getenv("KMDB_K0V")) : 0;
-        if (k0v == 1) hipLaunchKernelGGL((k0_short_direct_kernel<1>), dim3((P + 255) / 256), dim3(256), 0, st, q);
-        else if (k0v == 2) hipLaunchKernelGGL((k0_short_direct_kernel<2>), dim3((P + 511) / 512), dim3(256), 0, st, q);
-        else if (k0v == 4) hipLaunchKernelGGL((k0_short_direct_kernel<4>), dim3((P + 1023) / 1024), dim3(256), 0, st, q);
-        else hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
+        hipLaunchKernelGGL((k0_decode_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, st, q);
         if (db->n_long) {
             q.perm = db->long_nodes; q.P = db->n_long;
             hipLaunchKernelGGL((k0_decode_kernel<true>), dim3((db->n_long + 255) / 256), dim3(256), 0, st, q);
@@ -3223,14 +3053,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         const size_t wave_lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys, row_mode ? db->NB : 0u);
         const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(K1N_WAVES, (144u << 10) / wave_lds));
         const size_t lds = wave_lds * waves;
-        static const int k1nv = getenv("KMDB_K1NV") ? atoi(getenv("KMDB_K1NV")) : 0;       // (experiment, round 5)
-        if (k1nv) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k1n_kernel<1>, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
-        } else {
-            HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k1n_kernel<0>, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
-        }
+        HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
         HIP_TRY(hipGetLastError());
     }
     if (stage("narrow emit")) return 1;
@@ -3251,7 +3075,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             rocprim::transform_iterator<uint32_t*, U32toU64, unsigned long long> it(db->chunk_fill, U32toU64());
             HIP_TRY(prim::sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
         }
-        const uint32_t win = db->n_states <= CS_MAX_KEYS ? K2_WIN / 2 : K2_WIN;
+        uint32_t win = db->n_states <= CS_MAX_KEYS ? 16u : 32u;
+        if (const char* e = getenv("KMDB_K2_WIN")) win = std::max(4u, std::min<uint32_t>(K2_WIN, (uint32_t)atoi(e)));       // (experiment, round 5)
         uint32_t grid = (pool_cap + win - 1) / win;
         if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + win - 1) / win);
         if (grid)

@@ -56,7 +56,7 @@ struct kmdb_db {
     uint64_t* blkbase = nullptr;    // [P / 256]
     uint64_t* bits = nullptr;       // gamma streams bit-packed back to back
     uint64_t n_bit_words = 0;
-    uint32_t short_max_ids = 32;                    // (= KMDB_SHORT_MAX_IDS) local lists of more ids (or of more than KMDB_SHORT_MAX_BITS stream bits) are decoded by the long launch
+    uint32_t short_max_ids = 48;                    // (= KMDB_SHORT_MAX_IDS) local lists of more ids (or of more than KMDB_SHORT_MAX_BITS stream bits) are decoded by the long launch
     uint32_t* nl = nullptr;         // [P] n = ids of the node's full list
     int32_t* parent = nullptr;      // [P] DFS index of the parent, -1 for roots
     uint32_t* w = nullptr;          // [P+1] on-disk num_kmers truncated to u32 (last = 0); a prefix shard keeps only its own k-mers
@@ -229,7 +229,7 @@ __host__ __device__ inline uint2 kmdb_k0_pack(uint32_t l, uint32_t last, uint32_
 __host__ __device__ inline uint32_t kmdb_k0_l(uint2 km) { return km.x & (KMDB_MAX_SAMPLES - 1u); }
 __host__ __device__ inline uint32_t kmdb_k0_last(uint2 km) { return km.y & (KMDB_MAX_SAMPLES - 1u); }
 __host__ __device__ inline uint32_t kmdb_k0_bits(uint2 km) { return ((km.x >> KMDB_ID_BITS) << 12) | (km.y >> KMDB_ID_BITS); }
-constexpr uint32_t KMDB_SHORT_MAX_IDS = 32, KMDB_SHORT_MAX_BITS = 128;     // (ids: the default of kmdb_db.short_max_ids, KMDB_SHORT_IDS at upload)
+constexpr uint32_t KMDB_SHORT_MAX_IDS = 48, KMDB_SHORT_MAX_BITS = 128;     // (ids: the default of kmdb_db.short_max_ids, KMDB_SHORT_IDS at upload.  Measured, profiles/r05_j4: 32 -> 48 ids takes 0.14 ms off the decode at c2 and 0.5 ms at 10 000 samples — the lists of a clade of 50 fit —, 56 and 64 lose: the short launch walks a list that spans 64 ids or more twice)
 __host__ __device__ inline bool kmdb_long_node(uint32_t l, uint32_t num_bits, uint32_t max_ids) { return l > max_ids || num_bits > KMDB_SHORT_MAX_BITS; }
 constexpr int KMDB_CHAIN_MAX = 4096;  // longest root path (in nodes) the chain table of the narrow kernel holds (20 B of LDS per node and wave:
                                       // the deeper the tree, the fewer waves share a workgroup)

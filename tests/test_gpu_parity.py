@@ -317,6 +317,37 @@ def test_db2db_large_parts(K, O, dev, tmp_path, N, L, near):
     assert np.array_equal(da.db2db(db_), got.T)
 
 
+def test_db2db_with_more_than_65535_samples(K, O, dev, tmp_path):
+    """all2all-parts with a part of 66 000 samples (reference: 32-bit sample ids, src/types.h:15-18; src/console_all2all_parts.cpp:159-226): round
+    4's pair kernel kept its block indices in a fixed 1024-entry LDS array and refused.  Two pattern forests with fabricated k-mer
+    dictionaries that overlap in part (db2db looks k-mers up, it never extracts them), both directions against the oracle."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    rng = np.random.default_rng(660)
+    k = 18
+
+    def part(N, P, max_local, pool, n_kmers, path):
+        pat = _random_forest(rng, N, P, max_local, chain_frac=0.4)
+        pids = np.sort(rng.integers(1, P, size=n_kmers))
+        pat["num_kmers"] = torch.from_numpy(np.bincount(pids, minlength=P).astype(np.int64))
+        kmers = np.sort(pool[:n_kmers])
+        arr = S.to_view_arrays(pat)
+        tables = S.build_hashtables(torch.from_numpy(kmers.astype(np.int64)), torch.from_numpy(rng.permutation(pids).astype(np.int64)), k)
+        S.write_db(path, k, 1.0, ["s%d" % i for i in range(N)], [1] * N, arr, kmers_count=n_kmers, tables=tables)
+        return K.DeviceDB(K.HostDB(path), device=dev, with_hashtables=True), O.OracleDB(path)
+
+    universe = rng.choice(1 << 36, size=9000, replace=False).astype(np.uint64)
+    pa, pb = str(tmp_path / "a.db"), str(tmp_path / "b.db")
+    da, oa = part(66000, 2500, 400, universe, 6000, pa)                      # k-mers universe[0 .. 6000)
+    db_, ob = part(700, 600, 60, universe[3000:], 5000, pb)                  # k-mers universe[3000 .. 8000): 3000 shared
+    assert int(da.N) == 66000
+    got = db_.db2db(da)
+    exp = ob.db2db(oa)
+    assert got.shape == (700, 66000) and np.array_equal(got, exp) and got[:, 65536:].any() and got.any()
+    assert np.array_equal(da.db2db(db_), exp.T)
+
+
 def _synth_part(S, g, ids, k, path, device):
     """database (with hashtables) of the samples `ids` of the genome model g, written in kmer-db's format"""
     pat = S.build_patterns(lambda i: S.kmers_of(g.sample(ids[i]), k), len(ids), device)
