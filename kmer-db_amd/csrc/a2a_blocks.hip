@@ -96,7 +96,6 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
-    uint32_t lane_atomics;         // (experiment) row mode: one LDS atomic per lane instead of one per run of lanes with the same row
     uint32_t pshift;               // row mode, != 0: packed records — the weight digit (and its index) sit in the column mask word from bit `pshift` (= the
                                    // block width) on, 64 - pshift - 2 bits of digit; the key word beside the record holds the stream only and stays behind in the sort
 };
@@ -271,14 +270,8 @@ __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const
     for (;;) {
         const unsigned long long onm = __ballot(on);
         if (!onm) break;
-        uint32_t p, e;
-        if (pv.lane_atomics) {
-            // (experiment, round 5) every lane its own LDS atomic: lanes of the same row collide in the LDS unit instead of being grouped by
-            // the ~50 VALU instructions below
-            e = on ? R.end[X] : 0u;
-            p = on ? atomicAdd(&R.pos[X], 1u) : 0u;
-        } else {
-        // runs of consecutive lanes with the same row: the first lane of a run reserves for all of it
+        // runs of consecutive lanes with the same row: the first lane of a run reserves for all of it (one LDS atomic per LANE instead —
+        // the lanes of a row then collide in the LDS unit, the ~50 VALU instructions below are gone — measured no faster: profiles/r05_j5)
         const uint32_t pX = (uint32_t)__shfl_up((int)X, 1, WAVE);
         const bool lead = on && (lane == 0u || !((onm >> (lane - 1u)) & 1ull) || pX != X);
         const unsigned long long leaders = __ballot(lead);
@@ -291,9 +284,8 @@ __device__ __forceinline__ void row_emit(WaveArena& A, const PoolView& pv, const
         }
         uint32_t old = 0, end = 0;
         if (lead) { end = R.end[X]; old = atomicAdd(&R.pos[X], cnt); }
-        p = (uint32_t)__shfl((int)old, (int)ll, WAVE) + (lane - ll);
-        e = (uint32_t)__shfl((int)end, (int)ll, WAVE);
-        }
+        uint32_t p = (uint32_t)__shfl((int)old, (int)ll, WAVE) + (lane - ll);
+        const uint32_t e = (uint32_t)__shfl((int)end, (int)ll, WAVE);
         bool ovf = on && p >= e;
         unsigned long long pend = __ballot(ovf);
         while (pend) {
@@ -953,6 +945,8 @@ struct K1WLds {
     unsigned long long* e_mask;    // [e_cap] the chain list: the full list of the deepest node of the chain
     unsigned long long* ch_last;   // [chain_cap] per depth: the mask of the node's last entry (the chain list may hold more ids there)
     unsigned long long* own_m0;    // [64] first own pair of every lane's node
+    unsigned long long* own_desc;  // [64] what a walk needs of the lane's node in ONE read: first own block | link << 16 (parent's lane, WB_LANE, or chain slot,
+                                   //      WB_CHAIN) | ox << 32 (first copy of the further own pairs in ox_*, 0xFFFF: not copied) | own pairs << 48 | WB_* << 62
     uint32_t* ch_node;             // [chain_cap] the wide node of that depth on the current root path (0xFFFFFFFF: none)
     unsigned long long* ox_mask;   // [K1W_OXCAP] the batch's further own pairs (a copy: the walks read them once per descendant)
     uint32_t* own_po;              // [64] further own pairs: first entry in the pair pool
@@ -962,18 +956,13 @@ struct K1WLds {
     uint16_t* ent_blk;             // [arena_cap]
     uint16_t* e_blk;               // [e_cap]
     uint16_t* ch_len;              // [chain_cap] entries of the node's list = a prefix of the chain list
-    uint16_t* own_b0;              // [64]
-    uint16_t* own_np;              // [64]
-    uint16_t* own_link;            // [64] parent's lane (WB_LANE) or chain slot (WB_CHAIN)
-    uint16_t* own_ox;              // [64] first copy of the lane's further own pairs in ox_*, 0xFFFF: not copied (read from the pair pool)
     uint16_t* ox_blk;              // [K1W_OXCAP]
     uint16_t* st_start;            // [64] first arena entry of the lane's row
     uint16_t* st_pre;              // [64] entries of the lane's list that are NOT in its row: they are the first st_pre entries of the chain list
-    unsigned char* own_base;       // [64] WB_*
 };
 __host__ __device__ inline size_t k1w_core_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
-    const size_t b = (size_t)8 * (arena_cap + e_cap + chain_cap + 64 + K1W_OXCAP) + (size_t)4 * (chain_cap + 3 * 64 + K1W_QCAP) +
-                     (size_t)2 * (arena_cap + e_cap + chain_cap + 7 * 64 + K1W_OXCAP) + 64;
+    const size_t b = (size_t)8 * (arena_cap + e_cap + chain_cap + 2 * 64 + K1W_OXCAP) + (size_t)4 * (chain_cap + 3 * 64 + K1W_QCAP) +
+                     (size_t)2 * (arena_cap + e_cap + chain_cap + 2 * 64 + K1W_OXCAP);
     return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t k1w_wave_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap, uint32_t n_rows) {
@@ -982,11 +971,11 @@ __host__ __device__ inline size_t k1w_wave_bytes(uint32_t arena_cap, uint32_t e_
 __device__ __forceinline__ K1WLds k1w_carve(unsigned char* p, uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
     K1WLds L;
     L.ent_mask = (unsigned long long*)p;  L.e_mask = L.ent_mask + arena_cap;  L.ch_last = L.e_mask + e_cap;  L.own_m0 = L.ch_last + chain_cap;
-    L.ox_mask = L.own_m0 + 64;
+    L.own_desc = L.own_m0 + 64;
+    L.ox_mask = L.own_desc + 64;
     L.ch_node = (uint32_t*)(L.ox_mask + K1W_OXCAP);  L.own_po = L.ch_node + chain_cap;  L.own_node = L.own_po + 64;  L.st_w = L.own_node + 64;  L.queue = L.st_w + 64;
-    L.ent_blk = (uint16_t*)(L.queue + K1W_QCAP);  L.e_blk = L.ent_blk + arena_cap;  L.ch_len = L.e_blk + e_cap;  L.own_b0 = L.ch_len + chain_cap;
-    L.own_np = L.own_b0 + 64;  L.own_link = L.own_np + 64;  L.st_start = L.own_link + 64;  L.st_pre = L.st_start + 64;  L.own_ox = L.st_pre + 64;  L.ox_blk = L.own_ox + 64;
-    L.own_base = (unsigned char*)(L.ox_blk + K1W_OXCAP);
+    L.ent_blk = (uint16_t*)(L.queue + K1W_QCAP);  L.e_blk = L.ent_blk + arena_cap;  L.ch_len = L.e_blk + e_cap;  L.st_start = L.ch_len + chain_cap;
+    L.st_pre = L.st_start + 64;  L.ox_blk = L.st_pre + 64;
     return L;
 }
 
@@ -1246,7 +1235,16 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             const uint32_t info = valid ? q.p0_info[node] : 0u;
             const uint32_t np = info >> 16, b0 = info & 0xFFFFu;
             const unsigned long long m0 = valid ? q.p0_mask[node] : 0ull;
-            const uint32_t po = np > 1u ? q.pair_ofs[node] : 0u;
+            // (every load that needs only `node` or `par` is requested here, whether its value will be used or not: the batch start is a chain of
+            // dependent round trips — node, its fields, pair_ofs, the pairs; the parent's flags, then fn_* or wide_base — at four waves per SIMD.
+            // pair_ofs of a node without further pairs and fn_* of a node with a wide parent were never written: what is read is not used.)
+            const uint32_t po_raw = valid ? q.pair_ofs[node] : 0u;
+            const uint32_t fnb_raw = valid ? q.fn_blk[node] : 0u;
+            const ulonglong2 fnm_raw = valid ? q.fn_mask[node] : make_ulonglong2(0ull, 0ull);
+            const uint32_t pw = (valid && par >= 0) ? (uint32_t)par >> 6 : 0u;
+            const unsigned long long pwbits = (valid && par >= 0) ? q.widebits[pw] : 0ull;
+            const uint32_t pwbase = (valid && par >= 0) ? q.wide_base[pw] : 0u;
+            const uint32_t po = np > 1u ? po_raw : 0u;
             uint32_t lb = b0;
             unsigned long long lm = m0;
             if (np > 1u) { lb = q.pair_blk[po + np - 2u]; lm = q.pair_mask[po + np - 2u]; }
@@ -1254,12 +1252,11 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             uint32_t base = WB_NONE, link = 0, pre0 = 0;
             LSum Pb = lsum_none();
             if (valid && par >= 0) {
-                if (!iswide((uint32_t)par)) {
+                if (!((pwbits >> ((uint32_t)par & 63u)) & 1ull)) {
                     base = WB_FN;
-                    Pb = lsum_of_fn(q.fn_blk[node], q.fn_mask[node]);
+                    Pb = lsum_of_fn(fnb_raw, fnm_raw);
                 } else {
-                    const uint32_t pw = (uint32_t)par >> 6;
-                    const uint32_t prank = q.wide_base[pw] + (uint32_t)__popcll(q.widebits[pw] & ((1ull << ((uint32_t)par & 63u)) - 1ull));
+                    const uint32_t prank = pwbase + (uint32_t)__popcll(pwbits & ((1ull << ((uint32_t)par & 63u)) - 1ull));
                     if (prank >= k0) { base = WB_LANE; link = prank - k0; }
                     else {
                         base = WB_CHAIN; link = dep - 2u;
@@ -1289,16 +1286,18 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             const uint32_t len = valid ? S.c : 0u;
             pre = valid ? pre : 0u;
             const uint32_t slen = len - pre;                               // entries of the lane's row
-            L.own_np[lane] = (uint16_t)np; L.own_b0[lane] = (uint16_t)b0; L.own_m0[lane] = m0; L.own_po[lane] = po;
-            L.own_base[lane] = (unsigned char)base; L.own_link[lane] = (uint16_t)link; L.own_node[lane] = node;
+            L.own_m0[lane] = m0; L.own_po[lane] = po; L.own_node[lane] = node;
             {
                 // the further own pairs, copied once: a node's pairs are read by every in-batch descendant's walk
                 const uint32_t nx = np > 1u ? np - 1u : 0u;
                 const uint32_t xincl = wave_incl_scan(nx, lane);
                 const uint32_t x0 = xincl - nx;
                 const bool fits = nx && xincl <= K1W_OXCAP;
-                L.own_ox[lane] = fits ? (uint16_t)x0 : (uint16_t)0xFFFFu;
                 if (fits) for (uint32_t t = 0; t < nx; ++t) { L.ox_blk[x0 + t] = q.pair_blk[po + t]; L.ox_mask[x0 + t] = q.pair_mask[po + t]; }
+                // (a walk over the in-batch parents reads one descriptor and one mask per node: the walks are chains of dependent LDS reads,
+                // and five separate arrays made every step five of them — profiles/r05_j5: rows were 36 % of the kernel)
+                L.own_desc[lane] = (unsigned long long)(b0 & 0xFFFFu) | ((unsigned long long)(link & 0xFFFFu) << 16) | ((unsigned long long)(fits ? x0 : 0xFFFFu) << 32) |
+                                   ((unsigned long long)(np < 0x3FFFu ? np : 0x3FFFu) << 48) | ((unsigned long long)base << 62);
             }
             lds_sync();
             PT(1);
@@ -1316,25 +1315,30 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 const uint32_t start = incl - c;
                 if (on) {
                     // fill the row right to left: own pairs, the in-batch parents' pairs, then the base
+                    // (the entry being built stays in registers until the next block starts: no read-modify-write of the row)
                     uint32_t pos = start + slen, cur = 0xFFFFFFFFu;
+                    unsigned long long curm = 0;
+                    auto rflush = [&]() { if (cur != 0xFFFFFFFFu) { --pos; L.ent_blk[pos] = (uint16_t)cur; L.ent_mask[pos] = curm; } };
                     auto rpush = [&](uint32_t blk, unsigned long long mask) {
-                        if (blk == cur) L.ent_mask[pos] |= mask;
-                        else { --pos; L.ent_blk[pos] = (uint16_t)blk; L.ent_mask[pos] = mask; cur = blk; }
+                        if (blk == cur) curm |= mask;
+                        else { rflush(); cur = blk; curm = mask; }
                     };
                     uint32_t y = lane;
                     for (;;) {
-                        const uint32_t ynp = L.own_np[y];
+                        const unsigned long long dsc = L.own_desc[y];
+                        const unsigned long long ym0 = L.own_m0[y];
+                        const uint32_t ynp = (uint32_t)(dsc >> 48) & 0x3FFFu, yb = (uint32_t)(dsc >> 62), ylink = (uint32_t)(dsc >> 16) & 0xFFFFu;
                         if (ynp > 1u) {
-                            const uint32_t yox = L.own_ox[y];
-                            if (yox != 0xFFFFu) for (uint32_t t = ynp - 1u; t-- > 0u;) rpush(L.ox_blk[yox + t], L.ox_mask[yox + t]);
+                            const uint32_t yox = (uint32_t)(dsc >> 32) & 0xFFFFu;
+                            const uint32_t ynx = ynp == 0x3FFFu ? (q.p0_info[L.own_node[y]] >> 16) - 1u : ynp - 1u;       // (a count that did not fit the descriptor)
+                            if (yox != 0xFFFFu) for (uint32_t t = ynx; t-- > 0u;) rpush(L.ox_blk[yox + t], L.ox_mask[yox + t]);
                             else {
                                 const uint32_t ypo = L.own_po[y];
-                                for (uint32_t t = ynp - 1u; t-- > 0u;) rpush(q.pair_blk[ypo + t], q.pair_mask[ypo + t]);
+                                for (uint32_t t = ynx; t-- > 0u;) rpush(q.pair_blk[ypo + t], q.pair_mask[ypo + t]);
                             }
                         }
-                        if (ynp) rpush(L.own_b0[y], L.own_m0[y]);
-                        const uint32_t yb = L.own_base[y];
-                        if (yb == WB_LANE) { y = L.own_link[y]; continue; }
+                        if (ynp) rpush((uint32_t)dsc & 0xFFFFu, ym0);
+                        if (yb == WB_LANE) { y = ylink; continue; }
                         if (yb == WB_FN) {
                             const uint32_t ynode = L.own_node[y];
                             const uint32_t fb = q.fn_blk[ynode];
@@ -1344,12 +1348,13 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                         } else if (yb == WB_CHAIN) {
                             // the chain node's last entry (its mask may be the node's own: a deeper chain node can have more ids in that
                             // block); the entries before it stay in the chain list, shared by every lane that hangs below this node
-                            const uint32_t cs = L.own_link[y];
+                            const uint32_t cs = ylink;
                             const uint32_t cl = L.ch_len[cs];
                             if (cl) rpush(L.e_blk[cl - 1u], L.ch_last[cs]);
                         }
                         break;
                     }
+                    rflush();
                 }
                 L.st_start[lane] = (uint16_t)start; L.st_pre[lane] = (uint16_t)pre;
                 if (lane == nv - 1u && on) last_start = start;
@@ -1821,7 +1826,7 @@ void l2_join_apply_kernel(const unsigned long long* __restrict__ B, const uint32
     }
 }
 
-constexpr uint32_t K2_WIN = 64;            // sorted chunks per workgroup at most; the launch picks 16 (few streams: measured better) or 32
+constexpr uint32_t K2_WIN = 32;            // sorted chunks per workgroup at most; the launch picks 16 (few streams: measured better) or 32
 constexpr int K2A_MIN_WAVES = 3;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2A_MIN_WAVES, 8))) void k2_apply_kernel(const unsigned char* __restrict__ rec, const uint32_t* __restrict__ recw,
                                                        const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
@@ -2210,8 +2215,8 @@ __global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, 
     const uint32_t nb = job.X + 1u, sub = tri32(job.X), nch = job.ce - job.cb;
     WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
     uint32_t* st_dst = (uint32_t*)(st_rec + CS_TILE);                     // [CS_TILE] global destination
-    uint32_t* st_key = st_dst + CS_TILE;                                  // [CS_TILE]
-    uint32_t* hist = st_key + CS_TILE;                                    // [nb] records of the tile per bin
+    uint32_t* st_key = st_dst + CS_TILE;                                  // [CS_TILE]; not there for packed records (their key words stay behind: 8 KB
+    uint32_t* hist = st_key + (packed ? 0u : CS_TILE);                    //   less LDS per workgroup, one more workgroup per CU)  [nb] records of the tile per bin
     uint32_t* toff = hist + NB;                                           // [nb] first staging position of the bin
     uint32_t* cursor = toff + NB;                                         // [nb] next global position of the bin for this workgroup
     uint32_t* part = cursor + NB;                                         // [CS_THREADS] scan scratch
@@ -2264,7 +2269,7 @@ __global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, 
                 const uint32_t pp = toff[key[jj]] + rank[jj];
                 st_rec[pp] = rc[jj];
                 st_dst[pp] = cursor[key[jj]] + rank[jj];
-                st_key[pp] = kw[jj];
+                if (!packed) st_key[pp] = kw[jj];
             }
         }
         __syncthreads();
@@ -2277,7 +2282,7 @@ __global__ __launch_bounds__(CS_THREADS) void rs_scatter_kernel(const RsRows R, 
         __syncthreads();
     }
 }
-__host__ __device__ inline size_t rs_scatter_lds(uint32_t NB) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)NB * 12 + CS_THREADS * 4 + 64; }
+__host__ __device__ inline size_t rs_scatter_lds(uint32_t NB, bool packed) { return (size_t)CS_TILE * (sizeof(WideRec) + (packed ? 4 : 8)) + (size_t)NB * 12 + CS_THREADS * 4 + 64; }
 
 // K2 over records sorted by stream (dense mode): a window of K2S_WIN sorted positions, one 64 x 64 tile per run of equal streams
 constexpr uint32_t K2S_WIN = 4096;
@@ -2523,7 +2528,7 @@ inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, getenv("KMDB_ROW_LANE_ATOMICS") ? 1u : 0u, db->row_mode ? db->rec_pshift : 0u};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, db->row_mode ? db->rec_pshift : 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -3075,8 +3080,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             rocprim::transform_iterator<uint32_t*, U32toU64, unsigned long long> it(db->chunk_fill, U32toU64());
             HIP_TRY(prim::sum(db->sort_tmp, db->sort_tmp_bytes, it, (unsigned long long*)(db->counters + KCTR_RECORDS), (int)pool_cap, s2));
         }
-        uint32_t win = db->n_states <= CS_MAX_KEYS ? 16u : 32u;
-        if (const char* e = getenv("KMDB_K2_WIN")) win = std::max(4u, std::min<uint32_t>(K2_WIN, (uint32_t)atoi(e)));       // (experiment, round 5)
+        const uint32_t win = db->n_states <= CS_MAX_KEYS ? 16u : 32u;      // (8 / 32 / 64 chunks at few streams: within the boxes' noise, profiles/r05_j5)
         uint32_t grid = (pool_cap + win - 1) / win;
         if (db->have_counts) grid = std::min(grid, (db->last_n_chunks + win - 1) / win);
         if (grid)
@@ -3232,8 +3236,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
         // (Sorting and applying bands of block rows side by side on two streams was measured at 10 000 samples: 2 / 4 / 8 bands 18.4 / 17.0 /
         // 18.7 ms against 16.5 for one — the two kernels do not complement each other.)
-        HIP_TRY(hipFuncSetAttribute((const void*)rs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds(NB)));
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3((jobs + 7u) & ~7u), dim3(CS_THREADS), rs_scatter_lds(NB), st, R, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
+        HIP_TRY(hipFuncSetAttribute((const void*)rs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds(NB, db->rec_pshift != 0)));
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((jobs + 7u) & ~7u), dim3(CS_THREADS), rs_scatter_lds(NB, db->rec_pshift != 0), st, R, db->chunk_fill, db->recw, (const WideRec*)db->rec, kmask,
                            db->rs_offs, (uint32_t)db->sorted_cap, db->swkey, (WideRec*)db->swrec, db->counters, db->rec_pshift ? 1u : 0u);
         // the sorted records applied stream by stream (a long stream in parts of K2J_REC records): one write-back of a tile per job
         hipLaunchKernelGGL(k2j_starts_kernel, dim3((db->n_states + 1u + 255u) / 256u), dim3(256), 0, st, R, db->rs_offs, db->n_states, db->k2j_start);
