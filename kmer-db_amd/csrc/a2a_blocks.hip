@@ -96,6 +96,7 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
+    uint32_t grab;                 // stream chunks a wave takes per device atomic (ARENA_GRAB)
     uint32_t pshift;               // row mode, != 0: packed records — the weight digit (and its index) sit in the column mask word from bit `pshift` (= the
                                    // block width) on, 64 - pshift - 2 bits of digit; the key word beside the record holds the stream only and stays behind in the sort
 };
@@ -121,7 +122,8 @@ struct WaveArena {
     uint32_t dslot;                // wide pool: next slot of the wave's one open chunk (dopen == 0: none)
     uint32_t dopen;
 };
-constexpr uint32_t ARENA_GRAB = 4;         // stream chunks (256 records) per grab
+constexpr uint32_t ARENA_GRAB = 4;         // stream chunks (256 records) per grab (PoolView::grab; KMDB_ARENA_GRAB up to ARENA_GRAB_MAX: experiment, round 5)
+constexpr uint32_t ARENA_GRAB_MAX = 32;
 constexpr uint32_t WIDE_GRAB = 4;          // wide-pool chunks (64 records) per grab: every wave leaves an unfinished grab behind, and the
                                            // sort reads all slots up to the busiest sub-pool's cursor (16 -> 4: -0.35 ms at the benchmark database)
 __host__ __device__ inline uint32_t arena_table_bits(uint32_t n_states) {
@@ -146,13 +148,13 @@ __device__ __forceinline__ uint32_t arena_take(WaveArena& A, const PoolView& pv,
     if (A.stock == 0) {
         uint32_t base = 0;
         A.sub = (A.sub + 61u) % KMDB_SUBPOOLS;                        // every grab from another sub-pool: a wave with much output does not drain one
-        if (lane == 0) base = atomicAdd(&pv.sub_cursor[A.sub * 16u], ARENA_GRAB);
+        if (lane == 0) base = atomicAdd(&pv.sub_cursor[A.sub * 16u], pv.grab);
         base = bcast(base, 0);
-        if (base + ARENA_GRAB > pv.sub_cap) {                     // stays in range; the call is repeated with a larger pool
+        if (base + pv.grab > pv.sub_cap) {                        // stays in range; the call is repeated with a larger pool
             if (lane == 0) atomicOr(&pv.counters[KCTR_POOL_OVERFLOW], 1u);
-            base = pv.sub_cap - ARENA_GRAB;
+            base = pv.sub_cap - pv.grab;
         }
-        A.next = base; A.stock = ARENA_GRAB;
+        A.next = base; A.stock = pv.grab;
     }
     const uint32_t id = A.next * KMDB_SUBPOOLS + A.sub;
     ++A.next; --A.stock;
@@ -1014,6 +1016,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     // (PROF: where a wave's time goes — 0 run start + chain, 1 batch loads + list lengths, 2 rows, 3 second-level entries, 4 whole-wave records,
     // 5 record-parallel emission, 6 chain hand-over, 7 end)
     unsigned long long ph[K1W_NPH] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cn[K1W_NPH] = {0, 0, 0, 0, 0, 0, 0, 0};      // (PROF) batches, rounds, entries of the lists, entries of the rows, walk steps of all lanes, longest walk per round, light steps, light records
     unsigned long long t_last = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
     auto PT = [&](int k) {
         if (!PROF) return;
@@ -1119,6 +1122,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
         L.queue[lane] = rincl;
         L.st_w[lane] = wv;
         lds_sync();
+        if (PROF) { cn[6] += (T + 63u) / 64u; cn[7] += T; }
         for (uint32_t t0 = 0; t0 < T; t0 += WAVE) {
             const uint32_t t = t0 + lane;
             bool rec_on = false, diag = false;
@@ -1272,7 +1276,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             LSum S = np ? LSum{lm, np, b0, lb} : lsum_none();
             if (base != WB_LANE) S = lsum_merge(Pb, S);
             // (pre: the shared prefix of the lane's TOPMOST in-batch ancestor — the lane whose base is not another lane)
-            uint32_t pre = pre0;
+            uint32_t pre = pre0, topl = lane;
             {
                 int pl = base == WB_LANE ? (int)link : -1;
                 while (__ballot(pl >= 0)) {
@@ -1280,9 +1284,14 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     const LSum o = lsum_shfl(S, src);
                     const int opl = __shfl(pl, src, WAVE);                // -1 once that lane's stretch reaches its base
                     const uint32_t opre = (uint32_t)__shfl((int)pre, src, WAVE);
-                    if (pl >= 0) { S = lsum_merge(o, S); pl = opl; pre = opre; }
+                    const uint32_t otop = (uint32_t)__shfl((int)topl, src, WAVE);
+                    if (pl >= 0) { S = lsum_merge(o, S); pl = opl; pre = opre; topl = otop; }
                 }
             }
+            // the (blocks, masks) the narrow kernel left for the topmost in-batch ancestor, fetched across the lanes NOW: a walk that ended in a
+            // global load made every round of the batch wait for the record stores of the round before it (loads and stores return in order)
+            const uint32_t tfnb = (uint32_t)__shfl((int)fnb_raw, (int)topl, WAVE);
+            const unsigned long long tfnx = shfl64(fnm_raw.x, (int)topl), tfny = shfl64(fnm_raw.y, (int)topl);
             const uint32_t len = valid ? S.c : 0u;
             pre = valid ? pre : 0u;
             const uint32_t slen = len - pre;                               // entries of the lane's row
@@ -1305,7 +1314,9 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             // the last one (its list becomes the chain list).
             const bool need = valid && (act || lane == nv - 1u);
             uint32_t fin = 0, last_start = 0;
+            if (PROF) { cn[0] += 1; cn[2] += bcast(wave_incl_scan(need ? len : 0u, lane), WAVE - 1); cn[3] += bcast(wave_incl_scan(need ? slen : 0u, lane), WAVE - 1); }
             while (fin < nv) {
+                uint32_t wsteps = 0;
                 const uint32_t c = (lane >= fin && need) ? slen : 0u;
                 const uint32_t incl = wave_incl_scan(c, lane);
                 const unsigned long long over = __ballot(incl > q.arena_cap);
@@ -1325,6 +1336,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     };
                     uint32_t y = lane;
                     for (;;) {
+                        ++wsteps;
                         const unsigned long long dsc = L.own_desc[y];
                         const unsigned long long ym0 = L.own_m0[y];
                         const uint32_t ynp = (uint32_t)(dsc >> 48) & 0x3FFFu, yb = (uint32_t)(dsc >> 62), ylink = (uint32_t)(dsc >> 16) & 0xFFFFu;
@@ -1339,12 +1351,9 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                         }
                         if (ynp) rpush((uint32_t)dsc & 0xFFFFu, ym0);
                         if (yb == WB_LANE) { y = ylink; continue; }
-                        if (yb == WB_FN) {
-                            const uint32_t ynode = L.own_node[y];
-                            const uint32_t fb = q.fn_blk[ynode];
-                            const ulonglong2 fm = q.fn_mask[ynode];
-                            if ((fb >> 16) != BLK_NONE) rpush(fb >> 16, fm.y);
-                            if ((fb & 0xFFFFu) != BLK_NONE) rpush(fb & 0xFFFFu, fm.x);
+                        if (yb == WB_FN) {                       // (y is the lane's topmost in-batch ancestor: topl)
+                            if ((tfnb >> 16) != BLK_NONE) rpush(tfnb >> 16, tfny);
+                            if ((tfnb & 0xFFFFu) != BLK_NONE) rpush(tfnb & 0xFFFFu, tfnx);
                         } else if (yb == WB_CHAIN) {
                             // the chain node's last entry (its mask may be the node's own: a deeper chain node can have more ids in that
                             // block); the entries before it stay in the chain list, shared by every lane that hangs below this node
@@ -1355,6 +1364,13 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                         break;
                     }
                     rflush();
+                }
+                if (PROF) {
+                    cn[1] += 1;
+                    uint32_t mx = wsteps;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
+                    cn[5] += mx; cn[4] += bcast(wave_incl_scan(wsteps, lane), WAVE - 1);
                 }
                 L.st_start[lane] = (uint16_t)start; L.st_pre[lane] = (uint16_t)pre;
                 if (lane == nv - 1u && on) last_start = start;
@@ -1385,7 +1401,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
     arena_finish(A, q.pool, lane);
     if (q.n_rows) rowtab_finish(RT, q.pool, lane);
     PT(7);
-    if (PROF && lane == 0) for (int j = 0; j < K1W_NPH; ++j) q.prof[(size_t)wid * K1W_NPH + j] = ph[j];
+    if (PROF && lane == 0) for (int j = 0; j < K1W_NPH; ++j) { q.prof[(size_t)wid * K1W_NPH + j] = ph[j]; q.prof[(size_t)(q.n_waves + wid) * K1W_NPH + j] = cn[j]; }
     if (lane == 0 && n_miss) atomicAdd(&q.pool.counters[KCTR_SLOW], n_miss);
     if (lane == 0 && l2_nodes) atomicAdd(&q.pool.counters[KCTR_L2_NODES], l2_nodes);
 }
@@ -2525,10 +2541,14 @@ __global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t*
 
 // weight digit bits of the wide pool's key word: what the stream bits and the two digit-index bits leave (four digits cover 32 bits)
 inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits - 2); }
+inline uint32_t arena_grab() {
+    static const uint32_t g = getenv("KMDB_ARENA_GRAB") ? std::max(1u, std::min<uint32_t>(ARENA_GRAB_MAX, (uint32_t)atoi(getenv("KMDB_ARENA_GRAB")))) : ARENA_GRAB;
+    return g;
+}
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, db->row_mode ? db->rec_pshift : 0u};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, arena_grab(), db->row_mode ? db->rec_pshift : 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -2548,7 +2568,7 @@ int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->sort_tmp); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs); FREE_NULL(db->rs_tmp);
     db->pool_cap = 0;
-    chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB);
+    chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB_MAX - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB_MAX) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB_MAX);
     if (chunks >= pool_slot_limit(db) >> CH_SHIFT) return kmdb_set_error("kmdb: record pool would exceed its " + std::to_string(pool_slot_limit(db)) + " record slots");
     HIP_TRY(hipMalloc((void**)&db->chunk_key, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->chunk_fill, chunks * 4));
@@ -2927,7 +2947,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide records: the wide estimate at two thirds (+ a grab / the open row chunks per wave)
     if (db->row_mode) {
-        if (alloc_record_pool(db, (est_n + est_g) * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
+        if (alloc_record_pool(db, (est_n + est_g) * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + arena_grab()) + 4096)) return 1;
         if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + 4096)) return 1;
     } else {
         if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
@@ -3178,10 +3198,10 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(db->k1w_waves, q.n_runs), (uint32_t)atoi(e)));
         if (k1w_prof) {
             static unsigned long long* d_prof = nullptr;
-            if (!d_prof) HIP_TRY(hipMalloc((void**)&d_prof, (size_t)K1W_MAX_WAVES * K1W_NPH * 8));
+            if (!d_prof) HIP_TRY(hipMalloc((void**)&d_prof, (size_t)2 * K1W_MAX_WAVES * K1W_NPH * 8));
             q.prof = d_prof;
             hipLaunchKernelGGL(k1w_kernel<true>, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
-            std::vector<unsigned long long> h((size_t)q.n_waves * K1W_NPH);
+            std::vector<unsigned long long> h((size_t)2 * q.n_waves * K1W_NPH);
             HIP_TRY(hipMemcpyAsync(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             double sum[K1W_NPH] = {0}, mx = 0;
@@ -3190,6 +3210,10 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
             const char* nm[K1W_NPH] = {"run+chain", "loads+lengths", "rows", "l2 entries", "heavy records", "light records", "hand-over", "end"};
             for (int j = 0; j < K1W_NPH; ++j) fprintf(stderr, " %s %.1f", nm[j], sum[j] / q.n_waves * 0.01);
             fprintf(stderr, "\n");
+            double cs[K1W_NPH] = {0};
+            for (uint32_t w = 0; w < q.n_waves; ++w) for (int j = 0; j < K1W_NPH; ++j) cs[j] += (double)h[(size_t)(q.n_waves + w) * K1W_NPH + j];
+            fprintf(stderr, "[kmdb] k1w counts, totals: batches %.0f rounds %.0f list entries %.0f row entries %.0f walk steps %.0f (longest per round, summed: %.0f) light steps %.0f light records %.0f\n",
+                    cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[7]);
         } else
         hipLaunchKernelGGL(k1w_kernel<false>, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
         if (db->l2_on) {
