@@ -96,7 +96,6 @@ struct PoolView {
     uint32_t kbits, dbits;         // key word of the wide pool: stream bits, weight digit bits                // 1: this kernel writes into the wide pool
     uint32_t row_mode;             // 1: many streams — the wide records go to per-block-row chunks of the chunk pool instead of the arrival-order
     uint32_t n_states;             // pool, so that only the sort inside the rows remains
-    uint32_t grab;                 // stream chunks a wave takes per device atomic (ARENA_GRAB)
     uint32_t pshift;               // row mode, != 0: packed records — the weight digit (and its index) sit in the column mask word from bit `pshift` (= the
                                    // block width) on, 64 - pshift - 2 bits of digit; the key word beside the record holds the stream only and stays behind in the sort
 };
@@ -122,8 +121,8 @@ struct WaveArena {
     uint32_t dslot;                // wide pool: next slot of the wave's one open chunk (dopen == 0: none)
     uint32_t dopen;
 };
-constexpr uint32_t ARENA_GRAB = 4;         // stream chunks (256 records) per grab (PoolView::grab; KMDB_ARENA_GRAB up to ARENA_GRAB_MAX: experiment, round 5)
-constexpr uint32_t ARENA_GRAB_MAX = 32;
+constexpr uint32_t ARENA_GRAB = 4;         // stream chunks (256 records) per grab (16 per grab — a quarter of the returning device atomics, which wait for
+                                           // the wave's record stores to drain — measured no faster at 10 000 samples: profiles/r05_j8)
 constexpr uint32_t WIDE_GRAB = 4;          // wide-pool chunks (64 records) per grab: every wave leaves an unfinished grab behind, and the
                                            // sort reads all slots up to the busiest sub-pool's cursor (16 -> 4: -0.35 ms at the benchmark database)
 __host__ __device__ inline uint32_t arena_table_bits(uint32_t n_states) {
@@ -148,13 +147,13 @@ __device__ __forceinline__ uint32_t arena_take(WaveArena& A, const PoolView& pv,
     if (A.stock == 0) {
         uint32_t base = 0;
         A.sub = (A.sub + 61u) % KMDB_SUBPOOLS;                        // every grab from another sub-pool: a wave with much output does not drain one
-        if (lane == 0) base = atomicAdd(&pv.sub_cursor[A.sub * 16u], pv.grab);
+        if (lane == 0) base = atomicAdd(&pv.sub_cursor[A.sub * 16u], ARENA_GRAB);
         base = bcast(base, 0);
-        if (base + pv.grab > pv.sub_cap) {                        // stays in range; the call is repeated with a larger pool
+        if (base + ARENA_GRAB > pv.sub_cap) {                        // stays in range; the call is repeated with a larger pool
             if (lane == 0) atomicOr(&pv.counters[KCTR_POOL_OVERFLOW], 1u);
-            base = pv.sub_cap - pv.grab;
+            base = pv.sub_cap - ARENA_GRAB;
         }
-        A.next = base; A.stock = pv.grab;
+        A.next = base; A.stock = ARENA_GRAB;
     }
     const uint32_t id = A.next * KMDB_SUBPOOLS + A.sub;
     ++A.next; --A.stock;
@@ -935,9 +934,10 @@ constexpr int K1W_WAVES = 2;
 constexpr int K1W_NPH = 8;
 constexpr uint32_t L2_MIN_BLOCKS = 24;     // nodes with that many blocks take the second level (measured at 10 000 samples: 11 -> 21.9 ms, 24 -> 20.0; KMDB_L2_MIN moves it)
 constexpr uint32_t L2_NODE_GRAB = 16, L2_ENT_GRAB = 1024, L2_SUB = 16;   // node indices / entries a wave takes per device atomic, from one of L2_SUB cursors each
-constexpr uint32_t K1W_QCAP = 128;         // record descriptors queued per round
+constexpr uint32_t K1W_QCAP = 64;          // inclusive record counts of the lanes of a batch (the owner search of the record-parallel emission)
 constexpr uint32_t K1W_HEAVY = 11;         // a node with that many blocks (66 records and more) is emitted by the whole wave
-constexpr uint32_t K1W_OXCAP = 128;        // further own pairs of a batch's nodes kept in LDS
+constexpr uint32_t K1W_OXCAP = 96;         // further own pairs of a batch's nodes kept in LDS (with the queue and the node array trimmed the wave's LDS drops
+                                           // below 10 KB at 200 blocks: 16 instead of 14 waves per CU — the kernel waits more than it issues)
 constexpr uint32_t K1W_CTRS = 16;          // run counters: a wave takes its next run from the counter of its class
 constexpr uint32_t K1W_ARENA_MIN = 256;    // entries of a wave's row arena at least (and always one full list: as many as there are blocks)
 enum : uint32_t { WB_NONE = 0, WB_FN = 1, WB_LANE = 2, WB_CHAIN = 3 };
@@ -952,7 +952,6 @@ struct K1WLds {
     uint32_t* ch_node;             // [chain_cap] the wide node of that depth on the current root path (0xFFFFFFFF: none)
     unsigned long long* ox_mask;   // [K1W_OXCAP] the batch's further own pairs (a copy: the walks read them once per descendant)
     uint32_t* own_po;              // [64] further own pairs: first entry in the pair pool
-    uint32_t* own_node;            // [64]
     uint32_t* st_w;                // [64]
     uint32_t* queue;               // [K1W_QCAP] (first 64: inclusive record counts of the lanes of a batch)
     uint16_t* ent_blk;             // [arena_cap]
@@ -963,7 +962,7 @@ struct K1WLds {
     uint16_t* st_pre;              // [64] entries of the lane's list that are NOT in its row: they are the first st_pre entries of the chain list
 };
 __host__ __device__ inline size_t k1w_core_bytes(uint32_t arena_cap, uint32_t e_cap, uint32_t chain_cap) {
-    const size_t b = (size_t)8 * (arena_cap + e_cap + chain_cap + 2 * 64 + K1W_OXCAP) + (size_t)4 * (chain_cap + 3 * 64 + K1W_QCAP) +
+    const size_t b = (size_t)8 * (arena_cap + e_cap + chain_cap + 2 * 64 + K1W_OXCAP) + (size_t)4 * (chain_cap + 2 * 64 + K1W_QCAP) +
                      (size_t)2 * (arena_cap + e_cap + chain_cap + 2 * 64 + K1W_OXCAP);
     return (b + 15) & ~(size_t)15;
 }
@@ -975,7 +974,7 @@ __device__ __forceinline__ K1WLds k1w_carve(unsigned char* p, uint32_t arena_cap
     L.ent_mask = (unsigned long long*)p;  L.e_mask = L.ent_mask + arena_cap;  L.ch_last = L.e_mask + e_cap;  L.own_m0 = L.ch_last + chain_cap;
     L.own_desc = L.own_m0 + 64;
     L.ox_mask = L.own_desc + 64;
-    L.ch_node = (uint32_t*)(L.ox_mask + K1W_OXCAP);  L.own_po = L.ch_node + chain_cap;  L.own_node = L.own_po + 64;  L.st_w = L.own_node + 64;  L.queue = L.st_w + 64;
+    L.ch_node = (uint32_t*)(L.ox_mask + K1W_OXCAP);  L.own_po = L.ch_node + chain_cap;  L.st_w = L.own_po + 64;  L.queue = L.st_w + 64;
     L.ent_blk = (uint16_t*)(L.queue + K1W_QCAP);  L.e_blk = L.ent_blk + arena_cap;  L.ch_len = L.e_blk + e_cap;  L.st_start = L.ch_len + chain_cap;
     L.st_pre = L.st_start + 64;  L.ox_blk = L.st_pre + 64;
     return L;
@@ -1295,7 +1294,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             const uint32_t len = valid ? S.c : 0u;
             pre = valid ? pre : 0u;
             const uint32_t slen = len - pre;                               // entries of the lane's row
-            L.own_m0[lane] = m0; L.own_po[lane] = po; L.own_node[lane] = node;
+            L.own_m0[lane] = m0; L.own_po[lane] = po;
             {
                 // the further own pairs, copied once: a node's pairs are read by every in-batch descendant's walk
                 const uint32_t nx = np > 1u ? np - 1u : 0u;
@@ -1306,7 +1305,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 // (a walk over the in-batch parents reads one descriptor and one mask per node: the walks are chains of dependent LDS reads,
                 // and five separate arrays made every step five of them — profiles/r05_j5: rows were 36 % of the kernel)
                 L.own_desc[lane] = (unsigned long long)(b0 & 0xFFFFu) | ((unsigned long long)(link & 0xFFFFu) << 16) | ((unsigned long long)(fits ? x0 : 0xFFFFu) << 32) |
-                                   ((unsigned long long)(np < 0x3FFFu ? np : 0x3FFFu) << 48) | ((unsigned long long)base << 62);
+                                   ((unsigned long long)(np & 0x3FFFu) << 48) | ((unsigned long long)base << 62);
             }
             lds_sync();
             PT(1);
@@ -1342,7 +1341,7 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                         const uint32_t ynp = (uint32_t)(dsc >> 48) & 0x3FFFu, yb = (uint32_t)(dsc >> 62), ylink = (uint32_t)(dsc >> 16) & 0xFFFFu;
                         if (ynp > 1u) {
                             const uint32_t yox = (uint32_t)(dsc >> 32) & 0xFFFFu;
-                            const uint32_t ynx = ynp == 0x3FFFu ? (q.p0_info[L.own_node[y]] >> 16) - 1u : ynp - 1u;       // (a count that did not fit the descriptor)
+                            const uint32_t ynx = ynp - 1u;                       // (a node has fewer than 2897 pairs: fewer than 2^22 block pairs)
                             if (yox != 0xFFFFu) for (uint32_t t = ynx; t-- > 0u;) rpush(L.ox_blk[yox + t], L.ox_mask[yox + t]);
                             else {
                                 const uint32_t ypo = L.own_po[y];
@@ -1895,6 +1894,14 @@ __global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uin
     counters[KCTR_CHUNKS] = lo;
 }
 // slots of the wide pool in use = the busiest sub-pool's share of all
+// chunks of the chunk pool in use = the busiest sub-pool's share of all (one wave: a maximum over the 256 cursors)
+__global__ void pool_used_kernel(const uint32_t* __restrict__ sub_cursor, uint32_t* __restrict__ counters) {
+    uint32_t mx = 0;
+    for (uint32_t p = threadIdx.x; p < KMDB_SUBPOOLS; p += 64u) mx = max(mx, sub_cursor[p * 16u]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
+    if (threadIdx.x == 0) counters[KCTR_POOL_USED] = mx * KMDB_SUBPOOLS;
+}
 __global__ void count_raw_kernel(const uint32_t* __restrict__ wsub_cursor, uint32_t* __restrict__ counters) {
     uint32_t mx = 0;
     for (uint32_t p = 0; p < KMDB_SUBPOOLS; ++p) mx = max(mx, wsub_cursor[p * 16u]);
@@ -2541,14 +2548,10 @@ __global__ void v1_arrays_kernel(const uint2* __restrict__ k0in, const uint32_t*
 
 // weight digit bits of the wide pool's key word: what the stream bits and the two digit-index bits leave (four digits cover 32 bits)
 inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits - 2); }
-inline uint32_t arena_grab() {
-    static const uint32_t g = getenv("KMDB_ARENA_GRAB") ? std::max(1u, std::min<uint32_t>(ARENA_GRAB_MAX, (uint32_t)atoi(getenv("KMDB_ARENA_GRAB")))) : ARENA_GRAB;
-    return g;
-}
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, arena_grab(), db->row_mode ? db->rec_pshift : 0u};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, db->row_mode ? db->rec_pshift : 0u};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -2568,7 +2571,7 @@ int alloc_record_pool(kmdb_db* db, uint64_t chunks) {
     FREE_NULL(db->chunk_key); FREE_NULL(db->chunk_fill); FREE_NULL(db->sorted_key); FREE_NULL(db->sorted_id);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->sort_tmp); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs); FREE_NULL(db->rs_tmp);
     db->pool_cap = 0;
-    chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB_MAX - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB_MAX) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB_MAX);
+    chunks = (chunks + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB - 1) / ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB) * ((uint64_t)KMDB_SUBPOOLS * ARENA_GRAB);
     if (chunks >= pool_slot_limit(db) >> CH_SHIFT) return kmdb_set_error("kmdb: record pool would exceed its " + std::to_string(pool_slot_limit(db)) + " record slots");
     HIP_TRY(hipMalloc((void**)&db->chunk_key, chunks * 4));
     HIP_TRY(hipMalloc((void**)&db->chunk_fill, chunks * 4));
@@ -2947,7 +2950,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide records: the wide estimate at two thirds (+ a grab / the open row chunks per wave)
     if (db->row_mode) {
-        if (alloc_record_pool(db, (est_n + est_g) * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + arena_grab()) + 4096)) return 1;
+        if (alloc_record_pool(db, (est_n + est_g) * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
         if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + 4096)) return 1;
     } else {
         if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
@@ -3303,6 +3306,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         if (stage("sorted apply")) return 1;
     }
     HIP_TRY(hipStreamWaitEvent(st, db->ev_side[1], 0));          // the side stream's tiles are in the matrix too
+    hipLaunchKernelGGL(pool_used_kernel, dim3(1), dim3(64), 0, st, db->sub_cursor, db->counters);
     HIP_TRY(hipEventRecord(db->ev_k[3], st));
     // ---- what the call found
     HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
@@ -3374,6 +3378,19 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         // practice; if not: redo the call with upper bounds
         db->have_counts = false; *retry = true;
         return 0;
+    }
+    // Headroom: where the wide kernel's records land depends on which wave took which run, so a pool that was just large enough this time may
+    // be too small next time (a warm call would then take the enlarge-and-repeat path: seen once in the tests with pools of 1 %).  A pool
+    // more than 85 % in use grows by a quarter now, while nothing runs.
+    if ((uint64_t)c[KCTR_POOL_USED] * 100 > db->pool_cap * 85) {
+        if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] record pool %u of %llu chunks in use: enlarged by a quarter\n", c[KCTR_POOL_USED], (unsigned long long)db->pool_cap);
+        const uint64_t want = db->pool_cap + db->pool_cap / 4;
+        if (((want + (uint64_t)KMDB_SUBPOOLS * ARENA_GRAB) << CH_SHIFT) < pool_slot_limit(db) && alloc_record_pool(db, want)) return 1;
+    }
+    if (!row_mode && (uint64_t)c[KCTR_RAW] * 100 > db->wide_pool_cap * 85) {
+        if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] wide record pool %u of %llu chunks in use: enlarged by a quarter\n", c[KCTR_RAW], (unsigned long long)db->wide_pool_cap);
+        const uint64_t want = db->wide_pool_cap + db->wide_pool_cap / 4;
+        if (((want + (uint64_t)KMDB_SUBPOOLS * WIDE_GRAB) << WCH_SHIFT) < pool_slot_limit(db) && alloc_wide_pool(db, want)) return 1;
     }
     db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW]; db->last_n_slow = c[KCTR_SLOW];
     db->last_n_rowjobs = c[KCTR_ROWJOBS]; db->last_n_sorted = c[KCTR_WIDE_RECORDS]; db->last_l2_nodes = c[KCTR_L2_NODES]; db->last_n_k2jobs = c[KCTR_K2JOBS];

@@ -39,6 +39,7 @@ enum : uint32_t {
     KCTR_ROWJOBS = 11,      // row mode: workgroups of the sort inside the block rows
     KCTR_L2_OVERFLOW = 12,  // != 0: the second level's node indices or entries ran out (results invalid; repeated with larger arrays)
     KCTR_L2_NODES = 13,     // nodes that went to the second level
+    KCTR_POOL_USED = 15,    // chunks of the chunk pool in use (upper bound: busiest sub-pool x sub-pools)
     KCTR_K2JOBS = 14,       // row mode: jobs of the apply kernel over the sorted records (one stream, or one part of a long stream, each)
     KCTR_COUNT = 16
 };
