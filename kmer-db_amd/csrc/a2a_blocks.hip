@@ -928,10 +928,9 @@ struct WParams {
     uint32_t emit_lo, emit_hi;
     PoolView pool;
     L2View l2;
-    unsigned long long* prof;      // (profiling build of the kernel only: per wave K1W_NPH phase times in 10 ns ticks)
 };
 constexpr int K1W_WAVES = 2;
-constexpr int K1W_NPH = 8;
+
 constexpr uint32_t L2_MIN_BLOCKS = 24;     // nodes with that many blocks take the second level (measured at 10 000 samples: 11 -> 21.9 ms, 24 -> 20.0; KMDB_L2_MIN moves it)
 constexpr uint32_t L2_NODE_GRAB = 16, L2_ENT_GRAB = 1024, L2_SUB = 16;   // node indices / entries a wave takes per device atomic, from one of L2_SUB cursors each
 constexpr uint32_t K1W_QCAP = 64;          // inclusive record counts of the lanes of a batch (the owner search of the record-parallel emission)
@@ -1005,25 +1004,12 @@ __global__ void wrun_anc_kernel(const uint32_t* __restrict__ widx, uint32_t n_wi
 //   number of entries and the mask of the node's own last entry.  At the start of a run the chain is built from the root path of
 //   the slice's first node (a table made at upload): the lists of all its wide ancestors in one scan.
 // No node climbs parent links, and a list may have as many entries as there are blocks.
-template <bool PROF>
 __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + wave;         // 1 or K1W_WAVES waves per workgroup, by the LDS a wave needs
     if (wid >= q.n_waves) return;
-    // (PROF: where a wave's time goes — 0 run start + chain, 1 batch loads + list lengths, 2 rows, 3 second-level entries, 4 whole-wave records,
-    // 5 record-parallel emission, 6 chain hand-over, 7 end)
-    unsigned long long ph[K1W_NPH] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long cn[K1W_NPH] = {0, 0, 0, 0, 0, 0, 0, 0};      // (PROF) batches, rounds, entries of the lists, entries of the rows, walk steps of all lanes, longest walk per round, light steps, light records
-    unsigned long long t_last = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    auto PT = [&](int k) {
-        if (!PROF) return;
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-        for (int j = 0; j < K1W_NPH; ++j) if (j == k) ph[j] += now - t_last;
-        t_last = now;
-    };
     unsigned char* wbase = lds_raw + k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap, q.n_rows) * wave;
     const K1WLds L = k1w_carve(wbase, q.arena_cap, q.e_cap, q.chain_cap);
     RowTab RT{nullptr, nullptr, 0u};
@@ -1083,7 +1069,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     l2_enext += mj; l2_estock -= mj;
                     if (lane == 0) q.l2.node_w[g] = wj;
                     ++l2_nodes;
-                    PT(3);
                     continue;
                 }
                 const uint32_t Tj = mj * (mj + 1u) / 2u;
@@ -1107,7 +1092,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     if (q.n_rows) row_emit(A, q.pool, RT, rec_on, X, FX, FY, wj, stream, lane, lt_mask);
                     else wide_emit(A, q.pool, rec_on, FX, FY, wj, stream, lane, lt_mask);
                 }
-                PT(4);
             }
             on = on && m < K1W_HEAVY;
         }
@@ -1121,7 +1105,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
         L.queue[lane] = rincl;
         L.st_w[lane] = wv;
         lds_sync();
-        if (PROF) { cn[6] += (T + 63u) / 64u; cn[7] += T; }
         for (uint32_t t0 = 0; t0 < T; t0 += WAVE) {
             const uint32_t t = t0 + lane;
             bool rec_on = false, diag = false;
@@ -1151,7 +1134,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             else wide_emit(A, q.pool, rec_on, FX, diag ? FX : FY, ww, stream, lane, lt_mask);
         }
         lds_sync();
-        PT(5);
     };
 
     // The records per node differ by orders of magnitude (3 blocks: 6 records, 200 blocks: 20 100) and heavy nodes sit together
@@ -1224,7 +1206,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
             }
             lds_sync();
         }
-        PT(0);
         // ---- the batches of the run
         for (uint32_t k0 = kb; k0 < ke; k0 += WAVE) {
             const uint32_t nv = ke - k0 < (uint32_t)WAVE ? ke - k0 : (uint32_t)WAVE;
@@ -1308,14 +1289,11 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                                    ((unsigned long long)(np & 0x3FFFu) << 48) | ((unsigned long long)base << 62);
             }
             lds_sync();
-            PT(1);
             // ---- rows, as many lanes at a time as the arena holds, and their records.  Only the lanes that emit need a row, and
             // the last one (its list becomes the chain list).
             const bool need = valid && (act || lane == nv - 1u);
             uint32_t fin = 0, last_start = 0;
-            if (PROF) { cn[0] += 1; cn[2] += bcast(wave_incl_scan(need ? len : 0u, lane), WAVE - 1); cn[3] += bcast(wave_incl_scan(need ? slen : 0u, lane), WAVE - 1); }
             while (fin < nv) {
-                uint32_t wsteps = 0;
                 const uint32_t c = (lane >= fin && need) ? slen : 0u;
                 const uint32_t incl = wave_incl_scan(c, lane);
                 const unsigned long long over = __ballot(incl > q.arena_cap);
@@ -1335,7 +1313,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     };
                     uint32_t y = lane;
                     for (;;) {
-                        ++wsteps;
                         const unsigned long long dsc = L.own_desc[y];
                         const unsigned long long ym0 = L.own_m0[y];
                         const uint32_t ynp = (uint32_t)(dsc >> 48) & 0x3FFFu, yb = (uint32_t)(dsc >> 62), ylink = (uint32_t)(dsc >> 16) & 0xFFFFu;
@@ -1364,17 +1341,9 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                     }
                     rflush();
                 }
-                if (PROF) {
-                    cn[1] += 1;
-                    uint32_t mx = wsteps;
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
-                    cn[5] += mx; cn[4] += bcast(wave_incl_scan(wsteps, lane), WAVE - 1);
-                }
                 L.st_start[lane] = (uint16_t)start; L.st_pre[lane] = (uint16_t)pre;
                 if (lane == nv - 1u && on) last_start = start;
                 lds_sync();
-                PT(2);
                 emit(on && act, len, wv);
                 fin = hi;
             }
@@ -1393,14 +1362,11 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
                 const uint32_t ll = bcast(slen, nv - 1u), ls = bcast(last_start, nv - 1u), lp = bcast(pre, nv - 1u);
                 for (uint32_t e = lane; e < ll; e += WAVE) { L.e_blk[lp + e] = L.ent_blk[ls + e]; L.e_mask[lp + e] = L.ent_mask[ls + e]; }
                 lds_sync();
-                PT(6);
             }
         }
     }
     arena_finish(A, q.pool, lane);
     if (q.n_rows) rowtab_finish(RT, q.pool, lane);
-    PT(7);
-    if (PROF && lane == 0) for (int j = 0; j < K1W_NPH; ++j) { q.prof[(size_t)wid * K1W_NPH + j] = ph[j]; q.prof[(size_t)(q.n_waves + wid) * K1W_NPH + j] = cn[j]; }
     if (lane == 0 && n_miss) atomicAdd(&q.pool.counters[KCTR_SLOW], n_miss);
     if (lane == 0 && l2_nodes) atomicAdd(&q.pool.counters[KCTR_L2_NODES], l2_nodes);
 }
@@ -1660,9 +1626,13 @@ __global__ void l2_offsets_kernel(const uint32_t* __restrict__ len, uint32_t NB,
 // an entry's place in its block's list is its node's rank in the block's bitmap: no sort
 __global__ void l2_lists_kernel(const uint32_t* __restrict__ ent_g, const uint16_t* __restrict__ ent_blk, const unsigned long long* __restrict__ ent_mask,
                                 const uint32_t* __restrict__ node_w, uint32_t n, uint32_t W, const unsigned long long* __restrict__ B, const uint32_t* __restrict__ R,
-                                const uint32_t* __restrict__ loff, unsigned long long* __restrict__ L, uint32_t* __restrict__ Wt) {
+                                const uint32_t* __restrict__ loff, unsigned long long* __restrict__ L, uint32_t* __restrict__ Wt, const uint32_t* __restrict__ cursors) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // (the entry pool is sized with room to spare — four fifths of its slots were never handed out at 10 000 samples: a slot beyond its
+    // sub-range's cursor is not even looked at)
+    const uint32_t per_sub = n / L2_SUB, sub = i / per_sub;
+    if (sub < L2_SUB && i - sub * per_sub >= cursors[(L2_SUB + sub) * 16u]) return;
     const uint32_t X = ent_blk[i];
     if (X == 0xFFFFu) return;                                 // a slot no wave wrote (the rest of a grab)
     const uint32_t g = ent_g[i];
@@ -3182,16 +3152,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.n_rows = row_mode ? db->NB : 0u;
         const size_t wave_lds = k1w_wave_bytes(q.arena_cap, q.e_cap, q.chain_cap, q.n_rows);
         const uint32_t waves = wave_lds * K1W_WAVES <= (size_t)(64u << 10) ? (uint32_t)K1W_WAVES : 1u;
-        static const bool k1w_prof = getenv("KMDB_K1W_PROF") != nullptr;              // (experiment, round 5: phase times of the wide kernel on stderr)
-        HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
-        if (k1w_prof) HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k1w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds * waves)));
         // As many waves as the chip holds at once, each with an equal share of the runs (dealt round-robin): with more, the waves
         // beyond the first round start when the first ones end, and all take equally long — 1.6 rounds cost 2 (measured at 10 000
         // samples: 4096 waves at 10 per CU took 8.8 ms, of which every wave ran 4.4).
         if (!db->k1w_slots) {
             int per_cu = 0, dev = 0;
             hipDeviceProp_t prop;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k1w_kernel<false>, (int)(WAVE * waves), wave_lds * waves));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k1w_kernel, (int)(WAVE * waves), wave_lds * waves));
             HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipGetDeviceProperties(&prop, dev));
             db->k1w_slots = (uint32_t)std::max(1, per_cu) * waves * (uint32_t)std::max(1, prop.multiProcessorCount);
@@ -3199,33 +3167,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.n_waves = std::min<uint32_t>(std::min<uint32_t>(db->k1w_slots, db->k1w_waves), q.n_runs);
         q.run_ctr = db->run_ctr;
         if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(db->k1w_waves, q.n_runs), (uint32_t)atoi(e)));
-        if (k1w_prof) {
-            static unsigned long long* d_prof = nullptr;
-            if (!d_prof) HIP_TRY(hipMalloc((void**)&d_prof, (size_t)2 * K1W_MAX_WAVES * K1W_NPH * 8));
-            q.prof = d_prof;
-            hipLaunchKernelGGL(k1w_kernel<true>, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
-            std::vector<unsigned long long> h((size_t)2 * q.n_waves * K1W_NPH);
-            HIP_TRY(hipMemcpyAsync(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            double sum[K1W_NPH] = {0}, mx = 0;
-            for (uint32_t w = 0; w < q.n_waves; ++w) { double t = 0; for (int j = 0; j < K1W_NPH; ++j) { sum[j] += (double)h[(size_t)w * K1W_NPH + j]; t += (double)h[(size_t)w * K1W_NPH + j]; } mx = std::max(mx, t); }
-            fprintf(stderr, "[kmdb] k1w phases, mean per wave in us (%u waves, %u wide nodes; slowest wave %.1f us):", q.n_waves, n_wide, mx * 0.01);
-            const char* nm[K1W_NPH] = {"run+chain", "loads+lengths", "rows", "l2 entries", "heavy records", "light records", "hand-over", "end"};
-            for (int j = 0; j < K1W_NPH; ++j) fprintf(stderr, " %s %.1f", nm[j], sum[j] / q.n_waves * 0.01);
-            fprintf(stderr, "\n");
-            double cs[K1W_NPH] = {0};
-            for (uint32_t w = 0; w < q.n_waves; ++w) for (int j = 0; j < K1W_NPH; ++j) cs[j] += (double)h[(size_t)(q.n_waves + w) * K1W_NPH + j];
-            fprintf(stderr, "[kmdb] k1w counts, totals: batches %.0f rounds %.0f list entries %.0f row entries %.0f walk steps %.0f (longest per round, summed: %.0f) light steps %.0f light records %.0f\n",
-                    cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[7]);
-        } else
-        hipLaunchKernelGGL(k1w_kernel<false>, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
+        hipLaunchKernelGGL(k1w_kernel, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
         if (db->l2_on) {
             // rank directories, list offsets, lists, and the tile joins adding into M (a tile whose blocks have no list leaves at once)
             const uint32_t NB = db->NB, W = db->l2_node_cap / 64u;
             hipLaunchKernelGGL(l2_ranks_kernel, dim3(NB), dim3(256), 0, st, db->l2_bitmap, W, db->l2_rank, db->l2_len);
             hipLaunchKernelGGL(l2_offsets_kernel, dim3(1), dim3(64), 0, st, db->l2_len, NB, db->l2_cursors, W, db->l2_loff);
             hipLaunchKernelGGL(l2_lists_kernel, dim3((db->l2_ent_cap + 255u) / 256u), dim3(256), 0, st, db->l2_ent_g, db->l2_ent_blk, db->l2_ent_mask, db->l2_node_w,
-                               db->l2_ent_cap, W, db->l2_bitmap, db->l2_rank, db->l2_loff, db->l2_list_mask, db->l2_list_w);
+                               db->l2_ent_cap, W, db->l2_bitmap, db->l2_rank, db->l2_loff, db->l2_list_mask, db->l2_list_w, db->l2_cursors);
             hipLaunchKernelGGL(l2_join_apply_kernel, dim3(NB * (NB + 1u) / 2u), dim3(64 * L2_WAVES), 0, st, db->l2_bitmap, db->l2_rank, db->l2_list_mask, db->l2_list_w,
                                db->l2_loff, W, NB, M, (uint32_t)db->N, db->width, db->tile_touched);
         }
