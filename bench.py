@@ -345,6 +345,7 @@ def extra_workload(K, S, args, device, name, reference=True, definition_rows=0):
         _s = db.stats()
         ms.append(_s["kernel_ms"])
         parts.append((_s["k0_ms"], _s["k1n_ms"], _s["k1g_ms"], _s["k2_ms"]))
+        assert _s["sized_call"] == 0, "%s: a warm call measured its launch sizes again" % name
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) / args.steps * 1e3
     got = int(M[:cells].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
@@ -356,7 +357,8 @@ def extra_workload(K, S, args, device, name, reference=True, definition_rows=0):
     alg = st0["algorithmic_bytes"]
     traffic, traffic_src = replayed_traffic(name)
     out = {"workload": "%s: %d synthetic %g Mbp genomes (clades of %d), k=%d f=1.0, dense all2all" % (name, wl["samples"], wl["length"] / 1e6, wl["clade_size"], args.k),
-           "ms_per_step": wall_ms, "kernel_ms": kern_ms, "value": float(st0["sum_pairs"]) / (wall_ms * 1e-3), "unit": "kmer-pair-comparisons/s",
+           "ms_per_step": wall_ms, "kernel_ms": kern_ms, "step_kernel_ms": [round(float(x), 3) for x in ms],
+           "value": float(st0["sum_pairs"]) / (wall_ms * 1e-3), "unit": "kmer-pair-comparisons/s",
            "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg},
            "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3])},

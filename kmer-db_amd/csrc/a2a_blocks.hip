@@ -3167,6 +3167,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         q.n_waves = std::min<uint32_t>(std::min<uint32_t>(db->k1w_slots, db->k1w_waves), q.n_runs);
         q.run_ctr = db->run_ctr;
         if (const char* e = getenv("KMDB_K1W_WAVES")) q.n_waves = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(db->k1w_waves, q.n_runs), (uint32_t)atoi(e)));
+        if (!db->have_counts && getenv("KMDB_VERBOSE"))
+            fprintf(stderr, "[kmdb] wide kernel: %u wide nodes in %u runs, %u waves (%u fit the chip, %zu B of LDS per wave, %u per workgroup)\n", n_wide, q.n_runs, q.n_waves,
+                    db->k1w_slots, wave_lds, waves);
         hipLaunchKernelGGL(k1w_kernel, dim3((q.n_waves + waves - 1) / waves), dim3(WAVE * waves), wave_lds * waves, st, q);
         if (db->l2_on) {
             // rank directories, list offsets, lists, and the tile joins adding into M (a tile whose blocks have no list leaves at once)
@@ -3325,6 +3328,10 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                             (row_mode ? (c[KCTR_ROWJOBS] > jobs_launched || c[KCTR_WIDE_RECORDS] != db->last_n_sorted || c[KCTR_K2JOBS] > k2jobs_launched) : c[KCTR_RAW] > raw_launch))) {
         // the exact counts cannot differ for an unchanged database and emit range, and the varying ones stay inside their slack in
         // practice; if not: redo the call with upper bounds
+        if (getenv("KMDB_VERBOSE"))
+            fprintf(stderr, "[kmdb] a launch was sized too small (wide nodes %u / %u, chunks %u / %u, row jobs %u / %u, sorted %u / %u, apply jobs %u / %u, raw %u / %u): the call is repeated\n",
+                    c[KCTR_NWIDE], db->last_n_wide, c[KCTR_CHUNKS], db->last_n_chunks, c[KCTR_ROWJOBS], jobs_launched, c[KCTR_WIDE_RECORDS], db->last_n_sorted, c[KCTR_K2JOBS],
+                    k2jobs_launched, c[KCTR_RAW], raw_launch);
         db->have_counts = false; *retry = true;
         return 0;
     }
