@@ -964,7 +964,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "whole call: k0_decode_kernel x2 + k1n_kernel + wide list + k1w_kernel + cs_hist / cs_scatter (counting sort) + k2_sorted_kernel, with k2_apply_kernel on a side stream (+ zeroing, pool init)",
+                "kernel": "whole call: k0_decode_kernel x2 + k1n_kernel + wide list + k1w_kernel + cs_hist / cs_scatter (counting sort) + k2_jobs_kernel, with k2_apply_kernel on a side stream (+ zeroing, pool init)",
                 "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
                 "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3]),
                                   "whole_call": kern_ms},

@@ -230,7 +230,9 @@ __device__ __forceinline__ void arena_finish(const WaveArena& A, const PoolView&
 // Every lane of the wave calls.
 __device__ __forceinline__ void wide_emit(WaveArena& A, const PoolView& pv, bool on, unsigned long long rows, unsigned long long cols, uint32_t w, uint32_t stream,
                                           uint32_t lane, unsigned long long lt_mask) {
-    const uint32_t dmask = (1u << pv.dbits) - 1u;
+    // (packed records, pv.pshift != 0: the weight digit and its index in the spare bits of the column word, the key word = the stream only)
+    const uint32_t dbits = pv.pshift ? (64u - pv.pshift - 2u < 16u ? 64u - pv.pshift - 2u : 16u) : pv.dbits;
+    const uint32_t dmask = (1u << dbits) - 1u;
     uint32_t j = 0;
     for (;;) {
         const unsigned long long grp = __ballot(on);
@@ -238,10 +240,15 @@ __device__ __forceinline__ void wide_emit(WaveArena& A, const PoolView& pv, bool
         const Resv r = arena_reserve_wide(A, pv, (uint32_t)__popcll(grp), lane);
         if (on) {
             const uint32_t slot = resv_slot(r, (uint32_t)__popcll(grp & lt_mask));
-            pv.wrec[slot] = WideRec{rows, cols};
-            pv.wkey[slot] = stream | (((w & dmask) | (j << pv.dbits)) << pv.kbits);
+            if (pv.pshift) {
+                pv.wrec[slot] = WideRec{rows, cols | ((unsigned long long)((w & dmask) | (j << dbits)) << pv.pshift)};
+                pv.wkey[slot] = stream;
+            } else {
+                pv.wrec[slot] = WideRec{rows, cols};
+                pv.wkey[slot] = stream | (((w & dmask) | (j << dbits)) << pv.kbits);
+            }
         }
-        w >>= pv.dbits; ++j;
+        w >>= dbits; ++j;
         on = on && w != 0;
     }
 }
@@ -1965,15 +1972,15 @@ __global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict
 // contiguous burst.  LDS: the staged records, their destinations, and three per-bin arrays (tile histogram = rank source,
 // tile offsets, the workgroup's running global cursor).
 constexpr uint32_t CS_TILE = 2048, CS_THREADS = 256;
-__host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys) { return (size_t)CS_TILE * (sizeof(WideRec) + 8) + (size_t)n_keys * 12 + CS_THREADS * 4 + 64; }
+__host__ __device__ inline size_t cs_scatter_lds(uint32_t n_keys, bool packed) { return (size_t)CS_TILE * (sizeof(WideRec) + (packed ? 4 : 8)) + (size_t)n_keys * 12 + CS_THREADS * 4 + 64; }
 __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* __restrict__ wkey, const WideRec* __restrict__ wrec, uint32_t n, uint32_t n_valid,
                                                          uint32_t n_keys, int mode, const CsRows rows, uint32_t kmask, const uint32_t* __restrict__ O,
-                                                         uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec) {
+                                                         uint32_t* __restrict__ swkey, WideRec* __restrict__ swrec, uint32_t packed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
     WideRec* st_rec = (WideRec*)cs_raw;                                   // [CS_TILE]
     uint32_t* st_dst = (uint32_t*)(st_rec + CS_TILE);                     // [CS_TILE] global destination
-    uint32_t* st_key = st_dst + CS_TILE;                                  // [CS_TILE]
-    uint32_t* hist = st_key + CS_TILE;                                    // [n_keys] records of the tile per bin
+    uint32_t* st_key = st_dst + CS_TILE;                                  // [CS_TILE]; not there for packed records: their key words (the stream only) stay behind
+    uint32_t* hist = st_key + (packed ? 0u : CS_TILE);                    // [n_keys] records of the tile per bin
     uint32_t* toff = hist + n_keys;                                       // [n_keys] first staging position of the bin
     uint32_t* cursor = toff + n_keys;                                     // [n_keys] next global position of the bin for this workgroup
     uint32_t* part = cursor + n_keys;                                     // [CS_THREADS] scan scratch
@@ -2026,7 +2033,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
                 const uint32_t p = toff[key[j]] + rank[j];
                 st_rec[p] = rc[j];
                 st_dst[p] = cursor[key[j]] + rank[j];
-                st_key[p] = kw[j];
+                if (!packed) st_key[p] = kw[j];
             }
         }
         __syncthreads();
@@ -2034,7 +2041,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_scatter_kernel(const uint32_t* 
         for (uint32_t p = threadIdx.x; p < tile_n; p += CS_THREADS) {
             const uint32_t d = st_dst[p];
             swrec[d] = st_rec[p];
-            swkey[d] = st_key[p];
+            if (!packed) swkey[d] = st_key[p];
         }
         __syncthreads();
     }
@@ -2364,6 +2371,11 @@ __global__ void k2j_starts_kernel(const RsRows R, const uint32_t* __restrict__ O
     const uint32_t nj = R.row_job[X + 1] - R.row_job[X];                                   // a row without records has no jobs: its streams start where the next row does
     start[s] = O[(size_t)R.row_tab[X] + (size_t)Y * nj];
 }
+// few streams: O = the one-pass sort's offsets [stream][workgroup share] (+ the total): share 0 of a stream is where the stream starts
+__global__ void k2j_starts_flat_kernel(const uint32_t* __restrict__ O, uint32_t n_states, uint32_t shares, uint32_t* __restrict__ start) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= n_states) start[s] = O[(size_t)s * shares];
+}
 // the jobs in any order: one reservation per workgroup of streams
 __global__ __launch_bounds__(1024) void k2j_build_kernel(const uint32_t* __restrict__ start, uint32_t n_states, uint2* __restrict__ jobs, uint32_t cap,
                                                          uint32_t* __restrict__ counters) {
@@ -2521,7 +2533,7 @@ inline uint32_t wide_digit_bits(int key_bits) { return (uint32_t)(32 - key_bits 
 PoolView pool_view(const kmdb_db* db, bool dense) {
     return PoolView{db->counters, db->chunk_key, db->chunk_fill, db->rec, db->recw, db->sub_cursor, (uint32_t)(db->pool_cap / KMDB_SUBPOOLS),
                     (uint32_t)db->pool_cap, db->wkey, (WideRec*)db->wrec, db->wsub_cursor, (uint32_t)(db->wide_pool_cap / KMDB_SUBPOOLS), dense ? 1u : 0u,
-                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, db->row_mode ? db->rec_pshift : 0u};
+                    (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), db->row_mode ? 1u : 0u, db->n_states, db->rec_pshift};
 }
 
 void free_and_null(void** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
@@ -2586,11 +2598,11 @@ int alloc_wide_pool(kmdb_db* db, uint64_t chunks) {
     HIP_TRY(hipMalloc((void**)&db->swkey, slots * 4));
     HIP_TRY(hipMalloc(&db->swrec, slots * sizeof(WideRec)));
     db->sorted_cap = slots;
+    // jobs of the apply kernel: every stream at least one, a long one a job per K2J_REC records
+    FREE_NULL(db->k2j_jobs);
+    db->k2j_cap = slots / K2J_REC + db->n_states + 1;
+    HIP_TRY(hipMalloc((void**)&db->k2j_jobs, db->k2j_cap * sizeof(uint2)));
     if (db->row_mode) {
-        // jobs of the apply kernel: every stream at least one, a long one a job per K2J_REC records
-        FREE_NULL(db->k2j_jobs);
-        db->k2j_cap = slots / K2J_REC + db->n_states + 1;
-        HIP_TRY(hipMalloc((void**)&db->k2j_jobs, db->k2j_cap * sizeof(uint2)));
         db->wide_pool_cap = chunks;
         return 0;
     }
@@ -2729,9 +2741,9 @@ int kmdb_rect_sort_apply(hipStream_t st, uint32_t* wkey, void* wrec, uint32_t ns
         const CsRows no_rows{};
         hipLaunchKernelGGL(cs_hist_kernel, dim3(CS_BLOCKS_ONE), dim3(256), n_states * 4, st, wkey, nslots, n_states, n_states, (int)CS_BY_STREAM, no_rows, kmask, hist);
         RS_TRY(prim::exclusive_sum(tmp, tb, hist, offs, (int)ne, st));
-        RS_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(n_states)));
-        hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(n_states), st, wkey, (const WideRec*)wrec, nslots, n_states, n_states,
-                           (int)CS_BY_STREAM, no_rows, kmask, offs, swkey, swrec);
+        RS_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(n_states, false)));
+        hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(n_states, false), st, wkey, (const WideRec*)wrec, nslots, n_states, n_states,
+                           (int)CS_BY_STREAM, no_rows, kmask, offs, swkey, swrec, 0u);
         total_ptr = offs + (ne - 1);
     } else {
         size_t tb = 0;
@@ -2875,7 +2887,8 @@ static int blocks_prepare_impl(kmdb_db* db) {
     if (const char* e = getenv("KMDB_ROW_MODE")) if (*e) db->row_mode = atoi(e) != 0;          // (tests: small databases through the many-streams path)
     // packed records: a block width of at most 54 leaves the column mask 10 spare bits and more — an 8-bit weight digit at least and the digit's
     // index — so the records of the many-streams path travel as 16 bytes through the sort and the apply step (KMDB_REC_PACKED=0: 16 + 4, A/B)
-    db->rec_pshift = (db->row_mode && db->width <= 54u && !(getenv("KMDB_REC_PACKED") && getenv("KMDB_REC_PACKED")[0] == '0')) ? db->width : 0u;
+    // (round 5, later: the few-streams path as well — its one-pass sort moves 16 bytes per record and leaves the key words behind)
+    db->rec_pshift = (db->width <= 54u && !(getenv("KMDB_REC_PACKED") && getenv("KMDB_REC_PACKED")[0] == '0')) ? db->width : 0u;
     db->n_ckeys = db->n_states;                                  // keys of the grouped chunk table = the streams (row chunks sit in their rows' lists)
     {
         int key_bits = 1;
@@ -2915,8 +2928,8 @@ static int blocks_prepare_impl(kmdb_db* db) {
     if (db->row_mode) {
         db->k1w_waves = std::min<uint32_t>(db->k1w_waves, std::max<uint32_t>(256u, std::min<uint32_t>(4096u, (1u << 21) / std::max<uint32_t>(db->NB, 1u))));
         HIP_TRY(hipMalloc((void**)&db->rs_rows, (size_t)2 * (db->NB + 1) * 4));
-        HIP_TRY(hipMalloc((void**)&db->k2j_start, ((size_t)db->n_states + 2) * 4));
     }
+    HIP_TRY(hipMalloc((void**)&db->k2j_start, ((size_t)db->n_states + 2) * 4));
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide records: the wide estimate at two thirds (+ a grab / the open row chunks per wave)
     if (db->row_mode) {
@@ -3245,14 +3258,27 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
                                no_rows, kmask, db->cs_hist);
             size_t tb = db->cs_tmp_bytes;
             HIP_TRY(prim::exclusive_sum(db->cs_tmp, tb, db->cs_hist, db->cs_offs, (int)ne, st));
-            HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states)));
-            hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(db->n_states), st, db->wkey, (const WideRec*)db->wrec, nslots,
-                               db->n_states, db->n_states, (int)CS_BY_STREAM, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec);
+            const bool packed = db->rec_pshift != 0;
+            HIP_TRY(hipFuncSetAttribute((const void*)cs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_scatter_lds(db->n_states, packed)));
+            hipLaunchKernelGGL(cs_scatter_kernel, dim3(CS_BLOCKS_ONE), dim3(CS_THREADS), cs_scatter_lds(db->n_states, packed), st, db->wkey, (const WideRec*)db->wrec, nslots,
+                               db->n_states, db->n_states, (int)CS_BY_STREAM, no_rows, kmask, db->cs_offs, db->swkey, (WideRec*)db->swrec, packed ? 1u : 0u);
             const uint32_t* total_ptr = db->cs_offs + (ne - 1);
             HIP_TRY(hipMemcpyAsync(db->counters + KCTR_WIDE_RECORDS, total_ptr, 4, hipMemcpyDeviceToDevice, st));
-            const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
-            hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, nslots, total_ptr, (const uint32_t*)nullptr,
-                               db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u, db->tile_touched);
+            if (getenv("KMDB_K2_WINDOWS") && !packed) {
+                // (A/B: round 4's apply step over windows of 4096 sorted positions, run boundaries searched in the key words)
+                const uint32_t g2 = (nslots + K2S_WIN - 1) / K2S_WIN;
+                hipLaunchKernelGGL(k2_sorted_kernel, dim3(g2), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, nslots, total_ptr, (const uint32_t*)nullptr,
+                                   db->n_states, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, 0u, 0u, db->tile_touched);
+            } else {
+                // the sorted records applied stream by stream, as on the many-streams path: the streams start where the sort's offsets say (no run
+                // boundaries searched, no key word read for packed records), a tile is written back once per K2J_REC records of its stream
+                hipLaunchKernelGGL(k2j_starts_flat_kernel, dim3((db->n_states + 1u + 255u) / 256u), dim3(256), 0, st, db->cs_offs, db->n_states, CS_BLOCKS_ONE, db->k2j_start);
+                hipLaunchKernelGGL(k2j_build_kernel, dim3((db->n_states + 1023u) / 1024u), dim3(1024), 0, st, db->k2j_start, db->n_states, db->k2j_jobs, (uint32_t)db->k2j_cap, db->counters);
+                k2jobs_launched = db->have_counts ? db->last_n_k2jobs : (uint32_t)db->k2j_cap;
+                if (k2jobs_launched)
+                    hipLaunchKernelGGL(k2_jobs_kernel, dim3(k2jobs_launched), dim3(256), 0, st, db->swkey, (const WideRec*)db->swrec, db->k2j_start, db->k2j_jobs, db->counters + KCTR_K2JOBS,
+                                       (uint32_t)db->k2j_cap, (uint32_t)db->sorted_cap, db->rec_pshift, (uint32_t)db->key_bits, wide_digit_bits(db->key_bits), M, (uint32_t)db->N, db->width, db->tile_touched);
+            }
             HIP_TRY(hipGetLastError());
         }
         if (stage("sorted apply")) return 1;
@@ -3325,7 +3351,8 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         return 0;
     }
     if (db->have_counts && (c[KCTR_NWIDE] != db->last_n_wide || c[KCTR_CHUNKS] != db->last_n_chunks ||
-                            (row_mode ? (c[KCTR_ROWJOBS] > jobs_launched || c[KCTR_WIDE_RECORDS] != db->last_n_sorted || c[KCTR_K2JOBS] > k2jobs_launched) : c[KCTR_RAW] > raw_launch))) {
+                            (row_mode ? (c[KCTR_ROWJOBS] > jobs_launched || c[KCTR_WIDE_RECORDS] != db->last_n_sorted || c[KCTR_K2JOBS] > k2jobs_launched)
+                                      : (c[KCTR_RAW] > raw_launch || c[KCTR_K2JOBS] > k2jobs_launched)))) {
         // the exact counts cannot differ for an unchanged database and emit range, and the varying ones stay inside their slack in
         // practice; if not: redo the call with upper bounds
         if (getenv("KMDB_VERBOSE"))
