@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include <stdarg.h>
 #include <math.h>
 #include <sys/types.h>
@@ -358,16 +359,25 @@ static uint64_t minhash_hash(uint64_t kmer, uint64_t k_div_4) {  /* filter.h:96-
     return h1 ^ h2;
 }
 
-size_t kmo_extract_kmers(const char* seq, size_t len, uint32_t k, double fraction, double start_fraction,
-                         int preserve_strand, uint64_t* out) {
+/* KmerHelper::extract (kmer_extract.h:13-97) over any of the reference's alphabets (alphabet.h:22-66: the groups of a comma-separated
+ * description are the symbols, upper and lower case alike; bits per symbol = ceil(log2(groups)); alphabet.h:79-86 lists them:
+ * nt "A,C,G,TU", aa "K,R,E,D,Q,N,C,G,H,I,L,V,M,F,Y,W,P,S,T,A", aa11_diamond "KREDQN,C,G,H,ILV,M,F,Y,W,P,STA", aa12_mmseqs
+ * "AST,C,DN,EQ,FY,G,H,IV,KR,LM,P,W", aa6_dayhoff "STPAG,NDEQ,HRK,MILV,FYW,C"; every protein alphabet preserves the strand). */
+size_t kmo_extract_kmers_alphabet(const char* seq, size_t len, uint32_t k, const char* groups, double fraction, double start_fraction,
+                                  int preserve_strand, uint64_t* out) {
     int8_t map[256];
     memset(map, -1, sizeof map);
-    map['A'] = map['a'] = 0; map['C'] = map['c'] = 1; map['G'] = map['g'] = 2;
-    map['T'] = map['t'] = 3; map['U'] = map['u'] = 3;          /* alphabet.h:80 "A,C,G,TU" */
-    const int bits = 2;
+    int size = 1;
+    for (const char* g = groups; *g; ++g) {
+        if (*g == ',') { ++size; continue; }
+        const unsigned char c = (unsigned char)*g;
+        map[(unsigned char)tolower(c)] = map[(unsigned char)toupper(c)] = (int8_t)(size - 1);     /* alphabet.h:52-58 */
+    }
+    int bits = 0;
+    while ((1 << bits) < size) ++bits;                          /* alphabet.h:36 */
     if (len < k) return 0;
-    uint64_t mask = (k * bits >= 64) ? ~0ull : ((1ull << (bits * k)) - 1);
-    uint32_t shift_hi = (k - 1) * bits;
+    uint64_t mask = ((uint32_t)bits * k >= 64) ? ~0ull : ((1ull << ((uint32_t)bits * k)) - 1);
+    uint32_t shift_hi = (k - 1) * (uint32_t)bits;
     /* kmer_extract.h:37-45: force at least an 8-bit prefix above the 32-bit suffix */
     int prefix_bits = (int)k * bits - 32;
     uint32_t pshift = 0; uint64_t tail_mask = 0;
@@ -384,7 +394,7 @@ size_t kmo_extract_kmers(const char* seq, size_t len, uint32_t k, double fractio
         int s = map[(unsigned char)seq[i]];
         if (s < 0) { s = 0; omit = (i < k - 1) ? (int)i + 1 : (int)k; }   /* :52-56, :64-68 */
         fwd = ((fwd << bits) + (uint64_t)s) & mask;
-        rev = (rev >> bits) + ((uint64_t)(3 - s) << shift_hi);
+        rev = (rev >> bits) + ((uint64_t)(size - 1 - s) << shift_hi);     /* :59, :73 (3 - s in the prologue: the same for nt, unused otherwise) */
         if (i < k - 1) continue;
         if (omit > 0) { --omit; continue; }
         uint64_t can = preserve_strand ? fwd : (fwd < rev ? fwd : rev);
@@ -396,6 +406,10 @@ size_t kmo_extract_kmers(const char* seq, size_t len, uint32_t k, double fractio
         out[cnt++] = can;
     }
     return cnt;
+}
+size_t kmo_extract_kmers(const char* seq, size_t len, uint32_t k, double fraction, double start_fraction,
+                         int preserve_strand, uint64_t* out) {
+    return kmo_extract_kmers_alphabet(seq, len, k, "A,C,G,TU", fraction, start_fraction, preserve_strand, out);   /* alphabet.h:80 */
 }
 
 static int cmp_u64(const void* a, const void* b) {

@@ -94,6 +94,9 @@ int kmo_db2db_dense(const kmo_db* db_row, const kmo_db* db_col, uint32_t* out);
  * MinHashFilter (filter.h:28-115).  Returns number of k-mers written. */
 size_t kmo_extract_kmers(const char* seq, size_t len, uint32_t k, double fraction, double start_fraction,
                          int preserve_strand, uint64_t* out);
+/* the same over any alphabet of alphabet.h:79-86, given by its comma-separated groups (nt "A,C,G,TU", aa "K,R,E,...", aa11_diamond, ...) */
+size_t kmo_extract_kmers_alphabet(const char* seq, size_t len, uint32_t k, const char* groups, double fraction, double start_fraction,
+                                  int preserve_strand, uint64_t* out);
 /* sort + unique (kmer_extract.h:99-118); returns new count */
 size_t kmo_sort_unique(uint64_t* kmers, size_t n);
 

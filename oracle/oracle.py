@@ -74,6 +74,8 @@ def lib():
         L.kmo_db2db_dense.argtypes = [C.POINTER(_Db), C.POINTER(_Db), C.c_void_p]
         L.kmo_extract_kmers.restype = C.c_size_t
         L.kmo_extract_kmers.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.kmo_extract_kmers_alphabet.restype = C.c_size_t
+        L.kmo_extract_kmers_alphabet.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.kmo_sort_unique.restype = C.c_size_t
         L.kmo_sort_unique.argtypes = [C.c_void_p, C.c_size_t]
         _lib = L
@@ -220,6 +222,20 @@ def extract_seq(seq, k, fraction=1.0, start_fraction=0.0, preserve_strand=False)
     return out[:n]
 
 
+# the reference's alphabets (src/alphabet.h:79-86): name -> (groups, preserve strand)
+ALPHABETS = {"nt": ("A,C,G,TU", False), "nt-preserve": ("A,C,G,TU", True),
+             "aa": ("K,R,E,D,Q,N,C,G,H,I,L,V,M,F,Y,W,P,S,T,A", True), "aa11_diamond": ("KREDQN,C,G,H,ILV,M,F,Y,W,P,STA", True),
+             "aa12_mmseqs": ("AST,C,DN,EQ,FY,G,H,IV,KR,LM,P,W", True), "aa6_dayhoff": ("STPAG,NDEQ,HRK,MILV,FYW,C", True)}
+
+
+def extract_seq_alphabet(seq, k, alphabet, fraction=1.0, start_fraction=0.0):
+    """KmerHelper::extract over one of the reference's alphabets (`build -alphabet <name>`, src/params.cpp / src/alphabet.h)"""
+    groups, preserve = ALPHABETS[alphabet]
+    out = np.zeros(max(1, len(seq)), dtype=np.uint64)
+    n = lib().kmo_extract_kmers_alphabet(seq, len(seq), k, groups.encode(), fraction, start_fraction, int(preserve), out.ctypes.data)
+    return out[:n]
+
+
 def sort_unique(kmers):
     a = np.ascontiguousarray(kmers, dtype=np.uint64).copy()
     n = lib().kmo_sort_unique(a.ctypes.data, a.size)
@@ -274,8 +290,8 @@ def _run_ref(args):
     return json.loads(line)
 
 
-def ref_build(kmers_bin, out_db, threads=1):
-    return _run_ref(["build", kmers_bin, out_db, threads])
+def ref_build(kmers_bin, out_db, threads=1, alphabet="nt"):
+    return _run_ref(["build", kmers_bin, out_db, threads, alphabet])
 
 
 def ref_all2all(db_path, out_path, threads=1, buffer_mb=8):

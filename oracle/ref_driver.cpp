@@ -12,7 +12,7 @@
 //   SparseMatrix::compact2 / saveRowSparse                 (array.h:391-446, 625-637)
 //
 // Usage:
-//   ref_driver build    <kmers.bin> <out.db> [threads]
+//   ref_driver build    <kmers.bin> <out.db> [threads] [alphabet: nt (default), aa, aa11_diamond, aa12_mmseqs, aa6_dayhoff]
 //   ref_driver all2all  <db> <out.u32> [threads] [bufferMb]      raw lower-triangular matrix
 //   ref_driver all2all_sp <db> <out.txt> [threads] [bufferMb] [bubbleSize]
 //   ref_driver one2all  <db> <queries.bin> <out.u32> [threads]   nq x N dense rows
@@ -79,8 +79,10 @@ int main(int argc, char** argv) {
             refresh::active_thread_pool atp(4, 1024, std::chrono::milliseconds(2));
             PrefixKmerDb db(threads);
             double t0 = now_s();
+            // (the alphabet decides how many bits of a k-mer are prefix: console_build.cpp passes the -alphabet option's type on)
+            const AlphabetType alpha = argc > 5 ? AlphabetFactory::instance().str2type(argv[5]) : AlphabetType::nt;
             for (auto& s : samples)
-                db.addKmers(s.name, s.kmers.data(), (uint32_t)s.kmers.size(), k, fraction, AlphabetType::nt, atp);
+                db.addKmers(s.name, s.kmers.data(), (uint32_t)s.kmers.size(), k, fraction, alpha, atp);
             double t1 = now_s();
             std::ofstream ofs(argv[3], std::ios::binary);
             db.serialize(ofs, true);                 // console_build.cpp:149

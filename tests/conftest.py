@@ -59,4 +59,5 @@ def golden_dir(tmp_path_factory):
 
 
 DBS = ["virus_k18", "virus_k18_part1", "virus_k18_parts", "virus_k24", "virus_k18_f01", "synth_k21", "clade64",
-       "clade64_k25_f01", "protein_dna_k24", "protein_dna_k24_preserve"]
+       "clade64_k25_f01", "protein_dna_k24", "protein_dna_k24_preserve",
+       "protein_aa", "protein_aa11_diamond", "protein_aa12_mmseqs", "protein_aa6_dayhoff", "protein_aa_k7"]

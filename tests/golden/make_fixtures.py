@@ -36,12 +36,12 @@ def copy(src, dst):
     os.chmod(os.path.join(HERE, dst), 0o644)
 
 
-def build_db(samples, k, fraction, name, threads=4):
+def build_db(samples, k, fraction, name, threads=4, alphabet="nt"):
     with tempfile.TemporaryDirectory() as td:
         kb = os.path.join(td, "k.bin")
         O.write_kmers_bin(kb, k, fraction, samples)
         out = os.path.join(HERE, name)
-        info = O.ref_build(kb, out, threads)
+        info = O.ref_build(kb, out, threads, alphabet)
         print(name, info)
     return out
 
@@ -87,11 +87,33 @@ def protein_dna():
         ref_outputs(db, name[:-3])
 
 
+# test/protein/aa*.a2a (self-hosted.yml:404-427): `build -k 8 -multisample-fasta -alphabet <name>` of aa_100x1000.fasta + all2all; aa_k7.a2a is
+# the same at k = 7 with the aa alphabet (a golden the workflow does not run)
+PROTEIN_AA = (("aa", 8, "aa"), ("aa11_diamond", 8, "aa11_diamond"), ("aa12_mmseqs", 8, "aa12_mmseqs"), ("aa6_dayhoff", 8, "aa6_dayhoff"), ("aa_k7", 7, "aa"))
+
+
+def protein_aa():
+    """The protein goldens of test/protein: the 100 records of aa_100x1000.fasta as samples, k-mers over the amino-acid alphabets by the
+    oracle's restatement of KmerHelper::extract (n-bit symbols, alphabet.h), the databases from the real reference's addKmers (told the
+    alphabet: it sets the prefix bits) + serialize; the goldens are the reference's own files."""
+    recs = O._split_records(O._read_fasta_text(os.path.join(REF, "test/protein/aa_100x1000")))
+    for stem, k, alphabet in PROTEIN_AA:
+        copy("test/protein/%s.a2a" % stem, "protein.%s.a2a" % stem)
+        samples = [(h, O.sort_unique(O.extract_seq_alphabet(s, k, alphabet))) for h, s in recs]
+        db = build_db(samples, k, 1.0, "protein_%s.db" % stem, alphabet=alphabet)
+        ref_outputs(db, "protein_%s" % stem)
+
+
 def main():
     assert O.have_ref(), "build oracle/_ref first (make -C oracle)"
     if sys.argv[1:] == ["protein"]:
         protein_dna()
+        protein_aa()
         print("done (protein only)")
+        return
+    if sys.argv[1:] == ["protein-aa"]:
+        protein_aa()
+        print("done (protein aa only)")
         return
     # ---- 1. reference goldens + inputs -------------------------------------------------
     for f in ["k18.csv", "k18.sparse.csv", "k18.frac.csv", "k24.csv", "k18.n2a.csv",
@@ -159,6 +181,7 @@ def main():
         rows, _ = O.ref_one2all(db_cl, qb, os.path.join(td, "o2.u32"), threads=1)
         rows.tofile(os.path.join(HERE, "clade64.n2a.ref.u32"))
     protein_dna()
+    protein_aa()
     print("done")
 
 

@@ -431,6 +431,9 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
     _cli("all2all", g("protein_dna_k24.db"), t("dna.a2a")); _same(t("dna.a2a"), g("protein.dna.a2a"))
     _cli("all2all", g("protein_dna_k24_preserve.db"), t("dna-p.a2a")); _same(t("dna-p.a2a"), g("protein.dna-preserve.a2a"))
     _cli("all2all", "-gpus", "3", g("protein_dna_k24_preserve.db"), t("dna-p3.a2a")); _same(t("dna-p3.a2a"), g("protein.dna-preserve.a2a"))
+    # self-hosted.yml:404-427 (test/protein: amino-acid alphabets, k = 8; aa_k7.a2a at k = 7) — all2all never looks at the alphabet
+    for stem in ("aa", "aa11_diamond", "aa12_mmseqs", "aa6_dayhoff", "aa_k7"):
+        _cli("all2all", g("protein_%s.db" % stem), t(stem + ".a2a")); _same(t(stem + ".a2a"), g("protein.%s.a2a" % stem))
     # self-hosted.yml:110-146 (synth, with min/max filters)
     _cli("all2all", g("synth_k21.db"), t("a2a")); _same(t("a2a"), g("synth.a2a"))
     _cli("all2all", "-sparse", g("synth_k21.db"), t("a2a-sparse")); _same(t("a2a-sparse"), g("synth.a2a-sparse"))
@@ -1034,6 +1037,52 @@ def test_patterns_that_touch_every_block_of_many(K, O, dev):
     assert np.array_equal(got, exp)
     assert st["sum_pairs"] == int(exp.astype(np.uint64).sum())
     d.close()
+
+
+@pytest.mark.parametrize("form", ["packed", "unpacked", "windows"])
+def test_few_streams_record_forms(K, O, dev, tmp_path, form):
+    """The few-streams path (at most 2048 block pairs: BASELINE configs[1]) moves its block records in one of three forms: packed (block
+    width <= 54: 16 bytes, the weight digit in the column word's spare bits, the key words stay behind in the one-pass sort, apply step by
+    stream jobs), unpacked (KMDB_REC_PACKED=0, or any width above 54: 16 + 4 bytes, stream jobs) and round 4's (windows of 4096 sorted
+    positions, KMDB_K2_WINDOWS).  Random forests with weights of up to 32 bits (one to four digits of 8 - 16 bits) at widths 32 / 50 / 54 /
+    64 against the oracle: whole call, warm call, slices of the pattern stream (reference src/similarity_calculator.cpp:42-438)."""
+    import importlib
+    S = importlib.import_module("kmerdb_amd.synth")
+    env = {"packed": {}, "unpacked": {"KMDB_REC_PACKED": "0"}, "windows": {"KMDB_REC_PACKED": "0", "KMDB_K2_WINDOWS": "1"}}[form]
+    keys = ("KMDB_REC_PACKED", "KMDB_K2_WINDOWS", "KMDB_BLOCK_WIDTH", "KMDB_ROW_MODE")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        for seed, N, P, max_local, chain in ((31, 1000, 6000, 60, 0.2), (32, 2048, 3000, 300, 0.5), (33, 640, 20000, 8, 0.0)):
+            rng = np.random.default_rng(seed)
+            pat = _random_forest(rng, N, P, max_local, heavy_frac=0.4, chain_frac=chain)
+            arr = S.to_view_arrays(pat)
+            path = str(tmp_path / ("r%d.db" % seed))
+            S.write_db(path, 18, 1.0, ["s%d" % i for i in range(N)], [1] * N, arr)
+            exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
+            view = K.make_view(18, N, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"], arr["last_sample_id"], arr["num_bits"],
+                               arr["data_offset"], arr["data"])
+            for width in ("32", "50", "54", "64"):
+                os.environ["KMDB_BLOCK_WIDTH"] = width
+                d = K.DeviceDB(view, device=dev)
+                got = d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK)
+                st = d.stats()
+                assert st["path"] == K.capi.PATH_RECORDS and st["width"] == int(width), (seed, width, st)
+                assert np.array_equal(got, exp), (form, seed, width)
+                assert np.array_equal(d.all2all_dense(flags=K.capi.FLAG_NO_FALLBACK), exp) and d.stats()["sized_call"] == 0, (form, seed, width)
+                acc = np.zeros_like(exp)
+                for sh in range(2):
+                    acc += d.all2all_dense(shard=(sh, 2), flags=K.capi.FLAG_NO_FALLBACK)
+                assert np.array_equal(acc, exp), (form, seed, width)
+                d.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("l2min", ["11", "24"])

@@ -31,7 +31,12 @@ def test_dense_matches_reference_raw(O, golden_dir, stem):
     ("virus_k18_f01", "virus.k18.frac.csv", False), ("synth_k21", "synth.a2a", False),
     ("synth_k21", "synth.a2a-sparse", True),
     # test/protein/{dna,dna-preserve}.a2a (self-hosted.yml:393-403): k = 24, the records of one FASTA as samples; canonical k-mers / -preserve-strand
-    ("protein_dna_k24", "protein.dna.a2a", False), ("protein_dna_k24_preserve", "protein.dna-preserve.a2a", False)])
+    ("protein_dna_k24", "protein.dna.a2a", False), ("protein_dna_k24_preserve", "protein.dna-preserve.a2a", False),
+    # test/protein/aa*.a2a (self-hosted.yml:404-427): k = 8 over the amino-acid alphabets of src/alphabet.h:79-86 (5 / 4 / 4 / 3 bits per symbol);
+    # aa_k7.a2a: the aa alphabet at k = 7 (35 bits: the 8-bit-prefix rule of kmer_extract.h:37-45 applies)
+    ("protein_aa", "protein.aa.a2a", False), ("protein_aa11_diamond", "protein.aa11_diamond.a2a", False),
+    ("protein_aa12_mmseqs", "protein.aa12_mmseqs.a2a", False), ("protein_aa6_dayhoff", "protein.aa6_dayhoff.a2a", False),
+    ("protein_aa_k7", "protein.aa_k7.a2a", False)])
 def test_all2all_csv_matches_reference_golden(O, golden_dir, stem, golden, sparse):
     db = O.OracleDB(os.path.join(golden_dir, stem + ".db"))
     csv = O.format_all2all(db.k, db.fraction, db.names, db.sample_kmers, db.all2all_dense(), sparse=sparse)
