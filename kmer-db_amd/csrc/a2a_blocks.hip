@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
     }
     // extra pairs: one reservation per wave in the wave's region of the pair pool
     uint32_t out = 0;
-    {
+    if (__ballot(need != 0u)) {                                  // (most waves of the short launch hold no list with a second block: no scan for them)
         const uint32_t incl = wave_incl_scan(need, lane);
         const uint32_t total = bcast(incl, WAVE - 1);
         if (total) {
@@ -1960,9 +1960,19 @@ __global__ __launch_bounds__(256) void cs_hist_kernel(const uint32_t* __restrict
     const CsJob job = cs_job(mode, n, n_keys, rows);
     for (uint32_t k = threadIdx.x; k < job.n_bins; k += blockDim.x) cs_lds[k] = 0;
     __syncthreads();
-    for (uint32_t i = job.lo + threadIdx.x; i < job.hi; i += blockDim.x) {
-        const uint32_t bin = cs_bin(mode, wkey[i] & kmask, n_valid, job.sub);
-        if (bin < job.n_bins) atomicAdd(&cs_lds[bin], 1u);
+    // eight key words per thread requested together (the loop used to wait for one load per iteration)
+    for (uint32_t i0 = job.lo; i0 < job.hi; i0 += 8u * blockDim.x) {
+        uint32_t kw[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t i = i0 + j * blockDim.x + threadIdx.x;
+            kw[j] = i < job.hi ? wkey[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t bin = kw[j] == 0xFFFFFFFFu ? 0xFFFFFFFFu : cs_bin(mode, kw[j] & kmask, n_valid, job.sub);
+            if (bin < job.n_bins) atomicAdd(&cs_lds[bin], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < job.n_bins; k += blockDim.x) H[(size_t)job.tab + (size_t)k * job.stride] = cs_lds[k];
@@ -2171,6 +2181,7 @@ __device__ __forceinline__ bool rs_job(const RsRows& R, uint32_t job, uint32_t j
     j.ids = R.row_ids;
     return true;
 }
+template <uint32_t U>                                        // chunks whose key words a thread requests together (one round trip per U chunks)
 __global__ __launch_bounds__(256) void rs_hist_kernel(const RsRows R, const uint32_t* __restrict__ chunk_fill, const uint32_t* __restrict__ recw, uint32_t kmask,
                                                      uint32_t* __restrict__ H) {
     extern __shared__ uint32_t cs_lds[];
@@ -2182,15 +2193,15 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const RsRows R, const uint
     // the job's chunk ids and fills first (one round trip), then the key words of four chunks at a time
     if (threadIdx.x < nch) { const uint32_t id = j.ids[j.cb + threadIdx.x]; s_id[threadIdx.x] = id; s_fill[threadIdx.x] = chunk_fill[id]; }
     __syncthreads();
-    for (uint32_t c0 = 0; c0 < nch; c0 += 4) {
-        uint32_t kw[4];
+    for (uint32_t c0 = 0; c0 < nch; c0 += U) {
+        uint32_t kw[U];
 #pragma unroll
-        for (uint32_t jj = 0; jj < 4; ++jj) {
+        for (uint32_t jj = 0; jj < U; ++jj) {
             kw[jj] = 0xFFFFFFFFu;
             if (c0 + jj < nch && threadIdx.x < s_fill[c0 + jj]) kw[jj] = recw[((size_t)s_id[c0 + jj] << CH_SHIFT) + threadIdx.x];
         }
 #pragma unroll
-        for (uint32_t jj = 0; jj < 4; ++jj) {
+        for (uint32_t jj = 0; jj < U; ++jj) {
             const uint32_t bin = (kw[jj] & kmask) - sub;
             if (kw[jj] != 0xFFFFFFFFu && bin < nb) atomicAdd(&cs_lds[bin], 1u);
         }
@@ -3221,7 +3232,14 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         jobs_launched = jobs;
         const size_t ne = std::min<size_t>(db->rs_entries, (size_t)jobs * NB + 1);
         HIP_TRY(hipMemsetAsync(db->rs_hist, 0, ne * 4, st));
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(jobs), dim3(256), NB * 4, st, R, db->chunk_fill, db->recw, kmask, db->rs_hist);
+        {
+            // (4, round 4's, against 8 / 16 at 10 000 samples: apply step 6.08 / 5.88 / 5.85 ms, profiles/r05_j14 — the kernel waits for its loads)
+            const char* ue = getenv("KMDB_RSH_UNROLL");
+            const int u = ue ? atoi(ue) : 16;
+            if (u == 16) hipLaunchKernelGGL(rs_hist_kernel<16>, dim3(jobs), dim3(256), NB * 4, st, R, db->chunk_fill, db->recw, kmask, db->rs_hist);
+            else if (u == 8) hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(jobs), dim3(256), NB * 4, st, R, db->chunk_fill, db->recw, kmask, db->rs_hist);
+            else hipLaunchKernelGGL(rs_hist_kernel<4>, dim3(jobs), dim3(256), NB * 4, st, R, db->chunk_fill, db->recw, kmask, db->rs_hist);
+        }
         size_t tb = db->rs_tmp_bytes;
         HIP_TRY(prim::exclusive_sum(db->rs_tmp, tb, db->rs_hist, db->rs_offs, (int)ne, st));
         const uint32_t* total_ptr = db->rs_offs + (ne - 1);
