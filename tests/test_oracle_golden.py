@@ -147,3 +147,37 @@ def test_db2db_restatement_equals_the_real_reference(O, golden_dir, tmp_path):
     lines = txt.split(b"\n")
     for r in range(m.shape[0]):
         assert "".join("%d:%d," % (c + 1, v) for c, v in enumerate(m[r]) if v).encode() == lines[r]
+
+
+@pytest.mark.parametrize("stem,k,alphabet", [("aa", 8, "aa"), ("aa11_diamond", 8, "aa11_diamond"), ("aa12_mmseqs", 8, "aa12_mmseqs"),
+                                              ("aa6_dayhoff", 8, "aa6_dayhoff"), ("aa_k7", 7, "aa")])
+def test_protein_goldens_from_the_definition(O, stem, k, alphabet):
+    """test/protein/aa*.a2a (reference .github/workflows/self-hosted.yml:404-427) straight from the definition: the records of
+    aa_100x1000.fasta as samples, k-mers by the oracle's restatement of KmerHelper::extract over the alphabet (src/kmer_extract.h:13-97,
+    src/alphabet.h:22-86: n-bit symbols, '.' and every letter outside the groups invalidate the k-mers that hold them), cell (i, j) =
+    |K_i ∩ K_j| — no database, pattern or tree involved.  Pins the extractor the protein fixtures were built with."""
+    import lzma
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with lzma.open(os.path.join(here, "protein.aa_100x1000.fasta.xz")) as f:
+        recs = O._split_records(f.read())
+    sets = [O.sort_unique(O.extract_seq_alphabet(s, k, alphabet)) for _, s in recs]
+    with open(os.path.join(here, "protein.%s.a2a" % stem)) as f:
+        lines = f.read().split("\n")
+    head = lines[0].split(",")
+    assert head[0].startswith("kmer-length: %d " % k) and [h for h in head[2:] if h] == [h for h, _ in recs]
+    assert [int(x) for x in lines[1].split(",")[2:] if x] == [int(s.size) for s in sets]
+    for i, (name, _) in enumerate(recs):
+        cells = lines[2 + i].split(",")
+        assert cells[0] == name and int(cells[1]) == sets[i].size
+        want = [int(x) for x in cells[2:] if x]
+        assert want == [int(np.intersect1d(sets[i], sets[j], assume_unique=True).size) for j in range(i)], (stem, i)
+
+
+def test_alphabet_extractor_is_the_nucleotide_one_on_nt(O):
+    """kmo_extract_kmers_alphabet with the nt groups == kmo_extract_kmers (canonical and strand-preserving), invalid letters included"""
+    rng = np.random.default_rng(3)
+    seq = bytes(rng.choice(np.frombuffer(b"ACGTacgtNUu.", np.uint8), 5000, p=[.2, .2, .2, .2, .04, .04, .04, .04, .01, .01, .01, .01]))
+    for k in (7, 16, 18, 24, 31):
+        assert np.array_equal(O.extract_seq(seq, k), O.extract_seq_alphabet(seq, k, "nt"))
+        assert np.array_equal(O.extract_seq(seq, k, preserve_strand=True), O.extract_seq_alphabet(seq, k, "nt-preserve"))
+        assert np.array_equal(O.extract_seq(seq, k, 0.3), O.extract_seq_alphabet(seq, k, "nt", 0.3))
