@@ -91,6 +91,10 @@ class CladeGenomes:
         return ">%s\n%s\n" % (self.name(i), np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode())
 
 
+_WINDOWS_AT_ONCE = 1 << 16       # kmers_of: genomes up to this many k-mer windows take the (n, k) form
+_WEIGHTS = {}                    # (k, device) -> 4^j, j < k
+
+
 def kmers_of(codes, k, fraction=1.0, start_fraction=0.0, prefix_shard=None):
     """Sorted, duplicate-free k-mer words of one genome (torch int64 holding the uint64 bit pattern;
     all words are < 2^62 so signed order == unsigned order).  prefix_shard=(index, count): only the k-mers whose prefix
@@ -100,12 +104,26 @@ def kmers_of(codes, k, fraction=1.0, start_fraction=0.0, prefix_shard=None):
         return torch.zeros(0, dtype=torch.int64, device=codes.device)
     b = codes.to(torch.int64)
     n = L - k + 1
-    fwd = torch.zeros(n, dtype=torch.int64, device=codes.device)
-    rc = torch.zeros(n, dtype=torch.int64, device=codes.device)
-    for j in range(k):
-        seg = b[j: j + n]
-        fwd = (fwd << 2) | seg
-        rc = rc | ((3 - seg) << (2 * j))
+    fwd = rc = None
+    if n <= _WINDOWS_AT_ONCE and k <= 31:
+        # short genomes (the tests' collections of 10 000 - 70 000 samples): all windows as one (n, k) view, two products and two sums
+        # instead of 6 k launches — the generator's time there is launch overhead (profiles/r05_close_test_phases.txt)
+        try:
+            w = _WEIGHTS.get((k, codes.device))
+            if w is None:
+                w = _WEIGHTS[(k, codes.device)] = torch.tensor([1 << (2 * j) for j in range(k)], dtype=torch.int64, device=codes.device)
+            U = b.unfold(0, k, 1)
+            fwd = (U * w.flip(0)).sum(1)
+            rc = ((3 - U) * w).sum(1)
+        except RuntimeError:                      # (an operator the device lacks: the loop form below)
+            fwd = rc = None
+    if fwd is None:
+        fwd = torch.zeros(n, dtype=torch.int64, device=codes.device)
+        rc = torch.zeros(n, dtype=torch.int64, device=codes.device)
+        for j in range(k):
+            seg = b[j: j + n]
+            fwd = (fwd << 2) | seg
+            rc = rc | ((3 - seg) << (2 * j))
     can = torch.minimum(fwd, rc)
     prefix_bits = 2 * k - 32
     if prefix_bits < 8:
@@ -160,6 +178,9 @@ class _Grow:
         self.n = n
 
 
+_KEEP_KMERS = 1 << 26            # build_patterns: k-mers of all samples together (512 MB) up to which phase A's sets are kept for phase B
+
+
 def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progress=None):
     """Emulates `kmer-db build` over samples 0..n-1.
 
@@ -170,10 +191,19 @@ def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progre
     """
     dev = torch.device(device)
     # ---- phase A: the set of distinct k-mers --------------------------------------------------
+    kept, kept_n = None, 0              # the samples' k-mer sets of phase A, kept for phase B while they are few (collections of short genomes:
+                                        # deriving every sample twice was half of the generator's time there)
     if dictionary is None:
         parts, acc, acc_n = [], [], 0
+        kept = []
         for i in range(n_samples):
             km = sample_kmers_iter(i)
+            if kept is not None:
+                kept_n += km.numel()
+                if kept_n > _KEEP_KMERS:
+                    kept = None
+                else:
+                    kept.append(km)
             acc.append(km)
             acc_n += km.numel()
             if acc_n >= (1 << 28) or i == n_samples - 1:
@@ -196,7 +226,7 @@ def build_patterns(sample_kmers_iter, n_samples, device, dictionary=None, progre
     sample_counts = []
 
     for s in range(n_samples):
-        km = sample_kmers_iter(s)
+        km = kept[s] if kept is not None else sample_kmers_iter(s)
         sample_counts.append(int(km.numel()))
         if km.numel() == 0:
             continue
