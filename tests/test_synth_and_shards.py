@@ -59,6 +59,34 @@ def test_generator_reproduces_reference_build(S, O, N, cs, L, k, f):
             assert np.array_equal(mr, m)
 
 
+def test_generator_short_genome_forms_equal_the_loop_forms(S, monkeypatch):
+    """Collections of short genomes (the GPU suite's 10 000 - 70 000-sample databases) take two shortcuts in the generator: all k-mer
+    windows of a genome as one (n, k) view, and phase A's k-mer sets kept for phase B.  Both are bit-identical with the loop forms
+    (which long genomes keep): k-mer sets at several k with and without minhash, genomes shorter than k, and whole pattern sets."""
+    g = S.CladeGenomes(120, 30, 2500, seed=3)
+    for k in (7, 18, 24, 25, 31):
+        for f in (1.0, 0.1):
+            for i in (0, 31, 119):
+                monkeypatch.setattr(S, "_WINDOWS_AT_ONCE", 1 << 16)
+                a = S.kmers_of(g.sample(i), k, f)
+                monkeypatch.setattr(S, "_WINDOWS_AT_ONCE", 0)
+                assert torch.equal(a, S.kmers_of(g.sample(i), k, f)), (k, f, i)
+    for L in (0, 5, 17, 18, 19):
+        monkeypatch.setattr(S, "_WINDOWS_AT_ONCE", 1 << 16)
+        a = S.kmers_of(g.sample(3)[:L], 18)
+        monkeypatch.setattr(S, "_WINDOWS_AT_ONCE", 0)
+        assert torch.equal(a, S.kmers_of(g.sample(3)[:L], 18)) and (a.numel() == 0) == (L < 18)
+    pats = []
+    for keep, at_once in ((1 << 26, 1 << 16), (0, 0), (3000, 1 << 16)):          # (kept / loop forms / the cache given up half way)
+        monkeypatch.setattr(S, "_KEEP_KMERS", keep)
+        monkeypatch.setattr(S, "_WINDOWS_AT_ONCE", at_once)
+        pats.append(S.synth_database(300, 30, 600, k=18, seed=11)[1])
+    for other in pats[1:]:
+        for key, a in pats[0].items():
+            b = other[key]
+            assert torch.equal(a, b) if isinstance(a, torch.Tensor) else list(a) == list(b), key
+
+
 def test_prefix_shards_sum_to_full_matrix(S, O):
     N, cs, L, k = 32, 8, 6000, 18
     g = S.CladeGenomes(N, cs, L, seed=11)
