@@ -362,7 +362,7 @@ def extra_workload(K, S, args, device, name, reference=True, definition_rows=0):
            "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg},
            "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3])},
-           "patterns": db.P, "records": stl["n_records"], "wide_nodes": stl["n_wide"], "nodes_joined_per_tile": stl["n_joined"], "record_chunks": stl["n_chunks"], "block_width": stl["width"],
+           "patterns": db.P, "records": stl["n_records"], "records_applied_from_slices": stl["n_direct"], "wide_nodes": stl["n_wide"], "nodes_joined_per_tile": stl["n_joined"], "record_chunks": stl["n_chunks"], "block_width": stl["width"],
            "path": {1: "block-record pipeline", 2: "v1 tile kernel", 3: "v1 HBM-atomics kernel"}.get(stl["path"], "none"),
            "upload_s": upload_s, "cold_call_ms": cold_ms, "checks": "sum of the matrix == sum_p w_p C(n_p, 2); warm == cold", "reference_match": None}
     db.close()
@@ -964,13 +964,13 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "whole call: k0_decode_kernel x2 + k1n_kernel + wide list + k1w_kernel + cs_hist / cs_scatter (counting sort) + k2_jobs_kernel, with k2_apply_kernel on a side stream (+ zeroing, pool init)",
+                "kernel": "whole call: k0_decode_kernel x2 + k1n_kernel + wide list + k1w_kernel + cs_hist / cs_scatter (counting sort) + k2_jobs_kernel, with k2d_kernel (the slices' first-block records) on a side stream (+ zeroing, pool init)",
                 "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
                 "per_kernel_ms": {"decode": float(pk[0]), "emit_narrow": float(pk[1]), "wide_list+emit_wide": float(pk[2]), "apply": float(pk[3]),
                                   "whole_call": kern_ms},
                 "cold_call_frac": alg / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "measured_copy_GBs": measured_copy_gbs(device),      # what a plain copy reaches on this box (peak above is the nominal figure)
-                "block_records_per_launch": stl["n_records"], "wide_nodes": stl["n_wide"], "nodes_joined_per_tile": stl["n_joined"],
+                "block_records_per_launch": stl["n_records"], "first_block_records_per_launch": stl["n_direct"], "wide_nodes": stl["n_wide"], "nodes_joined_per_tile": stl["n_joined"],
                 "record_chunks": stl["n_chunks"],
             },
         }

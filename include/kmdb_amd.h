@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KMDB_ABI_VERSION 6
+#define KMDB_ABI_VERSION 7
 
 /* ---------------------------------------------------------------------------------------
  * Host-side view of a loaded database = what the reference hands to SimilarityCalculator:
@@ -144,6 +144,8 @@ typedef struct kmdb_stats {        /* measurements of the LAST call on this db h
     uint64_t n_patterns;           /* patterns resident in HBM: all of the view's, or for kmdb_db_upload_shard only the nodes whose subtree
                                       holds a k-mer of the shard */
     uint64_t h2d_bytes;            /* bytes kmdb_db_upload[_shard] copied to the device (ABI 6) */
+    uint64_t n_direct;             /* block records that were never written: first-block records (X, X) the narrow kernel applied where it emitted them,
+                                      tile in registers, one write-back per slice of the pattern stream (ABI 7; n_records counts the written ones) */
 } kmdb_stats;
 
 const char* kmdb_last_error(void);
@@ -237,6 +239,12 @@ int  kmdb_new2all_batch_sparse(kmdb_db* db, const uint64_t* const* kmers, const 
 int  kmdb_new2all_batch_seq(kmdb_db* db, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
                             double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
                             const kmdb_opts* opts);
+/* The same for a database over any of the reference's alphabets (ABI 7; alphabet.h:79-126, kmer_extract.h:13-97): `alphabet` =
+ * kmdbh_db_alphabet (KMDB_ALPHABET_*), e.g. protein queries against the databases of test/protein.  Records of one sample are
+ * joined by any byte that is not a symbol of the alphabet ('\n'). */
+int  kmdb_new2all_batch_seq_alphabet(kmdb_db* db, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
+                                     double start_fraction, int32_t alphabet, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                                     const kmdb_opts* opts);
 
 /* Replaces SimilarityCalculator::db2db_sp(db_row, db_col, SparseMatrix&, bubbles) (similarity_calculator.cpp:1225-1540),
  * the off-diagonal cell of the all2all-parts grid (call sites console_all2all_parts.cpp:180,226): both databases
@@ -324,6 +332,21 @@ int  kmdbh_shard_plan_counts(const kmdb_db_view* view, uint32_t n_shards, uint64
  * Writes at most len k-mers to out; returns the count. */
 size_t kmdbh_extract_kmers(const char* seq, size_t len, uint32_t k, double fraction, double start_fraction,
                            int preserve_strand, uint64_t* out);
+/* The same over any alphabet of the reference (alphabet.h:79-86; ABI 7): `alphabet` = the database's AlphabetType as stored in the
+ * file (kmdbh_db_alphabet; alphabet.h:10-18) — n-bit symbols (alphabet.h:36), k <= 64 / bits - 1 (:37), the strand preserved for
+ * nt-preserve and every protein alphabet.  Returns 0 for an unknown alphabet or a k the alphabet cannot hold. */
+#define KMDB_ALPHABET_NT            0
+#define KMDB_ALPHABET_NT_PRESERVE   1
+#define KMDB_ALPHABET_AA            2
+#define KMDB_ALPHABET_AA11_DIAMOND  3
+#define KMDB_ALPHABET_AA12_MMSEQS   4
+#define KMDB_ALPHABET_AA6_DAYHOFF   5
+#define KMDB_ALPHABET_COUNT         6
+size_t kmdbh_extract_kmers_alphabet(const char* seq, size_t len, uint32_t k, int32_t alphabet, double fraction, double start_fraction,
+                                    uint64_t* out);
+/* Alphabet::mapping (alphabet.h:41-58): symbol code of every byte (-1: not a symbol), number of symbols, bits per symbol, strand flag.
+ * 0 on success, 1 for an unknown alphabet. */
+int    kmdbh_alphabet_table(int32_t alphabet, int8_t* map256, uint32_t* n_symbols, uint32_t* bits_per_symbol, int* preserve_strand);
 /* KmerHelper::unique (kmer_extract.h:112-118): sort + dedupe in place, returns new count */
 size_t kmdbh_sort_unique(uint64_t* kmers, size_t n);
 

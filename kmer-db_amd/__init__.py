@@ -16,7 +16,9 @@ from .capi import (  # noqa: F401
     NodeDB,
     SparseRows,
     device_count,
+    ALPHABETS,
     extract_kmers,
+    extract_kmers_alphabet,
     format_dense_row,
     format_header,
     format_sparse_row,

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -56,7 +56,7 @@ class _Stats(C.Structure):
                 ("k1_ms", C.c_double), ("k2_ms", C.c_double), ("n_records", C.c_uint64), ("k0_ms", C.c_double),
                 ("k1n_ms", C.c_double), ("k1g_ms", C.c_double), ("upload_ms", C.c_double), ("n_wide", C.c_uint64),
                 ("n_chunks", C.c_uint64), ("path", C.c_uint32), ("width", C.c_uint32), ("sized_call", C.c_uint32),
-                ("n_joined", C.c_uint32), ("n_patterns", C.c_uint64), ("h2d_bytes", C.c_uint64)]
+                ("n_joined", C.c_uint32), ("n_patterns", C.c_uint64), ("h2d_bytes", C.c_uint64), ("n_direct", C.c_uint64)]
 
 
 class _NodeStats(C.Structure):
@@ -81,10 +81,10 @@ EXPORTS = [
     "kmdb_last_error", "kmdb_abi_version", "kmdb_device_count", "kmdb_device_prepare", "kmdb_db_upload", "kmdb_db_upload_shard", "kmdb_db_free", "kmdb_db_settle", "kmdb_db_stats", "kmdb_db_fallback_reason",
     "kmdb_node_upload", "kmdb_node_free", "kmdb_node_stats_get", "kmdb_node_device_stats_get", "kmdb_node_all2all_dense", "kmdb_node_all2all_sparse",
     "kmdb_all2all_dense", "kmdb_all2all_dense_device", "kmdb_all2all_sparse", "kmdb_all2all_sparse_filtered", "kmdb_sparse_from_dense_device", "kmdbh_metric", "kmdbh_metric_id", "kmdb_sparse_free",
-    "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_db2db_dense",
+    "kmdb_new2all_batch", "kmdb_new2all_batch_sparse", "kmdb_new2all_batch_seq", "kmdb_new2all_batch_seq_alphabet", "kmdb_db2db_dense",
     "kmdbh_shard_plan_counts", "kmdbh_db_load", "kmdbh_db_free", "kmdbh_db_release_patterns", "kmdbh_db_view", "kmdbh_db_kmer_length", "kmdbh_db_fraction",
     "kmdbh_db_start_fraction", "kmdbh_db_alphabet", "kmdbh_db_n_samples", "kmdbh_db_sample_name",
-    "kmdbh_db_sample_kmers", "kmdbh_db_pattern_section_bytes", "kmdbh_extract_kmers", "kmdbh_sort_unique",
+    "kmdbh_db_sample_kmers", "kmdbh_db_pattern_section_bytes", "kmdbh_extract_kmers", "kmdbh_extract_kmers_alphabet", "kmdbh_alphabet_table", "kmdbh_sort_unique",
     "kmdbh_format_header", "kmdbh_format_dense_row", "kmdbh_format_sparse_row",
 ]
 
@@ -133,6 +133,8 @@ def lib():
     L.kmdb_db2db_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdb_new2all_batch_seq.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_double, C.c_double, C.c_int,
                                          C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
+    L.kmdb_new2all_batch_seq_alphabet.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_double, C.c_double, C.c_int32,
+                                                  C.c_void_p, C.c_void_p, C.POINTER(_Opts)]
     L.kmdbh_db_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.kmdbh_db_free.argtypes = [C.c_void_p]
     L.kmdbh_db_release_patterns.argtypes = [C.c_void_p]
@@ -157,6 +159,9 @@ def lib():
     L.kmdbh_db_pattern_section_bytes.argtypes = [C.c_void_p]
     L.kmdbh_extract_kmers.restype = C.c_size_t
     L.kmdbh_extract_kmers.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    L.kmdbh_extract_kmers_alphabet.restype = C.c_size_t
+    L.kmdbh_extract_kmers_alphabet.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_int32, C.c_double, C.c_double, C.c_void_p]
+    L.kmdbh_alphabet_table.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     L.kmdbh_sort_unique.restype = C.c_size_t
     L.kmdbh_sort_unique.argtypes = [C.c_void_p, C.c_size_t]
     L.kmdbh_format_header.restype = C.c_size_t
@@ -403,9 +408,12 @@ class DeviceDB:
         _check(lib().kmdb_db2db_dense(self._d, col._d, buf.ctypes.data, C.byref(o)))
         return out
 
-    def new2all_seq(self, seqs, fraction=1.0, start_fraction=0.0, preserve_strand=False):
+    def new2all_seq(self, seqs, fraction=1.0, start_fraction=0.0, preserve_strand=False, alphabet=None):
         """queries given as sequence text (bytes / str); k-mer extraction, minhash filter, sort + unique on the device.
+        alphabet: the database's AlphabetType (HostDB.alphabet; ALPHABETS lists the names) — None: nt / nt-preserve by preserve_strand.
         Returns (similarities nq x N, unique k-mer count per query)."""
+        if alphabet is None:
+            alphabet = 1 if preserve_strand else 0
         bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
         nq = len(bs)
         ptrs = (C.c_char_p * max(nq, 1))(*bs)
@@ -413,8 +421,8 @@ class DeviceDB:
         out = np.zeros((nq, self.N), dtype=np.uint32)
         cnt = np.zeros(max(nq, 1), dtype=np.uint64)
         o = _opts(self.device)
-        _check(lib().kmdb_new2all_batch_seq(self._d, ptrs, lens, nq, float(fraction), float(start_fraction), int(preserve_strand),
-                                            out.ctypes.data if out.size else None, cnt.ctypes.data, C.byref(o)))
+        _check(lib().kmdb_new2all_batch_seq_alphabet(self._d, ptrs, lens, nq, float(fraction), float(start_fraction), int(alphabet),
+                                                     out.ctypes.data if out.size else None, cnt.ctypes.data, C.byref(o)))
         return out, cnt[:nq]
 
     def new2all_sparse(self, queries):
@@ -514,6 +522,19 @@ def extract_kmers(seq, k, fraction=1.0, start_fraction=0.0, preserve_strand=Fals
         seq = seq.encode()
     out = np.zeros(max(1, len(seq)), dtype=np.uint64)
     n = lib().kmdbh_extract_kmers(seq, len(seq), k, fraction, start_fraction, int(preserve_strand), out.ctypes.data)
+    return out[:n]
+
+
+ALPHABETS = ("nt", "nt-preserve", "aa", "aa11_diamond", "aa12_mmseqs", "aa6_dayhoff")      # AlphabetType order (reference src/alphabet.h:10-18)
+
+
+def extract_kmers_alphabet(seq, k, alphabet, fraction=1.0, start_fraction=0.0):
+    """k-mer words of a sequence over any alphabet of the reference (alphabet = index into ALPHABETS or its name)"""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    a = ALPHABETS.index(alphabet) if isinstance(alphabet, str) else int(alphabet)
+    out = np.zeros(max(1, len(seq)), dtype=np.uint64)
+    n = lib().kmdbh_extract_kmers_alphabet(seq, len(seq), k, a, fraction, start_fraction, out.ctypes.data)
     return out[:n]
 
 

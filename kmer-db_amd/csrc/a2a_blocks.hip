@@ -607,6 +607,64 @@ __global__ __launch_bounds__(256) void k0_decode_kernel(const K0Params q) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bit transposes and operand types of the matrix-core step (K1n's direct mode, K2, the second level)
+// ------------------------------------------------------------------------------------------
+// 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit.  Six butterfly stages; stage
+// 32 is one v_permlane32_swap over the two words.  Every stage below works on the 32-bit words separately: fetch the partner lane's
+// word (lane ^ s), rotate it by s towards this lane's side (v_alignbit_b32: right for the upper lane of a pair, left for the lower one)
+// and splice it in under a per-lane mask (v_bfi_b32) — three instructions per word and stage, with the rotate amounts and masks of
+// the five stages in ten registers that are computed once per run (TrConst).  The fetches are v_permlane16_swap (stage 16) and DPP row /
+// quad permutes: 35 VALU instructions per transpose, no LDS (fetching the stages 16 / 8 / 4 over the LDS crossbar with ds_swizzle_b32
+// was measured slower — profiles/r05_experiment_switches.diff; round 3's version, v_perm + ds_bpermute shuffles and 64-bit mask
+// arithmetic, took 72 VALU).  profiles/r04_transpose_probe.hip checks the variants against the definition and times them.
+struct TrConst { uint32_t amt[5], msk[5]; };
+__device__ __forceinline__ TrConst tr_const(uint32_t lane) {
+    TrConst c;
+    const uint32_t m[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t s = 16u >> k;
+        const bool up = (lane & s) != 0;
+        c.amt[k] = up ? s : 32u - s;          // the partner's word rotated right by s (upper lane of the pair) or left by s (lower lane)
+        c.msk[k] = up ? m[k] : ~m[k];         // the bits taken from the partner
+    }
+    return c;
+}
+__device__ __forceinline__ uint32_t tr_fetch(uint32_t v, int k, bool up16) {
+    // the word of lane ^ (16 >> k)
+    if (k == 0) {
+        const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // [0]: odd rows <- the even rows below them, [1]: even rows <- the odd rows above
+        return up16 ? a[0] : a[1];
+    }
+    if (k == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    if (k == 2) {
+        const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);      // row_shl:4 into the banks 0 and 2: lane i <- i + 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);        // row_shr:4 into the banks 1 and 3: lane i <- i - 4
+    }
+    if (k == 3) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);               // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, const TrConst& c) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    }
+    const bool up16 = c.msk[0] == 0x0000FFFFu;                         // (lane & 16) != 0
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t pl = tr_fetch(lo, k, up16), ph = tr_fetch(hi, k, up16);
+        const uint32_t rl = __builtin_amdgcn_alignbit(pl, pl, c.amt[k]), rh = __builtin_amdgcn_alignbit(ph, ph, c.amt[k]);
+        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(lo) : "v"(c.msk[k]), "v"(rl));      // (mask & partner) | (~mask & own)
+        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(hi) : "v"(c.msk[k]), "v"(rh));
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+typedef int k2_v4i __attribute__((ext_vector_type(4)));
+typedef int k2_v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
 // K1n: the DFS stream, nodes with at most two blocks
 // ------------------------------------------------------------------------------------------
 // Summary of a stretch of a root path: the first block and its mask, the second block and its mask, and whether
@@ -655,6 +713,16 @@ struct NParams {
     uint32_t tbits, n_keys;        // log2 of the open-chunk table, blocks
     uint32_t all_wide;             // 1: every record through the wide pool (the stream chunks did not work out)
     PoolView pool;
+    // direct mode (k1n_kernel<true>): the first-block records (X, X, F0) never leave the wave — see k1n_kernel
+    uint32_t* M;
+    uint32_t N, bwidth;
+    unsigned char* touched;
+    uint32_t* direct_ctr;          // [KMDB_SUBPOOLS * 16]
+    // flat mode (k1n_kernel<2>): the first-block records of slice s, compacted, in [s * nseg_nodes, + slice_cnt[s]) — applied by k2d_kernel
+    unsigned long long* dmask;     // [n_segs * nseg_nodes] F0
+    uint32_t* dwx;                 // [n_segs * nseg_nodes] w | X << 8
+    uint32_t* slice_cnt;           // [n_segs]
+    uint32_t dbg;                  // experiments (KMDB_K1N_DBG; results are WRONG with any bit set): 1 no write-back, 2 no matrix-core step
 };
 constexpr int K1N_WAVES = 4;
 __host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tbits, uint32_t n_states, uint32_t n_rows) {
@@ -664,11 +732,36 @@ __host__ __device__ inline size_t k1n_wave_bytes(uint32_t chain_cap, uint32_t tb
 // The node records are fetched TWO batches ahead (pair_ofs read unconditionally with them), the second pairs one batch ahead: no load of
 // the loop waits on another load of the same iteration.  (Round 4 fetched one batch ahead, the second pair of a node behind its p0_info and
 // pair_ofs — three dependent round trips inside the fetch: 0.07 - 0.2 ms slower, profiles/r05_j3 / r05_j4.)
-__global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) {
+//
+// DIRECT (round 6; north_star: "accumulated ... before a single HBM write-back per tile"; the reference adds a decoded pattern straight
+// into the matrix rows, similarity_calculator.cpp:206-241): all nodes of a slice of the DFS stream but a handful share their first
+// block X — the subtree of a root child holds the patterns whose smallest sample id is that child's (profiles/r06_tile_locality.txt:
+// 99.5 % of a slice's first-block records lie in its most frequent block) — so the wave that emits the records (X, X, F0, w) applies
+// them where they are: the 64 masks of a batch go through the bit transpose and the byte spreading of the apply kernels (k2_apply_mfma)
+// straight from the registers that hold them, six v_mfma_i32_32x32x32_i8 add them to the lower triangle of tile (X, X), which stays
+// in 48 accumulator registers for the whole slice and is written back ONCE, when the slice ends or its first block changes.  No record
+// of these is written, grouped or read again (C2: 47 M of 125 M records, the whole stream-chunk path and the apply kernel beside the
+// wide kernel).  The rare others — a lane whose first block is not the wave's current one, a weight of 128 or more — take the
+// records' way through the wide pool / the row chunks as in all_wide mode.
+template <int MODE, int MINW>
+__global__ __launch_bounds__(WAVE * K1N_WAVES) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k1n_kernel(const NParams q) {
+    constexpr bool DIRECT = MODE == 1, FLAT = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ unsigned long long lut_ff[DIRECT ? 256 : 1], lut_01[DIRECT ? 256 : 1];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[DIRECT ? K1N_WAVES : 1][64];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + wave;            // 1 .. K1N_WAVES waves per workgroup, by the LDS a wave needs
+    if (DIRECT) {
+        for (uint32_t b = threadIdx.x; b < 256u; b += blockDim.x) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v |= ((b >> i) & 1u) ? 0xFFull << (8 * i) : 0ull;
+            lut_ff[b] = v;
+            lut_01[b] = v & 0x0101010101010101ull;
+        }
+        __syncthreads();
+    }
     if (seg >= q.n_segs) return;
     const uint32_t n_rows = q.pool.row_mode ? q.n_keys : 0u;
     unsigned char* wbase = lds_raw + k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys, n_rows) * wave;
@@ -741,7 +834,30 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
     fetch2(first); advance();
     if (first + WAVE < end) fetch2(first + WAVE); else { n2_nl = 0; n2_w = 0; n2_par = -1; n2_df = 0x7FFFu; n2_info = 0; n2_m0 = 0; n2_po = 0; }
     WaveArena A;
-    arena_init(A, table, q.tbits, q.n_keys, seg, lane);
+    arena_init(A, table, MODE != 0 ? 0u : q.tbits, q.n_keys, seg, lane);
+    // direct mode: the lower triangle of tile (curX, curX) — rows 0..31 x cols 0..31, rows 32..63 x cols 0..31, rows 32..63 x cols 32..63
+    k2_v16i c00 = {}, c10 = {}, c11 = {};
+    uint32_t curX = BNONE, n_direct = 0;
+    uint32_t flat_n = 0;                                             // flat mode: records of the slice so far (wave-uniform)
+    auto dflush = [&]() {
+        // one HBM atomic per non-zero cell (D layout of the MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).  Cell (rb + r, rb + c)
+        // of the triangle sits at tri64(rb) + rb + [rb r + r (r - 1) / 2 + c]: a wave-uniform base and a 32-bit offset per lane
+        const uint32_t half = lane >> 5, l31 = lane & 31u;
+        const uint32_t rb = curX * q.bwidth;
+        uint32_t* const Mb = q.M + (tri64((uint64_t)rb) + rb);
+        const uint32_t lim = q.N - rb;                                  // rows of the block inside the matrix (masks never hold an id beyond N: belt and braces)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half, row1 = row0 + 32u;
+            const uint32_t o0 = rb * row0 + row0 * (row0 - 1u) / 2u + l31, o1 = rb * row1 + row1 * (row1 - 1u) / 2u + l31;
+            const uint32_t v00 = (uint32_t)c00[r], v10 = (uint32_t)c10[r], v11 = (uint32_t)c11[r];
+            if (v00 && l31 < row0 && row0 < lim) atomicAdd(Mb + o0, v00);
+            if (v10 && row1 < lim) atomicAdd(Mb + o1, v10);
+            if (v11 && l31 < row0 && row1 < lim) atomicAdd(Mb + o1 + 32u, v11);
+            c00[r] = 0; c10[r] = 0; c11[r] = 0;
+        }
+        if (lane == 0 && q.touched) q.touched[tri32(curX) + curX] = 1;      // (all2all-sp scans only the tiles a call added to)
+    };
     for (uint32_t base = first; base < end; base += WAVE) {
         const uint32_t idx = base + lane;
         const bool valid = idx < end;
@@ -789,24 +905,84 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
         // ---- records (flat form): (w0, w0, F0), and with a second block (w1, w0, F1, F0) and (w1, w1, F1).  A diagonal
         // record needs two ids to have a pair.
         const bool act = valid && !wide && w != 0 && nl >= 2u && w0 != BNONE && idx >= q.emit_lo && idx < q.emit_hi;
-        // (w0, w0, F0): the lanes of a batch mostly share the block — one reservation per block in that block's open chunk.
-        // (In wide mode, q.all_wide, these records take the wide pool as well.)
-        const bool d0 = act && __popcll(F0) >= 2;
-        if (!q.all_wide) {
-            unsigned long long pend = __ballot(d0);
-            while (pend) {
-                const uint32_t X0 = bcast(w0, (uint32_t)__builtin_ctzll(pend));
-                const bool mine = d0 && w0 == X0;
-                const unsigned long long bc = __ballot(mine);
-                const Resv r = arena_reserve(A, q.pool, X0, tri32(X0) + X0, (uint32_t)__popcll(bc), lane);
-                if (mine) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, w);
-                pend &= ~bc;
+        auto first_block_records = [&]() {
+            // (w0, w0, F0): the lanes of a batch mostly share the block — one reservation per block in that block's open chunk.
+            // (In wide mode, q.all_wide, these records take the wide pool as well.)
+            bool d0 = act && __popcll(F0) >= 2;
+            if (FLAT) {
+                // the slice's first-block records, compacted in DFS order: two coalesced stores, no reservation, no chunk table
+                const bool dd = d0 && w < 128u;                          // (an int8 operand holds a weight below 128; the others take the sort)
+                const unsigned long long bm = __ballot(dd);
+                if (dd) {
+                    const uint32_t slot = first + flat_n + (uint32_t)__popcll(bm & lt_mask);
+                    q.dmask[slot] = F0; q.dwx[slot] = w | (w0 << 8);
+                }
+                flat_n += (uint32_t)__popcll(bm);
+                d0 = d0 && !dd;
             }
-        } else if (n_rows) {
-            row_emit(A, q.pool, RT, d0, w0, F0, F0, w, tri32(w0) + w0, lane, lt_mask);
-        } else {
-            wide_emit(A, q.pool, d0, F0, F0, w, tri32(w0) + w0, lane, lt_mask);
-        }
+            if (DIRECT) {
+                const bool dd = d0 && w < 128u;                          // (an int8 operand holds a weight below 128; nearly every weight is)
+                const unsigned long long pend = __ballot(dd);
+                if (pend) {
+                    // ONE tile per wave: the block of the slice's first such record.  (Switching tiles where a slice crosses from one root child's
+                    // subtree into the next would put a second write-back — 48 conditional atomics — into the loop body; the straddling
+                    // slices are 2 - 6 % of all, and what they hold of the other block takes the records' way.)
+                    if (curX == BNONE) curX = bcast(w0, (uint32_t)__builtin_ctzll(pend));
+                    const bool mine = dd && w0 == curX;
+                    n_direct += (uint32_t)__popcll(__ballot(mine));
+                    if (!(q.dbg & 2u)) {
+                    const TrConst trc = tr_const(lane);                      // (ten registers: made here, not kept across the batch)
+                    const unsigned long long Rt = transpose64(mine ? F0 : 0ull, trc);        // lane r: bit k <=> node k of the batch has id r of the block
+                    unsigned long long ra0, ra1;
+                    {
+                        const auto a = __builtin_amdgcn_permlane32_swap((uint32_t)Rt, (uint32_t)Rt, false, false);                 // [0]: the lower half's words everywhere, [1]: the upper half's
+                        const auto b = __builtin_amdgcn_permlane32_swap((uint32_t)(Rt >> 32), (uint32_t)(Rt >> 32), false, false);
+                        ra0 = ((unsigned long long)b[0] << 32) | a[0];
+                        ra1 = ((unsigned long long)b[1] << 32) | a[1];
+                    }
+                    wbuf[wave][lane] = (unsigned char)(mine ? w : 0u);
+                    lds_sync();
+                    const uint32_t half = lane >> 5;
+                    auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> k2_v4i {
+                        const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
+                        k2_v4i r;
+                        const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
+                        r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
+                        return r;
+                    };
+    #pragma unroll 1
+                    for (uint32_t kh = 0; kh < 2; ++kh) {
+                        const uint32_t shift = 32u * kh + 16u * half;            // nodes 32 kh + 16 half .. + 15 of the batch
+                        k2_v4i a0 = spread(ra0, shift, lut_ff), a1 = spread(ra1, shift, lut_ff);
+                        const k2_v4i b0 = spread(ra0, shift, lut_01), b1 = spread(ra1, shift, lut_01);
+                        const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
+                        a0 &= wv; a1 &= wv;
+                        c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
+                        c10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c11, 0, 0, 0);
+                    }
+                    lds_sync();
+                    }
+                    d0 = d0 && !mine;                                        // what is left takes the records' way
+                }
+            }
+            if (MODE == 0 && !q.all_wide) {
+                unsigned long long pend = __ballot(d0);
+                while (pend) {
+                    const uint32_t X0 = bcast(w0, (uint32_t)__builtin_ctzll(pend));
+                    const bool mine = d0 && w0 == X0;
+                    const unsigned long long bc = __ballot(mine);
+                    const Resv r = arena_reserve(A, q.pool, X0, tri32(X0) + X0, (uint32_t)__popcll(bc), lane);
+                    if (mine) rec_store_diag(q.pool, resv_slot(r, (uint32_t)__popcll(bc & lt_mask)), F0, w);
+                    pend &= ~bc;
+                }
+            } else if (n_rows) {
+                row_emit(A, q.pool, RT, d0, w0, F0, F0, w, tri32(w0) + w0, lane, lt_mask);
+            } else {
+                wide_emit(A, q.pool, d0, F0, F0, w, tri32(w0) + w0, lane, lt_mask);
+            }
+        };
+        if (!DIRECT) first_block_records();
         // second blocks, (w1, w0, F1, F0) and (w1, w1, F1): the pairs differ from lane to lane, so these records go to the wide
         // pool in arrival order (one reservation for all lanes) and are grouped by the sort
         {
@@ -835,9 +1011,135 @@ __global__ __launch_bounds__(WAVE * K1N_WAVES) void k1n_kernel(const NParams q) 
             if (valid && dep < later) { chain_m[dep - 1u] = make_ulonglong2(S.m0, S.m1); chain_b[dep - 1u] = S.bw; }
             lds_sync();
         }
+        // (direct mode: the matrix-core step comes last in the batch — nothing of the batch but F0, w0 and w is live beside its operands)
+        if (DIRECT) first_block_records();
     }
+    if (DIRECT && curX != BNONE && !(q.dbg & 1u)) dflush();
+    if (DIRECT && lane == 0 && n_direct) atomicAdd(&q.direct_ctr[(seg % KMDB_SUBPOOLS) * 16u], n_direct);
+    if (FLAT && lane == 0) { q.slice_cnt[seg] = flat_n; if (flat_n) atomicAdd(&q.direct_ctr[(seg % KMDB_SUBPOOLS) * 16u], flat_n); }
     arena_finish(A, q.pool, lane);
     if (n_rows) rowtab_finish(RT, q.pool, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2d: the narrow kernel's first-block records, slice by slice
+// ------------------------------------------------------------------------------------------
+// Round 6.  The records (X, X, F0, w) of the nodes with at most two blocks are as clustered as records can be — a slice of the DFS stream is, but
+// for 0.5 - 2 % of its records, ONE tile (profiles/r06_tile_locality.txt) — so they need no chunk table, no grouping and no tile in LDS: the narrow
+// kernel leaves them compacted in DFS order (12 bytes per record, coalesced), and one wave per K2D_SLICES slices streams them through the
+// matrix-core step of the apply kernels (bit transpose, byte spreading, six v_mfma_i32_32x32x32_i8 per 64 records: the lower triangle of the tile)
+// with the tile in 48 accumulator registers, written back when the block changes: once per slice, nearly always.  Side stream, beside the wide
+// kernel.  (The same step INSIDE the narrow kernel — k1n_kernel<1> — writes no record at all, but its 48 accumulators beside the narrow kernel's 95
+// registers leave three waves per SIMD: the narrow kernel then takes 0.65 ms longer at C2 than this kernel costs beside the wide kernel:
+// profiles/r06_j3, r06_j4.)
+constexpr uint32_t K2D_SLICES = 2;
+struct DParams {
+    const unsigned long long* dmask;
+    const uint32_t* dwx;
+    const uint32_t* slice_cnt;
+    uint32_t n_segs, nseg_nodes, slices;
+    uint32_t* M;
+    uint32_t N, bwidth;
+    unsigned char* touched;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k2d_kernel(const DParams q) {
+    __shared__ unsigned long long lut_ff[256], lut_01[256];       // byte b -> its 8 bits spread over 8 bytes (0xFF / 0x01 where set)
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][64];
+    {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= ((threadIdx.x >> i) & 1u) ? 0xFFull << (8 * i) : 0ull;
+        lut_ff[threadIdx.x] = v;
+        lut_01[threadIdx.x] = v & 0x0101010101010101ull;
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t half = lane >> 5, l31 = lane & 31u;
+    const uint32_t s0 = (blockIdx.x * 4u + wave) * q.slices;
+    if (s0 >= q.n_segs) return;
+    const uint32_t s1 = s0 + q.slices < q.n_segs ? s0 + q.slices : q.n_segs;
+    k2_v16i c00 = {}, c10 = {}, c11 = {};
+    uint32_t curX = BNONE;
+    const TrConst trc = tr_const(lane);
+    auto flush = [&]() {
+        // one HBM atomic per non-zero cell (D layout of the MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).  Cell (rb + r, rb + c)
+        // of the triangle sits at tri64(rb) + rb + [rb r + r (r - 1) / 2 + c]: a wave-uniform base and a 32-bit offset per lane
+        const uint32_t rb = curX * q.bwidth;
+        uint32_t* const Mb = q.M + (tri64((uint64_t)rb) + rb);
+        const uint32_t lim = q.N - rb;                                  // rows of the block inside the matrix (masks never hold an id beyond N: belt and braces)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row0 = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * half, row1 = row0 + 32u;
+            const uint32_t o0 = rb * row0 + row0 * (row0 - 1u) / 2u + l31, o1 = rb * row1 + row1 * (row1 - 1u) / 2u + l31;
+            const uint32_t v00 = (uint32_t)c00[r], v10 = (uint32_t)c10[r], v11 = (uint32_t)c11[r];
+            if (v00 && l31 < row0 && row0 < lim) atomicAdd(Mb + o0, v00);
+            if (v10 && row1 < lim) atomicAdd(Mb + o1, v10);
+            if (v11 && l31 < row0 && row1 < lim) atomicAdd(Mb + o1 + 32u, v11);
+            c00[r] = 0; c10[r] = 0; c11[r] = 0;
+        }
+        if (lane == 0 && q.touched) q.touched[tri32(curX) + curX] = 1;      // (all2all-sp scans only the tiles a call added to)
+    };
+    auto spread = [&](unsigned long long word, uint32_t shift, const unsigned long long* lut) -> k2_v4i {
+        const uint32_t f = (uint32_t)(word >> shift) & 0xFFFFu;
+        k2_v4i r;
+        const unsigned long long lo = lut[f & 0xFFu], hi = lut[f >> 8];
+        r[0] = (int)(uint32_t)lo; r[1] = (int)(uint32_t)(lo >> 32); r[2] = (int)(uint32_t)hi; r[3] = (int)(uint32_t)(hi >> 32);
+        return r;
+    };
+    // the 64 records of a step, one per lane; the next step's are requested before this one is applied
+    uint32_t s = s0, n = q.slice_cnt[s0], b = 0;
+    auto skip_empty = [&]() { while (b >= n && s + 1u < s1) { ++s; n = q.slice_cnt[s]; b = 0; } };
+    skip_empty();
+    unsigned long long nm = 0; uint32_t nwx = 0;
+    auto fetch = [&]() {
+        nm = 0; nwx = 0;
+        if (b + lane < n) { const size_t i = (size_t)s * q.nseg_nodes + b + lane; nm = q.dmask[i]; nwx = q.dwx[i]; }
+    };
+    if (b < n) fetch();
+    for (;;) {
+        // a step of 64 records — or, behind the last one, an empty step whose "block" differs from every tile: the ONE write-back site serves the
+        // changes of block and the end (a second inlined copy of its 48 conditional atomics cost 60 registers)
+        const bool cur = b < n;
+        const unsigned long long m = cur ? nm : 0ull;
+        const uint32_t wx = cur ? nwx : 0u;
+        if (cur) {
+            b += WAVE;
+            skip_empty();
+            if (b < n) fetch();
+        }
+        unsigned long long pend = __ballot(m != 0ull);
+        for (;;) {
+            const uint32_t X0 = pend ? bcast(wx >> 8, (uint32_t)__builtin_ctzll(pend)) : BNONE;
+            if (X0 != curX) { if (curX != BNONE) flush(); curX = X0; }
+            if (!pend) break;
+            const bool mine = m != 0ull && (wx >> 8) == X0;
+            pend &= ~__ballot(mine);
+            const unsigned long long Rt = transpose64(mine ? m : 0ull, trc);        // lane r: bit k <=> record k of the step has id r of the block
+            unsigned long long ra0, ra1;
+            {
+                const auto a = __builtin_amdgcn_permlane32_swap((uint32_t)Rt, (uint32_t)Rt, false, false);                 // [0]: the lower half's words everywhere, [1]: the upper half's
+                const auto c = __builtin_amdgcn_permlane32_swap((uint32_t)(Rt >> 32), (uint32_t)(Rt >> 32), false, false);
+                ra0 = ((unsigned long long)c[0] << 32) | a[0];
+                ra1 = ((unsigned long long)c[1] << 32) | a[1];
+            }
+            wbuf[wave][lane] = (unsigned char)(mine ? (wx & 0xFFu) : 0u);
+            lds_sync();
+#pragma unroll 1
+            for (uint32_t kh = 0; kh < 2; ++kh) {
+                const uint32_t shift = 32u * kh + 16u * half;            // records 32 kh + 16 half .. + 15 of the step
+                k2_v4i a0 = spread(ra0, shift, lut_ff), a1 = spread(ra1, shift, lut_ff);
+                const k2_v4i b0 = spread(ra0, shift, lut_01), b1 = spread(ra1, shift, lut_01);
+                const k2_v4i wv = *(const k2_v4i*)(wbuf[wave] + shift);
+                a0 &= wv; a1 &= wv;
+                c00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, c00, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c11, 0, 0, 0);
+            }
+            lds_sync();
+            if (!pend) break;                                    // (the step's records are in; a change of block is seen with the next step)
+        }
+        if (!cur) break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1381,58 +1683,6 @@ __global__ __launch_bounds__(WAVE * K1W_WAVES) void k1w_kernel(const WParams q) 
 // ------------------------------------------------------------------------------------------
 // K2: records -> matrix
 // ------------------------------------------------------------------------------------------
-// 64 x 64 bit-matrix transpose across the lanes of a wave: lane i holds row i on entry, column i on exit.  Six butterfly stages; stage
-// 32 is one v_permlane32_swap over the two words.  Every stage below works on the 32-bit words separately: fetch the partner lane's
-// word (lane ^ s), rotate it by s towards this lane's side (v_alignbit_b32: right for the upper lane of a pair, left for the lower one)
-// and splice it in under a per-lane mask (v_bfi_b32) — three instructions per word and stage, with the rotate amounts and masks of
-// the five stages in ten registers that are computed once per run (TrConst).  The fetches are v_permlane16_swap (stage 16) and DPP row /
-// quad permutes: 35 VALU instructions per transpose, no LDS (fetching the stages 16 / 8 / 4 over the LDS crossbar with ds_swizzle_b32
-// was measured slower — profiles/r05_experiment_switches.diff; round 3's version, v_perm + ds_bpermute shuffles and 64-bit mask
-// arithmetic, took 72 VALU).  profiles/r04_transpose_probe.hip checks the variants against the definition and times them.
-struct TrConst { uint32_t amt[5], msk[5]; };
-__device__ __forceinline__ TrConst tr_const(uint32_t lane) {
-    TrConst c;
-    const uint32_t m[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const uint32_t s = 16u >> k;
-        const bool up = (lane & s) != 0;
-        c.amt[k] = up ? s : 32u - s;          // the partner's word rotated right by s (upper lane of the pair) or left by s (lower lane)
-        c.msk[k] = up ? m[k] : ~m[k];         // the bits taken from the partner
-    }
-    return c;
-}
-__device__ __forceinline__ uint32_t tr_fetch(uint32_t v, int k, bool up16) {
-    // the word of lane ^ (16 >> k)
-    if (k == 0) {
-        const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // [0]: odd rows <- the even rows below them, [1]: even rows <- the odd rows above
-        return up16 ? a[0] : a[1];
-    }
-    if (k == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
-    if (k == 2) {
-        const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);      // row_shl:4 into the banks 0 and 2: lane i <- i + 4
-        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);        // row_shr:4 into the banks 1 and 3: lane i <- i - 4
-    }
-    if (k == 3) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);               // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, const TrConst& c) {
-    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-        lo = r[0]; hi = r[1];
-    }
-    const bool up16 = c.msk[0] == 0x0000FFFFu;                         // (lane & 16) != 0
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const uint32_t pl = tr_fetch(lo, k, up16), ph = tr_fetch(hi, k, up16);
-        const uint32_t rl = __builtin_amdgcn_alignbit(pl, pl, c.amt[k]), rh = __builtin_amdgcn_alignbit(ph, ph, c.amt[k]);
-        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(lo) : "v"(c.msk[k]), "v"(rl));      // (mask & partner) | (~mask & own)
-        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(hi) : "v"(c.msk[k]), "v"(rh));
-    }
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 struct K2Item {
     uint32_t X, Y, count;                  // block pair, wave steps (64 records each) of this stream in the window
     const uint32_t* ids;                   // chunk mode: chunk ids of the run (LDS), CH_REC / 64 steps per chunk
@@ -1488,8 +1738,6 @@ __device__ __forceinline__ void k2_fetch(const K2Item& it, bool diag, uint32_t s
 // weight is split into base-128 digits, the run is accumulated once per digit that occurs (`digit`), and the digit's tile is
 // merged shifted left by 7 * digit — exact in the matrix's uint32 wrap-around arithmetic.  Almost every weight is below 128
 // (99.98 % at the benchmark database), so nearly every run takes one pass.  Returns (to every thread) the OR of the weights.
-typedef int k2_v4i __attribute__((ext_vector_type(4)));
-typedef int k2_v16i __attribute__((ext_vector_type(16)));
 
 template <bool DIAG, bool SORTED>
 __device__ __forceinline__ uint32_t k2_apply_mfma(const K2Item& it, uint32_t digit, uint32_t* acc,
@@ -1581,7 +1829,7 @@ __device__ __forceinline__ void k2_run(const K2Item& it, uint32_t* acc, uint32_t
                                           : k2_apply_mfma<false, SORTED>(it, digit, acc, wbuf, lut_ff, lut_01);
         if ((threadIdx.x & 63u) == 0 && wor) atomicOr(wor_sh, wor);
         __syncthreads();
-        if ((*wor_sh >> (7u * (digit + 1u))) == 0) break;           // no weight has a higher digit
+        if (digit == 4u || (*wor_sh >> (7u * (digit + 1u))) == 0) break;           // no weight has a higher digit (digit 4 is the last: a shift by 35 is not defined)
         __syncthreads();
     }
     // one HBM atomic per non-zero cell of the block
@@ -1805,7 +2053,7 @@ void l2_join_apply_kernel(const unsigned long long* __restrict__ B, const uint32
         for (int d = 32; d >= 1; d >>= 1) wor |= (uint32_t)__shfl_xor((int)wor, d, WAVE);
         if (lane == 0 && wor) atomicOr(&wor_sh, wor);
         __syncthreads();
-        if ((wor_sh >> (7u * (digit + 1u))) == 0) break;      // no weight has a higher digit
+        if (digit == 4u || (wor_sh >> (7u * (digit + 1u))) == 0) break;      // no weight has a higher digit (digit 4 is the last: a shift by 35 is not defined)
         __syncthreads();
     }
     // one HBM atomic per non-zero cell of the tile (the apply kernels add into the same matrix)
@@ -1872,12 +2120,12 @@ __global__ void count_chunks_kernel(const uint32_t* __restrict__ sorted_key, uin
 }
 // slots of the wide pool in use = the busiest sub-pool's share of all
 // chunks of the chunk pool in use = the busiest sub-pool's share of all (one wave: a maximum over the 256 cursors)
-__global__ void pool_used_kernel(const uint32_t* __restrict__ sub_cursor, uint32_t* __restrict__ counters) {
-    uint32_t mx = 0;
-    for (uint32_t p = threadIdx.x; p < KMDB_SUBPOOLS; p += 64u) mx = max(mx, sub_cursor[p * 16u]);
+__global__ void pool_used_kernel(const uint32_t* __restrict__ sub_cursor, const uint32_t* __restrict__ direct_ctr, uint32_t* __restrict__ counters) {
+    uint32_t mx = 0, nd = 0;
+    for (uint32_t p = threadIdx.x; p < KMDB_SUBPOOLS; p += 64u) { mx = max(mx, sub_cursor[p * 16u]); nd += direct_ctr[p * 16u]; }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
-    if (threadIdx.x == 0) counters[KCTR_POOL_USED] = mx * KMDB_SUBPOOLS;
+    for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE)); nd += (uint32_t)__shfl_xor((int)nd, d, WAVE); }
+    if (threadIdx.x == 0) { counters[KCTR_POOL_USED] = mx * KMDB_SUBPOOLS; counters[KCTR_DIRECT] = nd; }
 }
 __global__ void count_raw_kernel(const uint32_t* __restrict__ wsub_cursor, uint32_t* __restrict__ counters) {
     uint32_t mx = 0;
@@ -2880,6 +3128,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->sub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->wsub_cursor, KMDB_SUBPOOLS * 16 * 4));
     HIP_TRY(hipMalloc((void**)&db->run_ctr, K1W_CTRS * 16 * 4));
+    HIP_TRY(hipMalloc((void**)&db->direct_ctr, KMDB_SUBPOOLS * 16 * 4));
     // Where the records go.  The narrow kernel's first-block diagonal records follow the clustering of the DFS stream: per-stream
     // chunks (an open chunk per block and wave), applied straight from the grouped chunk table.  The other records spread over
     // many streams, a few per stream and wave:
@@ -2894,6 +3143,17 @@ static int blocks_prepare_impl(kmdb_db* db) {
     db->dense_wide = true;
     db->dense_narrow = false;
     if (const char* e = getenv("KMDB_DENSE")) db->dense_narrow = atoi(e) >= 2;
+    // Round 6: the narrow kernel's first-block records no longer travel through stream chunks (engine_state.h: k1n_mode; KMDB_K1N_MODE=0 / 1 / 2
+    // for the A/B): compacted per slice and applied by k2d_kernel beside the wide kernel (2, default), or applied inside the narrow kernel (1).
+    db->k1n_mode = 2;
+    if (const char* e = getenv("KMDB_K1N_MODE")) if (*e) db->k1n_mode = std::max(0, std::min(2, atoi(e)));
+    if (db->k1n_mode) db->dense_narrow = true;
+    if (db->k1n_mode == 2) {
+        const size_t slots = (size_t)db->n_nsegs * db->nseg_nodes;
+        HIP_TRY(hipMalloc((void**)&db->dmask, std::max<size_t>(slots, 1) * 8));
+        HIP_TRY(hipMalloc((void**)&db->dwx, std::max<size_t>(slots, 1) * 4));
+        HIP_TRY(hipMalloc((void**)&db->slice_cnt, std::max<size_t>(db->n_nsegs, 1) * 4));
+    }
     db->row_mode = db->n_states > CS_MAX_KEYS;
     if (const char* e = getenv("KMDB_ROW_MODE")) if (*e) db->row_mode = atoi(e) != 0;          // (tests: small databases through the many-streams path)
     // packed records: a block width of at most 54 leaves the column mask 10 spare bits and more — an 8-bit weight digit at least and the digit's
@@ -2943,11 +3203,14 @@ static int blocks_prepare_impl(kmdb_db* db) {
     HIP_TRY(hipMalloc((void**)&db->k2j_start, ((size_t)db->n_states + 2) * 4));
     // stream chunks: the narrow estimate at two thirds average fill, plus what the waves hold when they end (open chunks, an
     // unfinished grab); wide records: the wide estimate at two thirds (+ a grab / the open row chunks per wave)
+    // (modes 1 and 2: of the narrow kernel's first-block records only the stragglers go to the pools — weights of 128 and more, in mode 1 also a
+    // slice's nodes outside its tile: a sixteenth of the estimate is generous, and a pool that is too small is enlarged as ever)
+    if (db->k1n_mode) { est_g += est_n / 16 + 1; est_n = 0; }
     if (db->row_mode) {
         if (alloc_record_pool(db, (est_n + est_g) * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
         if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + 4096)) return 1;
     } else {
-        if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 8 + 4096)) return 1;
+        if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (db->dense_narrow ? 0u : (uint64_t)db->n_nsegs * 8) + 4096)) return 1;
         if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1W_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;
     }
     if (verbose) fprintf(stderr, "[kmdb] prepare: record pools %.2f GB\n", kmdb_blocks_device_bytes(db) / 1e9);
@@ -2963,7 +3226,7 @@ void kmdb_blocks_release(kmdb_db* db) {
     FREE_NULL(db->wkey); FREE_NULL(db->wrec); FREE_NULL(db->swkey); FREE_NULL(db->swrec); FREE_NULL(db->sort2_tmp); FREE_NULL(db->wsub_cursor); FREE_NULL(db->cs_hist); FREE_NULL(db->cs_offs); FREE_NULL(db->cs_rows); FREE_NULL(db->cs_tmp);
     FREE_NULL(db->rec); FREE_NULL(db->recw); FREE_NULL(db->counters); FREE_NULL(db->scan_tmp); FREE_NULL(db->sub_cursor);
     FREE_NULL(db->ct_hist); FREE_NULL(db->ct_offs); FREE_NULL(db->ct_cursor); FREE_NULL(db->ct_tmp); FREE_NULL(db->rs_rows); FREE_NULL(db->rs_hist); FREE_NULL(db->rs_offs);
-    FREE_NULL(db->run_ctr); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->k2j_start); FREE_NULL(db->k2j_jobs); FREE_NULL(db->tile_touched);
+    FREE_NULL(db->run_ctr); FREE_NULL(db->direct_ctr); FREE_NULL(db->dmask); FREE_NULL(db->dwx); FREE_NULL(db->slice_cnt); FREE_NULL(db->rs_tmp); FREE_NULL(db->rg_hist); FREE_NULL(db->rg_offs); FREE_NULL(db->rg_tmp); FREE_NULL(db->row_ids); FREE_NULL(db->k2j_start); FREE_NULL(db->k2j_jobs); FREE_NULL(db->tile_touched);
     FREE_NULL(db->l2_cursors); FREE_NULL(db->l2_bitmap); FREE_NULL(db->l2_rank); FREE_NULL(db->l2_len); FREE_NULL(db->l2_loff); FREE_NULL(db->l2_ent_g);
     FREE_NULL(db->l2_node_w); FREE_NULL(db->l2_list_w); FREE_NULL(db->l2_ent_blk); FREE_NULL(db->l2_ent_mask); FREE_NULL(db->l2_list_mask);
     db->l2_node_cap = 0; db->l2_ent_cap = 0;
@@ -2973,7 +3236,7 @@ void kmdb_blocks_release(kmdb_db* db) {
 
 uint64_t kmdb_blocks_device_bytes(const kmdb_db* db) {
     if (!db->counters) return 0;
-    return db->P * (8 + 4 + 4 + 16 + 4) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 16 + db->wide_cap * 4 + (db->P / 64) * 16 +
+    return db->P * (8 + 4 + 4 + 16 + 4) + (db->dmask ? (uint64_t)db->n_nsegs * db->nseg_nodes * 12 : 0u) + db->pair_cap * 10 + ((db->pool_cap << CH_SHIFT) * 20) + db->pool_cap * 16 + db->wide_cap * 4 + (db->P / 64) * 16 +
            (db->wide_pool_cap << WCH_SHIFT) * (db->row_mode ? 20 : 40) + db->rs_entries * 8 + (uint64_t)db->n_ckeys * 12 +
            (uint64_t)db->NB * (db->l2_node_cap / 64u) * 12 + (uint64_t)db->l2_ent_cap * 26 + (uint64_t)db->l2_node_cap * 4;
 }
@@ -3025,6 +3288,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     HIP_TRY(hipMemsetAsync(db->sub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->wsub_cursor, 0, KMDB_SUBPOOLS * 16 * 4, st));
     HIP_TRY(hipMemsetAsync(db->run_ctr, 0, K1W_CTRS * 16 * 4, st));
+    HIP_TRY(hipMemsetAsync(db->direct_ctr, 0, KMDB_SUBPOOLS * 16 * 4, st));
     // Sizes of the launches: measured by the previous call on this handle.  What the narrow kernel produces repeats exactly; where
     // the wide kernel's records land depends on which wave took which run, so the chunk counts behind it vary a little from call
     // to call: those launches get some slack, every kernel takes the true counts from device memory, and the call is repeated with
@@ -3075,8 +3339,19 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         const size_t wave_lds = k1n_wave_bytes(q.chain_cap, q.tbits, q.n_keys, row_mode ? db->NB : 0u);
         const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(K1N_WAVES, (144u << 10) / wave_lds));
         const size_t lds = wave_lds * waves;
-        HIP_TRY(hipFuncSetAttribute((const void*)k1n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k1n_kernel, dim3((q.n_segs + waves - 1) / waves), dim3(WAVE * waves), lds, st, q);
+        q.dbg = getenv("KMDB_K1N_DBG") ? (uint32_t)atoi(getenv("KMDB_K1N_DBG")) : 0u;
+        q.M = M; q.N = (uint32_t)db->N; q.bwidth = db->width; q.touched = db->tile_touched; q.direct_ctr = db->direct_ctr;
+        q.dmask = db->dmask; q.dwx = db->dwx; q.slice_cnt = db->slice_cnt;
+        // (mode 1 holds 48 accumulator registers beside the narrow kernel's 95: three waves per SIMD without spills, or four with 84 bytes of
+        // scratch per lane — KMDB_K1N_MINW=4, A/B)
+        static const int minw = getenv("KMDB_K1N_MINW") ? atoi(getenv("KMDB_K1N_MINW")) : 3;
+        const void* fn = db->k1n_mode == 2 ? (const void*)k1n_kernel<2, 4> : db->k1n_mode == 1 ? (minw >= 4 ? (const void*)k1n_kernel<1, 4> : (const void*)k1n_kernel<1, 3>) : (const void*)k1n_kernel<0, 4>;
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const dim3 grid((q.n_segs + waves - 1) / waves), block(WAVE * waves);
+        if (db->k1n_mode == 2) hipLaunchKernelGGL((k1n_kernel<2, 4>), grid, block, lds, st, q);
+        else if (db->k1n_mode == 0) hipLaunchKernelGGL((k1n_kernel<0, 4>), grid, block, lds, st, q);
+        else if (minw >= 4) hipLaunchKernelGGL((k1n_kernel<1, 4>), grid, block, lds, st, q);
+        else hipLaunchKernelGGL((k1n_kernel<1, 3>), grid, block, lds, st, q);
         HIP_TRY(hipGetLastError());
     }
     if (stage("narrow emit")) return 1;
@@ -3108,10 +3383,27 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         if (sync_debug) { const hipError_t e = hipStreamSynchronize(s2); fprintf(stderr, "[kmdb] stage %-14s %s\n", "chunk apply", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
         return 0;
     };
-    if (!row_mode) {
+    auto apply_slices = [&]() -> int {
+        // mode 2: the slices' first-block records through k2d_kernel, on the side stream beside the wide kernel
         HIP_TRY(hipEventRecord(db->ev_side[0], st));
         HIP_TRY(hipStreamWaitEvent(s2, db->ev_side[0], 0));
-        if (group_and_apply_chunks(s2)) return 1;
+        DParams d{};
+        d.dmask = db->dmask; d.dwx = db->dwx; d.slice_cnt = db->slice_cnt; d.n_segs = db->n_nsegs; d.nseg_nodes = db->nseg_nodes;
+        static const uint32_t sl = getenv("KMDB_K2D_SLICES") ? (uint32_t)std::max(1, atoi(getenv("KMDB_K2D_SLICES"))) : K2D_SLICES;
+        d.slices = sl; d.M = M; d.N = (uint32_t)db->N; d.bwidth = db->width; d.touched = db->tile_touched;
+        const uint32_t waves = (db->n_nsegs + sl - 1u) / sl;
+        if (waves) hipLaunchKernelGGL(k2d_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, s2, d);
+        HIP_TRY(hipGetLastError());
+        if (sync_debug) { const hipError_t e = hipStreamSynchronize(s2); fprintf(stderr, "[kmdb] stage %-14s %s\n", "slice apply", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
+        return 0;
+    };
+    if (db->k1n_mode == 2 && apply_slices()) return 1;
+    if (!row_mode) {
+        if (!db->dense_narrow) {
+            HIP_TRY(hipEventRecord(db->ev_side[0], st));
+            HIP_TRY(hipStreamWaitEvent(s2, db->ev_side[0], 0));
+            if (group_and_apply_chunks(s2)) return 1;
+        } else HIP_TRY(hipEventRecord(db->ev_side[1], s2));        // (no stream chunk is ever opened: nothing to group; the side stream holds the slices' apply kernel or nothing)
     }
     // ---- wide list
     hipLaunchKernelGGL(wide_count_kernel, dim3((n_words + 1 + 255) / 256), dim3(256), 0, st, db->widebits, n_words, db->wide_cnt);
@@ -3302,7 +3594,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         if (stage("sorted apply")) return 1;
     }
     HIP_TRY(hipStreamWaitEvent(st, db->ev_side[1], 0));          // the side stream's tiles are in the matrix too
-    hipLaunchKernelGGL(pool_used_kernel, dim3(1), dim3(64), 0, st, db->sub_cursor, db->counters);
+    hipLaunchKernelGGL(pool_used_kernel, dim3(1), dim3(64), 0, st, db->sub_cursor, db->direct_ctr, db->counters);
     HIP_TRY(hipEventRecord(db->ev_k[3], st));
     // ---- what the call found
     HIP_TRY(hipMemcpyAsync(db->h_counters, db->counters, KCTR_COUNT * 4, hipMemcpyDeviceToHost, st));
@@ -3399,6 +3691,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         fprintf(stderr, "[kmdb] second level: %u nodes with %u blocks or more joined per tile (indices for %u, entries for %u)\n", c[KCTR_L2_NODES], db->l2_min_blocks,
                 db->l2_node_cap, db->l2_ent_cap);
     db->last_records = ((uint64_t)c[KCTR_RECORDS] | ((uint64_t)c[KCTR_RECORDS_HI] << 32)) + (row_mode ? 0u : c[KCTR_WIDE_RECORDS]);
+    db->last_n_direct = c[KCTR_DIRECT];
     return 0;
 }
 

@@ -241,7 +241,8 @@ int upload_impl(const kmdb_db_view* v, const kmdb_opts* opts, int with_hashtable
     part("preparation of the all2all working set");
     if (hipStreamSynchronize(db->stream) != hipSuccess) { kmdb_set_error("kmdb_db_upload: device error"); return fail(); }
     part("final wait");
-    db->stats.device_bytes += kmdb_blocks_device_bytes(db);
+    db->blocks_bytes_counted = kmdb_blocks_device_bytes(db);
+    db->stats.device_bytes += db->blocks_bytes_counted;
     db->stats.width = db->width;
     db->stats.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("KMDB_VERBOSE")) fprintf(stderr, "[kmdb] upload: total %.3f s (%llu patterns, %llu samples)\n", db->stats.upload_ms * 1e-3,
@@ -339,12 +340,13 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
     if (cells) HIP_TRY(hipMemsetAsync(M, 0, cells * 4, st));
     db->stats.path = KMDB_PATH_NONE;
     db->stats.k0_ms = db->stats.k1_ms = db->stats.k1n_ms = db->stats.k1g_ms = db->stats.k2_ms = 0;
-    db->stats.n_records = 0; db->stats.n_wide = 0; db->stats.n_chunks = 0; db->stats.tile_flushes = 0; db->stats.sized_call = 0;
+    db->stats.n_records = 0; db->stats.n_direct = 0; db->stats.n_wide = 0; db->stats.n_chunks = 0; db->stats.tile_flushes = 0; db->stats.sized_call = 0;
     if (!cells || !P) { HIP_TRY(hipEventRecord(db->ev[1], st)); HIP_TRY(hipEventRecord(db->ev[2], st)); return 0; }
     const bool forced_v1 = (flags & (KMDB_FLAG_FORCE_GLOBAL_ATOMICS | KMDB_FLAG_FORCE_DIRECT | KMDB_FLAG_FORCE_TILE)) != 0;
     if (!forced_v1 && !db->blocks_prepared) {
         if (kmdb_blocks_prepare(db)) return 1;
-        db->stats.device_bytes += kmdb_blocks_device_bytes(db);
+        db->blocks_bytes_counted = kmdb_blocks_device_bytes(db);
+        db->stats.device_bytes += db->blocks_bytes_counted;
         db->stats.width = db->width;
     }
     if (!forced_v1 && db->fallback_reason.empty()) {
@@ -374,9 +376,9 @@ int run_dense(kmdb_db* db, uint32_t* M, const kmdb_opts* opts, hipStream_t st) {
         if (shard_count > 1) return kmdb_set_error("kmdb_all2all: slices of the pattern stream (kmdb_opts.shard_count > 1) need the block-record pipeline: " + db->fallback_reason);
     }
     // v1 kernels: tree form, subtree weights (reference similarity_calculator.cpp:64-72) = exclusive scan of w in DFS order
-    if (N > KMDB_V1_MAX_SAMPLES)
-        return kmdb_set_error("kmdb_all2all: the HBM-atomics kernels keep sample ids in 16 bits (at most " + std::to_string(KMDB_V1_MAX_SAMPLES) + " samples)" +
-                              (forced_v1 ? std::string() : "; the block-record pipeline cannot take this database: " + db->fallback_reason));
+    // (beyond 4096 samples every v1 call runs a2a_global_kernel, whose stack and decoder hold 32-bit ids: no sample limit of its own — round 5
+    // refused 65 536 samples and more here, so a tree deeper than the chain table on such a collection had no path at all; the LDS kernels
+    // with their 16-bit ids are only ever chosen up to 4096 samples, kmdb_v1_run)
     if (kmdb_ensure_v1_arrays(db)) return 1;
     HIP_TRY(hipMemsetAsync(db->v1_counters, 0, 8 * sizeof(unsigned long long), st));
     HIP_TRY(prim::exclusive_sum(db->v1_scan_tmp, db->v1_scan_tmp_bytes, db->w, db->wprefix, (int)(P + 1), st));
@@ -405,6 +407,12 @@ int finish_stats(kmdb_db* db, hipStream_t st) {
         db->stats.k0_ms = k0; db->stats.k1n_ms = k1n; db->stats.k1g_ms = k1g; db->stats.k1_ms = k1n + k1g; db->stats.k2_ms = k2;
         db->stats.n_records = db->last_records; db->stats.n_wide = db->last_n_wide; db->stats.n_chunks = db->last_n_chunks;
         db->stats.n_joined = db->l2_on ? db->last_l2_nodes : 0u;
+        db->stats.n_direct = db->last_n_direct;
+        // the pipeline's arrays grow inside calls (second-level arrays on the first call, pools enlarged by a quarter or doubled): what is
+        // resident NOW, not what the preparation allocated
+        const uint64_t now = kmdb_blocks_device_bytes(db);
+        db->stats.device_bytes = db->stats.device_bytes - db->blocks_bytes_counted + now;
+        db->blocks_bytes_counted = now;
     } else if (db->v1_counters && db->stats.path != KMDB_PATH_NONE) {
         unsigned long long c[8];
         HIP_TRY(hipMemcpy(c, db->v1_counters, sizeof c, hipMemcpyDeviceToHost));

@@ -7,7 +7,6 @@
 struct kmdb_db;
 
 constexpr uint32_t KMDB_ID_BITS = 20, KMDB_MAX_SAMPLES = 1u << KMDB_ID_BITS;   // sample ids in the device layout (engine_state.h: kmdb_k0_pack)
-constexpr uint32_t KMDB_V1_MAX_SAMPLES = 65535;   // the HBM-atomics kernels of a2a_v1.hip (fallback) and db2db.hip keep sample ids in 16 bits
 constexpr uint32_t KMDB_CK_IDS = 32;   // list index of new2all: one checkpoint per 32 local ids of a long list
 
 struct kmdb_engine_view {

@@ -41,7 +41,8 @@ enum : uint32_t {
     KCTR_L2_NODES = 13,     // nodes that went to the second level
     KCTR_POOL_USED = 15,    // chunks of the chunk pool in use (upper bound: busiest sub-pool x sub-pools)
     KCTR_K2JOBS = 14,       // row mode: jobs of the apply kernel over the sorted records (one stream, or one part of a long stream, each)
-    KCTR_COUNT = 16
+    KCTR_DIRECT = 16,       // first-block records the narrow kernel applied where it emitted them (never written: k1n_kernel<true>)
+    KCTR_COUNT = 17
 };
 constexpr uint32_t KMDB_PAIR_REGIONS = 4096;
 constexpr uint32_t KMDB_SUBPOOLS = 256;      // sub-pools of the record chunk pool (one allocation cursor each)   // sub-pools of the extra-pair pool (one allocation cursor each)
@@ -116,6 +117,16 @@ struct kmdb_db {
     // wide pool: records in arrival order + a device-wide sort by stream (the wide kernel always; the narrow kernel if its
     // per-stream chunks do not work out)
     bool dense_wide = false, dense_narrow = false;
+    // the narrow kernel's first-block records (X, X): 0 stream chunks + k2_apply_kernel (round 5), 1 applied inside the narrow kernel (tile in its
+    // registers, nothing written), 2 compacted per slice in DFS order + k2d_kernel on the side stream (default).  1 and 2: what they cannot take
+    // (weights of 128 and more) goes the dense_narrow way, nothing uses stream chunks
+    int k1n_mode = 2;
+    unsigned long long* dmask = nullptr;    // mode 2: [n_nsegs * nseg_nodes] F0 of the slice's records
+    uint32_t* dwx = nullptr;                //         w | X << 8
+    uint32_t* slice_cnt = nullptr;          //         [n_nsegs] records of every slice
+    uint32_t* direct_ctr = nullptr; // [KMDB_SUBPOOLS * 16] records applied directly, counted per wave on spread addresses
+    uint64_t last_n_direct = 0;
+    uint64_t blocks_bytes_counted = 0;   // the block-record pipeline's share of stats.device_bytes as last counted (its arrays grow inside calls)
     uint32_t *wkey = nullptr, *swkey = nullptr;     // wide pool: stream of every record slot (0xFFFFFFFF = never written), and sorted
     void *wrec = nullptr, *swrec = nullptr;         // wide pool: 16-byte records {rows, cols} (weight digit in the key word), and sorted by stream
     uint64_t wide_pool_cap = 0;     // chunks of 64 records

@@ -89,6 +89,71 @@ extern "C" size_t kmdbh_extract_kmers(const char* seq, size_t len, uint32_t k, d
     return n_out;
 }
 
+// ---- every alphabet of the reference (src/alphabet.h:79-86): nt, nt-preserve and the four protein alphabets.  The groups of a description
+// are the symbols, upper and lower case alike (alphabet.h:41-58); bits per symbol = ceil(log2(groups)) (:36); a k-mer of k symbols must leave
+// the word's top bit free (:37: maxKmerLen = 64 / bits - 1).  Every protein alphabet preserves the strand; the reverse word exists for the
+// two nucleotide alphabets only (kmer_extract.h:59,73: size - 1 - symbol).
+namespace {
+struct AlphabetDesc { const char* groups; int preserve; };
+const AlphabetDesc kAlphabets[KMDB_ALPHABET_COUNT] = {
+    {"A,C,G,TU", 0}, {"A,C,G,TU", 1}, {"K,R,E,D,Q,N,C,G,H,I,L,V,M,F,Y,W,P,S,T,A", 1}, {"KREDQN,C,G,H,ILV,M,F,Y,W,P,STA", 1},
+    {"AST,C,DN,EQ,FY,G,H,IV,KR,LM,P,W", 1}, {"STPAG,NDEQ,HRK,MILV,FYW,C", 1}};
+}  // namespace
+
+extern "C" int kmdbh_alphabet_table(int32_t alphabet, int8_t* map256, uint32_t* n_symbols, uint32_t* bits_per_symbol, int* preserve_strand) {
+    if (alphabet < 0 || alphabet >= KMDB_ALPHABET_COUNT || !map256) return 1;
+    for (int i = 0; i < 256; ++i) map256[i] = -1;
+    uint32_t size = 1;
+    for (const char* g = kAlphabets[alphabet].groups; *g; ++g) {
+        if (*g == ',') { ++size; continue; }
+        const unsigned char c = (unsigned char)*g;
+        map256[c | 0x20] = map256[c & ~0x20] = (int8_t)(size - 1);        // (letters only: either case)
+    }
+    uint32_t bits = 0;
+    while ((1u << bits) < size) ++bits;
+    if (n_symbols) *n_symbols = size;
+    if (bits_per_symbol) *bits_per_symbol = bits;
+    if (preserve_strand) *preserve_strand = kAlphabets[alphabet].preserve;
+    return 0;
+}
+
+extern "C" size_t kmdbh_extract_kmers_alphabet(const char* seq, size_t len, uint32_t k, int32_t alphabet, double fraction, double start_fraction,
+                                               uint64_t* out) {
+    int8_t map[256];
+    uint32_t size = 0, bits = 0;
+    int preserve = 0;
+    if (kmdbh_alphabet_table(alphabet, map, &size, &bits, &preserve)) return 0;
+    if (k == 0 || k > 64u / bits - 1u || len < k) return 0;
+    const uint64_t word_mask = (1ull << (bits * k)) - 1;
+    const unsigned top_shift = bits * (k - 1);
+    const int prefix_bits = (int)(bits * k) - 32;
+    const unsigned widen = prefix_bits < 8 ? (unsigned)(8 - prefix_bits) : 0u;
+    const uint64_t tail = widen ? ((1ull << widen) - 1) : 0ull;
+    const bool subsample = fraction < 1.0;
+    const double u64max = (double)std::numeric_limits<uint64_t>::max();
+    const uint64_t lo = (uint64_t)(u64max * start_fraction);
+    const uint64_t hi = (uint64_t)(u64max * (start_fraction + fraction));
+    const uint64_t quarter_len = (uint64_t)std::ceil((double)k / 4.0);
+    uint64_t fwd = 0, rc = 0;
+    uint32_t valid_run = 0;
+    size_t n_out = 0;
+    for (size_t i = 0; i < len; ++i) {
+        int c = map[(unsigned char)seq[i]];
+        if (c < 0) { c = 0; valid_run = 0; } else if (valid_run < k) ++valid_run;
+        fwd = ((fwd << bits) | (uint64_t)c) & word_mask;
+        rc = (rc >> bits) | ((uint64_t)(size - 1 - (uint32_t)c) << top_shift);
+        if (valid_run < k) continue;
+        uint64_t w = (preserve || fwd < rc) ? fwd : rc;
+        w = (w << widen) | (w & tail);
+        if (subsample) {
+            const uint64_t h = minhash_value(w, quarter_len);
+            if (h < lo || h >= hi) continue;
+        }
+        out[n_out++] = w;
+    }
+    return n_out;
+}
+
 extern "C" size_t kmdbh_sort_unique(uint64_t* kmers, size_t n) {
     std::sort(kmers, kmers + n);
     return (size_t)(std::unique(kmers, kmers + n) - kmers);

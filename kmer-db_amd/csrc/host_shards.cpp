@@ -15,6 +15,9 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <new>
+#include <stdexcept>
+#include <string>
 #include <thread>
 
 namespace {
@@ -36,8 +39,10 @@ void kmdb_shard_plan::release_weights(uint32_t shard) {
 
 extern "C" int kmdbh_shard_plan_counts(const kmdb_db_view* view, uint32_t n_shards, uint64_t* kept_nodes, uint64_t* kmers) {
     if (!view || !kept_nodes || !kmers || n_shards == 0) return kmdb_set_error("kmdbh_shard_plan_counts: null argument / no shards");
+    if (n_shards > KMDB_MAX_SHARDS) return kmdb_set_error("kmdbh_shard_plan_counts: more than " + std::to_string(KMDB_MAX_SHARDS) + " shards");
     kmdb_shard_plan plan;
-    std::vector<uint32_t> all(n_shards);
+    std::vector<uint32_t> all;
+    try { all.resize(n_shards); } catch (const std::exception&) { return kmdb_set_error("kmdbh_shard_plan_counts: out of host memory"); }
     for (uint32_t s = 0; s < n_shards; ++s) all[s] = s;
     if (kmdb_shard_plan_build(view, n_shards, all, &plan)) return 1;
     for (uint32_t s = 0; s < n_shards; ++s) {
@@ -49,7 +54,36 @@ extern "C" int kmdbh_shard_plan_counts(const kmdb_db_view* view, uint32_t n_shar
     return 0;
 }
 
+namespace {
+// work(t) for t < T on T threads; a thread that cannot be started (std::system_error) has its share done by the caller, and every
+// started thread is joined before anything propagates (a joinable std::thread that is destroyed calls std::terminate)
+template <class F>
+void run_shares(unsigned T, F&& work) {
+    std::vector<std::thread> pool;
+    std::vector<unsigned> inline_shares{0u};
+    for (unsigned t = 1; t < T; ++t) {
+        try { pool.emplace_back(work, t); }
+        catch (...) { inline_shares.push_back(t); }
+    }
+    for (unsigned t : inline_shares) work(t);
+    for (auto& th : pool) th.join();
+}
+}  // namespace
+
+static int shard_plan_build_impl(const kmdb_db_view* v, uint32_t n_shards, const std::vector<uint32_t>& shards, kmdb_shard_plan* plan);
+// (nothing may leave through the extern "C" entry points above this: allocation and thread failures end in kmdb_set_error — ADVICE round 5)
 int kmdb_shard_plan_build(const kmdb_db_view* v, uint32_t n_shards, const std::vector<uint32_t>& shards, kmdb_shard_plan* plan) {
+    // a shard per prefix bucket is the finest partition there is, and the plan keeps a counter array per shard: implausible counts are refused
+    if (n_shards == 0 || n_shards > KMDB_MAX_SHARDS) return kmdb_set_error("kmdb_db_upload_shard: shard_count must be between 1 and " + std::to_string(KMDB_MAX_SHARDS));
+    try {
+        return shard_plan_build_impl(v, n_shards, shards, plan);
+    } catch (const std::bad_alloc&) {
+        return kmdb_set_error("kmdb_db_upload_shard: out of host memory for the shard plan");
+    } catch (const std::exception& e) {
+        return kmdb_set_error(std::string("kmdb_db_upload_shard: ") + e.what());
+    }
+}
+static int shard_plan_build_impl(const kmdb_db_view* v, uint32_t n_shards, const std::vector<uint32_t>& shards, kmdb_shard_plan* plan) {
     const uint64_t P = v->n_patterns;
     if (!v->n_buckets) return kmdb_set_error("kmdb_db_upload_shard: the view carries no hashtables (load the database with mode Everything)");
     plan->P = P; plan->n_shards = n_shards;
@@ -67,7 +101,6 @@ int kmdb_shard_plan_build(const kmdb_db_view* v, uint32_t n_shards, const std::v
     const uint64_t n_slots = v->bucket_offset[v->n_buckets];
     const unsigned T = (unsigned)std::min<uint64_t>(std::min(64u, hw), std::max<uint64_t>(1, n_slots / (1u << 20)));
     {
-        std::vector<std::thread> pool;
         auto work = [&](unsigned t) {
             const uint64_t blo = v->n_buckets * t / T, bhi = v->n_buckets * (t + 1) / T;
             for (uint64_t b = blo; b < bhi; ++b) {
@@ -83,9 +116,7 @@ int kmdb_shard_plan_build(const kmdb_db_view* v, uint32_t n_shards, const std::v
                 }
             }
         };
-        for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto& th : pool) th.join();
+        run_shares(T, work);
     }
     // ---- one sweep, children before parents: a kept node keeps its parent (all shards at once: the masks are ORed upwards)
     const size_t G = plan->mask.size();
@@ -98,7 +129,6 @@ int kmdb_shard_plan_build(const kmdb_db_view* v, uint32_t n_shards, const std::v
     // nodes kept per shard
     {
         std::vector<std::vector<uint64_t>> part(T, std::vector<uint64_t>(n_shards, 0));
-        std::vector<std::thread> pool;
         auto work = [&](unsigned t) {
             for (uint64_t p = P * t / T; p < P * (t + 1) / T; ++p)
                 for (size_t g = 0; g < G; ++g) {
@@ -106,9 +136,7 @@ int kmdb_shard_plan_build(const kmdb_db_view* v, uint32_t n_shards, const std::v
                     while (m) { const unsigned k = (unsigned)__builtin_ctz(m); m &= m - 1u; ++part[t][g * 8 + k]; }
                 }
         };
-        for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto& th : pool) th.join();
+        run_shares(T, work);
         for (unsigned t = 0; t < T; ++t) for (uint32_t s = 0; s < n_shards; ++s) plan->kept[s] += part[t][s];
     }
     return 0;

@@ -21,6 +21,8 @@ void kmdb_drop_pages(const std::vector<std::pair<void*, size_t>>& regions, unsig
 // when its subtree holds a k-mer of s (bit s & 7 of mask[s >> 3][p]).  Every device then receives only the nodes and streams its
 // shards keep — not the whole tree and the hashtables once per device.
 struct kmdb_db_view;
+// prefix shards per database at most (the plan keeps a counter array per shard; a count beyond this is a caller's mistake, not a configuration)
+constexpr uint32_t KMDB_MAX_SHARDS = 4096;
 struct kmdb_shard_plan {
     uint64_t P = 0;
     uint32_t n_shards = 0;

@@ -630,20 +630,12 @@ __device__ __forceinline__ uint64_t n2_mix64(uint64_t v) {
     return v;
 }
 
-__device__ __forceinline__ int n2_base(unsigned char c) {
-    switch (c | 0x20) {
-        case 'a': return 0;
-        case 'c': return 1;
-        case 'g': return 2;
-        case 't': case 'u': return 3;
-        default: return -1;
-    }
-}
-
 struct ExtractParams {
     const char* seq; const uint64_t* soff; uint32_t nq; uint64_t total_len;
     uint32_t k, widen; int preserve, subsample; uint64_t lo, hi, quarter_len;
     unsigned long long* kmer; uint32_t* qid;
+    uint32_t bits, size;           // bits per symbol and symbols of the alphabet (alphabet.h:35-36); nt: 2, 4
+    int8_t map[256];               // Alphabet::mapping (alphabet.h:41-58) — travels with the kernel arguments
 };
 
 __global__ __launch_bounds__(256) void n2a_extract_kernel(ExtractParams p) {
@@ -657,12 +649,12 @@ __global__ __launch_bounds__(256) void n2a_extract_kernel(ExtractParams p) {
     if (i + p.k <= p.soff[lo + 1]) {
         uint64_t fwd = 0, rc = 0;
         bool ok = true;
-        const unsigned top = 2 * (p.k - 1);
+        const unsigned top = p.bits * (p.k - 1);
         for (uint32_t t = 0; t < p.k; ++t) {
-            const int c = n2_base((unsigned char)p.seq[i + t]);
+            const int c = p.map[(unsigned char)p.seq[i + t]];
             if (c < 0) { ok = false; break; }
-            fwd = (fwd << 2) | (uint64_t)c;
-            rc = (rc >> 2) | ((uint64_t)(3 - c) << top);
+            fwd = (fwd << p.bits) | (uint64_t)c;
+            rc = (rc >> p.bits) | ((uint64_t)(p.size - 1u - (uint32_t)c) << top);     // (kmer_extract.h:73; compared only where the strand is not preserved: nt)
         }
         if (ok) {
             uint64_t w = (p.preserve || fwd < rc) ? fwd : rc;
@@ -720,13 +712,21 @@ static uint64_t n2_seq_budget() {                        // bases per piece (one
 }
 
 static int new2all_seq_once(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
-                            double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                            double start_fraction, int32_t alphabet, uint32_t* out_dense, uint64_t* out_kmer_counts,
                             const kmdb_opts* opts);
 
 extern "C" int kmdb_new2all_batch_seq(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
                                       double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
                                       const kmdb_opts* opts) {
+    return kmdb_new2all_batch_seq_alphabet(dbh, seqs, seq_lens, nq, fraction, start_fraction, preserve_strand ? KMDB_ALPHABET_NT_PRESERVE : KMDB_ALPHABET_NT,
+                                           out_dense, out_kmer_counts, opts);
+}
+
+extern "C" int kmdb_new2all_batch_seq_alphabet(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
+                                               double start_fraction, int32_t alphabet, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                                               const kmdb_opts* opts) {
     if (!dbh || (nq && (!seqs || !seq_lens || !out_dense || !out_kmer_counts))) return kmdb_set_error("kmdb_new2all_batch_seq: null argument");
+    if (alphabet < 0 || alphabet >= KMDB_ALPHABET_COUNT) return kmdb_set_error("kmdb_new2all_batch_seq: unknown alphabet " + std::to_string(alphabet));
     kmdb_engine_view e;
     if (kmdb_engine_get(dbh, &e)) return 1;
     // rows of different queries are independent: cut the batch where the accumulated bases pass the budget
@@ -735,7 +735,7 @@ extern "C" int kmdb_new2all_batch_seq(kmdb_db* dbh, const char* const* seqs, con
         size_t q1 = q0;
         uint64_t bases = 0;
         do { bases += seq_lens[q1]; ++q1; } while (q1 < nq && bases + seq_lens[q1] <= budget);
-        if (new2all_seq_once(dbh, seqs + q0, seq_lens + q0, q1 - q0, fraction, start_fraction, preserve_strand, out_dense + q0 * e.N,
+        if (new2all_seq_once(dbh, seqs + q0, seq_lens + q0, q1 - q0, fraction, start_fraction, alphabet, out_dense + q0 * e.N,
                              out_kmer_counts + q0, opts)) return 1;
         q0 = q1;
     }
@@ -743,13 +743,16 @@ extern "C" int kmdb_new2all_batch_seq(kmdb_db* dbh, const char* const* seqs, con
 }
 
 static int new2all_seq_once(kmdb_db* dbh, const char* const* seqs, const size_t* seq_lens, size_t nq, double fraction,
-                            double start_fraction, int preserve_strand, uint32_t* out_dense, uint64_t* out_kmer_counts,
+                            double start_fraction, int32_t alphabet, uint32_t* out_dense, uint64_t* out_kmer_counts,
                             const kmdb_opts* opts) {
     kmdb_engine_view e;
     if (kmdb_engine_get(dbh, &e)) return 1;
     if (!e.n_buckets || !e.slots) return kmdb_set_error("kmdb_new2all_batch_seq: database was uploaded without hashtables");
     const uint32_t k = e.kmer_length;
-    if (k == 0 || k > 31) return kmdb_set_error("kmdb_new2all_batch_seq: k-mer length must be 1..31");
+    ExtractParams p{};
+    int preserve_strand = 0;
+    if (kmdbh_alphabet_table(alphabet, p.map, &p.size, &p.bits, &preserve_strand)) return kmdb_set_error("kmdb_new2all_batch_seq: unknown alphabet");
+    if (k == 0 || k > 64u / p.bits - 1u) return kmdb_set_error("kmdb_new2all_batch_seq: k-mer length must be 1.." + std::to_string(64u / p.bits - 1u) + " for this alphabet (alphabet.h:37)");
     if (!nq) return 0;
     N2_TRY(hipSetDevice(e.device));
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : (hipStream_t)e.stream;
@@ -771,8 +774,7 @@ static int new2all_seq_once(kmdb_db* dbh, const char* const* seqs, const size_t*
     std::vector<uint64_t> qoff(nq + 1, 0);
     size_t total = 0;
     if (L) {
-        const int prefix_bits = 2 * (int)k - 32;
-        ExtractParams p{};
+        const int prefix_bits = (int)(p.bits * k) - 32;
         p.seq = d_seq.as<char>(); p.soff = d_soff.as<uint64_t>(); p.nq = (uint32_t)nq; p.total_len = L; p.k = k;
         p.widen = prefix_bits < 8 ? (uint32_t)(8 - prefix_bits) : 0u;
         p.preserve = preserve_strand; p.subsample = fraction < 1.0;
@@ -784,7 +786,7 @@ static int new2all_seq_once(kmdb_db* dbh, const char* const* seqs, const size_t*
         const unsigned blocks = (unsigned)((L + 255) / 256);
         hipLaunchKernelGGL(n2a_extract_kernel, dim3(blocks), dim3(256), 0, st, p);
         N2_TRY(hipGetLastError());
-        const int kbits = (int)std::min<uint32_t>(64u, 2 * k + p.widen);
+        const int kbits = (int)std::min<uint32_t>(64u, p.bits * k + p.widen);
         int qbits = 1;
         while ((1ull << qbits) < nq) ++qbits;
         size_t tb1 = 0, tb2 = 0, tb3 = 0;

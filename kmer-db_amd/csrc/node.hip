@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -31,6 +32,7 @@ struct Rccl {
     decltype(&ncclGetVersion) GetVersion = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;            // (optional: a failed collective's peers are released with it)
     decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -46,6 +48,7 @@ int rccl_load(Rccl& r) {
         loaded.GetVersion = (decltype(loaded.GetVersion))dlsym(loaded.lib, "ncclGetVersion");
         loaded.CommInitAll = (decltype(loaded.CommInitAll))dlsym(loaded.lib, "ncclCommInitAll");
         loaded.CommDestroy = (decltype(loaded.CommDestroy))dlsym(loaded.lib, "ncclCommDestroy");
+        loaded.CommAbort = (decltype(loaded.CommAbort))dlsym(loaded.lib, "ncclCommAbort");
         loaded.ReduceScatter = (decltype(loaded.ReduceScatter))dlsym(loaded.lib, "ncclReduceScatter");
         loaded.GetErrorString = (decltype(loaded.GetErrorString))dlsym(loaded.lib, "ncclGetErrorString");
         if (!loaded.GetVersion || !loaded.CommInitAll || !loaded.CommDestroy || !loaded.ReduceScatter || !loaded.GetErrorString) {
@@ -107,6 +110,7 @@ struct kmdb_node {
                                                              // one-rank communicator (what a one-GPU box can exercise of the RCCL path)
     kmdb_node_stats stats{};
     Rendezvous meet;
+    std::atomic<bool> aborted{false};                        // a collective failed after the rendezvous: the communicators are gone
 };
 
 namespace {
@@ -149,7 +153,7 @@ int node_own_shards(kmdb_node* nd, size_t d, const kmdb_opts* opts) {
         uint32_t* dst = k == 0 ? s.acc : s.tmp;
         if (kmdb_all2all_dense_device(s.shards[k], dst, &o)) return 1;
         kmdb_stats st{};
-        if (!kmdb_db_stats(s.shards[k], &st)) s.n_records += st.n_records;
+        if (!kmdb_db_stats(s.shards[k], &st)) s.n_records += st.n_records + st.n_direct;      // (block records, written or applied where they were emitted)
         if (k && nd->cells) {
             hipLaunchKernelGGL(add_u32_kernel, dim3((unsigned)((nd->cells + 255) / 256)), dim3(256), 0, s.stream, s.acc, s.tmp, nd->cells);
             NODE_TRY(hipGetLastError());
@@ -169,9 +173,21 @@ int node_accumulate(kmdb_node* nd, size_t d, bool dev_ok, const kmdb_opts* opts)
     const std::string own_msg = own ? kmdb_last_error() : "";
     if (nd->use_rccl && nd->per) {
         // every device thread arrives here, failed or not; the collective is entered by all or by none
-        if (!nd->meet.arrive(own == 0)) return kmdb_set_error(own ? own_msg : std::string("another device failed before the reduce-scatter: the collective was not entered"));
+        if (!nd->meet.arrive(own == 0)) {
+            // nobody enters the collective.  A thread that succeeded still has its kernels queued: they finish before the call returns, so that
+            // the caller may free or reuse what they write
+            if (dev_ok) (void)hipStreamSynchronize(s.stream);
+            return kmdb_set_error(own ? own_msg : std::string("another device failed before the reduce-scatter: the collective was not entered"));
+        }
         const ncclResult_t r = nd->rccl.ReduceScatter(s.acc, s.chunk, nd->per, ncclUint32, ncclSum, s.comm, s.stream);
-        if (r != ncclSuccess) return kmdb_set_error(std::string("ncclReduceScatter: ") + nd->rccl.GetErrorString(r));
+        if (r != ncclSuccess) {
+            // a rank that fails AFTER the rendezvous leaves its peers inside the collective: every communicator of the node is aborted (they are
+            // all this process's), which releases them with an error; the handle's collectives are unusable from here on
+            const std::string msg = std::string("ncclReduceScatter: ") + nd->rccl.GetErrorString(r);
+            if (nd->rccl.CommAbort && !nd->aborted.exchange(true))
+                for (auto& o : nd->dev) if (o.comm) { (void)nd->rccl.CommAbort(o.comm); o.comm = nullptr; }
+            return kmdb_set_error(msg);
+        }
     } else if (own) return kmdb_set_error(own_msg);
     NODE_TRY(hipEventRecord(s.ev[2], s.stream));
     return 0;
@@ -214,6 +230,7 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
     *out = nullptr;
     if (!view || view->abi_version != KMDB_ABI_VERSION) return kmdb_set_error("kmdb_node_upload: bad view / ABI version");
     if (n_shards == 0 || n_devices == 0 || !devices) return kmdb_set_error("kmdb_node_upload: no shards / no devices");
+    if (n_shards > KMDB_MAX_SHARDS) return kmdb_set_error("kmdb_node_upload: more than " + std::to_string(KMDB_MAX_SHARDS) + " shards");
     if (n_shards > 1 && view->n_buckets == 0) return kmdb_set_error("kmdb_node_upload: prefix shards need the hashtables (load the database with mode Everything)");
     const uint32_t D = std::min(n_shards, n_devices);           // a device without a shard would only add zeros to the reduce
     for (uint32_t a = 0; a < D; ++a)
@@ -308,6 +325,7 @@ extern "C" int kmdb_node_device_stats_get(const kmdb_node* nd, uint32_t slot, km
 
 extern "C" int kmdb_node_all2all_dense(kmdb_node* nd, uint32_t* out_lower_tri, const kmdb_opts* opts) {
     if (!nd || (!out_lower_tri && nd->cells)) return kmdb_set_error("kmdb_node_all2all_dense: null argument");
+    if (nd->aborted) return kmdb_set_error("kmdb_node_all2all_dense: an earlier collective failed and the node's communicators were aborted (upload again)");
     const int rc = on_devices(nd, [&](size_t d, bool dev_ok) -> int {
         if (node_accumulate(nd, d, dev_ok, opts)) return 1;
         DevSlot& s = nd->dev[d];
@@ -326,6 +344,7 @@ extern "C" int kmdb_node_all2all_dense(kmdb_node* nd, uint32_t* out_lower_tri, c
 extern "C" int kmdb_node_all2all_sparse(kmdb_node* nd, const kmdb_cell_filter* filters, size_t n_filters, const uint32_t* sample_kmers, int measure,
                                         kmdb_sparse_rows* out, const kmdb_opts* opts) {
     if (!nd || !out) return kmdb_set_error("kmdb_node_all2all_sparse: null argument");
+    if (nd->aborted) return kmdb_set_error("kmdb_node_all2all_sparse: an earlier collective failed and the node's communicators were aborted (upload again)");
     std::memset(out, 0, sizeof *out);
     const size_t D = nd->dev.size();
     std::vector<kmdb_sparse_rows> part(D);

@@ -561,8 +561,8 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const uint32_t k = kmdbh_db_kmer_length(db.h);
     const double fraction = kmdbh_db_fraction(db.h), fstart = kmdbh_db_start_fraction(db.h);
-    const int preserve = kmdbh_db_alphabet(db.h) == 1;             // AlphabetType::nt_preserve (alphabet.h:10-18)
-    if (kmdbh_db_alphabet(db.h) > 1) throw std::runtime_error("protein alphabets are not supported by the GPU front-end");
+    const int32_t alphabet = kmdbh_db_alphabet(db.h);              // AlphabetType as the file stores it (alphabet.h:10-18): nt, nt-preserve, four protein alphabets
+    if (alphabet < 0 || alphabet >= KMDB_ALPHABET_COUNT) throw std::runtime_error("Invalid alphabet type");
 
     std::ifstream lst(args[1]);
     if (!lst) throw std::runtime_error("Unable to open sample list " + args[1]);
@@ -608,7 +608,7 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
             std::vector<uint64_t> uniq(by_text.size());
             std::vector<uint32_t> part(by_text.size() * n + 1);
             for (size_t t = 0; t < by_text.size(); ++t) { ptrs[t] = batch[by_text[t]].text.data(); lens[t] = batch[by_text[t]].text.size(); }
-            check(kmdb_new2all_batch_seq(db.d, ptrs.data(), lens.data(), by_text.size(), fraction, fstart, preserve, part.data(), uniq.data(), &o));
+            check(kmdb_new2all_batch_seq_alphabet(db.d, ptrs.data(), lens.data(), by_text.size(), fraction, fstart, alphabet, part.data(), uniq.data(), &o));
             for (size_t t = 0; t < by_text.size(); ++t) {
                 cnts[by_text[t]] = (size_t)uniq[t];
                 std::copy(part.begin() + t * n, part.begin() + (t + 1) * n, out.begin() + by_text[t] * n);
@@ -649,7 +649,7 @@ int run_new2all(std::vector<std::string>& args, Common& c) {
         for (auto* s : seqs) total += s->size();
         q.kmers.resize(total + 1);
         size_t cnt = 0;
-        for (auto* s : seqs) cnt += kmdbh_extract_kmers(s->data(), s->size(), k, fraction, fstart, preserve, q.kmers.data() + cnt);
+        for (auto* s : seqs) cnt += kmdbh_extract_kmers_alphabet(s->data(), s->size(), k, alphabet, fraction, fstart, q.kmers.data() + cnt);
         cnt = kmdbh_sort_unique(q.kmers.data(), cnt);              // KmerHelper::unique (console_new2all.cpp:73)
         q.kmers.resize(cnt);
         return q;
@@ -720,8 +720,8 @@ int run_one2all(std::vector<std::string>& args, Common& c) {
     std::cerr << "OK (" << since(t0) << " seconds)" << std::endl;
     const uint64_t n = kmdbh_db_n_samples(db.h);
     const uint32_t k = kmdbh_db_kmer_length(db.h);
-    const int preserve = kmdbh_db_alphabet(db.h) == 1;
-    if (kmdbh_db_alphabet(db.h) > 1) throw std::runtime_error("protein alphabets are not supported by the GPU front-end");
+    const int32_t alphabet = kmdbh_db_alphabet(db.h);
+    if (alphabet < 0 || alphabet >= KMDB_ALPHABET_COUNT) throw std::runtime_error("Invalid alphabet type");
     std::string data;
     if (!slurp(args[1], data)) throw std::runtime_error("Cannot open sample file: " + args[1]);
     std::vector<Record> recs;
@@ -739,12 +739,12 @@ int run_one2all(std::vector<std::string>& args, Common& c) {
         for (auto& r : recs) { text += r.seq; text += '\n'; }
         const char* tp = text.data();
         size_t tl = text.size();
-        check(kmdb_new2all_batch_seq(db.d, &tp, &tl, 1, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, sims.data(), &cnt, &o));
+        check(kmdb_new2all_batch_seq_alphabet(db.d, &tp, &tl, 1, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), alphabet, sims.data(), &cnt, &o));
     } else {
         std::vector<uint64_t> kmers(bases + 1);
         size_t kc = 0;
         for (auto& r : recs)
-            kc += kmdbh_extract_kmers(r.seq.data(), r.seq.size(), k, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), preserve, kmers.data() + kc);
+            kc += kmdbh_extract_kmers_alphabet(r.seq.data(), r.seq.size(), k, alphabet, kmdbh_db_fraction(db.h), kmdbh_db_start_fraction(db.h), kmers.data() + kc);
         kc = kmdbh_sort_unique(kmers.data(), kc);
         const uint64_t* kp = kmers.data();
         check(kmdb_new2all_batch(db.d, &kp, &kc, 1, sims.data(), &o));

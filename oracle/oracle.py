@@ -82,8 +82,23 @@ def lib():
     return _lib
 
 
+# Which comparisons against the REAL reference (oracle/_ref, a git-ignored binary that ships to the GPU box) actually ran: every call of
+# have_ref() is recorded with its caller, so that a test log says whether a test compared with the reference or with the oracle alone
+# (tests/conftest.py prints the list).  KMDB_REQUIRE_REF=1: a missing reference build is an error, not a silently weaker test.
+REF_BRANCHES = {}          # "file:function" -> True (reference compared) / False (reference absent)
+
+
 def have_ref():
-    return os.path.exists(REF_DRIVER)
+    import inspect
+    ok = os.path.exists(REF_DRIVER)
+    try:
+        fr = inspect.stack()[1]
+        REF_BRANCHES[os.path.basename(fr.filename) + ":" + fr.function] = ok
+    except Exception:                            # (never let the bookkeeping break a comparison)
+        pass
+    if not ok and os.environ.get("KMDB_REQUIRE_REF", "") == "1":
+        raise AssertionError("KMDB_REQUIRE_REF=1: oracle/_ref/ref_driver (the compiled reference) is missing — build it where /root/reference exists (make -C oracle)")
+    return ok
 
 
 # ----------------------------------------------------------------------------------------

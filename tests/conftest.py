@@ -15,6 +15,45 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The compiled reference (oracle/_ref: ref_driver = the reference's own similarity_calculator etc., bridge_driver = INTEGRATION.md's glue inside
+# it) is a git-ignored binary that travels to the GPU box with the snapshot.  Whether it is there decides how strong some tests are, so the log
+# says so up front, names at the end every test branch that compared with it (or could not), and KMDB_REQUIRE_REF=1 — set by the job scripts
+# under profiles/ — turns a missing reference build into a failure instead of a skip / an oracle-only comparison.
+def _ref_state():
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    return os.path.exists(os.path.join(ref, "ref_driver")), os.path.exists(os.path.join(ref, "bridge_driver"))
+
+
+def pytest_report_header(config):
+    r, b = _ref_state()
+    return ["reference driver: %s; bridge driver: %s; KMDB_REQUIRE_REF=%s" %
+            ("present" if r else "ABSENT", "present" if b else "ABSENT", os.environ.get("KMDB_REQUIRE_REF", "0"))]
+
+
+def pytest_terminal_summary(terminalreporter):
+    try:
+        from oracle import oracle
+    except Exception:
+        return
+    r, b = _ref_state()
+    terminalreporter.write_line("reference driver: %s; bridge driver: %s" % ("present" if r else "ABSENT", "present" if b else "ABSENT"))
+    ran = sorted(k for k, v in oracle.REF_BRANCHES.items() if v)
+    missed = sorted(k for k, v in oracle.REF_BRANCHES.items() if not v)
+    if ran:
+        terminalreporter.write_line("compared with the real reference in: " + ", ".join(ran))
+    if missed:
+        terminalreporter.write_line("REFERENCE ABSENT, oracle only in: " + ", ".join(missed))
+
+
+def require_ref_or_skip(path, what):
+    """a test that cannot run without a reference build: skipped where the build is absent, FAILED under KMDB_REQUIRE_REF=1"""
+    if os.path.exists(path):
+        return
+    if os.environ.get("KMDB_REQUIRE_REF", "") == "1":
+        pytest.fail("KMDB_REQUIRE_REF=1: %s is missing (%s)" % (path, what))
+    pytest.skip(what)
+
+
 # The parity tests against the oracle, the reference's raw outputs and its golden files run FIRST; the long tests — tens of thousands of
 # samples (property checks: checksum identity, rows from the definition) and the bench.py contract tests (subprocesses) — run LAST, so that a
 # box slow enough to hit the driver's step limit loses the least informative tests, not the parity proper (VERDICT round 4, item 6).

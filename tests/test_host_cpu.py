@@ -273,6 +273,34 @@ def test_kmer_extraction_matches_oracle(K, O, golden_dir):
     assert int(K.extract_kmers(seq, 18).max()) >> 32 < 256
 
 
+def test_kmer_extraction_over_every_alphabet_matches_oracle(K, O):
+    """kmdbh_extract_kmers_alphabet (the front-end's query loader for databases over the protein alphabets, reference src/alphabet.h:79-126,
+    src/kmer_extract.h:13-97) == the oracle's restatement: the records of test/protein/aa_100x1000.fasta and random text with invalid
+    letters, every alphabet, several k (n-bit symbols; k beyond 64 / bits - 1 is refused, alphabet.h:37), minhash fractions."""
+    import lzma
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with lzma.open(os.path.join(here, "protein.aa_100x1000.fasta.xz")) as f:
+        recs = O._split_records(f.read())
+    rng = np.random.default_rng(11)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdefghiklmnpqrstvwyBJOUXZ.*-", np.uint8)
+    rnd = [bytes(letters[rng.integers(0, letters.size, size=int(n))]) for n in (0, 5, 9, 300, 4000)]
+    bits = {"nt": 2, "nt-preserve": 2, "aa": 5, "aa11_diamond": 4, "aa12_mmseqs": 4, "aa6_dayhoff": 3}
+    for a, name in enumerate(K.ALPHABETS):
+        assert name in O.ALPHABETS
+        for k, frac in ((3, 1.0), (7, 1.0), (8, 1.0), (8, 0.25), (64 // bits[name] - 1, 1.0)):
+            for s in [r for _, r in recs[:12]] + rnd:
+                got = K.extract_kmers_alphabet(s, k, a, frac)
+                assert np.array_equal(got, O.extract_seq_alphabet(s, k, name, frac)), (name, k, frac, len(s))
+                assert np.array_equal(got, K.extract_kmers_alphabet(s, k, name, frac))
+        # a k the alphabet's symbols do not fit 63 bits with
+        assert K.extract_kmers_alphabet(recs[0][1], 64 // bits[name], a).size == 0
+    # the nucleotide entry points are the alphabets 0 and 1
+    seq = bytes(np.frombuffer(b"ACGTacgtNU", np.uint8)[rng.integers(0, 10, size=3000)])
+    assert np.array_equal(K.extract_kmers(seq, 18), K.extract_kmers_alphabet(seq, 18, "nt"))
+    assert np.array_equal(K.extract_kmers(seq, 18, preserve_strand=True), K.extract_kmers_alphabet(seq, 18, "nt-preserve"))
+    assert K.extract_kmers_alphabet(seq, 18, 6).size == 0 and K.extract_kmers_alphabet(seq, 18, -1).size == 0      # unknown alphabet
+
+
 def test_csv_formatting_matches_oracle(K, O, golden_dir):
     path = os.path.join(golden_dir, "virus_k18.db")
     h = K.HostDB(path, skip_hashtables=True)

@@ -139,7 +139,7 @@ def test_db2db_restatement_equals_the_real_reference(O, golden_dir, tmp_path):
     """when oracle/_ref is built: the reference's own db2db_sp + compact2 (ref_driver db2db_sp) on the two virus parts"""
     import os
     import pytest
-    if not O.have_ref():
+    if not O.have_ref():                        # (raises under KMDB_REQUIRE_REF=1)
         pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
     a, b = os.path.join(golden_dir, "virus_k18_part2.db"), os.path.join(golden_dir, "virus_k18_part1.db")
     txt, _ = O.ref_db2db_sp(a, b, str(tmp_path / "o.txt"), threads=2)
