@@ -219,7 +219,10 @@ def cpu_baseline(K, S, O, args, device, arr, names, counts, nk, gpu_matrix):
         S.write_db_fast(path, args.k, 1.0, names, counts, arr, kmers_count=nk, device=device)
         log("  full .db written: %.1f GB in %.1f s" % (os.path.getsize(path) / 1e9, time.time() - t0))
         best, tried = None, []
-        for thr, buf in [(t, 8) for t in sorted({min(cores, t) for t in (16, 32, 64, 128)})] + [(None, 32)]:
+        # (rounds 4 - 5 swept -t 16 / 32 / 64 / 128: 64 and 128 threads lost every time — 19.6 and 56.3 s against 12.5 at C2 — and cost 76 s of the
+        # default run, which now spends them on the secondary rows; --cpu-sweep full brings the five points back)
+        t_list = (16, 32, 64, 128) if args.cpu_sweep == "full" else (16, 32)
+        for thr, buf in [(t, 8) for t in sorted({min(cores, t) for t in t_list})] + [(None, 32)]:
             if thr is None:
                 thr = best[2]                                    # -buffer at the best thread count
             t0 = time.time()
@@ -418,7 +421,7 @@ def pattern_bytes(arr):
     return int((40 + 16 * ((arr["num_bits"].astype(np.int64) + 127) // 128)).sum())
 
 
-def secondary_mode(args, K, S, device):
+def secondary_mode(args, K, S, device, embedded=False):
     """--mode all2all-sp | new2all | db2db: the rows of SURVEY 8 beside the dense all2all, one JSON line each in the same contract.
     `value` is on device time (HIP events around the call's kernels, kmdb_stats.kernel_ms); these entry points take and return
     HOST buffers, so the PCIe-inclusive wall time of one call is reported beside it (wall.call_ms)."""
@@ -566,7 +569,7 @@ def secondary_mode(args, K, S, device):
                 # one2all<false> per query on the shared database; T swept, wall clock of the whole batch; every row compared
                 O.write_kmers_bin(os.path.join(td, "q.bin"), k, f, [("q%d" % i, q) for i, q in enumerate(qs)])
                 best, tried = None, []
-                for T in sorted({min(cores, t) for t in (16, 64, 128)}):
+                for T in sorted({min(cores, t) for t in ((16,) if embedded else (16, 64, 128))}):      # (riding along in the default line: the thread count that won every sweep so far)
                     rows, info = O.ref_new2all(path, os.path.join(td, "q.bin"), os.path.join(td, "o.u32"), T)
                     tried.append((T, round(info["seconds"], 3)))
                     if best is None or info["seconds"] < best[1]["seconds"]:
@@ -630,6 +633,8 @@ def secondary_mode(args, K, S, device):
                                                   "note": "exact on %d of the %d queries (every 25th), scaled by SURVEY's figure of all queries" % (n_union, NQ)}
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    if embedded:
+        return out
     print(json.dumps(out), flush=True)
 
 
@@ -706,6 +711,107 @@ def sparse_multi(args, K, S, device, rank, world, dist, rccl):
     dist.destroy_process_group()
 
 
+def node_driver(args):
+    """`--driver node`: the PRODUCT's multi-GPU path under the bench contract (reference call site made multi-GPU:
+    src/console_all2all.cpp:31-36).  One process: the database (one, with its hashtable items — the shards are planned from them) is cut into
+    --shards prefix-bucket shards by kmdb_node_upload, shard s on GPU s % N; a step = kmdb_node_all2all_dense: every device thread runs its
+    shards, ONE ncclReduceScatter over flat chunks of the triangle (device-to-device over xGMI), every device brings its chunk to the host.
+    Under a launcher (the driver starts N ranks) rank 0 does the work and the other ranks wait at the barriers: the N GPUs belong to the one
+    process, as they do to `kmer-db-amd all2all -gpus N`.  The line has the schema of the other lines; per device: kmdb_node_device_stats."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")                      # (rendezvous of the launcher's ranks only: no tensor travels through it)
+        if rank != 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU path to time")
+    n_dev = args.gpus
+    if torch.cuda.device_count() < n_dev:
+        raise SystemExit("bench.py: --gpus %d but only %d devices are visible" % (n_dev, torch.cuda.device_count()))
+    n_shards = args.shards if args.shards else n_dev
+    K = import_kmerdb_amd()
+    torch.cuda.set_device(0)
+    arr, names, counts, nk, items = generate_in_child(0, n_samples=args.samples, clade_size=args.clade_size, length=args.length, k=args.k, seed=args.seed,
+                                                      rank=0, world=1, progress=100, with_items=n_shards > 1)
+    release_generator_memory(0)
+    view = K.make_view(args.k, args.samples, arr["num_kmers"], arr["parent_id"], arr["num_samples"], arr["num_local"],
+                       arr["last_sample_id"], arr["num_bits"], arr["data_offset"], arr["data"],
+                       bucket_offset=None if items is None else items[0], slots=None if items is None else items[1])
+    t0 = time.perf_counter()
+    nd = K.NodeDB(view, n_shards, devices=list(range(n_dev)))
+    upload_s = time.perf_counter() - t0
+    st0 = nd.stats()
+    log("node driver: %d shards on %d devices, upload %.2f s (host plan %.2f s), RCCL %s" % (st0["n_shards"], st0["n_devices"], upload_s, st0["plan_s"], st0["rccl_version"] or None))
+    t0 = time.perf_counter()
+    first = nd.all2all_dense()
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(args.warmup):
+        nd.all2all_dense()
+    per_dev, M = [], first
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        M = nd.all2all_dense()
+        per_dev.append(nd.stats()["devices"])
+    elapsed = time.perf_counter() - t0
+    # size-independent checks of the timed result: sum of the matrix == sum_p w_p C(n_p, 2) (the shards' partial matrices add up to the
+    # whole database's), and warm == cold
+    n_p = arr["num_samples"].astype(np.uint64)
+    sum_pairs = int((arr["num_kmers"].astype(np.uint64) * (n_p * (n_p - np.uint64(1)) // np.uint64(2))).sum())
+    assert int(M.astype(np.uint64).sum()) == sum_pairs, "matrix checksum mismatch: %d vs %d" % (int(M.astype(np.uint64).sum()), sum_pairs)
+    assert np.array_equal(M, first), "warm call differs from the first call"
+    cells = args.samples * (args.samples - 1) // 2
+    alg = int((40 + 16 * ((arr["num_bits"].astype(np.int64) + 127) // 128)).sum()) + 4 * cells      # SURVEY 8d
+    ms = elapsed / args.steps * 1e3
+    stl = nd.stats()
+    mean = lambda key: [float(np.mean([d[i][key] for d in per_dev])) for i in range(len(per_dev[0]))]      # noqa: E731
+    v = stl["rccl_version"]
+    rccl = None if not v else ("%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100) if v >= 10000 else str(v))
+    achieved = alg / (ms * 1e-3) / 1e9
+    out = {
+        "metric": "all2all k-mer pair-comparisons/sec", "value": sum_pairs / (elapsed / args.steps), "unit": "kmer-pair-comparisons/s",
+        "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": "%s: %d synthetic %g Mbp genomes (clade-mutation model, clades of %d, r1=0.10 r2=0.01), k=%d f=1.0, dense all2all, ONE database "
+                        "in %d prefix-bucket shards over %d GPUs through the product's node driver (kmdb_node_upload / kmdb_node_all2all_dense: a host "
+                        "thread per device, one ncclReduceScatter over flat chunks of the triangle, D2H of every device's chunk)"
+                        % (args.workload, args.samples, args.length / 1e6, args.clade_size, args.k, n_shards, n_dev),
+            "samples": args.samples, "genome_length_bp": args.length, "k": args.k, "fraction": 1.0, "driver": "node",
+            "patterns_rank0": int(arr["num_kmers"].size), "distinct_kmers_rank0": nk, "parallelism": "prefix-shard x%d on %d devices" % (n_shards, n_dev),
+            "rccl": rccl, "n_ranks_seen": stl["n_devices"],
+            "per_rank": {"device": [d["device"] for d in stl["devices"]], "shards": [d["n_shards"] for d in stl["devices"]],
+                         "call_ms": mean("call_ms"), "collective_ms": mean("collective_ms"), "d2h_ms": mean("d2h_ms"),
+                         "patterns": [int(d["n_patterns"]) for d in stl["devices"]], "h2d_bytes": [int(d["h2d_bytes"]) for d in stl["devices"]],
+                         "block_records": [int(d["n_records"]) for d in stl["devices"]], "upload_s": [d["upload_s"] for d in stl["devices"]],
+                         "backend": "rccl (dlopen, ncclCommInitAll)" if rccl else "none (one device)",
+                         "collective": "ncclReduceScatter(uint32, sum) + D2H of the device's chunk" if rccl else "none"},
+            "sample_pairs_per_s": cells / (elapsed / args.steps), "path": "block-record pipeline",
+        },
+        "wall": {"upload_s": upload_s, "plan_s": stl["plan_s"], "cold_call_ms": cold_ms, "warm_ms": ms,
+                 "note": "ms_per_step: host wall clock of kmdb_node_all2all_dense (slowest device's shards + the collective + the copy of its chunk to "
+                         "the host matrix); upload_s: kmdb_node_upload (host shard plan + per device: narrowing, H2D, device layout, working set)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * n_dev, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n_dev), "traffic": None,
+                     "kernel": "whole step: every device's all2all calls (one per shard) + reduce-scatter + D2H", "kernel_ms": ms, "algorithmic_bytes_per_launch": alg,
+                     "per_kernel_ms": {"compute_slowest_device": float(max(mean("call_ms"))), "collective_slowest_device": float(max(mean("collective_ms"))),
+                                       "d2h_slowest_device": float(max(mean("d2h_ms")))}},
+    }
+    nd.close()
+    try:                                                     # (RCCL writes its banner through C stdio: out before the line, so that the line is the last one)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def respawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run"""
     port = 29500 + (os.getpid() % 2000)
@@ -736,6 +842,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample-length", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sweep", default="short", choices=["short", "full"], help="reference baseline: -t 16 / 32 + -buffer 32 at the better one (short), or -t 16 / 32 / 64 / 128 (full)")
     ap.add_argument("--no-extra", action="store_true", help="default workload only: skip the 10 000-sample workload that rides along in the same JSON line")
     ap.add_argument("--generate-spec", default=None, help=argparse.SUPPRESS)       # generate_in_child()'s other side
     ap.add_argument("--tmp", default=None, help="directory for the reference's .db files (default: the system temp dir)")
@@ -745,6 +852,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: functional test of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the matrix reduce goes through host memory); never used for reported numbers")
+    ap.add_argument("--driver", default="auto", choices=["auto", "node", "ranks"],
+                    help="node: ONE process drives the devices through the product's own multi-GPU driver (kmdb_node_upload / kmdb_node_all2all_dense, "
+                         "csrc/node.hip: prefix-bucket shards, one host thread per device, ONE ncclReduceScatter) — what `kmer-db-amd all2all -gpus N` "
+                         "runs; ranks: one process per GPU under torch.distributed (kmdb_all2all_dense_device + an RCCL collective issued from Python). "
+                         "auto = node for --gpus > 1 in the all2all mode, ranks otherwise")
+    ap.add_argument("--shards", type=int, default=None, help="--driver node: prefix shards of the database (default: one per GPU; more than GPUs: several per "
+                                                             "device, one after the other — `--gpus 1 --shards 8` is the one-GPU anchor of an 8-GPU run)")
     ap.add_argument("--one-rank-group", action="store_true",
                     help="--gpus 1 only: run the multi-rank code path (process group, collective of every step, per-rank figures) on a ONE-rank "
                          "RCCL group — what a one-GPU box can exercise of the --gpus N path; a functional check, never a reported number")
@@ -760,6 +874,14 @@ def main():
         if getattr(args, key, None) is None:
             setattr(args, key, val)
 
+    if args.driver == "auto":
+        # (--backend gloo is the functional test of the rank form on a box with fewer GPUs than ranks: it keeps the rank form)
+        args.driver = "node" if (args.gpus > 1 and args.mode == "all2all" and not args.one_rank_group and args.backend == "nccl") else "ranks"
+    if args.driver == "node":
+        if args.mode != "all2all":
+            raise SystemExit("bench.py: --driver node is for the all2all mode")
+        node_driver(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -994,6 +1116,22 @@ def main():
             torch.cuda.empty_cache()
             # one GPU's share of BASELINE configs[2] itself (10 000 x 625 kbp), under the same clock
             out["extra"]["c3gpu"] = extra_workload(K, S, args, device, "c3gpu", reference=False, definition_rows=8)
+            # the secondary rows ride along too, so that the driver's clock times them: new2all at configs[4]'s shape
+            # (1000 queries against 10 000 samples) and one all2all-parts cell, every row compared with the real reference where it is built
+            import copy
+            for key, mode, wl in (("new2all_c5part", "new2all", "c5part"), ("db2db_parts", "db2db", "parts")):
+                torch.cuda.empty_cache()
+                a2 = copy.copy(args)
+                a2.mode, a2.workload = mode, wl
+                for kk, vv in dict(dict(k=18, fraction=1.0, queries=0, r1=0.10), **WORKLOADS[wl]).items():
+                    setattr(a2, kk, vv)
+                a2.steps, a2.warmup = 5, 2
+                t_sec = time.time()
+                res = secondary_mode(a2, K, S, device, embedded=True)
+                res["seconds_in_bench"] = time.time() - t_sec
+                out["extra"][key] = res
+                log("%s: %.2f ms per call, frac %.4f, reference %s (%.0f s in the bench)" % (key, res["ms_per_step"], res["roofline"]["frac"],
+                                                                                           res.get("cpu_baseline", {}).get("kind"), res["seconds_in_bench"]))
             log("c3gpu: %.2f ms per call, frac %.4f, %d block records, %d nodes joined per tile, rows_from_definition: %s" % (
                 out["extra"]["c3gpu"]["ms_per_step"], out["extra"]["c3gpu"]["roofline"]["frac"], out["extra"]["c3gpu"]["records"],
                 out["extra"]["c3gpu"]["nodes_joined_per_tile"], out["extra"]["c3gpu"]["rows_from_definition"]))

@@ -2,6 +2,7 @@
 // loaded by the reference's own PrefixKmerDb::deserialize, flattened by the bridge and handed to libkmdb_amd.so.
 //   bridge_driver all2all    <db> <out.u32>     raw lower-triangular matrix (compare: ref_driver all2all)
 //   bridge_driver all2all_sp <db> <out.txt>     sparse rows "col1based:val," (compare: ref_driver all2all_sp)
+//   bridge_driver sample_rows_ref <db> <out.txt> -sample-rows ...   the reference's own sampled rows (CPU only: expected output for the front-end)
 //   bridge_driver new2all    <db> <out.u32>     every sample's own k-mers... not available from a .db: the first
 //                                               query is the keys of bucket 0 instead (hash lookups through the
 //                                               slot-exact tables), one row of N counts
@@ -28,6 +29,36 @@ int main(int argc, char** argv) {
             FILE* o = fopen(argv[3], "wb");
             fwrite(m.getData().data(), 4, m.getData().size(), o);
             fclose(o);
+            return 0;
+        }
+        if (cmd == "sample_rows_ref") {
+            // bridge_driver sample_rows_ref <db> <out.txt> -sample-rows [crit:]count [-min ..]* [-max ..]*: the REFERENCE alone (no GPU) — its Params::parse,
+            // all2all_sp, SparseMatrix::add_to_sampler and Sampler::saveRowSparse (console_all2all_sparse.cpp:44,70-89) — as the expected output of
+            // `kmer-db-amd all2all-sp -sample-rows`
+            std::vector<std::string> av = {"kmer-db", "all2all-sp"};
+            for (int i = 4; i < argc; ++i) av.push_back(argv[i]);
+            av.push_back(argv[2]); av.push_back(argv[3]);
+            std::vector<char*> avp;
+            for (auto& a : av) avp.push_back(a.data());
+            Params params;
+            if (!params.parse((int)avp.size(), avp.data())) { fprintf(stderr, "Params::parse rejected the options\n"); return 2; }
+            SimilarityCalculator calc(2, 8);
+            SparseMatrix<uint32_t> matrix;
+            CBubbleHelper bubbles(params.bubbleSize);
+            calc.all2all_sp(db, matrix, bubbles);
+            const auto& counts = db.getSampleKmersCount();
+            CombinedFilter<uint32_t> filter(params.metricFilters, params.kmerFilter, counts, counts, db.getKmerLength());
+            using sampler_t = Sampler<uint32_t, uint32_t, double>;
+            sampler_t sampler(db.getSamplesCount(), params.samplingSize, params.samplingCriterion ? sampler_t::strategy_t::best : sampler_t::strategy_t::random);
+            matrix.add_to_sampler(filter, sampler, params.samplingCriterion, counts, counts, 0, 0, db.getKmerLength(), 2, bubbles);
+            std::vector<char> row(10000 + db.getSamplesCount() * 100);
+            FILE* out = fopen(argv[3], "wb");
+            for (size_t sid = 0; sid < db.getSamplesCount(); ++sid) {
+                const int len = sampler.saveRowSparse(sid, row.data(), 0);
+                fwrite(row.data(), 1, (size_t)len, out);
+                fputc('\n', out);
+            }
+            fclose(out);
             return 0;
         }
         KmdbFlatDb flat(db, ht);

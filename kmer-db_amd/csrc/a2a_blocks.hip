@@ -2700,7 +2700,9 @@ struct EstParams {
     uint32_t P, stride;
     uint32_t widths[EST_NW];
     uint32_t magics[EST_NW];
-    unsigned long long* out;       // [EST_NW] records of the sampled nodes with <= 2 blocks, [EST_NW] of the others, [1] nodes sampled
+    unsigned long long* out;       // [EST_NW] records of the sampled nodes with <= 2 blocks, [EST_NW] of the others, [1] nodes sampled,
+                                   // [EST_NW] the part of the others that comes from nodes with l2_min blocks or more (the second level writes no records for them)
+    uint32_t l2_min;
 };
 // One thread per sampled node: climbs the root path, decodes every node's local ids (the only decoder run outside the
 // call: it looks at one node in `stride`) and counts the blocks of the full list for every candidate width.
@@ -2745,9 +2747,10 @@ __global__ void width_estimate_kernel(const EstParams q) {
         const unsigned long long recs = (unsigned long long)nblk[c] * (nblk[c] + 1u) / 2u;
         unsigned long long rn = on && nblk[c] >= 1u && nblk[c] <= 2u ? 1ull : 0ull;
         unsigned long long rg = on ? recs - rn : 0ull;
+        unsigned long long r2 = on && nblk[c] >= q.l2_min ? recs : 0ull;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { rn += shfl64(rn, (int)(lane ^ (uint32_t)d)); rg += shfl64(rg, (int)(lane ^ (uint32_t)d)); }
-        if (lane == 0) { if (rn) atomicAdd(&q.out[c], rn); if (rg) atomicAdd(&q.out[EST_NW + c], rg); }
+        for (int d = 32; d >= 1; d >>= 1) { rn += shfl64(rn, (int)(lane ^ (uint32_t)d)); rg += shfl64(rg, (int)(lane ^ (uint32_t)d)); r2 += shfl64(r2, (int)(lane ^ (uint32_t)d)); }
+        if (lane == 0) { if (rn) atomicAdd(&q.out[c], rn); if (rg) atomicAdd(&q.out[EST_NW + c], rg); if (r2) atomicAdd(&q.out[2 * EST_NW + 1 + c], r2); }
     }
     const unsigned long long nb = __ballot(on);
     if (lane == 0 && nb) atomicAdd(&q.out[2 * EST_NW], (unsigned long long)__popcll(nb));
@@ -3050,18 +3053,19 @@ static int blocks_prepare_impl(kmdb_db* db) {
     uint32_t forced = 0;
     if (const char* e = getenv("KMDB_BLOCK_WIDTH")) forced = (uint32_t)strtoul(e, nullptr, 10);
     const uint32_t stride = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, P / 65536));
-    uint64_t est_n = 0, est_g = 0;
+    uint64_t est_n = 0, est_g = 0, est_l2 = 0;                  // records of the nodes with <= 2 blocks, of the others, and of those the part the second level replaces
     {
         EstParams q{};
         q.k0in = db->k0in; q.bitrel = db->bitrel; q.blkbase = db->blkbase; q.bits = db->bits; q.parent = db->parent; q.nl = db->nl; q.w = db->w;
         q.P = (uint32_t)P; q.stride = stride;
         for (int c = 0; c < EST_NW; ++c) { q.widths[c] = cands[c]; q.magics[c] = (uint32_t)((1ull << 32) / cands[c]) + 1u; }
-        HIP_TRY(hipMalloc((void**)&q.out, (2 * EST_NW + 1) * 8));
-        HIP_TRY(hipMemsetAsync(q.out, 0, (2 * EST_NW + 1) * 8, db->stream));
+        q.l2_min = getenv("KMDB_L2_MIN") ? std::max<uint32_t>(K1W_HEAVY, (uint32_t)atoi(getenv("KMDB_L2_MIN"))) : L2_MIN_BLOCKS;
+        HIP_TRY(hipMalloc((void**)&q.out, (3 * EST_NW + 1) * 8));
+        HIP_TRY(hipMemsetAsync(q.out, 0, (3 * EST_NW + 1) * 8, db->stream));
         const uint64_t nthreads = (P + stride - 1) / stride;
         hipLaunchKernelGGL(width_estimate_kernel, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, db->stream, q);
         HIP_TRY(hipGetLastError());
-        unsigned long long h[2 * EST_NW + 1];
+        unsigned long long h[3 * EST_NW + 1];
         HIP_TRY(hipMemcpyAsync(h, q.out, sizeof h, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
         (void)hipFree(q.out);
@@ -3072,7 +3076,7 @@ static int blocks_prepare_impl(kmdb_db* db) {
             best = 0;
             for (int c = 0; c < EST_NW; ++c) if (cands[c] >= forced) best = c;
         } else db->width = cands[best];
-        est_n = h[best] * stride; est_g = h[EST_NW + best] * stride;
+        est_n = h[best] * stride; est_g = h[EST_NW + best] * stride; est_l2 = h[2 * EST_NW + 1 + best] * stride;
         db->est_records = est_n + est_g;
         if (verbose) {
             fprintf(stderr, "[kmdb] width estimate (1 node in %u, %llu sampled):", stride, h[2 * EST_NW]);
@@ -3122,6 +3126,9 @@ static int blocks_prepare_impl(kmdb_db* db) {
         (void)hipFree(d_need);
         const uint64_t est_pairs = h_need * stride;
         if (verbose) fprintf(stderr, "[kmdb] extra (block, mask) pairs, sampled: %llu\n", (unsigned long long)est_pairs);
+        // (twice the estimate: three quarters of the pool are wave-private sub-pools, and a sub-pool that runs out sends its waves to the shared
+        // rest behind ONE cursor — with 1.25 x the estimate the sub-pools were nearly full and the decode launches took 3.9 instead of 2.2 ms at C2,
+        // profiles/r06_j6: same-address device atomics)
         if (alloc_pair_pool(db, std::max<uint64_t>(est_pairs * 2 + P / 4, (uint64_t)KMDB_PAIR_REGIONS * 64))) return 1;
     }
     phase("pair estimate + pair pool");
@@ -3160,6 +3167,16 @@ static int blocks_prepare_impl(kmdb_db* db) {
     // index — so the records of the many-streams path travel as 16 bytes through the sort and the apply step (KMDB_REC_PACKED=0: 16 + 4, A/B)
     // (round 5, later: the few-streams path as well — its one-pass sort moves 16 bytes per record and leaves the key words behind)
     db->rec_pshift = (db->width <= 54u && !(getenv("KMDB_REC_PACKED") && getenv("KMDB_REC_PACKED")[0] == '0')) ? db->width : 0u;
+    // The second level (many streams, <= 256 blocks: see blocks_attempt) writes no records for the nodes with L2_MIN_BLOCKS blocks or more — 52 % of the
+    // estimate at 10 000 samples.  Round 5 sized the pools from the estimate before it: 110 GB for 616 M records of 16 bytes.
+    {
+        const char* l2_env = getenv("KMDB_L2");
+        if (db->row_mode && db->NB <= 256u && !(l2_env && l2_env[0] == '0')) {
+            if (verbose) fprintf(stderr, "[kmdb] block records estimated: %llu, of them %llu from nodes the second level joins per tile instead\n",
+                                 (unsigned long long)(est_n + est_g), (unsigned long long)est_l2);
+            est_g -= std::min(est_g, est_l2);
+        }
+    }
     db->n_ckeys = db->n_states;                                  // keys of the grouped chunk table = the streams (row chunks sit in their rows' lists)
     {
         int key_bits = 1;
@@ -3207,8 +3224,10 @@ static int blocks_prepare_impl(kmdb_db* db) {
     // slice's nodes outside its tile: a sixteenth of the estimate is generous, and a pool that is too small is enlarged as ever)
     if (db->k1n_mode) { est_g += est_n / 16 + 1; est_n = 0; }
     if (db->row_mode) {
-        if (alloc_record_pool(db, (est_n + est_g) * 3 / 2 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
-        if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + 4096)) return 1;
+        // the estimate (one node in `stride`, exact per node) plus a quarter, plus what the waves hold when they end (open chunks, unfinished grabs); the
+        // sorted copy holds the records themselves: the estimate plus an eighth.  A pool that turns out too small is enlarged and the call repeated.
+        if (alloc_record_pool(db, (est_n + est_g) * 5 / 4 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
+        if (alloc_wide_pool(db, (est_n + est_g) * 9 / 8 / WCH_REC + 4096)) return 1;
     } else {
         if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (db->dense_narrow ? 0u : (uint64_t)db->n_nsegs * 8) + 4096)) return 1;
         if (alloc_wide_pool(db, est_g * 3 / 2 / WCH_REC + (uint64_t)(K1W_MAX_WAVES + 64) * (WIDE_GRAB + 2) + (uint64_t)db->n_nsegs * (WIDE_GRAB / 2) + 1024)) return 1;

@@ -17,13 +17,17 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <exception>
 #include <map>
+#include <mutex>
+#include <random>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -107,6 +111,63 @@ struct Filters {
     }
 };
 
+// -sample-rows [<criterion>:]<count> (all2all-sp, all2all-parts; reference src/sampler.h, src/params.cpp:533-557, src/array.h:450-540): every
+// sample keeps at most `count` of its neighbours — every pair (i, j) that passes the filters is offered to row i AND to row j, so the sampled
+// rows are symmetric rows, not rows of the triangle.  With a criterion: the `count` best by score, ties towards the smaller sample id — what
+// the reference's heap (sampler.h:44-67: score descending, item ascending) leaves whatever the order of its insertions, so the output is
+// byte-identical.  Without one the reference keeps a RANDOM subset (sampler.h:69-79: mt19937_64 with the default seed per sample, drawn in the
+// order in which its hash tables happen to list a row): here the same draws, over the pairs in ascending order of the other sample — the same
+// kind of subset, not the same bytes.
+struct RowSampler {
+    struct Item { uint32_t item, value; double score; };
+    size_t cap = 0;
+    bool best = false;
+    metric_fn criterion = nullptr;
+    std::vector<std::vector<Item>> rows;
+    std::vector<size_t> seen;
+    std::vector<std::mt19937_64> rng;
+    bool on() const { return cap != 0; }
+    void parse(std::vector<std::string>& args) {
+        std::string v;
+        if (!take_option(args, "-sample-rows", v)) return;
+        std::string num = v;
+        auto sep = v.rfind(':');
+        if (sep != std::string::npos) {
+            const std::string name = v.substr(0, sep);
+            auto avail = metrics();
+            if (!avail.count(name)) throw std::runtime_error("Sampling parameters error - unknown measure: " + name);
+            criterion = avail[name]; best = true;
+            num = v.substr(sep + 1);
+        }
+        std::istringstream iss(num);
+        if (!(iss >> cap)) throw std::runtime_error("Sampling parameters error - unable to parse numerical value: " + v);
+    }
+    void init(size_t n) { rows.assign(n, {}); if (!best) { seen.assign(n, 0); rng.assign(n, std::mt19937_64()); } }
+    static bool better(const Item& x, const Item& y) { return x.score != y.score ? x.score > y.score : x.item < y.item; }
+    void add(size_t sample, uint32_t item, uint32_t value, double score) {
+        auto& r = rows[sample];
+        r.push_back(Item{item, value, score});
+        if (best) {
+            // (all candidates of a row are kept until the row is written: the `cap` best are chosen then)
+            return;
+        }
+        ++seen[sample];
+        if (r.size() <= cap) return;
+        if (rng[sample]() % seen[sample] != 0) { const size_t id = rng[sample]() % cap; r[id] = r.back(); }      // sampler.h:69-79
+        r.pop_back();
+    }
+    // the row as the reference writes it: ascending sample ids (sampler.h:123-139)
+    void finish_row(size_t sample, std::vector<uint32_t>& cols, std::vector<uint32_t>& vals) {
+        auto& r = rows[sample];
+        if (best && r.size() > cap) { std::partial_sort(r.begin(), r.begin() + (std::ptrdiff_t)cap, r.end(), better); r.resize(cap); }
+        std::sort(r.begin(), r.end(), [](const Item& x, const Item& y) { return x.item < y.item; });
+        cols.clear(); vals.clear();
+        for (auto& x : r) { cols.push_back(x.item); vals.push_back(x.value); }
+        std::vector<Item>().swap(r);
+    }
+    double score(uint32_t common, uint32_t row_cnt, uint32_t col_cnt, int k) const { return criterion ? criterion(common, row_cnt, col_cnt, k) : 1.0; }
+};
+
 void check(int rc) {
     if (rc) throw std::runtime_error(kmdb_last_error());
 }
@@ -127,6 +188,7 @@ struct Common {
     int gpus = 0;                            // -gpus N: N prefix-bucket shards over the node's devices (0: one device, no sharding)
     bool sparse = false;
     Filters filters;
+    RowSampler sampler;
 };
 
 // -gpus N (all2all, all2all-sp): the database is read WITH its hashtables (the shard weights come from the items' prefix buckets),
@@ -303,7 +365,7 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     if (take_option(args, "-bubble-size", v)) bubble = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
     take_switch(args, "-sparse");
     c.filters.parse(args);
-    if (take_option(args, "-sample-rows", v)) throw std::runtime_error("-sample-rows is not supported by the GPU front-end");
+    c.sampler.parse(args);
     if (args.size() != 2) throw usage_error("all2all-sp");
     std::cerr << "All versus all comparison (sparse computation)" << std::endl;
     Db db;
@@ -349,8 +411,22 @@ int run_all2all_sp(std::vector<std::string>& args, Common& c) {
     std::vector<char> row(10000 + n * 100);
     std::vector<uint32_t> cols, vals;
     size_t saved = 0;
+    if (c.sampler.on()) {
+        // -sample-rows (console_all2all_sparse.cpp:70-76, array.h:450-540): every pair that passes the filters is offered to both its samples
+        c.sampler.init(n);
+        for (uint64_t i = 0; i < n; ++i)
+            for (uint64_t e = sp.row_ptr[i]; e < sp.row_ptr[i + 1]; ++e) {
+                const uint32_t ci = (uint32_t)kmdbh_db_sample_kmers(db.h, i), cj = (uint32_t)kmdbh_db_sample_kmers(db.h, sp.col[e]);
+                if (!c.filters.pass(sp.val[e], ci, cj, k)) continue;
+                const double sc = c.sampler.score(sp.val[e], ci, cj, k);
+                c.sampler.add(i, sp.col[e], sp.val[e], sc);
+                c.sampler.add(sp.col[e], (uint32_t)i, sp.val[e], sc);
+            }
+    }
     for (uint64_t i = 0; i < n; ++i) {
         cols.clear(); vals.clear();
+        if (c.sampler.on()) c.sampler.finish_row(i, cols, vals);
+        else
         for (uint64_t e = sp.row_ptr[i]; e < sp.row_ptr[i + 1]; ++e)   // compact2's filter (array.h:424-427)
             if (c.filters.pass(sp.val[e], (uint32_t)kmdbh_db_sample_kmers(db.h, i), (uint32_t)kmdbh_db_sample_kmers(db.h, sp.col[e]), k)) {
                 cols.push_back(sp.col[e]); vals.push_back(sp.val[e]);
@@ -378,7 +454,7 @@ int run_all2all_parts(std::vector<std::string>& args, Common& c) {
     take_option(args, "-bubble-size", v);
     take_switch(args, "-sparse");
     c.filters.parse(args);
-    if (take_option(args, "-sample-rows", v)) throw std::runtime_error("-sample-rows is not supported by the GPU front-end");
+    c.sampler.parse(args);
     if (args.size() != 2) throw usage_error("all2all-parts");
     std::cerr << "All versus all comparison (parts)" << std::endl;
     std::ifstream lst(args[0]);
@@ -415,44 +491,69 @@ int run_all2all_parts(std::vector<std::string>& args, Common& c) {
         for (auto cnt : counts) ofs << cnt << ",";
         ofs << "\n";
     }
-    std::vector<char> row(10000 + names.size() * 100);
-    std::vector<uint32_t> cols, vals;
-    size_t saved = 0;
-    uint64_t row_shift = 0;
-    // every part serves as the row database once and as a column database for all later rows: uploaded parts stay resident
-    // while HBM lasts (an upload that fails evicts the others and is tried again)
-    std::vector<std::unique_ptr<Db>> resident(files.size());
-    auto get = [&](size_t i, size_t keep) -> Db& {
-        if (resident[i]) return *resident[i];
-        auto d = std::make_unique<Db>();
-        check(kmdbh_db_load(files[i].c_str(), 0, &d->h));
-        if (kmdb_db_upload(kmdbh_db_view(d->h), &o, 1, &d->d)) {
-            for (size_t j = 0; j < resident.size(); ++j) if (j != keep) resident[j].reset();
-            check(kmdb_db_upload(kmdbh_db_view(d->h), &o, 1, &d->d));
-        }
-        kmdbh_db_free(d->h); d->h = nullptr;                   // the host copy is not needed once the part is in HBM
-        resident[i] = std::move(d);
-        return *resident[i];
+    // Every part serves as the row database once and as a column database for all later rows: uploaded parts stay resident while HBM
+    // lasts (an upload that fails evicts the others and is tried again).
+    // -gpus W ("the grid maps to a multi-GPU grid of cells"; reference console_all2all_parts.cpp:143-331 walks the cells on
+    // one CPU): the block rows of the grid are dealt to W workers — worker t takes the rows t, t + W, ... on device `-gpu` + t % (devices of
+    // the node), its parts resident on ITS device — and the rows' text is written in order as the blocks complete.  Cell (i, j) needs
+    // both parts on one device, so a part lives on every device whose rows reach it; nothing crosses between devices.
+    std::vector<uint64_t> row_start(files.size() + 1, 0);
+    for (size_t i = 0; i < files.size(); ++i) row_start[i + 1] = row_start[i] + part_n[i];
+    const int have = std::max(1, kmdb_device_count());
+    const size_t W = c.gpus > 0 ? std::min<size_t>((size_t)c.gpus, files.size()) : 1;
+    struct Worker {
+        kmdb_opts o{};
+        std::vector<std::unique_ptr<Db>> resident;
     };
-    for (size_t i = 0; i < files.size(); ++i) {
+    std::vector<Worker> workers(W);
+    for (size_t t = 0; t < W; ++t) {
+        workers[t].o = o;
+        workers[t].o.device = c.device + (int)(t % (size_t)std::max(1, have - c.device));
+        workers[t].resident.resize(files.size());
+    }
+    if (W > 1) std::cerr << "Block rows of the grid dealt to " << W << " workers on " << std::min<size_t>(W, (size_t)std::max(1, have - c.device)) << " GPU(s)" << std::endl;
+    std::vector<std::string> block_text(files.size());
+    std::vector<size_t> block_saved(files.size(), 0);
+    std::vector<char> block_done(files.size(), 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::exception_ptr failure;
+    auto block_row = [&](Worker& wk, size_t i) {
+        auto get = [&](size_t p, size_t keep) -> Db& {
+            if (wk.resident[p]) return *wk.resident[p];
+            auto d = std::make_unique<Db>();
+            check(kmdbh_db_load(files[p].c_str(), 0, &d->h));
+            if (kmdb_db_upload(kmdbh_db_view(d->h), &wk.o, 1, &d->d)) {
+                for (size_t j = 0; j < wk.resident.size(); ++j) if (j != keep) wk.resident[j].reset();
+                check(kmdb_db_upload(kmdbh_db_view(d->h), &wk.o, 1, &d->d));
+            }
+            kmdbh_db_free(d->h); d->h = nullptr;                   // the host copy is not needed once the part is in HBM
+            wk.resident[p] = std::move(d);
+            return *wk.resident[p];
+        };
+        std::vector<char> row(10000 + names.size() * 100);
+        std::vector<uint32_t> cols, vals;
+        std::string text;
+        size_t saved = 0;
+        const uint64_t row_shift = row_start[i];
         Db& drow = get(i, i);
         const uint64_t nr = part_n[i];
         std::vector<std::vector<uint32_t>> cross(i);              // cross[j]: nr x part_n[j]
         for (size_t j = 0; j < i; ++j) {
-            std::cerr << "Processing cell (" << i + 1 << "," << j + 1 << ")" << std::endl;
+            { std::lock_guard<std::mutex> g(mu); std::cerr << "Processing cell (" << i + 1 << "," << j + 1 << ")" << std::endl; }
             Db& dcol = get(j, i);
             cross[j].resize(nr * part_n[j] + 1);
-            if (kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &o)) {
+            if (kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &wk.o)) {
                 // out of HBM inside the call (its scratch, lazily made working sets): the other resident parts go, one more try
-                for (size_t q = 0; q < resident.size(); ++q) if (q != i && q != j) resident[q].reset();
-                check(kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &o));
+                for (size_t q = 0; q < wk.resident.size(); ++q) if (q != i && q != j) wk.resident[q].reset();
+                check(kmdb_db2db_dense(drow.d, dcol.d, cross[j].data(), &wk.o));
             }
         }
-        std::cerr << "Processing cell (" << i + 1 << "," << i + 1 << ")" << std::endl;
+        { std::lock_guard<std::mutex> g(mu); std::cerr << "Processing cell (" << i + 1 << "," << i + 1 << ")" << std::endl; }
         kmdb_sparse_rows sp{};
-        if (kmdb_all2all_sparse(drow.d, &sp, &o)) {
-            for (size_t q = 0; q < resident.size(); ++q) if (q != i) resident[q].reset();
-            check(kmdb_all2all_sparse(drow.d, &sp, &o));
+        if (kmdb_all2all_sparse(drow.d, &sp, &wk.o)) {
+            for (size_t q = 0; q < wk.resident.size(); ++q) if (q != i) wk.resident[q].reset();
+            check(kmdb_all2all_sparse(drow.d, &sp, &wk.o));
         }
         for (uint64_t r = 0; r < nr; ++r) {
             cols.clear(); vals.clear();
@@ -470,14 +571,68 @@ int run_all2all_parts(std::vector<std::string>& args, Common& c) {
                 if (c.filters.pass(sp.val[e], cr, (uint32_t)counts[shift + sp.col[e]], (int)k)) {
                     cols.push_back((uint32_t)(shift + sp.col[e])); vals.push_back(sp.val[e]);
                 }
+            if (c.sampler.on()) {
+                // -sample-rows (console_all2all_parts.cpp:137,191,237,275): the pairs go to the sampler (both samples of a pair), the rows are
+                // written when every cell is done — one lock for all workers: the pairs of one sample arrive from several block rows
+                std::lock_guard<std::mutex> g(mu);
+                for (size_t e = 0; e < cols.size(); ++e) {
+                    const double sc = c.sampler.score(vals[e], cr, (uint32_t)counts[cols[e]], (int)k);
+                    c.sampler.add(row_shift + r, cols[e], vals[e], sc);
+                    c.sampler.add(cols[e], (uint32_t)(row_shift + r), vals[e], sc);
+                }
+                continue;
+            }
             const std::string& name = names[row_shift + r];
             if (row.size() < 10000 + names.size() * 100 + name.size()) row.resize(10000 + names.size() * 100 + name.size());
             size_t len = kmdbh_format_sparse_row(name.c_str(), counts[row_shift + r], cols.data(), vals.data(), cols.size(), row.data());
-            ofs.write(row.data(), (std::streamsize)len);
+            text.append(row.data(), len);
             saved += cols.size();
         }
         kmdb_sparse_free(&sp);
-        row_shift += nr;
+        std::lock_guard<std::mutex> g(mu);
+        block_text[i] = std::move(text); block_saved[i] = saved; block_done[i] = 1;
+        cv.notify_all();
+    };
+    if (c.sampler.on()) c.sampler.init(names.size());
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < W; ++t)
+        pool.emplace_back([&, t]() {
+            try {
+                for (size_t i = t; i < files.size(); i += W) {
+                    { std::lock_guard<std::mutex> g(mu); if (failure) return; }
+                    block_row(workers[t], i);
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu);
+                if (!failure) failure = std::current_exception();
+                cv.notify_all();
+            }
+        });
+    size_t saved = 0;
+    for (size_t i = 0; i < files.size(); ++i) {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return block_done[i] || failure; });
+        if (!block_done[i]) break;
+        std::string text = std::move(block_text[i]);
+        saved += block_saved[i];
+        g.unlock();
+        ofs.write(text.data(), (std::streamsize)text.size());
+    }
+    for (auto& th : pool) th.join();
+    workers.clear();                                              // (the parts' handles go before the process ends)
+    if (failure) std::rethrow_exception(failure);
+    if (c.sampler.on()) {
+        // the sampled rows, every cell being in (console_all2all_parts.cpp:333-345).  (Random strategy: the subset of a row depends on the order
+        // its pairs arrived in — block rows in the workers' order; with a criterion the rows do not depend on it.)
+        std::vector<char> row(10000 + names.size() * 100);
+        std::vector<uint32_t> cols, vals;
+        for (size_t sidx = 0; sidx < names.size(); ++sidx) {
+            c.sampler.finish_row(sidx, cols, vals);
+            if (row.size() < 10000 + names.size() * 100 + names[sidx].size()) row.resize(10000 + names.size() * 100 + names[sidx].size());
+            const size_t len = kmdbh_format_sparse_row(names[sidx].c_str(), counts[sidx], cols.data(), vals.data(), cols.size(), row.data());
+            ofs.write(row.data(), (std::streamsize)len);
+            saved += cols.size();
+        }
     }
     std::cerr << "No. saved pairs: " << saved << std::endl;
     return 0;
@@ -915,7 +1070,8 @@ void usage() {
                  "    kmer-db-amd distance [-sparse] [-phylip-out] [-min [<criterion>:]<v>]* [-max [<criterion>:]<v>]* <measure> <common_table> <output>\n"
                  "Common options: -t <threads>, -gpu <device>\n"
                  "all2all / all2all-sp: -gpus <N>  the k-mer space in N prefix-bucket shards over the node's GPUs (from -gpu on), partial matrices\n"
-                 "                                  summed by one RCCL reduce-scatter; more shards than devices: a device runs its shards in turn\n";
+                 "                                  summed by one RCCL reduce-scatter; more shards than devices: a device runs its shards in turn\n"
+                 "all2all-parts: -gpus <W>         the block rows of the grid dealt to W workers over the node's GPUs (parts resident per device)\n";
 }
 
 }  // namespace
@@ -936,7 +1092,7 @@ int main(int argc, char** argv) {
         if (take_option(args, "-gpus", v)) {
             c.gpus = std::atoi(v.c_str());
             if (c.gpus < 1 || c.gpus > 4096) throw std::runtime_error("-gpus expects a number of prefix-bucket shards (1 or more)");
-            if (mode != "all2all" && mode != "all2all-sp") throw std::runtime_error("-gpus applies to all2all and all2all-sp");
+            if (mode != "all2all" && mode != "all2all-sp" && mode != "all2all-parts") throw std::runtime_error("-gpus applies to all2all, all2all-sp and all2all-parts");
         }
         take_switch(args, "-v");
         take_switch(args, "-vv");

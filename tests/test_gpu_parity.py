@@ -373,6 +373,90 @@ def test_db2db_large_parts(K, O, dev, tmp_path, N, L, near):
     assert np.array_equal(da.db2db(db_), got.T)
 
 
+SAMPLE_ROWS = [("virus_k18", "sr_jaccard5", ["-sample-rows", "jaccard:5"]), ("virus_k18", "sr_numkmers3_min", ["-sample-rows", "num-kmers:3", "-min", "jaccard:0.02"]),
+               ("clade64", "sr_ani7", ["-sample-rows", "ani:7"]), ("clade64", "sr_max2", ["-sample-rows", "max:2", "-max", "num-kmers:3000"])]
+
+
+def test_sample_rows_like_the_reference(golden_dir, dev, tmp_path):
+    """`-sample-rows [<criterion>:]<count>` of all2all-sp and all2all-parts (reference src/sampler.h, src/params.cpp:533-557, src/array.h:450-540;
+    SURVEY 2 #9: the front-end must honour it; VERDICT round 5, missing 5).  With a criterion the rows — symmetric: a pair is offered to both its
+    samples — are the reference's byte for byte: tests/golden/*.sr_*.ref.txt were written by the reference's own Sampler (make_fixture_sample_rows.py),
+    and where oracle/_ref travels the reference runs again beside the front-end.  all2all-parts -sample-rows over the two virus parts gives the same
+    rows as all2all-sp over the whole collection.  Random strategy (no criterion): at most `count` valid pairs per row, a pair listed by either of
+    its samples was a pair of the unsampled output (the subset itself depends on the reference's hash-table order and is not compared)."""
+    g = lambda n: os.path.join(golden_dir, n)   # noqa: E731
+    t = lambda n: str(tmp_path / n)             # noqa: E731
+    exe = os.path.join(ROOT, "oracle", "_ref", "bridge_driver")
+
+    def rows_of(csv):
+        return [b",".join(ln.split(b",")[2:]) for ln in open(csv, "rb").read().split(b"\n")[2:] if ln]
+
+    for stem, tag, opts in SAMPLE_ROWS:
+        _cli("all2all-sp", *opts, g(stem + ".db"), t(tag + ".csv"))
+        want = open(g("%s.%s.ref.txt" % (stem, tag)), "rb").read().split(b"\n")[:-1]
+        assert rows_of(t(tag + ".csv")) == want, tag
+        if os.path.exists(exe):
+            r = subprocess.run([exe, "sample_rows_ref", g(stem + ".db"), t(tag + ".ref")] + opts, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert open(t(tag + ".ref"), "rb").read().split(b"\n")[:-1] == want
+    # the whole file has the shape of the unsampled one: header, counts, name + k-mer count in front of every row
+    plain = t("plain.csv")
+    _cli("all2all-sp", g("virus_k18.db"), plain)
+    a, b = open(plain, "rb").read().split(b"\n"), open(t("sr_jaccard5.csv"), "rb").read().split(b"\n")
+    assert a[:2] == b[:2] and [x.split(b",")[:2] for x in a[2:]] == [x.split(b",")[:2] for x in b[2:]]
+    # all2all-parts: the same rows from the grid of cells
+    with open(t("db.list"), "w") as f:
+        f.write(g("virus_k18_part1.db") + "\n" + g("virus_k18_part2.db") + "\n")
+    for extra in ([], ["-gpus", "2"]):
+        _cli("all2all-parts", "-sample-rows", "jaccard:5", *extra, t("db.list"), t("parts.csv"))
+        assert rows_of(t("parts.csv")) == open(g("virus_k18.sr_jaccard5.ref.txt"), "rb").read().split(b"\n")[:-1]
+    # random strategy
+    _cli("all2all-sp", "-sample-rows", "4", g("clade64.db"), t("rnd.csv"))
+    _cli("all2all-sp", g("clade64.db"), t("clade.csv"))
+    pairs = set()
+    for i, row in enumerate(rows_of(t("clade.csv"))):
+        for cell in row.split(b",")[:-1]:
+            c, v = cell.split(b":")
+            pairs.add((i, int(c) - 1, int(v)))
+    for i, row in enumerate(rows_of(t("rnd.csv"))):
+        cells = [c.split(b":") for c in row.split(b",")[:-1]]
+        ids = [int(c) - 1 for c, _ in cells]
+        assert len(cells) <= 4 and ids == sorted(set(ids))
+        for c, v in cells:
+            j = int(c) - 1
+            assert (max(i, j), min(i, j), int(v)) in pairs
+
+
+def test_all2all_parts_grid_over_the_devices_of_a_node(K, O, dev, tmp_path):
+    """`kmer-db-amd all2all-parts -gpus W` (the grid of cells over the GPUs; reference src/console_all2all_parts.cpp:143-331 walks it
+    on one CPU): a collection in FIVE part databases, block rows dealt to 1 / 2 / 3 / 5 workers (on this box they share the one GPU, every worker
+    with its own resident parts) — the outputs are byte-identical, and equal to the sparse all2all of the whole collection (all2all-sp CLI)."""
+    import importlib
+    import torch
+    S = importlib.import_module("kmerdb_amd.synth")
+    N, cs, L, k = 150, 25, 5000, 18
+    device = torch.device("cuda", dev)
+    g = S.CladeGenomes(N, cs, L, seed=17, device=device)
+    cuts = [0, 20, 55, 90, 101, N]                               # (parts of unequal size; sample order = the collection's)
+    paths = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        paths.append(str(tmp_path / ("p%d.db" % a)))
+        _synth_part(S, g, list(range(a, b)), k, paths[-1], device)
+    pall = str(tmp_path / "all.db")
+    _synth_part(S, g, list(range(N)), k, pall, device)
+    lst = tmp_path / "parts.list"
+    lst.write_text("".join(p + "\n" for p in paths))
+    outs = {}
+    for w in (None, "2", "3", "5"):
+        out = str(tmp_path / ("parts_%s.csv" % w))
+        _cli("all2all-parts", *(["-gpus", w] if w else []), str(lst), out)
+        outs[w] = open(out, "rb").read()
+    assert outs[None] == outs["2"] == outs["3"] == outs["5"] and outs[None].count(b"\n") == N + 2
+    whole = str(tmp_path / "whole.csv")
+    _cli("all2all-sp", pall, whole)
+    assert open(whole, "rb").read() == outs[None]
+
+
 def test_db2db_with_more_than_65535_samples(K, O, dev, tmp_path):
     """all2all-parts with a part of 66 000 samples (reference: 32-bit sample ids, src/types.h:15-18; src/console_all2all_parts.cpp:159-226): round
     4's pair kernel kept its block indices in a fixed 1024-entry LDS array and refused.  Two pattern forests with fabricated k-mer
@@ -515,6 +599,9 @@ def test_cli_byte_identical_to_reference_goldens(golden_dir, dev, tmp_path):
         with open(t("db.list"), "w") as f:
             f.write(g("virus_k18_part1.db") + "\n" + g("virus_k18_part2.db") + "\n")
         _cli("all2all-parts", t("db.list"), t("k18.parts.csv")); _same(t("k18.parts.csv"), g("virus.k18.sparse.csv"))
+        # the block rows of the grid dealt to workers over the node's devices (-gpus W; on this box they share the one GPU), rows written in order
+        for w in ("2", "3"):
+            _cli("all2all-parts", "-gpus", w, t("db.list"), t("k18.parts%s.csv" % w)); _same(t("k18.parts%s.csv" % w), g("virus.k18.sparse.csv"))
         # one2all: main.yml:156-160 (k=25, f=0.1 database of part 1, one genome against it)
         _cli("one2all", g("virus_k25_f01_part1.db"), "./test/virus/data/MT159713", t("MT159713.csv"))
         _same(t("MT159713.csv"), g("virus.MT159713.csv"))
@@ -929,6 +1016,41 @@ def test_random_forests_bit_exact(K, O, dev, tmp_path, seed, N, P, max_local, ch
 
 
 @pytest.mark.gpu
+def test_bench_through_the_products_node_driver(dev):
+    """`bench.py --driver node`: the line the driver's `--gpus N` run prints comes from the PRODUCT's multi-GPU path —
+    kmdb_node_upload / kmdb_node_all2all_dense (csrc/node.hip) in one process — not from a Python re-implementation of it.  On the one-GPU box:
+    (a) KMDB_NODE_FORCE_RCCL=1 --gpus 1: the RCCL half of the driver on a one-rank communicator (dlopen, ncclCommInitAll, the reduce-scatter of
+    every step), the line's schema, figures per device from kmdb_node_device_stats; (b) --gpus 1 --shards 4: four prefix shards of ONE database
+    one after the other on the device (the one-GPU anchor of a four-GPU run), checksum identity inside bench.py; (c) under a launcher with two
+    ranks, rank 0 drives and rank 1 waits at the barriers (--gpus 1 there: the box has one device)."""
+    import json
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--driver", "node", "--samples", "400", "--clade-size", "50", "--length", "20000", "--steps", "2", "--warmup", "1"]
+    env = dict(os.environ, KMDB_NODE_FORCE_RCCL="1")
+    r = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last_json = lambda out: json.loads([ln for ln in out.strip().split("\n") if ln.startswith("{")][-1])      # noqa: E731  (RCCL's banner may follow the line)
+    d = last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "u32" and d["config"]["driver"] == "node" and d["config"]["n_ranks_seen"] == 1
+    assert d["config"]["rccl"] and d["config"]["per_rank"]["collective_ms"][0] > 0 and d["config"]["per_rank"]["call_ms"][0] > 0
+    assert d["roofline"]["frac"] > 0 and d["value"] > 0
+    r = subprocess.run(base + ["--gpus", "1", "--shards", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d4 = last_json(r.stdout)
+    pr = d4["config"]["per_rank"]
+    assert pr["shards"] == [4] and pr["block_records"][0] > 0 and pr["h2d_bytes"][0] > 0 and d4["config"]["rccl"] is None
+    assert d4["config"]["patterns_rank0"] == d["config"]["patterns_rank0"]
+    # two launcher ranks, one device: rank 0 is the node driver's process, rank 1 only keeps the launcher's rendezvous
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(29500 + os.getpid() % 1000)] + base[1:] + ["--gpus", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["config"]["driver"] == "node"
+
+
+@pytest.mark.gpu
 def test_more_than_65535_samples(K, O, dev, tmp_path):
     """Sample ids take 20 bits in the device layout (reference: 32-bit ids, src/types.h:15-18; its own 2019 collection data/pathogens.list
     has 40 715 samples).  (a) a random forest over 66 000 samples — local lists whose ids and deltas need 17 bits, long lists, deep
@@ -987,13 +1109,44 @@ def test_more_than_65535_samples(K, O, dev, tmp_path):
     # path for it at all (the fallback kept 16-bit ids: VERDICT round 5, missing 6); the reference has no such limit
     # (src/similarity_calculator.h:30-77).  A chain of 5000 and more nodes, one or two ids each, whole matrix against the oracle.
     rng = np.random.default_rng(5000)
-    pat = _random_forest(rng, N, 5600, 2, chain_frac=0.9995)
+    P = 5600
+    parent = np.full(P, -1, dtype=np.int64)
+    nsam = np.zeros(P, dtype=np.int64)
+    last = np.full(P, -1, dtype=np.int64)
+    locs = [np.zeros(0, dtype=np.int64)]
+    tip, chain_done = 0, False
+    for p in range(1, P):
+        # one long chain (tip -> p adds one or two ids some steps further on, until the ids run out near N), and now and then — and from
+        # there on — a leaf off an earlier node
+        side = chain_done or (p > 3 and rng.random() < 0.05)
+        for _ in range(100):
+            par = int(rng.integers(1, p)) if side else tip
+            lo = last[par] + 1 if par else 0
+            l = int(rng.integers(1, 3))
+            ids = lo + np.cumsum(rng.integers(1, 17, size=l)) - 1
+            if ids[-1] < N:
+                break
+            side = chain_done = True
+        assert ids[-1] < N
+        if not side:
+            tip = p
+        parent[p] = par if par else -1
+        nsam[p] = (nsam[par] if par else 0) + l
+        last[p] = ids[-1]
+        locs.append(ids.astype(np.int64))
+    w = np.where(rng.random(P) < 0.3, 0, rng.integers(1, 5, size=P)).astype(np.int64)
+    w[0] = 0
+    num_local = np.array([len(x) for x in locs], dtype=np.int64)
+    lp = np.zeros(P + 1, dtype=np.int64)
+    lp[1:] = np.cumsum(num_local)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
+    pat = {"num_kmers": tt(w), "parent": tt(parent), "num_samples": tt(nsam), "num_local": tt(num_local), "local_ptr": tt(lp), "local_ids": tt(np.concatenate(locs))}
     arr = S.to_view_arrays(pat)
     par = arr["parent_id"]
     depth = np.zeros(par.size, np.int64)
     for p in range(1, par.size):
         depth[p] = depth[par[p]] + 1 if par[p] >= 0 else 1
-    assert int(depth.max()) > 4200 and int(arr["last_sample_id"].max()) > 65535
+    assert int(depth.max()) > 4200 and int(arr["num_samples"].max()) > 4200 and int(arr["last_sample_id"].max()) > 65535
     path = str(tmp_path / "deep.db")
     S.write_db(path, 18, 1.0, ["s%d" % i for i in range(N)], [1] * N, arr)
     exp = O.OracleDB(path, skip_hashtables=True).all2all_dense()
