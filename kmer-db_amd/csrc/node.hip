@@ -236,7 +236,9 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
     for (uint32_t a = 0; a < D; ++a)
         for (uint32_t b = a + 1; b < D; ++b)
             if (devices[a] == devices[b]) return kmdb_set_error("kmdb_node_upload: device " + std::to_string(devices[a]) + " listed twice");
-    auto* nd = new kmdb_node();
+    kmdb_node* nd = nullptr;
+    try {                                                       // (nothing may leave through the C boundary: allocation and thread failures end in kmdb_set_error)
+    nd = new kmdb_node();
     nd->N = view->n_samples; nd->cells = nd->N ? nd->N * (nd->N - 1) / 2 : 0; nd->n_shards = n_shards;
     nd->per = D > 1 ? (nd->cells + D - 1) / D : nd->cells;
     nd->dev.resize(D);
@@ -245,33 +247,56 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
     const char* force = getenv("KMDB_NODE_FORCE_RCCL");
     nd->use_rccl = D > 1 || (force && force[0] == '1');
     const auto t0 = std::chrono::steady_clock::now();
-    // all shards planned at once on the host: one pass over the hashtable items, one sweep over the tree (host_shards.cpp); every device
-    // thread then narrows, packs and copies only what its own shards keep
-    kmdb_shard_plan plan;
-    if (n_shards > 1) {
-        std::vector<uint32_t> all(n_shards);
-        for (uint32_t s = 0; s < n_shards; ++s) all[s] = s;
-        if (kmdb_shard_plan_build(view, n_shards, all, &plan)) { delete nd; return 1; }
-        nd->stats.plan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    }
+    // The shards are planned on the host (host_shards.cpp: one pass over the hashtable items, one sweep over the tree) — all at once while their
+    // weight counters (4 bytes per pattern and shard until a shard's upload releases its own) fit a budget, else in rounds of whole multiples of
+    // the devices (64 shards of a 10^8-pattern database would have held 25 GB of counters at once); every device thread then
+    // narrows, packs and copies only what its own shards keep.
     int rc = on_devices(nd, [&](size_t d, bool dev_ok) -> int {
         if (!dev_ok) return 1;
         DevSlot& s = nd->dev[d];
-        const auto u0 = std::chrono::steady_clock::now();
         NODE_TRY(hipStreamCreate(&s.stream));
         for (auto& e : s.ev) NODE_TRY(hipEventCreate(&e));
-        kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = s.device; o.shard_count = 1;
-        for (uint32_t sh = (uint32_t)d; sh < n_shards; sh += D) {
-            kmdb_db* db = nullptr;
-            if (n_shards == 1 ? kmdb_db_upload(view, &o, 0, &db) : kmdb_db_upload_planned(view, &o, 0, sh, n_shards, &plan, &db)) return 1;
-            s.shards.push_back(db);
-            kmdb_stats st{};
-            if (!kmdb_db_stats(db, &st)) { s.h2d_bytes += st.h2d_bytes; s.n_patterns += st.n_patterns; }
+        return 0;
+    });
+    uint64_t budget = 16ull << 30;
+    if (const char* e = getenv("KMDB_PLAN_BUDGET_MB")) if (*e) budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;      // (tests: several rounds on a small database)
+    const uint64_t per_shard = std::max<uint64_t>(view->n_patterns * 4, 1);
+    const uint32_t group = n_shards == 1 ? 1u : (uint32_t)std::min<uint64_t>(n_shards, std::max<uint64_t>(D, budget / per_shard / D * D));
+    for (uint32_t g0 = 0; g0 < n_shards && !rc; g0 += group) {
+        const uint32_t g1 = std::min(n_shards, g0 + group);
+        kmdb_shard_plan plan;
+        if (n_shards > 1) {
+            const auto p0 = std::chrono::steady_clock::now();
+            std::vector<uint32_t> subset;
+            for (uint32_t sh = g0; sh < g1; ++sh) subset.push_back(sh);
+            if (kmdb_shard_plan_build(view, n_shards, subset, &plan)) { rc = 1; break; }
+            nd->stats.plan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count();
         }
+        rc = on_devices(nd, [&](size_t d, bool dev_ok) -> int {
+            if (!dev_ok) return 1;
+            DevSlot& s = nd->dev[d];
+            const auto u0 = std::chrono::steady_clock::now();
+            kmdb_opts o{}; o.abi_version = KMDB_ABI_VERSION; o.device = s.device; o.shard_count = 1;
+            for (uint32_t sh = g0; sh < g1; ++sh) {
+                if (sh % D != d) continue;
+                kmdb_db* db = nullptr;
+                if (n_shards == 1 ? kmdb_db_upload(view, &o, 0, &db) : kmdb_db_upload_planned(view, &o, 0, sh, n_shards, &plan, &db)) return 1;
+                s.shards.push_back(db);
+                kmdb_stats st{};
+                if (!kmdb_db_stats(db, &st)) { s.h2d_bytes += st.h2d_bytes; s.n_patterns += st.n_patterns; }
+            }
+            s.upload_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
+            return 0;
+        });
+    }
+    if (!rc) rc = on_devices(nd, [&](size_t d, bool dev_ok) -> int {
+        if (!dev_ok) return 1;
+        DevSlot& s = nd->dev[d];
+        const auto u0 = std::chrono::steady_clock::now();
         NODE_TRY(hipMalloc((void**)&s.acc, std::max<uint64_t>(nd->per * D, 1) * 4));
         if (s.shards.size() > 1) NODE_TRY(hipMalloc((void**)&s.tmp, std::max<uint64_t>(nd->cells, 1) * 4));
         if (nd->use_rccl) NODE_TRY(hipMalloc((void**)&s.chunk, std::max<uint64_t>(nd->per, 1) * 4));
-        s.upload_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
+        s.upload_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
         return 0;
     });
     if (!rc && nd->use_rccl) {
@@ -292,6 +317,10 @@ extern "C" int kmdb_node_upload(const kmdb_db_view* view, uint32_t n_shards, con
     node_fill_stats(nd);
     *out = nd;
     return 0;
+    } catch (const std::exception& e) {
+        if (nd) kmdb_node_free(nd);
+        return kmdb_set_error(std::string("kmdb_node_upload: ") + e.what());
+    }
 }
 
 extern "C" void kmdb_node_free(kmdb_node* nd) {

@@ -14,7 +14,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BA=${BENCH_ARGS:-}
 # counters only for the engine's kernels (the synthetic generator's thousands of torch kernels would be serialised too)
-KRE=${KERNEL_REGEX:-"k0_|k1n_|k1w_|k2_|k2j_|l2_|cs_|rs_|rg_|ct_|wide_|wrun_|n2a_|d2_|row_nnz|row_compact|lay_|width_estimate|pair_estimate|iota_u32"}
+KRE=${KERNEL_REGEX:-"k0_|k1n_|k1w_|k2_|k2d_|k2j_|l2_|cs_|rs_|rg_|ct_|wide_|wrun_|n2a_|d2_|row_nnz|row_compact|lay_|width_estimate|pair_estimate|iota_u32"}
 declare -A G
 G[sq1]="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
 G[sq2]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM"

@@ -743,6 +743,18 @@ def test_node_driver_over_the_devices_of_the_box(K, golden_dir, dev, stem, shard
         K.NodeDB(K.HostDB(os.path.join(golden_dir, stem + ".db"), skip_hashtables=True), 2, devices)
     with pytest.raises(K.KmdbError, match="listed twice"):
         K.NodeDB(h, 2, [0, 0])
+    # the shards planned in rounds (the plan's weight counters held to a budget: here so small that every round holds as many shards as
+    # there are devices) give the same handle
+    os.environ["KMDB_PLAN_BUDGET_MB"] = "1"
+    try:
+        nd2 = K.NodeDB(h, shards, devices)
+        assert np.array_equal(nd2.all2all_dense(), ref)
+        assert sum(x["n_patterns"] for x in nd2.stats()["devices"]) == int(kept.sum())
+        nd2.close()
+    finally:
+        del os.environ["KMDB_PLAN_BUDGET_MB"]
+    with pytest.raises(K.KmdbError, match="shards"):
+        K.NodeDB(h, 5000, devices)
 
 
 def test_node_driver_rccl_calls_on_a_one_rank_communicator(K, golden_dir, dev, monkeypatch):
