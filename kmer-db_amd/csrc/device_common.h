@@ -237,15 +237,26 @@ struct RunCursor32 {
         if (z < limit && z < 32u) {
             const uint32_t rest = win << z;                          // starts with a 1 bit
             uint32_t ones = (uint32_t)__clz((int)~rest);
-            ones = ones > 15u ? 15u : ones;                          // a valid code of an id below 2^16 has at most 15 leading ones
-            const uint32_t len = 2u * ones + 1u;
-            if (z + len <= 32u) {
-                v = ((rest << ones) >> (31u - ones)) | (1u << ones);
-                used += len;
+            if (ones <= 15u) {                                       // a delta below 2^16: the code has at most 31 bits
+                const uint32_t len = 2u * ones + 1u;
+                if (z + len <= 32u) {
+                    v = ((rest << ones) >> (31u - ones)) | (1u << ones);
+                    used += len;
+                }
+            } else if (z == 0u) {
+                // A delta of 2^16 and more (collections beyond 65 536 samples: ids take KMDB_ID_BITS = 20 bits) — a code of 33 to 39 bits, read
+                // through a 64-bit window over three units.  (Round 5 clamped the count of leading ones to 15 here: such a delta — rare, it
+                // needs a list that jumps over 65 536 ids at once — was decoded wrongly.)  Behind zeros the code waits for the next step, which
+                // starts at it.
+                const unsigned long long w64 = (((unsigned long long)c[0] << 32) | c[1]) << s | (s ? (unsigned long long)(c[2] >> (32u - s)) : 0ull);
+                uint32_t o64 = (uint32_t)__clzll((long long)~w64);
+                o64 = o64 > 31u ? 31u : o64;
+                v = (uint32_t)((w64 << o64) >> (63u - o64)) | (1u << o64);
+                used = 2u * o64 + 1u;
             }
         }
         s += used;
-        if (s >= 32u) { s -= 32u; shift_unit(); }
+        while (s >= 32u) { s -= 32u; shift_unit(); }
     }
 };
 

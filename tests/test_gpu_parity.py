@@ -1077,6 +1077,22 @@ def test_more_than_65535_samples(K, O, dev, tmp_path):
     N = 66000
     rng = np.random.default_rng(65536)
     pat = _random_forest(rng, N, 4000, 300, chain_frac=0.5)
+    # local lists that JUMP over 65 536 ids at once: a gamma code of 33 - 39 bits, more than the decode kernel's 32-bit window holds (round 5
+    # clamped such a code to 31 bits and read a wrong delta; the random forest above has no such list) — two ids, a short list with the jump in
+    # the middle, one behind a run of consecutive ids, a long list (the second decode launch), and children that extend them
+    import torch
+    extra = [(-1, [3, 65990]), (-1, [10, 11, 65800, 65801]), (-1, list(range(100, 140)) + [65950]), (-1, list(range(200, 290)) + [65960, 65961]),
+             (-1, [0, 65536]), (-1, [7, 65543, 65999])]
+    P0 = int(pat["num_kmers"].numel())
+    extra += [(P0 + 0, [65995]), (P0 + 1, [65900, 65999]), (P0 + 2, [65951])]
+    par, nsam, nloc, ids, w = (pat[k].tolist() for k in ("parent", "num_samples", "num_local", "local_ids", "num_kmers"))
+    for pp, lst in extra:
+        par.append(pp); nloc.append(len(lst)); ids += lst; w.append(3)
+        nsam.append(len(lst) + (nsam[pp] if pp >= 0 else 0))
+    lp = np.zeros(len(par) + 1, dtype=np.int64)
+    lp[1:] = np.cumsum(nloc)
+    pat = {"num_kmers": torch.tensor(w), "parent": torch.tensor(par), "num_samples": torch.tensor(nsam), "num_local": torch.tensor(nloc),
+           "local_ptr": torch.from_numpy(lp), "local_ids": torch.tensor(ids)}
     arr = S.to_view_arrays(pat)
     assert int(arr["last_sample_id"].max()) > 65535 and int(arr["num_samples"].max()) > 500 and int(arr["num_bits"].max()) > 4096
     path = str(tmp_path / "f.db")
