@@ -60,6 +60,23 @@ def main():
     torch.cuda.synchronize()
     con = (time.perf_counter() - t0) / calls * 1e3
     assert torch.equal(Ms[0], Ms[1])
+    # the same with the second chain half a call behind the first: decode / narrow emit of one beside wide emit / sort / apply of the other
+    stag = []
+    for frac in (0.35, 0.5, 0.65):
+        def run_late(i, n, delay):
+            if delay:
+                time.sleep(delay)
+            run(i, n)
+        th = [threading.Thread(target=run_late, args=(i, calls, one * 1e-3 * frac * i)) for i in range(2)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        stag.append((frac, (time.perf_counter() - t0 - one * 1e-3 * frac) / calls * 1e3))
+    assert torch.equal(Ms[0], Ms[1])
+    print("%s: staggered starts (fraction of a call, ms per pair of calls): %s" % (wl, ", ".join("%.2f: %.3f" % x for x in stag)))
     print("%s: one call %.3f ms; two calls one after the other %.3f ms; two calls side by side (two host threads, own streams and pools) %.3f ms = %.2f x one call" %
           (wl, one, seq, con, con / one))
 
