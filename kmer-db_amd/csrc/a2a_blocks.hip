@@ -3226,7 +3226,11 @@ static int blocks_prepare_impl(kmdb_db* db) {
     if (db->row_mode) {
         // the estimate (one node in `stride`, exact per node) plus a quarter, plus what the waves hold when they end (open chunks, unfinished grabs); the
         // sorted copy holds the records themselves: the estimate plus an eighth.  A pool that turns out too small is enlarged and the call repeated.
-        if (alloc_record_pool(db, (est_n + est_g) * 5 / 4 / CH_REC + (uint64_t)db->n_nsegs * 12 + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
+        // (chunks, not records, are what runs out: every wave keeps an open chunk per block row it writes to — the wide kernel's waves all rows, a
+        // slice of the narrow kernel the rows of its nodes' second blocks, up to 48 counted here — and leaves it partly filled.  Round 5's pools hid
+        // that behind the records the second level no longer writes; with the estimate after the second level and 12 chunks per slice the first
+        // call at 10 000 samples ran out and doubled its pool: profiles/r06_close_bench.err)
+        if (alloc_record_pool(db, (est_n + est_g) * 5 / 4 / CH_REC + (uint64_t)db->n_nsegs * std::min<uint32_t>(db->NB, 48u) + (uint64_t)db->k1w_waves * (db->NB + ARENA_GRAB) + 4096)) return 1;
         if (alloc_wide_pool(db, (est_n + est_g) * 9 / 8 / WCH_REC + 4096)) return 1;
     } else {
         if (alloc_record_pool(db, est_n * 3 / 2 / CH_REC + (db->dense_narrow ? 0u : (uint64_t)db->n_nsegs * 8) + 4096)) return 1;
@@ -3413,10 +3417,15 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         const uint32_t waves = (db->n_nsegs + sl - 1u) / sl;
         if (waves) hipLaunchKernelGGL(k2d_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, s2, d);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(db->ev_side[1], s2));               // (the call's end waits for the side stream; many streams: recorded again behind the chunk table's work)
         if (sync_debug) { const hipError_t e = hipStreamSynchronize(s2); fprintf(stderr, "[kmdb] stage %-14s %s\n", "slice apply", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
         return 0;
     };
-    if (db->k1n_mode == 2 && apply_slices()) return 1;
+    // (the slices' apply kernel starts right behind the narrow kernel, beside the wide list's small kernels — scan, expand, root paths of the runs,
+    // which then take 0.28 ms at C2 instead of their own 0.05.  KMDB_K2D_EARLY=0 starts it with the wide kernel: the wide stage gains 0.1 ms, the
+    // sort beside which the kernel then ends loses them — profiles/r06_j13: 6.70 / 6.98 against 6.86 / 6.93 ms at C2, 18.45 against 19.11 at 10 000 samples)
+    static const bool k2d_early = !(getenv("KMDB_K2D_EARLY") && getenv("KMDB_K2D_EARLY")[0] == '0');
+    if (db->k1n_mode == 2 && k2d_early && apply_slices()) return 1;
     if (!row_mode) {
         if (!db->dense_narrow) {
             HIP_TRY(hipEventRecord(db->ev_side[0], st));
@@ -3444,6 +3453,7 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
     if (!db->widx) { HIP_TRY(hipMalloc((void**)&db->widx, 4)); db->wide_cap = std::max<uint64_t>(db->wide_cap, 1); }
     hipLaunchKernelGGL(wide_expand_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, db->widebits, db->wide_base, n_words, db->widx,
                        (uint32_t)db->wide_cap, db->counters);
+    if (db->k1n_mode == 2 && !k2d_early && apply_slices()) return 1;
     // ---- K1w
     if (n_wide) {
         WParams q{};
@@ -3704,6 +3714,9 @@ int blocks_attempt(kmdb_db* db, uint32_t* M, uint32_t emit_lo, uint32_t emit_hi,
         const uint64_t want = db->wide_pool_cap + db->wide_pool_cap / 4;
         if (((want + (uint64_t)KMDB_SUBPOOLS * WIDE_GRAB) << WCH_SHIFT) < pool_slot_limit(db) && alloc_wide_pool(db, want)) return 1;
     }
+    if (!db->have_counts && getenv("KMDB_VERBOSE"))
+        fprintf(stderr, "[kmdb] record pool: %u of %llu chunks in use (busiest sub-pool x sub-pools); wide pool / sorted arrays: %llu slots\n", c[KCTR_POOL_USED],
+                (unsigned long long)db->pool_cap, (unsigned long long)db->sorted_cap);
     db->last_n_wide = c[KCTR_NWIDE]; db->last_n_chunks = c[KCTR_CHUNKS]; db->last_n_raw = c[KCTR_RAW]; db->last_n_slow = c[KCTR_SLOW];
     db->last_n_rowjobs = c[KCTR_ROWJOBS]; db->last_n_sorted = c[KCTR_WIDE_RECORDS]; db->last_l2_nodes = c[KCTR_L2_NODES]; db->last_n_k2jobs = c[KCTR_K2JOBS];
     if (db->l2_on && !db->have_counts && getenv("KMDB_VERBOSE"))

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 tag, out = sys.argv[1:3]
 files = sys.argv[3:]          # per-dispatch CSVs; none: the table is re-made from <out>/<tag>_counters.json
-KERNELS = ("k0_decode_kernel", "k0_short_direct_kernel", "l2_ranks_kernel", "l2_lists_kernel", "l2_join_apply_kernel", "k2j_build_kernel", "k2_jobs_kernel", "k1n_kernel", "k1g_kernel", "k1w_kernel", "k2_apply_kernel", "k2_sorted_kernel", "cs_hist_kernel", "cs_scatter_kernel",
+KERNELS = ("k0_decode_kernel", "k0_short_direct_kernel", "l2_ranks_kernel", "l2_lists_kernel", "l2_join_apply_kernel", "k2j_build_kernel", "k2_jobs_kernel", "k2d_kernel", "k1n_kernel", "k1g_kernel", "k1w_kernel", "k2_apply_kernel", "k2_sorted_kernel", "cs_hist_kernel", "cs_scatter_kernel",
            "rs_hist_kernel", "rs_scatter_kernel", "rs_rows_kernel", "rg_hist_kernel", "rg_scatter_kernel", "ct_hist_kernel", "ct_scatter_kernel", "wrun_anc_kernel",
            "wide_count_kernel", "wide_expand_kernel", "n2a_walk_kernel", "n2a_probe_kernel", "n2a_extract_kernel", "d2_emit_kernel", "d2_probe_kernel", "row_nnz_kernel",
            "row_compact_kernel")

@@ -7,7 +7,7 @@ from collections import defaultdict
 
 tag, fetch_csv, write_csv, out = sys.argv[1:5]
 CALLS = 1 + 1 + 2          # bench.py --steps 2 --warmup 1: the cold call, one warm-up, two timed calls
-OURS = ("k0_decode_kernel", "k0_short_direct_kernel", "l2_ranks_kernel", "l2_offsets_kernel", "l2_lists_kernel", "l2_join_apply_kernel", "k2j_starts_kernel", "k2j_starts_flat_kernel", "k2j_build_kernel", "k2_jobs_kernel", "k1n_kernel", "k1w_kernel", "wrun_anc_kernel", "ct_hist_kernel", "ct_scatter_kernel", "ct_count_kernel", "rs_rows_kernel", "rs_hist_kernel", "rs_scatter_kernel", "k1g_kernel", "k2_apply_kernel", "k2_sorted_kernel", "cs_hist_kernel", "cs_scatter_kernel", "csl_scatter_kernel", "wide_count_kernel", "wide_expand_kernel",
+OURS = ("k0_decode_kernel", "k0_short_direct_kernel", "l2_ranks_kernel", "l2_offsets_kernel", "l2_lists_kernel", "l2_join_apply_kernel", "k2j_starts_kernel", "k2j_starts_flat_kernel", "k2j_build_kernel", "k2_jobs_kernel", "k2d_kernel", "k1n_kernel", "k1w_kernel", "wrun_anc_kernel", "ct_hist_kernel", "ct_scatter_kernel", "ct_count_kernel", "rs_rows_kernel", "rs_hist_kernel", "rs_scatter_kernel", "k1g_kernel", "k2_apply_kernel", "k2_sorted_kernel", "cs_hist_kernel", "cs_scatter_kernel", "csl_scatter_kernel", "wide_count_kernel", "wide_expand_kernel",
         "count_chunks_kernel", "fill_u32_kernel", "rg_hist_kernel", "rg_scatter_kernel", "n2a_", "d2_", "row_nnz_kernel", "row_compact_kernel")
 
 
